@@ -1,0 +1,127 @@
+"""Pins oracle/model_oracle.py: head / losses / frame bookkeeping against
+fixtures from the reference's own classes; log-mel + encoder + decoder against
+the independent HF transformers implementation (openai-whisper is absent:
+that part of the oracle is 'parity unpinned').  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_json, load_npz
+from oracle import model_oracle as mo
+
+
+def test_head_matches_reference_rnn_class():
+    z = load_npz("head_rnn.npz")
+    p = {"align_rnn." + k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}
+    y = mo.gru_head_forward(p, torch.from_numpy(z["x"]))
+    np.testing.assert_allclose(y.numpy(), z["y"], rtol=0, atol=1e-5)
+
+
+def test_head_state_dict_layout():
+    keys = load_json("head_state_dict_keys.json")
+    p = mo.random_head_params(1024, 384, 21129)
+    assert {k[len("align_rnn."):]: list(v.shape) for k, v in p.items()} == keys
+
+
+def test_head_matches_torch_gru():
+    p = mo.random_head_params(32, 12, 19, seed=3)
+    gru = torch.nn.GRU(32, 12, num_layers=2, batch_first=True, bidirectional=True)
+    gru.load_state_dict({k[len("align_rnn.rnn."):]: v for k, v in p.items() if ".rnn." in k})
+    x = torch.randn(3, 21, 32, generator=torch.Generator().manual_seed(4))
+    with torch.no_grad():
+        h, _ = gru(x)
+        ref = torch.nn.functional.linear(torch.nn.functional.mish(h), p["align_rnn.fc.weight"], p["align_rnn.fc.bias"])
+    np.testing.assert_allclose(mo.gru_head_forward(p, x).numpy(), ref.numpy(), rtol=0, atol=2e-6)
+
+
+def test_frame_bookkeeping_matches_reference_alignmodel():
+    for row in load_json("frame_counts.json")["rows"]:
+        n_mel = row["n_samples"] // 160
+        if row["get_orig_len"]:
+            plan = mo.chunk_plan(n_mel)
+            assert sum(k for _, _, k in plan) == row["out_shape"][1], row
+            assert len(plan) == len(row["encoder_calls"]), row
+        else:
+            assert row["out_shape"][1] == 1500 and len(row["encoder_calls"]) == 1
+    assert mo.frame_count(301) == 150 and mo.frame_count(303) == 152  # banker's rounding
+
+
+def test_losses_match_reference():
+    z = load_npz("losses.npz")
+    logits = torch.from_numpy(z["logits"]).requires_grad_(True)
+    V = int(z["vocab_size"])
+    ce = mo.ce_loss(logits, torch.from_numpy(z["frame_labels"]), vocab_size=V)
+    (g,) = torch.autograd.grad(ce, logits)
+    np.testing.assert_allclose(ce.item(), z["ce"], rtol=1e-6)
+    np.testing.assert_allclose(g.numpy(), z["g_ce"], atol=1e-7)
+    ctc = mo.ctc_loss(logits[:, :, :V], torch.from_numpy(z["labels"]))
+    (g2,) = torch.autograd.grad(ctc, logits)
+    np.testing.assert_allclose(ctc.item(), z["ctc"], rtol=1e-5)
+    np.testing.assert_allclose(g2.numpy(), z["g_ctc"], atol=1e-5)  # reference CTC is fp32, oracle accumulates in fp64
+
+
+def test_mel_filters_match_transformers():
+    from transformers.audio_utils import mel_filter_bank
+    hf = mel_filter_bank(201, 80, 0.0, 8000.0, 16000, norm="slaney", mel_scale="slaney").T
+    np.testing.assert_allclose(mo.mel_filters(), hf.astype(np.float32), rtol=0, atol=1e-7)
+
+
+def test_log_mel_matches_hf_feature_extractor():
+    from transformers import WhisperFeatureExtractor
+    fe = WhisperFeatureExtractor()
+    rs = np.random.RandomState(0)
+    t = np.arange(60096) / 16000.0
+    wav = (rs.randn(60096) * 0.05 + 0.3 * np.sin(2 * np.pi * 220 * t) + 0.2 * np.sin(2 * np.pi * 3000 * t)).astype(np.float32)
+    ours = mo.log_mel_spectrogram(wav)
+    hf = fe._torch_extract_fbank_features(wav) if hasattr(fe, "_torch_extract_fbank_features") else None
+    if hf is None:
+        pytest.skip("HF torch fbank path missing")
+    hf = torch.as_tensor(hf)
+    hf = hf.reshape(hf.shape[-2], hf.shape[-1])
+    np.testing.assert_allclose(ours.numpy(), hf[:, : ours.shape[-1]].numpy(), rtol=0, atol=2e-5)
+    assert ours.shape == (80, 375)
+    # batch coupling of the -8 floor: global max over the whole tensor
+    two = mo.log_mel_spectrogram(np.stack([wav, wav * 1e-3]))
+    assert two.shape == (2, 80, 375)
+    assert float(two[1].min()) >= float((two.max() * 4 - 4 - 8 + 4) / 4) - 1e-6
+
+
+def _hf_encoder(n_state, n_head, n_layer, seed):
+    from transformers import WhisperConfig
+    from transformers.models.whisper.modeling_whisper import WhisperEncoder
+    cfg = WhisperConfig(d_model=n_state, encoder_layers=n_layer, encoder_attention_heads=n_head,
+                        encoder_ffn_dim=4 * n_state, num_mel_bins=80, max_source_positions=1500,
+                        decoder_layers=1, decoder_attention_heads=n_head, decoder_ffn_dim=4 * n_state)
+    cfg._attn_implementation = "eager"
+    enc = WhisperEncoder(cfg).eval()
+    p = mo.random_encoder_params(n_state, n_layer, seed=seed)
+    sd = {"conv1.weight": p["encoder.conv1.weight"], "conv1.bias": p["encoder.conv1.bias"],
+          "conv2.weight": p["encoder.conv2.weight"], "conv2.bias": p["encoder.conv2.bias"],
+          "embed_positions.weight": p["encoder.positional_embedding"],
+          "layer_norm.weight": p["encoder.ln_post.weight"], "layer_norm.bias": p["encoder.ln_post.bias"]}
+    names = {"attn.query": "self_attn.q_proj", "attn.key": "self_attn.k_proj", "attn.value": "self_attn.v_proj",
+             "attn.out": "self_attn.out_proj", "attn_ln": "self_attn_layer_norm", "mlp.0": "fc1", "mlp.2": "fc2",
+             "mlp_ln": "final_layer_norm"}
+    for i in range(n_layer):
+        for ours, hf in names.items():
+            for wb in ("weight", "bias"):
+                k = f"encoder.blocks.{i}.{ours}.{wb}"
+                if k in p:
+                    sd[f"layers.{i}.{hf}.{wb}"] = p[k]
+    missing, unexpected = enc.load_state_dict(sd, strict=False)
+    assert not unexpected
+    for i in range(n_layer):
+        b = enc.layers[i].self_attn.k_proj.bias
+        if b is not None:
+            b.data.zero_()
+    return enc, p
+
+
+def test_encoder_matches_hf_whisper_encoder():
+    enc, p = _hf_encoder(64, 4, 2, seed=11)
+    mel = torch.rand(2, 80, 3000, generator=torch.Generator().manual_seed(12)) * 2 - 1
+    with torch.no_grad():
+        hf = enc(mel).last_hidden_state
+    ours = mo.encoder_forward(p, mel, n_head=4)
+    assert ours.shape == (2, 1500, 64)
+    np.testing.assert_allclose(ours.numpy(), hf.numpy(), rtol=0, atol=2e-5)
