@@ -1,0 +1,229 @@
+/*
+ * lyricalign.h -- C ABI of liblyricalign_hip.so (MI355X / gfx950 only).
+ *
+ * The reference (navi0105/LyricAlignment) is pure Python and has no FFI: its
+ * "operator interface" for the alignment hot path is the set of Python calls
+ *
+ *   whisper.audio.log_mel_spectrogram(audios)        module/align_model.py:84
+ *   whisper_model.embed_audio(mel)                   module/align_model.py:91,101,112,137
+ *   align_rnn(embed)   (GRU -> Mish -> Linear)        module/align_model.py:35-38,107,115
+ *   perform_viterbi_ctc / perform_viterbi            utils/alignment.py:121-188 / :13-71
+ *   run_viterbi_core                                 utils/alignment.py:73-119
+ *
+ * Every entry point below names the call it replaces.  The Python packages in
+ * lyricalignment_amd/ (same names and signatures as the reference's modules)
+ * bind these symbols with ctypes; INTEGRATION.md shows the stub a maintainer
+ * of the reference would add.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no C++ / torch types cross the boundary;
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - the caller owns every buffer; scratch comes from a caller-provided
+ *     workspace sized by the matching *_workspace_bytes() query;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream);
+ *     calls only enqueue work, they never synchronise, allocate or free;
+ *   - return value: la_status.  Nothing throws across the boundary.
+ *     Per-utterance outcomes of the DP are reported in a device `status`
+ *     array with the same codes.
+ *   - re-entrant: no global mutable state except the optional kernel timer
+ *     (la_timer_*), which is for bench.py only.
+ */
+#ifndef LYRICALIGN_H
+#define LYRICALIGN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum la_status {
+    LA_OK = 0,
+    LA_EINVAL = 1,       /* bad argument (shape / alignment / null pointer)            */
+    LA_EINFEASIBLE = 2,  /* a label state is never visited -> reference: ValueError    */
+                         /*   ("k is not in list", utils/alignment.py:183)             */
+    LA_EEMPTY = 3,       /* utterance without labels -> reference: IndexError (:152)   */
+    LA_EHIP = 4,         /* HIP runtime error, see la_last_error()                     */
+    LA_ETIMEOUT = 5,     /* a bounded in-kernel wait gave up (persistent GRU kernel)   */
+    LA_EUNSUPPORTED = 6  /* shape outside what the gfx950 kernels are built for        */
+} la_status;
+
+typedef enum la_dtype {
+    LA_F32 = 0,  /* parity mode: f32 storage, f32-input MFMA (exact fmaf chains)      */
+    LA_BF16 = 1  /* throughput mode: bf16 operands, f32 accumulate, f32 residual      */
+} la_dtype;
+
+typedef enum la_variant {
+    LA_VARIANT_PLAIN = 0, /* perform_viterbi:      log_softmax over all V, silence = col 0          */
+    LA_VARIANT_CTC = 1    /* perform_viterbi_ctc:  log_softmax over cols 1..V-2, silence = sigmoid  */
+                          /*                       of the last column (naive log, clip -1000)       */
+} la_variant;
+
+/* ------------------------------------------------------------------------- */
+/* library                                                                    */
+/* ------------------------------------------------------------------------- */
+int la_version(void);                 /* ABI version, currently 1                              */
+const char *la_last_error(void);      /* thread-local text of the last LA_EHIP / LA_EINVAL     */
+int la_device_arch_ok(void);          /* 1 if the current device is gfx950                     */
+
+/* Optional per-kernel HIP-event timer (bench.py roofline leg).  When enabled,
+ * launches of the kernel family `name` ("gemm_bf16", "attention", ...) on any
+ * stream are bracketed by hipEvents; la_timer_read() synchronises those events
+ * and returns the summed milliseconds and the launch count since reset.      */
+int la_timer_enable(const char *name);
+int la_timer_disable(void);
+int la_timer_read(double *total_ms, int64_t *launches);
+int la_timer_reset(void);
+
+/* ------------------------------------------------------------------------- */
+/* forced-alignment DP   (replaces utils/alignment.py:73-119 + :141-185)      */
+/* ------------------------------------------------------------------------- */
+/*
+ * Emissions use the COMPACT layout the fused head produces:
+ *   em[b][t][0]     = log-prob of silence at frame t      (reference: ls[t][0])
+ *   em[b][t][1 + n] = log-prob of label n's class          (reference: lp[t][label[n]-1])
+ * float32, strides given in elements.  labels[b][n] are class ids (only equality
+ * of neighbours is used, utils/alignment.py:104); n_labels[b] = L_b, n_frames[b] = T_b.
+ *
+ * Scores are accumulated in float64 with the reference's comparison order and
+ * tie rules; backpointers are 2-bit offsets {0,1,2}.  Outputs are INTEGER
+ * frame indices: onset[b][n] = first frame in state 2n+1, offset[b][n] = last
+ * such frame + 1 (the Python layer multiplies by hop_size_second exactly as
+ * utils/alignment.py:185 does).  status[b] is LA_OK / LA_EINFEASIBLE / LA_EEMPTY
+ * / LA_EINVAL.  Rows n >= L_b of onset/offset are set to -1.
+ */
+int la_viterbi_workspace_bytes(int32_t batch, int32_t max_frames, int32_t max_labels, size_t *bytes);
+
+int la_viterbi_batch(const float *em, int64_t em_batch_stride, int64_t em_row_stride,
+                     const int32_t *labels, int32_t labels_stride,
+                     const int32_t *n_labels, const int32_t *n_frames,
+                     int32_t batch, int32_t max_frames, int32_t max_labels,
+                     int32_t *onset, int32_t *offset, int32_t out_stride,
+                     double *final_score, int32_t *status,
+                     void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------- */
+/* emission prep from materialised logits                                     */
+/*   (replaces utils/alignment.py:123-134 [CTC] and :14-20 [plain])           */
+/* ------------------------------------------------------------------------- */
+/*
+ * logits [batch][frames][vocab] float32 (device).  Computes the row normaliser
+ * over the variant's column range and writes only the columns the DP reads:
+ * em[b][t][0] and em[b][t][1+n] for n < n_labels[b] (compact layout above).
+ */
+int la_emissions_from_logits(const float *logits, int64_t batch_stride, int64_t row_stride,
+                             int32_t batch, int32_t frames, int32_t vocab, int32_t variant,
+                             const int32_t *labels, int32_t labels_stride, const int32_t *n_labels,
+                             int32_t max_labels,
+                             float *em, int64_t em_batch_stride, int64_t em_row_stride, void *stream);
+
+/* ------------------------------------------------------------------------- */
+/* log-mel front end   (replaces whisper.audio.log_mel_spectrogram + pad_or_trim, */
+/*                      call sites module/align_model.py:84,89,100,109)           */
+/* ------------------------------------------------------------------------- */
+/*
+ * audio [batch][n_samples] float32 -> mel [batch][80][n_frames], n_frames =
+ * n_samples / 160, float32.  The "-8" floor uses the max over the WHOLE batch
+ * tensor, as upstream whisper does.  mel_filters is the [80][201] Slaney table
+ * (device), window the 400-tap periodic Hann (device).
+ */
+int la_logmel_workspace_bytes(int32_t batch, int32_t n_samples, size_t *bytes);
+int la_logmel_f32(const float *audio, int32_t batch, int32_t n_samples,
+                  const float *mel_filters, const float *window,
+                  float *mel, int64_t mel_batch_stride, int64_t mel_row_stride,
+                  void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------- */
+/* building blocks of embed_audio / align_rnn                                 */
+/* ------------------------------------------------------------------------- */
+/* epilogue flags for la_gemm */
+enum {
+    LA_EPI_BIAS = 1,      /* + bias[n] (f32)                                          */
+    LA_EPI_GELU = 2,      /* exact erf GELU after the bias                            */
+    LA_EPI_RESIDUAL = 4,  /* + residual[m][n] (f32, own strides; batch stride may be 0) */
+    LA_EPI_OUT_F32 = 8,   /* C is f32 regardless of the operand dtype                 */
+    LA_EPI_MISH = 16      /* x * tanh(softplus(x)) after the bias                     */
+};
+
+/*
+ * C[z][m][n] = epi( sum_k A[z][m][k] * W[n][k] ),  z < batch.
+ * A: `dtype`, row stride lda (elements; may be < K: the conv-as-GEMM views
+ * overlap rows), batch stride strideA.  W: `dtype`, [N][K] row-major (nn.Linear
+ * layout).  C: `dtype` (or f32 with LA_EPI_OUT_F32), row stride ldc, batch
+ * stride strideC.  K % 64 == 0 (bf16) / K % 32 == 0 (f32); A, W, C 16-byte aligned;
+ * M, N arbitrary (edge tiles are predicated).
+ * Replaces every nn.Linear / nn.Conv1d of whisper.model.AudioEncoder and the
+ * GRU input projections of module/align_model.py:23-28.
+ */
+int la_gemm(int32_t dtype, int32_t M, int32_t N, int32_t K, int32_t batch,
+            const void *A, int64_t lda, int64_t strideA,
+            const void *W,
+            void *C, int64_t ldc, int64_t strideC,
+            const float *bias,
+            const float *residual, int64_t ldr, int64_t strideR,
+            int32_t epilogue, void *stream);
+
+/* y[m][:] = LayerNorm(x[m][:]) * gamma + beta, eps 1e-5; x f32 [M][d], y `out_dtype`. */
+int la_layernorm(const float *x, int64_t ldx, int32_t M, int32_t d,
+                 const float *gamma, const float *beta,
+                 void *y, int64_t ldy, int32_t out_dtype, void *stream);
+
+/*
+ * Non-causal multi-head self-attention over packed QKV rows.
+ * qkv [batch*frames][3*n_head*64] (`dtype`): columns [q | k | v], head h at
+ * h*64; q is expected PRE-SCALED by head_dim^-0.5 (folded into the projection
+ * weights at pack time; the reference scales q and k by head_dim^-0.25 each,
+ * whisper MultiHeadAttention.qkv_attention).  softmax in f32.
+ * out [batch*frames][n_head*64] (`dtype`).  head_dim is 64 for every Whisper size.
+ */
+int la_attention(int32_t dtype, const void *qkv, int64_t ld_qkv, void *out, int64_t ld_out,
+                 int32_t batch, int32_t frames, int32_t n_head, void *stream);
+
+/* mel [batch][n_mels][frames] f32 -> channels-last zero-padded rows for the conv-as-GEMM view:
+ * out[b][1 + t][c] (`dtype`), row pitch `c_pad`, (frames + 2) rows per clip, rows 0 and frames+1
+ * and channels >= n_mels zeroed. */
+int la_mel_to_rows(const float *mel, int64_t mel_batch_stride, int64_t mel_row_stride,
+                   int32_t batch, int32_t n_mels, int32_t frames,
+                   void *out, int32_t c_pad, int32_t dtype, void *stream);
+
+/*
+ * One bidirectional GRU layer recurrence (nn.GRU gate order r,z,n;
+ * module/align_model.py:23-28).  gi [batch][frames][2][3H] f32 holds the input
+ * projections W_ih x + b_ih of both directions; w_hh [2][3H][H] (`dtype`),
+ * b_hh [2][3H] f32.  out [batch][frames][2H] (`dtype`) receives h_t (forward in
+ * columns 0..H-1, reverse in H..2H-1); out_mish (optional, same shape) receives
+ * Mish(h_t) (module/align_model.py:37).  Persistent kernel: 2 * H/64 (bf16) workgroups
+ * exchange h through `out` with write-through stores and per-step arrival
+ * counters in `workspace` (zeroed on the stream by this call).  H % 64 == 0.
+ * `timeout_flag` (device int32, optional) is set non-zero if a bounded wait
+ * gave up; the host wrapper maps it to LA_ETIMEOUT.
+ */
+int la_gru_workspace_bytes(int32_t batch, int32_t frames, int32_t hidden, size_t *bytes);
+int la_gru_layer(int32_t dtype, const float *gi, const void *w_hh, const float *b_hh,
+                 void *out, void *out_mish, int32_t batch, int32_t frames, int32_t hidden,
+                 void *workspace, size_t workspace_bytes, int32_t *timeout_flag, void *stream);
+
+/*
+ * Fused head tail: Linear(2H -> V) + emission prep, WITHOUT materialising the
+ * [batch][frames][V] logits (replaces module/align_model.py:38 followed by
+ * utils/alignment.py:123-134 / :14-20 and the device->host copy at
+ * inference_alignment.py:161).  act [batch*frames][2H] (`dtype`) = Mish(GRU out);
+ * w_fc [V][2H] (`dtype`), b_fc [V] f32.  Writes compact emissions (layout above).
+ */
+int la_fc_emissions_workspace_bytes(int32_t rows, int32_t vocab, size_t *bytes);
+int la_fc_emissions(int32_t dtype, const void *act, int64_t ld_act, const void *w_fc, const float *b_fc,
+                    int32_t batch, int32_t frames, int32_t in_dim, int32_t vocab, int32_t variant,
+                    const int32_t *labels, int32_t labels_stride, const int32_t *n_labels,
+                    int32_t max_labels,
+                    float *em, int64_t em_batch_stride, int64_t em_row_stride,
+                    void *workspace, size_t workspace_bytes, void *stream);
+
+/* elementwise helpers used by the host-side plumbing */
+int la_cast_f32_to_bf16(const float *x, void *y, int64_t n, void *stream);
+int la_cast_bf16_to_f32(const void *x, float *y, int64_t n, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LYRICALIGN_H */

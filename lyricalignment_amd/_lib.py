@@ -1,0 +1,114 @@
+"""ctypes binding of liblyricalign_hip.so (see include/lyricalign.h).
+
+The HIP library is the product: if it is missing or cannot be loaded this module
+raises -- there is deliberately no CPU or PyTorch fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_int32, c_int64, c_size_t, c_void_p
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "liblyricalign_hip.so")
+
+LA_OK, LA_EINVAL, LA_EINFEASIBLE, LA_EEMPTY, LA_EHIP, LA_ETIMEOUT, LA_EUNSUPPORTED = range(7)
+LA_F32, LA_BF16 = 0, 1
+LA_VARIANT_PLAIN, LA_VARIANT_CTC = 0, 1
+EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_OUT_F32, EPI_MISH = 1, 2, 4, 8, 16
+
+# every symbol include/lyricalign.h declares: (name, restype, argtypes)
+_I32, _I64, _P, _SZ = c_int32, c_int64, c_void_p, c_size_t
+SYMBOLS = {
+    "la_version": (c_int32, []),
+    "la_last_error": (c_char_p, []),
+    "la_device_arch_ok": (c_int32, []),
+    "la_timer_enable": (c_int32, [c_char_p]),
+    "la_timer_disable": (c_int32, []),
+    "la_timer_read": (c_int32, [POINTER(c_double), POINTER(c_int64)]),
+    "la_timer_reset": (c_int32, []),
+    "la_viterbi_workspace_bytes": (c_int32, [_I32, _I32, _I32, POINTER(_SZ)]),
+    "la_viterbi_batch": (c_int32, [_P, _I64, _I64, _P, _I32, _P, _P, _I32, _I32, _I32, _P, _P, _I32, _P, _P, _P, _SZ, _P]),
+    "la_emissions_from_logits": (c_int32, [_P, _I64, _I64, _I32, _I32, _I32, _I32, _P, _I32, _P, _I32, _P, _I64, _I64, _P]),
+    "la_logmel_workspace_bytes": (c_int32, [_I32, _I32, POINTER(_SZ)]),
+    "la_logmel_f32": (c_int32, [_P, _I32, _I32, _P, _P, _P, _I64, _I64, _P, _SZ, _P]),
+    "la_gemm": (c_int32, [_I32, _I32, _I32, _I32, _I32, _P, _I64, _I64, _P, _P, _I64, _I64, _P, _P, _I64, _I64, _I32, _P]),
+    "la_layernorm": (c_int32, [_P, _I64, _I32, _I32, _P, _P, _P, _I64, _I32, _P]),
+    "la_attention": (c_int32, [_I32, _P, _I64, _P, _I64, _I32, _I32, _I32, _P]),
+    "la_mel_to_rows": (c_int32, [_P, _I64, _I64, _I32, _I32, _I32, _P, _I32, _I32, _P]),
+    "la_gru_workspace_bytes": (c_int32, [_I32, _I32, _I32, POINTER(_SZ)]),
+    "la_gru_layer": (c_int32, [_I32, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _SZ, _P, _P]),
+    "la_fc_emissions_workspace_bytes": (c_int32, [_I32, _I32, POINTER(_SZ)]),
+    "la_fc_emissions": (c_int32, [_I32, _P, _I64, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _I32, _P, _I32, _P, _I64, _I64, _P, _SZ, _P]),
+    "la_cast_f32_to_bf16": (c_int32, [_P, _P, _I64, _P]),
+    "la_cast_bf16_to_f32": (c_int32, [_P, _P, _I64, _P]),
+}
+
+_lib = None
+
+
+class LyricAlignHipError(RuntimeError):
+    pass
+
+
+def lib() -> ctypes.CDLL:
+    """Load the HIP library (build it with `python -m lyricalignment_amd.build`)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LyricAlignHipError(
+                f"{LIB_PATH} is missing: the HIP extension is the product path and has no fallback. "
+                "Build it with `python -m lyricalignment_amd.build`.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)  # AttributeError if the .so is stale
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def last_error() -> str:
+    msg = lib().la_last_error()
+    return msg.decode() if msg else ""
+
+
+def check(rc: int, what: str = "") -> None:
+    """Map la_status to the exception types the reference raises."""
+    if rc == LA_OK:
+        return
+    detail = f"{what}: {last_error()}" if what else last_error()
+    if rc == LA_EINVAL:
+        raise ValueError(f"liblyricalign_hip invalid argument: {detail}")
+    if rc == LA_EUNSUPPORTED:
+        raise NotImplementedError(f"liblyricalign_hip unsupported shape: {detail}")
+    if rc == LA_ETIMEOUT:
+        raise TimeoutError(f"liblyricalign_hip in-kernel wait timed out: {detail}")
+    raise LyricAlignHipError(f"liblyricalign_hip status {rc}: {detail}")
+
+
+def ptr(t) -> int:
+    if t is None:
+        return 0
+    return t.data_ptr()
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.float32:
+        return LA_F32
+    if dt == torch.bfloat16:
+        return LA_BF16
+    raise ValueError(f"unsupported compute dtype {dt} (float32 or bfloat16)")
+
+
+def require_gpu() -> None:
+    if not torch.cuda.is_available():
+        raise LyricAlignHipError("no HIP device visible: lyricalignment_amd runs on MI355X (gfx950) only")
+    if not lib().la_device_arch_ok():
+        raise LyricAlignHipError("current device is not gfx950; the kernels are built for MI355X only")

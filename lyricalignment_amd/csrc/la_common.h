@@ -1,0 +1,86 @@
+// la_common.h -- shared host/device helpers for liblyricalign_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/lyricalign.h"
+
+namespace la {
+
+// ---- thread-local error text (la_last_error) -------------------------------
+char *err_buf();
+void set_error(const char *fmt, ...);
+
+#define LA_CHECK_ARG(cond, ...)                \
+    do {                                       \
+        if (!(cond)) {                         \
+            la::set_error(__VA_ARGS__);        \
+            return LA_EINVAL;                  \
+        }                                      \
+    } while (0)
+
+#define LA_HIP(expr)                                                                     \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess) {                                                          \
+            la::set_error("%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return LA_EHIP;                                                              \
+        }                                                                                \
+    } while (0)
+
+#define LA_LAUNCH_CHECK()                                                               \
+    do {                                                                                \
+        hipError_t _e = hipGetLastError();                                              \
+        if (_e != hipSuccess) {                                                         \
+            la::set_error("%s:%d launch -> %s", __FILE__, __LINE__, hipGetErrorString(_e)); \
+            return LA_EHIP;                                                             \
+        }                                                                               \
+    } while (0)
+
+// ---- optional per-kernel-family event timer (bench.py roofline leg) ---------
+struct TimerScope {
+    bool active;
+    hipStream_t stream;
+    TimerScope(const char *family, hipStream_t s);
+    ~TimerScope();
+};
+
+inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---- bf16 <-> f32 on device --------------------------------------------------
+typedef unsigned short bf16_t;  // raw bits
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+
+// round-to-nearest-even; a plain cast lowers to v_cvt_pk_bf16_f32 on gfx950 and keeps NaN a NaN
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(unsigned short, b);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static constexpr int kDtype = LA_F32;
+    __device__ static __forceinline__ float load(const float *p) { return *p; }
+    __device__ static __forceinline__ void store(float *p, float v) { *p = v; }
+};
+template <> struct Elem<bf16_t> {
+    static constexpr int kDtype = LA_BF16;
+    __device__ static __forceinline__ float load(const bf16_t *p) { return bf16_to_f32(*p); }
+    __device__ static __forceinline__ void store(bf16_t *p, float v) { *p = f32_to_bf16(v); }
+};
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// nn.Mish: x * tanh(softplus(x)); softplus with torch's threshold 20
+__device__ __forceinline__ float mish(float x) {
+    float sp = x > 20.0f ? x : log1pf(expf(x));
+    return x * tanhf(sp);
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+}  // namespace la

@@ -1,0 +1,118 @@
+// la_runtime.cpp -- library-level entry points: version, error text, arch check, kernel timer.
+#include <stdarg.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "la_common.h"
+
+namespace la {
+
+char *err_buf() {
+    static thread_local char buf[512] = {0};
+    return buf;
+}
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(err_buf(), 512, fmt, ap);
+    va_end(ap);
+}
+
+// ---- kernel-family timer ------------------------------------------------------
+namespace {
+struct TimerState {
+    std::mutex mu;
+    bool enabled = false;
+    std::string family;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pairs;  // recorded
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;   // reusable
+};
+TimerState &ts() {
+    static TimerState s;
+    return s;
+}
+}  // namespace
+
+TimerScope::TimerScope(const char *family, hipStream_t s) : active(false), stream(s) {
+    TimerState &t = ts();
+    if (!t.enabled) return;
+    std::lock_guard<std::mutex> lk(t.mu);
+    if (!t.enabled || t.family != family) return;
+    std::pair<hipEvent_t, hipEvent_t> pr;
+    if (!t.pool.empty()) {
+        pr = t.pool.back();
+        t.pool.pop_back();
+    } else {
+        if (hipEventCreate(&pr.first) != hipSuccess) return;
+        if (hipEventCreate(&pr.second) != hipSuccess) { (void)hipEventDestroy(pr.first); return; }
+    }
+    (void)hipEventRecord(pr.first, stream);
+    t.pairs.push_back(pr);
+    active = true;
+}
+
+TimerScope::~TimerScope() {
+    if (!active) return;
+    TimerState &t = ts();
+    std::lock_guard<std::mutex> lk(t.mu);
+    if (!t.pairs.empty()) (void)hipEventRecord(t.pairs.back().second, stream);
+}
+
+}  // namespace la
+
+extern "C" int la_version(void) { return 1; }
+
+extern "C" const char *la_last_error(void) { return la::err_buf(); }
+
+extern "C" int la_device_arch_ok(void) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    return strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
+}
+
+extern "C" int la_timer_enable(const char *name) {
+    if (!name) return LA_EINVAL;
+    la::TimerState &t = la::ts();
+    std::lock_guard<std::mutex> lk(t.mu);
+    t.family = name;
+    t.enabled = true;
+    return LA_OK;
+}
+
+extern "C" int la_timer_disable(void) {
+    la::TimerState &t = la::ts();
+    std::lock_guard<std::mutex> lk(t.mu);
+    t.enabled = false;
+    return LA_OK;
+}
+
+extern "C" int la_timer_reset(void) {
+    la::TimerState &t = la::ts();
+    std::lock_guard<std::mutex> lk(t.mu);
+    for (auto &p : t.pairs) t.pool.push_back(p);
+    t.pairs.clear();
+    return LA_OK;
+}
+
+extern "C" int la_timer_read(double *total_ms, int64_t *launches) {
+    if (!total_ms || !launches) return LA_EINVAL;
+    la::TimerState &t = la::ts();
+    std::lock_guard<std::mutex> lk(t.mu);
+    double sum = 0.0;
+    for (auto &p : t.pairs) {
+        hipError_t e = hipEventSynchronize(p.second);
+        if (e != hipSuccess) { la::set_error("timer: %s", hipGetErrorString(e)); return LA_EHIP; }
+        float ms = 0.f;
+        e = hipEventElapsedTime(&ms, p.first, p.second);
+        if (e != hipSuccess) { la::set_error("timer: %s", hipGetErrorString(e)); return LA_EHIP; }
+        sum += ms;
+    }
+    *total_ms = sum;
+    *launches = (int64_t)t.pairs.size();
+    return LA_OK;
+}

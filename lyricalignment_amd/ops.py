@@ -1,0 +1,163 @@
+"""Host-side plumbing over the C ABI: torch tensors in, kernels enqueued on the
+current HIP stream.  Every wrapper validates shapes / dtypes / contiguity on the
+host before a hand-written kernel is launched.  No arithmetic happens here.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import (EPI_BIAS, EPI_GELU, EPI_MISH, EPI_OUT_F32, EPI_RESIDUAL, LA_BF16, LA_F32, LA_VARIANT_CTC,
+                   LA_VARIANT_PLAIN, check, dtype_code, lib, ptr, stream_ptr)
+
+
+def _dev(t: torch.Tensor, name: str, dtype=None):
+    if not t.is_cuda:
+        raise ValueError(f"{name} must be a device tensor")
+    if dtype is not None and t.dtype != dtype:
+        raise ValueError(f"{name} must be {dtype}, got {t.dtype}")
+
+
+def _capacity(t: torch.Tensor) -> int:
+    """Elements addressable from t.data_ptr() to the end of its storage."""
+    return t.untyped_storage().nbytes() // t.element_size() - t.storage_offset()
+
+
+# --------------------------------------------------------------------------- #
+# alignment DP                                                                  #
+# --------------------------------------------------------------------------- #
+def viterbi_batch(em: torch.Tensor, labels: torch.Tensor, n_labels: torch.Tensor, n_frames: torch.Tensor
+                  ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """em [B,T,E] f32 (E >= Lmax+1), labels [B,Lmax] i32, n_labels [B] i32, n_frames [B] i32 (device).
+    -> onset [B,Lmax] i32, offset [B,Lmax] i32, final_score [B] f64, status [B] i32 (device)."""
+    _dev(em, "em", torch.float32); _dev(labels, "labels", torch.int32)
+    _dev(n_labels, "n_labels", torch.int32); _dev(n_frames, "n_frames", torch.int32)
+    if em.dim() != 3 or labels.dim() != 2 or em.stride(2) != 1 or labels.stride(1) != 1:
+        raise ValueError("viterbi_batch: em [B,T,E] / labels [B,Lmax] with unit inner stride expected")
+    B, T, E = em.shape
+    Lmax = labels.shape[1]
+    if labels.shape[0] != B or n_labels.shape != (B,) or n_frames.shape != (B,) or E < Lmax + 1:
+        raise ValueError("viterbi_batch: inconsistent shapes")
+    n_labels = n_labels.contiguous(); n_frames = n_frames.contiguous()
+    onset = torch.empty((B, Lmax), dtype=torch.int32, device=em.device)
+    offset = torch.empty((B, Lmax), dtype=torch.int32, device=em.device)
+    score = torch.empty((B,), dtype=torch.float64, device=em.device)
+    status = torch.empty((B,), dtype=torch.int32, device=em.device)
+    need = ctypes.c_size_t(0)
+    check(lib().la_viterbi_workspace_bytes(B, T, Lmax, ctypes.byref(need)), "viterbi_workspace_bytes")
+    ws = torch.empty((max(need.value, 16),), dtype=torch.uint8, device=em.device)
+    check(lib().la_viterbi_batch(ptr(em), em.stride(0), em.stride(1), ptr(labels), labels.stride(0), ptr(n_labels),
+                                 ptr(n_frames), B, T, Lmax, ptr(onset), ptr(offset), Lmax, ptr(score), ptr(status),
+                                 ptr(ws), need.value, stream_ptr()), "viterbi_batch")
+    return onset, offset, score, status
+
+
+def emissions_from_logits(logits: torch.Tensor, labels: torch.Tensor, n_labels: torch.Tensor, variant: int) -> torch.Tensor:
+    """logits [B,T,V] f32 device -> compact emissions [B,T,Lmax+1] f32."""
+    _dev(logits, "logits", torch.float32); _dev(labels, "labels", torch.int32); _dev(n_labels, "n_labels", torch.int32)
+    if logits.dim() != 3 or logits.stride(2) != 1:
+        raise ValueError("emissions_from_logits: logits [B,T,V] with unit inner stride expected")
+    B, T, V = logits.shape
+    Lmax = labels.shape[1]
+    if labels.shape[0] != B or n_labels.shape != (B,) or labels.stride(1) != 1:
+        raise ValueError("emissions_from_logits: inconsistent label shapes")
+    em = torch.empty((B, T, Lmax + 1), dtype=torch.float32, device=logits.device)
+    check(lib().la_emissions_from_logits(ptr(logits), logits.stride(0), logits.stride(1), B, T, V, variant, ptr(labels),
+                                         labels.stride(0), ptr(n_labels.contiguous()), Lmax, ptr(em), em.stride(0),
+                                         em.stride(1), stream_ptr()), "emissions_from_logits")
+    return em
+
+
+# --------------------------------------------------------------------------- #
+# encoder / head building blocks                                                #
+# --------------------------------------------------------------------------- #
+def gemm(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None, *, bias: Optional[torch.Tensor] = None,
+         residual: Optional[torch.Tensor] = None, gelu: bool = False, mish: bool = False, out_f32: bool = False,
+         M: Optional[int] = None, lda: Optional[int] = None, batch: int = 1, stride_a: int = 0, stride_c: int = 0,
+         stride_r: int = 0, ldc: Optional[int] = None, ldr: Optional[int] = None) -> torch.Tensor:
+    """out[z][m][n] = epi(sum_k a[z][m][k] w[n][k]).  `a` may be a flat buffer addressed through
+    (M, lda, stride_a): that is how the conv-as-GEMM views (overlapping rows) are expressed."""
+    _dev(a, "a"); _dev(w, "w")
+    dt = dtype_code(w.dtype)
+    if a.dtype != w.dtype:
+        raise ValueError("gemm: a and w dtypes differ")
+    if w.dim() != 2 or not w.is_contiguous():
+        raise ValueError("gemm: w must be contiguous [N,K]")
+    N, K = w.shape
+    if M is None:
+        if a.dim() != 2 or a.stride(1) != 1 or a.shape[1] != K:
+            raise ValueError("gemm: a must be [M,K] with unit inner stride (or pass M/lda)")
+        M, lda = a.shape[0], a.stride(0)
+    if _capacity(a) < (batch - 1) * stride_a + (M - 1) * lda + K:
+        raise ValueError("gemm: a buffer smaller than the addressed view")
+    c_dtype = torch.float32 if (out_f32 or dt == LA_F32) else w.dtype
+    if out is None:
+        if batch != 1:
+            raise ValueError("gemm: batched call needs an explicit out buffer")
+        out = torch.empty((M, N), dtype=c_dtype, device=a.device)
+    if out.dtype != c_dtype:
+        raise ValueError(f"gemm: out must be {c_dtype}")
+    ldc = out.stride(-2) if ldc is None else ldc
+    if _capacity(out) < (batch - 1) * stride_c + (M - 1) * ldc + N:
+        raise ValueError("gemm: out buffer smaller than the addressed view")
+    epi = 0
+    if bias is not None:
+        _dev(bias, "bias", torch.float32)
+        if bias.numel() < N:
+            raise ValueError("gemm: bias shorter than N")
+        epi |= EPI_BIAS
+    if residual is not None:
+        _dev(residual, "residual", torch.float32)
+        ldr = residual.stride(-2) if ldr is None else ldr
+        if _capacity(residual) < (batch - 1) * stride_r + (M - 1) * ldr + N:
+            raise ValueError("gemm: residual buffer smaller than the addressed view")
+        epi |= EPI_RESIDUAL
+    if gelu:
+        epi |= EPI_GELU
+    if mish:
+        epi |= EPI_MISH
+    if c_dtype == torch.float32 and dt == LA_BF16:
+        epi |= EPI_OUT_F32
+    check(lib().la_gemm(dt, M, N, K, batch, ptr(a), lda, stride_a, ptr(w), ptr(out), ldc, stride_c, ptr(bias),
+                        ptr(residual), ldr or 0, stride_r, epi, stream_ptr()), "gemm")
+    return out
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out_dtype: torch.dtype,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _dev(x, "x", torch.float32); _dev(gamma, "gamma", torch.float32); _dev(beta, "beta", torch.float32)
+    if x.dim() != 2 or x.stride(1) != 1:
+        raise ValueError("layernorm: x must be [M,d] with unit inner stride")
+    M, d = x.shape
+    if gamma.numel() != d or beta.numel() != d:
+        raise ValueError("layernorm: gamma/beta size mismatch")
+    if out is None:
+        out = torch.empty((M, d), dtype=out_dtype, device=x.device)
+    if out.dtype != out_dtype or out.shape != (M, d) or out.stride(1) != 1:
+        raise ValueError("layernorm: bad out buffer")
+    check(lib().la_layernorm(ptr(x), x.stride(0), M, d, ptr(gamma), ptr(beta), ptr(out), out.stride(0),
+                             dtype_code(out_dtype), stream_ptr()), "layernorm")
+    return out
+
+
+def mel_to_rows(mel: torch.Tensor, c_pad: int, dtype: torch.dtype) -> torch.Tensor:
+    """mel [B,n_mels,frames] f32 -> [B, frames+2, c_pad] channels-last, zero border rows / pad channels."""
+    _dev(mel, "mel", torch.float32)
+    if mel.dim() != 3 or mel.stride(2) != 1:
+        raise ValueError("mel_to_rows: mel [B,n_mels,frames] with unit inner stride expected")
+    B, n_mels, frames = mel.shape
+    out = torch.empty((B, frames + 2, c_pad), dtype=dtype, device=mel.device)
+    check(lib().la_mel_to_rows(ptr(mel), mel.stride(0), mel.stride(1), B, n_mels, frames, ptr(out), c_pad,
+                               dtype_code(dtype), stream_ptr()), "mel_to_rows")
+    return out
+
+
+def cast_bf16(x: torch.Tensor) -> torch.Tensor:
+    _dev(x, "x", torch.float32)
+    x = x.contiguous()
+    y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    check(lib().la_cast_f32_to_bf16(ptr(x), ptr(y), x.numel(), stream_ptr()), "cast_f32_to_bf16")
+    return y

@@ -1,0 +1,101 @@
+"""GPU numerics of the encoder / head building blocks through the C ABI, against plain
+torch fp32 references of the same op (floating-point kernels: tolerance stated per test)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 128), (1500, 1152, 384), (257, 21129 // 8, 768), (48, 36, 1024)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_plain(M, N, K, dtype):
+    from lyricalignment_amd import ops
+    a = _rand(M, K, seed=1, scale=0.5); w = _rand(N, K, seed=2, scale=0.5)
+    ad, wd = a.to(dtype).cuda(), w.to(dtype).cuda()
+    out = ops.gemm(ad, wd, out_f32=True)
+    ref = ad.float().cpu().double() @ wd.float().cpu().double().T
+    tol = 2e-4 if dtype == torch.float32 else 2e-3  # f32: fmaf-chain rounding over K; bf16: exact products, f32 accumulate
+    np.testing.assert_allclose(out.cpu().double().numpy(), ref.numpy(), rtol=0, atol=tol * (K / 64) ** 0.5)
+
+
+def test_gemm_asymmetric_identity():
+    """A = I with an asymmetric W catches a transposed C write (cdna guide, 'Always A=I-check')."""
+    from lyricalignment_amd import ops
+    K = 128
+    a = torch.eye(K)
+    w = torch.arange(200 * K, dtype=torch.float32).reshape(200, K) % 251
+    out = ops.gemm(a.cuda(), w.cuda())
+    assert torch.equal(out.cpu(), w.T.contiguous())
+    outb = ops.gemm(a.bfloat16().cuda(), w.bfloat16().cuda(), out_f32=True)
+    assert torch.equal(outb.cpu(), w.bfloat16().float().T.contiguous())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_epilogues(dtype):
+    from lyricalignment_amd import ops
+    M, N, K = 200, 136, 192
+    a = _rand(M, K, seed=3, scale=0.3).to(dtype); w = _rand(N, K, seed=4, scale=0.3).to(dtype)
+    bias = _rand(N, seed=5); res = _rand(M, N, seed=6)
+    base = a.float() @ w.float().T + bias
+    tol = 1e-4 if dtype == torch.float32 else 1e-3
+    out = ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda(), gelu=True, out_f32=True).cpu()
+    np.testing.assert_allclose(out.numpy(), torch.nn.functional.gelu(base).numpy(), rtol=0, atol=tol)
+    out = ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda(), residual=res.cuda(), out_f32=True).cpu()
+    np.testing.assert_allclose(out.numpy(), (base + res).numpy(), rtol=0, atol=tol)
+    out = ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda(), mish=True, out_f32=True).cpu()
+    np.testing.assert_allclose(out.numpy(), torch.nn.functional.mish(base).numpy(), rtol=0, atol=tol)
+    if dtype == torch.bfloat16:
+        out = ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda()).cpu()
+        assert out.dtype == torch.bfloat16
+        np.testing.assert_allclose(out.float().numpy(), base.numpy(), rtol=1e-2, atol=1e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_as_gemm_views(dtype):
+    """Conv1d(k=3, pad=1, stride s) on channels-last rows == GEMM over overlapping row views."""
+    from lyricalignment_amd import ops
+    B, C, T, Cout = 2, 128, 64, 96
+    x = _rand(B, C, T, seed=7, scale=0.5)
+    wconv = _rand(Cout, C, 3, seed=8, scale=0.2)
+    bias = _rand(Cout, seed=9)
+    rows = torch.zeros(B, T + 2, C)
+    rows[:, 1:T + 1] = x.permute(0, 2, 1)
+    wk = wconv.permute(0, 2, 1).reshape(Cout, 3 * C).contiguous()  # [out][tap][in]
+    for stride in (1, 2):
+        To = T // stride
+        ref = torch.nn.functional.conv1d(x.to(dtype).float(), wconv.to(dtype).float(), bias, stride=stride, padding=1).permute(0, 2, 1)
+        out = torch.empty(B, To, Cout, dtype=torch.float32, device="cuda")
+        ops.gemm(rows.to(dtype).cuda(), wk.to(dtype).cuda(), out, bias=bias.cuda(), out_f32=True, M=To, lda=stride * C,
+                 batch=B, stride_a=(T + 2) * C, stride_c=To * Cout, ldc=Cout)
+        np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=0, atol=2e-4 if dtype == torch.float32 else 2e-3)
+
+
+@pytest.mark.parametrize("d", [384, 1024, 1280])
+def test_layernorm(d):
+    from lyricalignment_amd import ops
+    x = _rand(77, d, seed=10, scale=3.0) + 0.5
+    g = 1 + _rand(d, seed=11, scale=0.1); b = _rand(d, seed=12, scale=0.1)
+    ref = torch.nn.functional.layer_norm(x, (d,), g, b, 1e-5)
+    out = ops.layernorm(x.cuda(), g.cuda(), b.cuda(), torch.float32).cpu()
+    np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=0, atol=2e-5)
+    outb = ops.layernorm(x.cuda(), g.cuda(), b.cuda(), torch.bfloat16).cpu()
+    np.testing.assert_allclose(outb.float().numpy(), ref.numpy(), rtol=1e-2, atol=1e-2)
+
+
+def test_mel_to_rows_and_cast():
+    from lyricalignment_amd import ops
+    mel = _rand(3, 80, 100, seed=13)
+    out = ops.mel_to_rows(mel.cuda(), 128, torch.float32).cpu()
+    assert out.shape == (3, 102, 128)
+    assert torch.equal(out[:, 1:101, :80], mel.permute(0, 2, 1))
+    assert out[:, 0].abs().sum() == 0 and out[:, 101].abs().sum() == 0 and out[:, :, 80:].abs().sum() == 0
+    outb = ops.mel_to_rows(mel.cuda(), 128, torch.bfloat16).cpu()
+    assert torch.equal(outb[:, 1:101, :80], mel.permute(0, 2, 1).bfloat16())
+    x = _rand(1001, seed=14)
+    assert torch.equal(ops.cast_bf16(x.cuda()).cpu(), x.bfloat16())
