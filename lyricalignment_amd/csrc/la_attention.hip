@@ -1,0 +1,367 @@
+// la_attention.hip -- non-causal multi-head self-attention for the Whisper encoder
+// (whisper.model.MultiHeadAttention.qkv_attention; head_dim = 64 for every model size),
+// flash-style: the [T x T] score matrix never leaves the CU.
+//
+// Work split: grid = (ceil(T/128) query tiles, heads, clips); 4 waves per workgroup, each wave
+// owns 32 query rows and sweeps the clip's keys in tiles of 64.  K and V tiles are staged by
+// global_load_lds (16 B per lane) into a double-buffered, XOR-swizzled LDS image.
+//
+// The score tile is computed TRANSPOSED (S^T = K Q^T, 32 keys x 32 queries per MFMA) so that a
+// lane holds one query's scores in its accumulator registers: the row max / row sum are
+// register-local plus one cross-half exchange, and the exponentiated tile is directly the
+// B-operand of O^T += V^T P^T (cdna guide, "An accumulator tile as the next MFMA's operand").
+//   bf16: v_mfma_f32_32x32x16_bf16; V^T fragments come from ds_read_b64_tr_b16 on the row-major
+//         V image; P is rounded to bf16 for the second product (f32 accumulate, f32 softmax).
+//   f32 : v_mfma_f32_32x32x2_f32 (exact fmaf chains): parity mode, P stays f32.
+// Softmax runs in the exp2 domain (v_exp_f32): p = exp2(s*log2e - m*log2e).
+#include "la_common.h"
+
+using la::bf16_t;
+
+namespace {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+constexpr int QT = 128;   // queries per workgroup (4 waves x 32)
+constexpr int KT = 64;    // keys per tile
+constexpr float kLog2e = 1.4426950408889634f;
+
+struct AttnParams {
+    const void *qkv;
+    int64_t ld_qkv;
+    void *out;
+    int64_t ld_out;
+    int frames, n_head;
+};
+
+// accumulator register -> row (key / dv index) inside a 32x32 tile for lane half h
+__device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+__device__ __forceinline__ void glds16(const void *g, void *l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                     (__attribute__((address_space(3))) void *)l, 16, 0, 0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// bf16
+// ---------------------------------------------------------------------------------------------
+// K image: [64 keys][128 B], 16-B slot s of row r stored at slot s ^ ((r >> 1) & 7)   (ds_read_b128 rows)
+// V image: [64 keys][128 B], slot s of row r stored at slot s ^ (((r >> 1) & 1) << 2) (ds_read_b64_tr_b16)
+__device__ __forceinline__ int kswz(int r) { return (r >> 1) & 7; }
+__device__ __forceinline__ int vswz(int r) { return ((r >> 1) & 1) << 2; }
+
+__device__ __forceinline__ void stage_kv_bf16(const bf16_t *kbase, const bf16_t *vbase, int64_t ld, int key0, int T,
+                                              unsigned char *kl, unsigned char *vl, int wave, int lane) {
+    const int r8 = lane >> 3, ps = lane & 7;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int piece = wave * 2 + i;
+        const int r = piece * 8 + r8;
+        int key = key0 + r;
+        key = key < T ? key : T - 1;
+        glds16(kbase + (int64_t)key * ld + ((ps ^ kswz(r)) << 3), kl + piece * 1024);
+        glds16(vbase + (int64_t)key * ld + ((ps ^ vswz(r)) << 3), vl + piece * 1024);
+    }
+}
+
+__global__ __launch_bounds__(256) void attention_bf16_kernel(AttnParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * KT * 128];  // [buf][K|V][64][128 B] = 32 KiB
+    const int T = p.frames;
+    const int qt = blockIdx.x, head = blockIdx.y, clip = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i32 = lane & 31, h = lane >> 5;
+    const int d = p.n_head * 64;
+    const bf16_t *base = reinterpret_cast<const bf16_t *>(p.qkv) + (int64_t)clip * T * p.ld_qkv + head * 64;
+    const bf16_t *kbase = base + d, *vbase = base + 2 * d;
+
+    // Q fragments (B operand): lane (q = i32, h) holds Q[q][16c + 8h .. +8], c = 0..3
+    int qrow = qt * QT + wave * 32 + i32;
+    const bool q_valid = qrow < T;
+    qrow = q_valid ? qrow : T - 1;
+    uint4 qf[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) qf[c] = *reinterpret_cast<const uint4 *>(base + (int64_t)qrow * p.ld_qkv + 16 * c + 8 * h);
+
+    f32x16 o[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[b][r] = 0.f;
+    float m_run = -INFINITY, l_part = 0.f;
+
+    const int nkv = (T + KT - 1) / KT;
+    stage_kv_bf16(kbase, vbase, p.ld_qkv, 0, T, lds, lds + KT * 128, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // per-lane constant parts of the V^T transposed-read address
+    const int g = lane >> 4, q4 = (lane & 15) >> 2, pp = lane & 3;
+
+    int cur = 0;
+    for (int t = 0; t < nkv; ++t) {
+        const unsigned char *kl = lds + cur * (2 * KT * 128);
+        const unsigned char *vl = kl + KT * 128;
+        if (t + 1 < nkv) {
+            unsigned char *nk = lds + (cur ^ 1) * (2 * KT * 128);
+            stage_kv_bf16(kbase, vbase, p.ld_qkv, (t + 1) * KT, T, nk, nk + KT * 128, wave, lane);
+        }
+        // ---- S^T = K Q^T : two 32-key sub-tiles ----
+        f32x16 s[2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[sub][r] = 0.f;
+            const int row = sub * 32 + i32;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const uint4 kf = *reinterpret_cast<const uint4 *>(kl + row * 128 + (((2 * c + h) ^ kswz(row)) << 4));
+                s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf),
+                                                                 __builtin_bit_cast(bf16x8, qf[c]), s[sub], 0, 0, 0);
+            }
+        }
+        // ---- mask keys >= T (last tile only) ----
+        if ((t + 1) * KT > T) {
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (t * KT + sub * 32 + acc_row(r, h) >= T) s[sub][r] = -INFINITY;
+        }
+        // ---- online softmax (exp2 domain) ----
+        float mx = -INFINITY;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[sub][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx * kLog2e);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // exp2(-inf) = 0 on the first tile
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(fmaf(s[sub][r], kLog2e, -m_new));
+                s[sub][r] = pv;
+                psum += pv;
+            }
+        l_part = l_part * alpha + psum;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[b][r] *= alpha;
+        // ---- O^T += V^T P^T ----
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 pf;  // element j <-> accumulator register 8*ks + j <-> key sub*32 + 16ks + 8(j>>2) + 4h + (j&3)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[j] = (__bf16)s[sub][8 * ks + j];
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    // lane (dv = 32b + 16(g&1) + (lane&15), half h = g>>1): 4 keys key0 .. key0+3 per read
+                    const int key0 = sub * 32 + 16 * ks + 4 * (g >> 1);
+                    const int slot = b * 4 + 2 * (g & 1) + (pp >> 1);
+                    const int r0 = key0 + q4, r1 = key0 + 8 + q4;
+                    const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4 *)(vl + r0 * 128 + ((slot ^ vswz(r0)) << 4) + (pp & 1) * 8));
+                    const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4 *)(vl + r1 * 128 + ((slot ^ vswz(r1)) << 4) + (pp & 1) * 8));
+                    typedef __attribute__((ext_vector_type(8))) short s16x8;
+                    const s16x8 vf = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    o[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), pf, o[b], 0, 0, 0);
+                }
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: O[q][dv] = O^T / l ----
+    const float l = l_part + __shfl_xor(l_part, 32);
+    const float inv = 1.0f / l;
+    if (q_valid) {
+        bf16_t *orow = reinterpret_cast<bf16_t *>(p.out) + ((int64_t)clip * T + qrow) * p.ld_out + head * 64;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                ushort4 pk;
+                pk.x = la::f32_to_bf16(o[b][4 * r4 + 0] * inv);
+                pk.y = la::f32_to_bf16(o[b][4 * r4 + 1] * inv);
+                pk.z = la::f32_to_bf16(o[b][4 * r4 + 2] * inv);
+                pk.w = la::f32_to_bf16(o[b][4 * r4 + 3] * inv);
+                *reinterpret_cast<ushort4 *>(orow + 32 * b + 8 * r4 + 4 * h) = pk;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// f32 (parity mode)
+// ---------------------------------------------------------------------------------------------
+// K / V images: [64 keys][256 B], 16-B slot s of row r stored at slot s ^ (r & 15).
+__device__ __forceinline__ void stage_kv_f32(const float *kbase, const float *vbase, int64_t ld, int key0, int T,
+                                             unsigned char *kl, unsigned char *vl, int wave, int lane) {
+    const int r4 = lane >> 4, ps = lane & 15;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int piece = wave * 4 + i;
+        const int r = piece * 4 + r4;
+        int key = key0 + r;
+        key = key < T ? key : T - 1;
+        const int ls = ps ^ (r & 15);
+        glds16(kbase + (int64_t)key * ld + (ls << 2), kl + piece * 1024);
+        glds16(vbase + (int64_t)key * ld + (ls << 2), vl + piece * 1024);
+    }
+}
+
+__global__ __launch_bounds__(256) void attention_f32_kernel(AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // [buf][K|V][64][256 B] = 64 KiB
+    const int T = p.frames;
+    const int qt = blockIdx.x, head = blockIdx.y, clip = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i32 = lane & 31, h = lane >> 5;
+    const int d = p.n_head * 64;
+    const float *base = reinterpret_cast<const float *>(p.qkv) + (int64_t)clip * T * p.ld_qkv + head * 64;
+    const float *kbase = base + d, *vbase = base + 2 * d;
+
+    int qrow = qt * QT + wave * 32 + i32;
+    const bool q_valid = qrow < T;
+    qrow = q_valid ? qrow : T - 1;
+    // lane (q, h) holds Q[q][8c + 4h + e], c = 0..7, e = 0..3: element e feeds the e-th MFMA of chunk c
+    float4 qf[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) qf[c] = *reinterpret_cast<const float4 *>(base + (int64_t)qrow * p.ld_qkv + 8 * c + 4 * h);
+
+    f32x16 o[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[b][r] = 0.f;
+    float m_run = -INFINITY, l_part = 0.f;
+
+    constexpr int TILE = KT * 256;
+    const int nkv = (T + KT - 1) / KT;
+    stage_kv_f32(kbase, vbase, p.ld_qkv, 0, T, lds, lds + TILE, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    int cur = 0;
+    for (int t = 0; t < nkv; ++t) {
+        const unsigned char *kl = lds + cur * (2 * TILE);
+        const unsigned char *vl = kl + TILE;
+        if (t + 1 < nkv) {
+            unsigned char *nk = lds + (cur ^ 1) * (2 * TILE);
+            stage_kv_f32(kbase, vbase, p.ld_qkv, (t + 1) * KT, T, nk, nk + TILE, wave, lane);
+        }
+        f32x16 s[2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[sub][r] = 0.f;
+            const int row = sub * 32 + i32;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float4 kf = *reinterpret_cast<const float4 *>(kl + row * 256 + (((2 * c + h) ^ (row & 15)) << 4));
+                s[sub] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[c].x, s[sub], 0, 0, 0);
+                s[sub] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[c].y, s[sub], 0, 0, 0);
+                s[sub] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[c].z, s[sub], 0, 0, 0);
+                s[sub] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[c].w, s[sub], 0, 0, 0);
+            }
+        }
+        if ((t + 1) * KT > T) {
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (t * KT + sub * 32 + acc_row(r, h) >= T) s[sub][r] = -INFINITY;
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[sub][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx * kLog2e);
+        const float alpha = exp2f(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = exp2f(fmaf(s[sub][r], kLog2e, -m_new));
+                s[sub][r] = pv;
+                psum += pv;
+            }
+        l_part = l_part * alpha + psum;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[b][r] *= alpha;
+        // O^T += V^T P^T: MFMA `reg` contracts keys {acc_row(reg,0), acc_row(reg,1)}; B operand = s[sub][reg] as it stands,
+        // A operand: lane (dv = 32b + i32, h) supplies V[key acc_row(reg,h)][dv]
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = sub * 32 + acc_row(r, h);
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int col = 32 * b + i32;  // dv
+                    const float vv = *reinterpret_cast<const float *>(vl + key * 256 + ((((col >> 2) ^ (key & 15)) << 4) | ((col & 3) << 2)));
+                    o[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, s[sub][r], o[b], 0, 0, 0);
+                }
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    const float l = l_part + __shfl_xor(l_part, 32);
+    const float inv = 1.0f / l;
+    if (q_valid) {
+        float *orow = reinterpret_cast<float *>(p.out) + ((int64_t)clip * T + qrow) * p.ld_out + head * 64;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4)
+                *reinterpret_cast<float4 *>(orow + 32 * b + 8 * r4 + 4 * h) =
+                    make_float4(o[b][4 * r4 + 0] * inv, o[b][4 * r4 + 1] * inv, o[b][4 * r4 + 2] * inv, o[b][4 * r4 + 3] * inv);
+    }
+}
+
+}  // namespace
+
+extern "C" int la_attention(int32_t dtype, const void *qkv, int64_t ld_qkv, void *out, int64_t ld_out, int32_t batch,
+                            int32_t frames, int32_t n_head, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (batch == 0 || frames == 0) return LA_OK;
+    LA_CHECK_ARG(qkv && out && batch > 0 && frames > 0 && n_head > 0, "attention: bad arguments");
+    LA_CHECK_ARG(dtype == LA_F32 || dtype == LA_BF16, "attention: bad dtype");
+    const int es = dtype == LA_BF16 ? 2 : 4;
+    LA_CHECK_ARG(ld_qkv >= 3 * n_head * 64 && ld_out >= n_head * 64, "attention: leading dimensions too small");
+    LA_CHECK_ARG((ld_qkv * es) % 16 == 0 && (ld_out * es) % 16 == 0 && (uintptr_t)qkv % 16 == 0 && (uintptr_t)out % 16 == 0,
+                 "attention: rows must be 16-byte aligned");
+    AttnParams p{qkv, ld_qkv, out, ld_out, frames, n_head};
+    const dim3 grid(la::cdiv(frames, QT), n_head, batch), block(256);
+    if (dtype == LA_BF16) {
+        la::TimerScope ts("attention_bf16", stream);
+        hipLaunchKernelGGL(attention_bf16_kernel, grid, block, 0, stream, p);
+    } else {
+        static bool attr_done = false;
+        if (!attr_done) {
+            LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_f32_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 4 * KT * 256));
+            attr_done = true;
+        }
+        la::TimerScope ts("attention_f32", stream);
+        hipLaunchKernelGGL(attention_f32_kernel, grid, block, 4 * KT * 256, stream, p);
+    }
+    LA_LAUNCH_CHECK();
+    return LA_OK;
+}

@@ -161,3 +161,19 @@ def cast_bf16(x: torch.Tensor) -> torch.Tensor:
     y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
     check(lib().la_cast_f32_to_bf16(ptr(x), ptr(y), x.numel(), stream_ptr()), "cast_f32_to_bf16")
     return y
+
+
+def attention(qkv: torch.Tensor, batch: int, frames: int, n_head: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """qkv [batch*frames, 3*n_head*64] (q pre-scaled by 1/8) -> out [batch*frames, n_head*64], same dtype."""
+    _dev(qkv, "qkv")
+    dt = dtype_code(qkv.dtype)
+    d = n_head * 64
+    if qkv.dim() != 2 or qkv.stride(1) != 1 or qkv.shape[1] != 3 * d or qkv.shape[0] < batch * frames:
+        raise ValueError("attention: qkv must be [>=batch*frames, 3*n_head*64] with unit inner stride")
+    if out is None:
+        out = torch.empty((qkv.shape[0], d), dtype=qkv.dtype, device=qkv.device)
+    if out.dtype != qkv.dtype or out.dim() != 2 or out.shape[1] != d or out.shape[0] < batch * frames or out.stride(1) != 1:
+        raise ValueError("attention: bad out buffer")
+    check(lib().la_attention(dt, ptr(qkv), qkv.stride(0), ptr(out), out.stride(0), batch, frames, n_head, stream_ptr()),
+          "attention")
+    return out

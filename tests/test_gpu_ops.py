@@ -99,3 +99,37 @@ def test_mel_to_rows_and_cast():
     assert torch.equal(outb[:, 1:101, :80], mel.permute(0, 2, 1).bfloat16())
     x = _rand(1001, seed=14)
     assert torch.equal(ops.cast_bf16(x.cuda()).cpu(), x.bfloat16())
+
+
+@pytest.mark.parametrize("B,T,H", [(1, 5, 1), (2, 64, 2), (1, 200, 3), (2, 1500, 2), (1, 129, 1)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_attention(B, T, H, dtype):
+    """softmax(q k^T) v per head, q pre-scaled; fp64 reference on the host over the FULL tensor."""
+    from lyricalignment_amd import ops
+    d = H * 64
+    qkv = _rand(B * T, 3 * d, seed=20 + T, scale=1.0)
+    qkv[:, :d] *= 0.125 * 3.0  # pre-scaled q (x3 so the softmax is peaked and the online rescale is exercised)
+    x = qkv.to(dtype)
+    out = ops.attention(x.cuda(), B, T, H).float().cpu()
+    xd = x.double().reshape(B, T, 3, H, 64)
+    q, k, v = xd[:, :, 0].transpose(1, 2), xd[:, :, 1].transpose(1, 2), xd[:, :, 2].transpose(1, 2)
+    ref = (torch.softmax(q @ k.transpose(-1, -2), dim=-1) @ v).transpose(1, 2).reshape(B * T, d)
+    tol = 2e-5 if dtype == torch.float32 else 2e-2  # bf16: P and the output are rounded to bf16 (8-bit mantissa), |v| ~ 1
+    np.testing.assert_allclose(out.double().numpy(), ref.numpy(), rtol=0, atol=tol)
+
+
+def test_attention_online_rescale_spike():
+    """Force the running-max update: one key late in the sequence dominates one query (cdna guide rule 26)."""
+    from lyricalignment_amd import ops
+    T, H = 300, 1
+    qkv = _rand(T, 192, seed=31, scale=0.3)
+    qkv[7, :64] = 0.0; qkv[7, 0] = 4.0           # query 7 looks at feature 0
+    qkv[:, 64] = 0.0; qkv[250, 64] = 10.0         # key 250 spikes on feature 0 (tile 3), key 10 a smaller spike (tile 0)
+    qkv[10, 64] = 5.0
+    for dtype, tol in ((torch.float32, 2e-5), (torch.bfloat16, 2e-2)):
+        x = qkv.to(dtype)
+        out = ops.attention(x.cuda(), 1, T, H).float().cpu()
+        xd = x.double()
+        q, k, v = xd[:, :64], xd[:, 64:128], xd[:, 128:]
+        ref = torch.softmax(q @ k.T, dim=-1) @ v
+        np.testing.assert_allclose(out.double().numpy(), ref.numpy(), rtol=0, atol=tol)
