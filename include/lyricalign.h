@@ -83,6 +83,7 @@ int la_timer_reset(void);
  * Emissions use the COMPACT layout the fused head produces:
  *   em[b][t][0]     = log-prob of silence at frame t      (reference: ls[t][0])
  *   em[b][t][1 + n] = log-prob of label n's class          (reference: lp[t][label[n]-1])
+ * (equal neighbouring labels therefore carry identical columns, as they read one class column)
  * float32, strides given in elements.  labels[b][n] are class ids (only equality
  * of neighbours is used, utils/alignment.py:104); n_labels[b] = L_b, n_frames[b] = T_b.
  *
@@ -211,7 +212,8 @@ int la_gru_layer(int32_t dtype, const float *gi, const void *w_hh, const float *
  * inference_alignment.py:161).  act [batch*frames][2H] (`dtype`) = Mish(GRU out);
  * w_fc [V][2H] (`dtype`), b_fc [V] f32.  Writes compact emissions (layout above).
  */
-int la_fc_emissions_workspace_bytes(int32_t rows, int32_t vocab, size_t *bytes);
+int la_fc_emissions_workspace_bytes(int32_t dtype, int32_t batch, int32_t frames, int32_t in_dim, int32_t vocab,
+                                    int32_t max_labels, size_t *bytes);
 int la_fc_emissions(int32_t dtype, const void *act, int64_t ld_act, const void *w_fc, const float *b_fc,
                     int32_t batch, int32_t frames, int32_t in_dim, int32_t vocab, int32_t variant,
                     const int32_t *labels, int32_t labels_stride, const int32_t *n_labels,

@@ -47,6 +47,11 @@ struct TimerScope {
     ~TimerScope();
 };
 
+// generic GEMM launcher with per-batch W / bias strides (la_gemm.hip); la_gemm is its strideW = 0 face
+int gemm_run(int dtype, int M, int N, int K, int batch, const void *A, int64_t lda, int64_t strideA, const void *W,
+             int64_t strideW, void *C, int64_t ldc, int64_t strideC, const float *bias, int64_t strideBias,
+             const float *residual, int64_t ldr, int64_t strideR, int epilogue, hipStream_t stream);
+
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 

@@ -16,9 +16,11 @@ struct GemmParams {
     const void *A;
     int64_t lda, strideA;
     const void *W;
+    int64_t strideW;
     void *C;
     int64_t ldc, strideC;
     const float *bias;
+    int64_t strideBias;
     const float *residual;
     int64_t ldr, strideR;
     int epilogue;
@@ -34,7 +36,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmParams p) {
     const int m0 = tm * BM, n0 = tn * BN;
     const int z = blockIdx.y;
     const T *A = reinterpret_cast<const T *>(p.A) + (int64_t)z * p.strideA;
-    const T *W = reinterpret_cast<const T *>(p.W);
+    const T *W = reinterpret_cast<const T *>(p.W) + (int64_t)z * p.strideW;
+    const float *bias = p.bias ? p.bias + (int64_t)z * p.strideBias : nullptr;
 
     f32x4 acc[4][4];
     mainloop<T>(A, p.lda, p.M, W, p.K, p.N, p.K, m0, n0, lds, acc);
@@ -47,7 +50,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmParams p) {
     const int r = lane & 15, q = lane >> 4;
     const bool vec_c = (p.ldc % 4 == 0) && (p.N % 4 == 0);
     const bool vec_r = R && (p.ldr % 4 == 0) && (p.N % 4 == 0);
-    const bool has_bias = (p.epilogue & LA_EPI_BIAS) && p.bias;
+    const bool has_bias = (p.epilogue & LA_EPI_BIAS) && bias;
     const bool do_gelu = p.epilogue & LA_EPI_GELU;
     const bool do_mish = p.epilogue & LA_EPI_MISH;
     const bool do_res = (p.epilogue & LA_EPI_RESIDUAL) && R;
@@ -65,7 +68,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmParams p) {
             if (has_bias) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    if (j < nv) v[j] += p.bias[n + j];
+                    if (j < nv) v[j] += bias[n + j];
             }
             if (do_gelu) {
 #pragma unroll
@@ -121,10 +124,9 @@ int launch(const GemmParams &p, int batch, hipStream_t stream, const char *famil
 
 }  // namespace
 
-extern "C" int la_gemm(int32_t dtype, int32_t M, int32_t N, int32_t K, int32_t batch, const void *A, int64_t lda,
-                       int64_t strideA, const void *W, void *C, int64_t ldc, int64_t strideC, const float *bias,
-                       const float *residual, int64_t ldr, int64_t strideR, int32_t epilogue, void *stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
+int la::gemm_run(int dtype, int M, int N, int K, int batch, const void *A, int64_t lda, int64_t strideA, const void *W,
+                 int64_t strideW, void *C, int64_t ldc, int64_t strideC, const float *bias, int64_t strideBias,
+                 const float *residual, int64_t ldr, int64_t strideR, int epilogue, hipStream_t stream) {
     if (M == 0 || N == 0 || batch == 0) return LA_OK;
     LA_CHECK_ARG(A && W && C, "gemm: null pointer");
     LA_CHECK_ARG(M > 0 && N > 0 && K > 0 && batch > 0, "gemm: bad sizes");
@@ -136,10 +138,18 @@ extern "C" int la_gemm(int32_t dtype, int32_t M, int32_t N, int32_t K, int32_t b
                  "gemm: A/W rows must be 16-byte aligned");
     LA_CHECK_ARG(!(epilogue & LA_EPI_RESIDUAL) || residual, "gemm: residual epilogue without pointer");
     LA_CHECK_ARG(!(epilogue & LA_EPI_BIAS) || bias, "gemm: bias epilogue without pointer");
-    GemmParams p{M, N, K, A, lda, strideA, W, C, ldc, strideC, bias, residual, ldr, strideR, epilogue,
+    LA_CHECK_ARG((strideW * es) % 16 == 0, "gemm: W batch stride must be 16-byte aligned");
+    GemmParams p{M, N, K, A, lda, strideA, W, strideW, C, ldc, strideC, bias, strideBias, residual, ldr, strideR, epilogue,
                  la::cdiv(M, BM), la::cdiv(N, BN)};
     const bool out_f32 = epilogue & LA_EPI_OUT_F32;
     if (dtype == LA_BF16)
         return out_f32 ? launch<bf16_t, true>(p, batch, stream, "gemm_bf16") : launch<bf16_t, false>(p, batch, stream, "gemm_bf16");
     return launch<float, true>(p, batch, stream, "gemm_f32");
+}
+
+extern "C" int la_gemm(int32_t dtype, int32_t M, int32_t N, int32_t K, int32_t batch, const void *A, int64_t lda,
+                       int64_t strideA, const void *W, void *C, int64_t ldc, int64_t strideC, const float *bias,
+                       const float *residual, int64_t ldr, int64_t strideR, int32_t epilogue, void *stream_) {
+    return la::gemm_run(dtype, M, N, K, batch, A, lda, strideA, W, 0, C, ldc, strideC, bias, 0, residual, ldr, strideR,
+                        epilogue, (hipStream_t)stream_);
 }

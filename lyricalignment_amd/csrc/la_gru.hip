@@ -1,0 +1,293 @@
+// la_gru.hip -- persistent bidirectional GRU recurrence (nn.GRU, gate order r,z,n;
+// module/align_model.py:23-28,36).  The input projections W_ih x + b_ih of both directions are one
+// big GEMM (la_gemm) done beforehand; this kernel runs the T strictly sequential steps
+//     r = sigmoid(gi_r + W_hr h + b_hr)      z = sigmoid(gi_z + W_hz h + b_hz)
+//     n = tanh(gi_n + r * (W_hn h + b_hn))   h' = (1 - z) * n + z * h
+// for both directions at once.
+//
+// Decomposition (DESIGN.md "GRU"): W_hh of one direction (3H x H) does not fit one CU, so the H
+// hidden units are split over H/(16*NW) workgroups per direction; each of a workgroup's NW waves
+// owns 16 hidden units and keeps the 48 matching rows of W_hh RESIDENT for the whole sequence
+// (bf16: in VGPRs as MFMA B-fragments; f32: in LDS), so a step costs only the h exchange.  Per step
+// a wave computes [batch x H] * [H x 48] with MFMA 16x16 tiles (batch on the rows), applies the
+// gates lane-locally (the r/z/n accumulators share one layout), writes its h slice into `out`
+// (which IS the exchange buffer: the next layer / the FC read it anyway) and signals a per-step
+// arrival counter.  Hand-off = agent-scope release / acquire (cdna guide, Guideline 16): plain
+// stores -> every wave vmcnt(0) -> barrier -> lane 0 release fence -> counter add; consumers poll
+// the counter relaxed, one lane acquires, barrier, then plain loads.  Every wait is bounded.
+// Clips are independent, so batches larger than 32 become extra workgroup groups (grid.z).
+#include "la_common.h"
+
+using la::bf16_t;
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+constexpr int MT = 2;          // 16-row batch tiles per workgroup group (32 clips)
+constexpr int GROUP = 16 * MT;
+
+struct GruParams {
+    const float *gi;     // [B][T][2][3H]
+    const void *w_hh;    // [2][3H][H]
+    const float *b_hh;   // [2][3H]
+    void *out;           // [B][T][2H]
+    void *out_mish;      // optional
+    int B, T, H;
+    unsigned *counters;  // [groups][2][T] arrival counters, zeroed per call
+    int *abort_flag;     // workspace word, zeroed per call
+    int *timeout_flag;   // caller's (optional)
+    int nsplit;
+};
+
+__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// bounded wait for `*ctr >= target`; returns false on timeout / abort
+__device__ __forceinline__ bool wait_counter(unsigned *ctr, unsigned target, int *abort_flag) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
+    unsigned spins = 0;
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 255u) == 0) {
+            if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 300000000ull) {  // 3 s
+                __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+        }
+    }
+    return true;
+}
+
+template <typename T> struct GruTraits;
+template <> struct GruTraits<bf16_t> {
+    static constexpr int NW = 4;        // waves per workgroup
+    static constexpr int KSTEP = 32;    // k elements per 16-byte-per-lane fragment step
+    static constexpr bool W_IN_REGS = true;
+};
+template <> struct GruTraits<float> {
+    static constexpr int NW = 2;
+    static constexpr int KSTEP = 16;
+    static constexpr bool W_IN_REGS = false;
+};
+
+__device__ __forceinline__ void mma_step(const uint4 &a, const uint4 &w, f32x4 &acc, bf16_t) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, w), acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma_step(const uint4 &a, const uint4 &w, f32x4 &acc, float) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(w.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(w.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(w.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(w.w), acc, 0, 0, 0);
+}
+
+// MAXKS: compile-time bound on H / KSTEP (register-resident W for bf16: H <= 512)
+template <typename T, int MAXKS>
+__global__ __launch_bounds__(GruTraits<T>::NW * 64, 1) void gru_kernel(GruParams p) {
+    typedef GruTraits<T> TR;
+    constexpr int NW = TR::NW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int slice = blockIdx.x, dir = blockIdx.y, group = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, q = lane >> 4;
+    const int H = p.H, T_ = p.T;
+    const int nks = H / TR::KSTEP;
+    const int j0 = (slice * NW + wave) * 16;       // first hidden unit of this wave
+    const int jcol = j0 + r16;                      // this lane's hidden unit (C layout: col = lane & 15)
+    const int b0 = group * GROUP;
+    const int nb = min(GROUP, p.B - b0);            // clips in this group
+    const T *Wd = reinterpret_cast<const T *>(p.w_hh) + (int64_t)dir * 3 * H * H;
+    const float *bh = p.b_hh + dir * 3 * H;
+    T *out = reinterpret_cast<T *>(p.out);
+    T *outm = reinterpret_cast<T *>(p.out_mish);
+    const int64_t out_bs = (int64_t)T_ * 2 * H, out_ts = 2 * H;
+    const int64_t gi_bs = (int64_t)T_ * 6 * H, gi_ts = 6 * H;
+    unsigned *ctr = p.counters + ((int64_t)group * 2 + dir) * T_;
+
+    // ---- resident W_hh slice: B-operand fragments, lane (n = r16, q): W[g*H + j0 + n][KSTEP*ks + (16/sizeof T)*q ..] ----
+    uint4 wreg[TR::W_IN_REGS ? 3 : 1][TR::W_IN_REGS ? MAXKS : 1];
+    const int row_bytes = H * (int)sizeof(T);
+    if constexpr (TR::W_IN_REGS) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int ks = 0; ks < MAXKS; ++ks)
+                if (ks < nks)
+                    wreg[g][ks] = *reinterpret_cast<const uint4 *>(
+                        reinterpret_cast<const unsigned char *>(Wd + (int64_t)(g * H + jcol) * H) + ks * 64 + q * 16);
+    } else {
+        // LDS image [wave][gate][16 rows][row_bytes], 16-B slot s of row n stored at s ^ n (low 4 bits)
+        const int slots = row_bytes / 16;
+        for (int idx = tid; idx < NW * 3 * 16 * slots; idx += NW * 64) {
+            const int s = idx % slots, n = (idx / slots) % 16, g = (idx / (slots * 16)) % 3, w = idx / (slots * 48);
+            const uint4 v = *reinterpret_cast<const uint4 *>(
+                reinterpret_cast<const unsigned char *>(Wd + (int64_t)(g * H + (slice * NW + w) * 16 + n) * H) + s * 16);
+            *reinterpret_cast<uint4 *>(lds + 16 + ((int64_t)((w * 3 + g) * 16 + n)) * row_bytes + ((s ^ n) << 4)) = v;
+        }
+        __syncthreads();
+    }
+    int *ok_s = reinterpret_cast<int *>(lds);  // first 16 B of the dynamic region (no static LDS: keeps it 16-B aligned)
+    const unsigned char *wl = lds + 16 + (int64_t)(wave * 3) * 16 * row_bytes;
+
+    const float bhr = bh[jcol], bhz = bh[H + jcol], bhn = bh[2 * H + jcol];
+    float hprev[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) hprev[mt][i] = 0.f;
+
+    // clip rows of this lane: A-fragment row (b0 + mt*16 + r16), C rows (b0 + mt*16 + 4q + i)
+    int arow[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) arow[mt] = b0 + min(mt * 16 + r16, nb - 1);
+
+    float gin[MT][4][3];  // prefetched input projections of the current step
+    auto load_gi = [&](int t) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int bl = min(mt * 16 + 4 * q + i, nb - 1);
+                const float *g = p.gi + (int64_t)(b0 + bl) * gi_bs + (int64_t)t * gi_ts + dir * 3 * H + jcol;
+                gin[mt][i][0] = g[0];
+                gin[mt][i][1] = g[H];
+                gin[mt][i][2] = g[2 * H];
+            }
+    };
+    load_gi(dir == 0 ? 0 : T_ - 1);
+
+    bool alive = true;
+    for (int step = 0; step < T_; ++step) {
+        const int t = dir == 0 ? step : T_ - 1 - step;
+        const int tprev = dir == 0 ? t - 1 : t + 1;
+        f32x4 acc[3][MT];
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[g][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        if (step > 0) {
+            // ---- wait until every slice of this (direction, group) has published h_{t-1} ----
+            if (tid == 0) {
+                const bool ok = wait_counter(ctr + (step - 1), (unsigned)p.nsplit, p.abort_flag);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                *ok_s = ok ? 1 : 0;
+            }
+            __syncthreads();
+            alive = *ok_s != 0;
+            if (!alive) break;
+            // ---- gh = h_{t-1} W_hh^T for this wave's 48 gate columns ----
+#pragma unroll
+            for (int ks = 0; ks < MAXKS; ++ks) {
+                if (ks < nks) {
+                    uint4 a[MT];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        a[mt] = *reinterpret_cast<const uint4 *>(
+                            reinterpret_cast<const unsigned char *>(out + (int64_t)arow[mt] * out_bs + (int64_t)tprev * out_ts + dir * H) +
+                            ks * 64 + q * 16);
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) {
+                        uint4 w;
+                        if constexpr (TR::W_IN_REGS) w = wreg[g][ks];
+                        else w = *reinterpret_cast<const uint4 *>(wl + (int64_t)(g * 16 + r16) * row_bytes + (((ks * 4 + q) ^ r16) << 4));
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) mma_step(a[mt], w, acc[g][mt], T{});
+                    }
+                }
+            }
+        }
+        // ---- gates (lane-local: acc[g][mt][i] <-> clip b0 + mt*16 + 4q + i, hidden unit jcol) ----
+        float hnew[MT][4];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float r = sigm(gin[mt][i][0] + (acc[0][mt][i] + bhr));
+                const float z = sigm(gin[mt][i][1] + (acc[1][mt][i] + bhz));
+                const float n = tanhf(gin[mt][i][2] + r * (acc[2][mt][i] + bhn));
+                hnew[mt][i] = (1.0f - z) * n + z * hprev[mt][i];
+                hprev[mt][i] = hnew[mt][i];
+            }
+        // ---- publish h_t into out (and Mish(h_t) into out_mish) ----
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int bl = mt * 16 + 4 * q + i;
+                if (bl < nb) {
+                    const int64_t o = (int64_t)(b0 + bl) * out_bs + (int64_t)t * out_ts + dir * H + jcol;
+                    la::Elem<T>::store(out + o, hnew[mt][i]);
+                    if (outm) la::Elem<T>::store(outm + o, la::mish(hnew[mt][i]));
+                }
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(ctr + step, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (step + 1 < T_) load_gi(dir == 0 ? t + 1 : t - 1);  // independent of h: in flight during the next wait
+    }
+    if (!alive && tid == 0 && p.timeout_flag) *p.timeout_flag = 1;
+}
+
+}  // namespace
+
+static int gru_groups(int batch) { return la::cdiv(batch, GROUP); }
+
+extern "C" int la_gru_workspace_bytes(int32_t batch, int32_t frames, int32_t hidden, size_t *bytes) {
+    LA_CHECK_ARG(bytes && batch > 0 && frames > 0 && hidden > 0, "gru_workspace_bytes: bad arguments");
+    // [16 B header: abort flag] + counters [groups][2][frames] u32, padded to 16 B
+    *bytes = 16 + (size_t)la::round_up((int64_t)gru_groups(batch) * 2 * frames * 4, 16);
+    return LA_OK;
+}
+
+extern "C" int la_gru_layer(int32_t dtype, const float *gi, const void *w_hh, const float *b_hh, void *out, void *out_mish,
+                            int32_t batch, int32_t frames, int32_t hidden, void *workspace, size_t workspace_bytes,
+                            int32_t *timeout_flag, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (batch == 0 || frames == 0) return LA_OK;
+    LA_CHECK_ARG(gi && w_hh && b_hh && out && workspace, "gru_layer: null pointer");
+    LA_CHECK_ARG(dtype == LA_F32 || dtype == LA_BF16, "gru_layer: bad dtype");
+    LA_CHECK_ARG(batch > 0 && frames > 0 && hidden > 0, "gru_layer: bad sizes");
+    LA_CHECK_ARG((uintptr_t)w_hh % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)workspace % 16 == 0, "gru_layer: alignment");
+    size_t need = 0;
+    la_gru_workspace_bytes(batch, frames, hidden, &need);
+    LA_CHECK_ARG(workspace_bytes >= need, "gru_layer: workspace too small (%zu < %zu)", workspace_bytes, need);
+    const int groups = gru_groups(batch);
+    const int nw = dtype == LA_BF16 ? 4 : 2;
+    if (hidden % 64 != 0 || (dtype == LA_BF16 && hidden > 512) || (dtype == LA_F32 && hidden > 384)) {
+        la::set_error("gru_layer: hidden=%d unsupported (multiple of 64; bf16 <= 512, f32 <= 384)", hidden);
+        return LA_EUNSUPPORTED;
+    }
+    const int nsplit = hidden / (16 * nw);
+    if (nsplit * 2 * groups > 224) {
+        la::set_error("gru_layer: %d co-resident workgroups needed (batch too large for one launch; split the batch)", nsplit * 2 * groups);
+        return LA_EUNSUPPORTED;
+    }
+    LA_HIP(hipMemsetAsync(workspace, 0, need, stream));
+    GruParams p{gi, w_hh, b_hh, out, out_mish, batch, frames, hidden,
+                reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(workspace) + 16),
+                reinterpret_cast<int *>(workspace), timeout_flag, nsplit};
+    const dim3 grid(nsplit, 2, groups);
+    if (dtype == LA_BF16) {
+        la::TimerScope ts("gru_bf16", stream);
+        hipLaunchKernelGGL((gru_kernel<bf16_t, 16>), grid, dim3(256), 16, stream, p);
+    } else {
+        const size_t lds_bytes = 16 + (size_t)2 * 3 * 16 * hidden * 4;
+        static bool attr_done = false;
+        if (!attr_done) {
+            LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gru_kernel<float, 24>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 16 + 2 * 3 * 16 * 384 * 4));
+            attr_done = true;
+        }
+        la::TimerScope ts("gru_f32", stream);
+        hipLaunchKernelGGL((gru_kernel<float, 24>), grid, dim3(128), lds_bytes, stream, p);
+    }
+    LA_LAUNCH_CHECK();
+    return LA_OK;
+}

@@ -7,10 +7,3 @@
 extern "C" int la_logmel_workspace_bytes(int32_t, int32_t, size_t *) { LA_STUB(la_logmel_workspace_bytes); }
 extern "C" int la_logmel_f32(const float *, int32_t, int32_t, const float *, const float *, float *, int64_t, int64_t,
                              void *, size_t, void *) { LA_STUB(la_logmel_f32); }
-extern "C" int la_gru_workspace_bytes(int32_t, int32_t, int32_t, size_t *) { LA_STUB(la_gru_workspace_bytes); }
-extern "C" int la_gru_layer(int32_t, const float *, const void *, const float *, void *, void *, int32_t, int32_t, int32_t,
-                            void *, size_t, int32_t *, void *) { LA_STUB(la_gru_layer); }
-extern "C" int la_fc_emissions_workspace_bytes(int32_t, int32_t, size_t *) { LA_STUB(la_fc_emissions_workspace_bytes); }
-extern "C" int la_fc_emissions(int32_t, const void *, int64_t, const void *, const float *, int32_t, int32_t, int32_t, int32_t,
-                               int32_t, const int32_t *, int32_t, const int32_t *, int32_t, float *, int64_t, int64_t, void *,
-                               size_t, void *) { LA_STUB(la_fc_emissions); }

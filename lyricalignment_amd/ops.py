@@ -177,3 +177,53 @@ def attention(qkv: torch.Tensor, batch: int, frames: int, n_head: int, out: Opti
     check(lib().la_attention(dt, ptr(qkv), qkv.stride(0), ptr(out), out.stride(0), batch, frames, n_head, stream_ptr()),
           "attention")
     return out
+
+
+def gru_layer(gi: torch.Tensor, w_hh: torch.Tensor, b_hh: torch.Tensor, out: Optional[torch.Tensor] = None,
+              want_mish: bool = False):
+    """gi [B,T,2,3H] f32; w_hh [2,3H,H] (f32 | bf16); b_hh [2,3H] f32 -> out [B,T,2H] (w_hh dtype) [, Mish(out)]."""
+    _dev(gi, "gi", torch.float32); _dev(w_hh, "w_hh"); _dev(b_hh, "b_hh", torch.float32)
+    dt = dtype_code(w_hh.dtype)
+    if gi.dim() != 4 or gi.shape[2] != 2 or not gi.is_contiguous() or not w_hh.is_contiguous() or not b_hh.is_contiguous():
+        raise ValueError("gru_layer: gi must be contiguous [B,T,2,3H]")
+    B, T, _, H3 = gi.shape
+    H = H3 // 3
+    if w_hh.shape != (2, 3 * H, H) or b_hh.shape != (2, 3 * H):
+        raise ValueError("gru_layer: weight shapes do not match gi")
+    if out is None:
+        out = torch.empty((B, T, 2 * H), dtype=w_hh.dtype, device=gi.device)
+    if out.shape != (B, T, 2 * H) or out.dtype != w_hh.dtype or not out.is_contiguous():
+        raise ValueError("gru_layer: bad out buffer")
+    out_mish = torch.empty_like(out) if want_mish else None
+    need = ctypes.c_size_t(0)
+    check(lib().la_gru_workspace_bytes(B, T, H, ctypes.byref(need)), "gru_workspace_bytes")
+    ws = torch.empty((need.value,), dtype=torch.uint8, device=gi.device)
+    flag = torch.zeros((1,), dtype=torch.int32, device=gi.device)
+    check(lib().la_gru_layer(dt, ptr(gi), ptr(w_hh), ptr(b_hh), ptr(out), ptr(out_mish), B, T, H, ptr(ws), need.value,
+                             ptr(flag), stream_ptr()), "gru_layer")
+    return (out, out_mish, flag) if want_mish else (out, flag)
+
+
+def fc_emissions(act: torch.Tensor, w_fc: torch.Tensor, b_fc: torch.Tensor, batch: int, frames: int,
+                 labels: torch.Tensor, n_labels: torch.Tensor, variant: int) -> torch.Tensor:
+    """act [batch*frames, 2H] (Mish(GRU out)), w_fc [V,2H], b_fc [V] -> compact emissions [batch, frames, Lmax+1] f32.
+    The [batch, frames, V] logits are never materialised."""
+    _dev(act, "act"); _dev(w_fc, "w_fc"); _dev(b_fc, "b_fc", torch.float32)
+    _dev(labels, "labels", torch.int32); _dev(n_labels, "n_labels", torch.int32)
+    dt = dtype_code(w_fc.dtype)
+    if act.dtype != w_fc.dtype or act.dim() != 2 or act.stride(1) != 1 or not w_fc.is_contiguous():
+        raise ValueError("fc_emissions: act [rows,2H] / w_fc [V,2H] of one dtype expected")
+    V, K = w_fc.shape
+    if act.shape[1] != K or act.shape[0] < batch * frames or b_fc.numel() != V:
+        raise ValueError("fc_emissions: inconsistent shapes")
+    Lmax = labels.shape[1]
+    if labels.shape[0] != batch or n_labels.shape != (batch,) or labels.stride(1) != 1:
+        raise ValueError("fc_emissions: inconsistent label shapes")
+    em = torch.empty((batch, frames, Lmax + 1), dtype=torch.float32, device=act.device)
+    need = ctypes.c_size_t(0)
+    check(lib().la_fc_emissions_workspace_bytes(dt, batch, frames, K, V, Lmax, ctypes.byref(need)), "fc_emissions_workspace_bytes")
+    ws = torch.empty((need.value,), dtype=torch.uint8, device=act.device)
+    check(lib().la_fc_emissions(dt, ptr(act), act.stride(0), ptr(w_fc), ptr(b_fc), batch, frames, K, V, variant, ptr(labels),
+                                labels.stride(0), ptr(n_labels.contiguous()), Lmax, ptr(em), em.stride(0), em.stride(1),
+                                ptr(ws), need.value, stream_ptr()), "fc_emissions")
+    return em

@@ -133,3 +133,59 @@ def test_attention_online_rescale_spike():
         q, k, v = xd[:, :64], xd[:, 64:128], xd[:, 128:]
         ref = torch.softmax(q @ k.T, dim=-1) @ v
         np.testing.assert_allclose(out.double().numpy(), ref.numpy(), rtol=0, atol=tol)
+
+
+@pytest.mark.parametrize("B,T,H", [(1, 1, 64), (3, 7, 64), (32, 50, 128), (40, 23, 384), (2, 300, 384)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gru_layer(B, T, H, dtype):
+    """Persistent bidirectional GRU recurrence vs torch.nn.GRU (CPU fp32) fed the same input projections."""
+    from lyricalignment_amd import ops
+    I = 48
+    gru = torch.nn.GRU(I, H, num_layers=1, batch_first=True, bidirectional=True)
+    g = torch.Generator().manual_seed(40 + T)
+    with torch.no_grad():
+        for prm in gru.parameters():
+            prm.copy_((torch.rand(prm.shape, generator=g) * 2 - 1) * (1.0 / H ** 0.5))
+        w_hh = torch.stack([gru.weight_hh_l0, gru.weight_hh_l0_reverse])
+        if dtype == torch.bfloat16:  # the reference net uses the same (rounded) recurrent weights
+            gru.weight_hh_l0.copy_(w_hh[0].bfloat16().float()); gru.weight_hh_l0_reverse.copy_(w_hh[1].bfloat16().float())
+        x = torch.randn(B, T, I, generator=g)
+        ref, _ = gru(x)
+        gi = torch.stack([x @ gru.weight_ih_l0.T + gru.bias_ih_l0, x @ gru.weight_ih_l0_reverse.T + gru.bias_ih_l0_reverse], dim=2)
+        b_hh = torch.stack([gru.bias_hh_l0, gru.bias_hh_l0_reverse])
+    out, out_mish, flag = ops.gru_layer(gi.contiguous().cuda(), w_hh.to(dtype).contiguous().cuda(), b_hh.contiguous().cuda(), want_mish=True)
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 0, "bounded wait in the persistent GRU kernel timed out"
+    tol = 2e-5 if dtype == torch.float32 else 2e-2  # bf16: h is rounded to bf16 before every recurrent product
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), rtol=0, atol=tol)
+    np.testing.assert_allclose(out_mish.float().cpu().numpy(), torch.nn.functional.mish(ref).numpy(), rtol=0, atol=tol)
+
+
+@pytest.mark.parametrize("variant", ["ctc", "plain"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,T,K,V", [(2, 37, 128, 300), (3, 150, 768, 21129)])
+def test_fc_emissions_fused(variant, dtype, B, T, K, V):
+    """Fused FC + row normaliser + gather vs (fp64 logits of the same rounded operands) -> the oracle's emission prep."""
+    from lyricalignment_amd import ops
+    from oracle import model_oracle as mo
+    act = _rand(B * T, K, seed=50, scale=1.0).to(dtype)
+    w = _rand(V, K, seed=51, scale=2.0 / K ** 0.5).to(dtype)
+    bias = _rand(V, seed=52, scale=0.5)
+    bias[-1] = 0.3
+    rs = np.random.RandomState(53)
+    Lmax = 26
+    ncls = V - 2 if variant == "ctc" else V - 1
+    labels = torch.from_numpy(rs.randint(1, ncls + 1, size=(B, Lmax)).astype(np.int32))
+    labels[0, 5] = labels[0, 4]
+    n_labels = torch.tensor([26, 11, 1][:B], dtype=torch.int32)
+    var = 1 if variant == "ctc" else 0
+    em = ops.fc_emissions(act.cuda(), w.cuda(), bias.cuda(), B, T, labels.cuda(), n_labels.cuda(), var).cpu()
+    logits = (act.double() @ w.double().T + bias.double()).float().reshape(B, T, V)
+    lp, ls = (mo.emission_prep_ctc if variant == "ctc" else mo.emission_prep_plain)(logits)
+    tol = 2e-4 if dtype == torch.float32 else 1e-3  # same rounded operands; only accumulation order / exp2 differ
+    for b in range(B):
+        L = int(n_labels[b])
+        np.testing.assert_allclose(em[b, :, 0].numpy(), ls[b, :, 0].numpy(), rtol=0, atol=tol)
+        idx = labels[b, :L].long() - 1
+        np.testing.assert_allclose(em[b, :, 1:1 + L].numpy(), lp[b][:, idx].numpy(), rtol=0, atol=tol)
+        assert torch.equal(em[b, :, 5], em[b, :, 6]) if b == 0 else True  # repeated label -> identical columns
