@@ -104,6 +104,19 @@ int la_viterbi_batch(const float *em, int64_t em_batch_stride, int64_t em_row_st
                      double *final_score, int32_t *status,
                      void *workspace, size_t workspace_bytes, void *stream);
 
+/*
+ * run_viterbi_core(dp, bt, lp, ls, label) (utils/alignment.py:73-119) for ONE utterance, for callers
+ * that want the full matrices: row 0 of dp [T][S] (float64, S = 2L+1) is READ as the caller initialised
+ * it (the reference does the same, :144-152); rows >= 1 of dp and of bt [T][S] (int64 predecessor state)
+ * are written.  em is the compact emission layout of that utterance ([T][>= L+1]).  n_labels / n_frames
+ * are 1-element device arrays holding the same L and T as the host arguments; scratch_i32 has 2L+1
+ * elements, scratch_f64 one.
+ */
+int la_viterbi_core(const float *em, int64_t em_row_stride, const int32_t *labels, int32_t n_labels_host,
+                    int32_t n_frames_host, const int32_t *n_labels, const int32_t *n_frames,
+                    double *dp, long long *bt, int32_t *scratch_i32, double *scratch_f64,
+                    void *workspace, size_t workspace_bytes, void *stream);
+
 /* ------------------------------------------------------------------------- */
 /* emission prep from materialised logits                                     */
 /*   (replaces utils/alignment.py:123-134 [CTC] and :14-20 [plain])           */

@@ -31,6 +31,7 @@ SYMBOLS = {
     "la_timer_reset": (c_int32, []),
     "la_viterbi_workspace_bytes": (c_int32, [_I32, _I32, _I32, POINTER(_SZ)]),
     "la_viterbi_batch": (c_int32, [_P, _I64, _I64, _P, _I32, _P, _P, _I32, _I32, _I32, _P, _P, _I32, _P, _P, _P, _SZ, _P]),
+    "la_viterbi_core": (c_int32, [_P, _I64, _P, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "la_emissions_from_logits": (c_int32, [_P, _I64, _I64, _I32, _I32, _I32, _I32, _P, _I32, _P, _I32, _P, _I64, _I64, _P]),
     "la_logmel_workspace_bytes": (c_int32, [_I32, _I32, POINTER(_SZ)]),
     "la_logmel_f32": (c_int32, [_P, _I32, _I32, _P, _P, _P, _I64, _I64, _P, _SZ, _P]),

@@ -35,6 +35,9 @@ struct VitParams {
     int32_t *status;
     unsigned long long *bt_global;  // [batch][max_frames][NW][2] when !bt_in_lds
     int32_t bt_in_lds;
+    // run_viterbi_core face (DUMP instantiation only, batch 1): row 0 of dp is READ, rows >= 1 of dp / bt are written
+    double *dp_dump;    // [T][S]
+    long long *bt_dump; // [T][S]
 };
 
 __device__ __forceinline__ double wave_shr1(double x) {
@@ -45,7 +48,7 @@ __device__ __forceinline__ double wave_shr1(double x) {
     return __hiloint2double(hi, lo);
 }
 
-template <int NW, bool DPP>
+template <int NW, bool DPP, bool DUMP = false>
 __global__ __launch_bounds__(NW * 64) void viterbi_kernel(VitParams p) {
     static_assert(!DPP || NW == 1, "DPP neighbour exchange is single-wave only");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -93,8 +96,9 @@ __global__ __launch_bounds__(NW * 64) void viterbi_kernel(VitParams p) {
     }
     const float *emb = p.em + (int64_t)b * p.em_bs + col;
 
-    // row 0 (:144-152)
+    // row 0 (:144-152); the run_viterbi_core face takes row 0 from the caller like the reference does (:73-76)
     double cur = (k <= 1) ? (double)emb[0] : kNeg;
+    if (DUMP) cur = valid ? p.dp_dump[k] : kNeg;
 
     if (!DPP) {
         if (k < 2) { rowbuf[k] = kNeg; rowbuf[NT + 2 + k] = kNeg; }  // slots for k-1, k-2 of states 0,1
@@ -138,6 +142,10 @@ __global__ __launch_bounds__(NW * 64) void viterbi_kernel(VitParams p) {
             double best = skip ? p2 : (stay ? p0 : p1);
             if (k == 0) { code = 0; best = p0; }                         // (:78-82)
             cur = best + (double)e_cur[i];
+            if (DUMP && valid) {
+                p.dp_dump[(int64_t)j * S + k] = cur;
+                p.bt_dump[(int64_t)j * S + k] = k - code;
+            }
             const unsigned long long lo = __ballot(code & 1);
             const unsigned long long hi = __ballot(code >> 1);
             if (lane == 0) {
@@ -254,7 +262,7 @@ extern "C" int la_viterbi_batch(const float *em, int64_t em_batch_stride, int64_
                  "viterbi_batch: workspace too small (%zu < %zu)", workspace_bytes, pl.ws_bytes);
     VitParams p{em, em_batch_stride, em_row_stride, labels, labels_stride, n_labels, n_frames, max_frames,
                 max_labels, onset, offset, out_stride, final_score, status,
-                reinterpret_cast<unsigned long long *>(workspace), pl.bt_in_lds ? 1 : 0};
+                reinterpret_cast<unsigned long long *>(workspace), pl.bt_in_lds ? 1 : 0, nullptr, nullptr};
     static const bool no_dpp = getenv("LA_VITERBI_NO_DPP") != nullptr;
     switch (pl.nw) {
         case 1: return no_dpp ? launch_viterbi<1, false>(p, pl, batch, stream) : launch_viterbi<1, true>(p, pl, batch, stream);
@@ -264,4 +272,41 @@ extern "C" int la_viterbi_batch(const float *em, int64_t em_batch_stride, int64_
         case 16: return launch_viterbi<16, false>(p, pl, batch, stream);
     }
     return LA_EUNSUPPORTED;
+}
+
+// run_viterbi_core(dp, bt, lp, ls, label) of the reference (utils/alignment.py:73-119) for ONE utterance: same
+// kernel, instantiated so that it also writes every dp row (float64) and backpointer (int64 predecessor state).
+extern "C" int la_viterbi_core(const float *em, int64_t em_row_stride, const int32_t *labels, int32_t n_labels_host,
+                               int32_t n_frames_host, const int32_t *n_labels, const int32_t *n_frames, double *dp,
+                               long long *bt, int32_t *scratch_i32, double *scratch_f64, void *workspace,
+                               size_t workspace_bytes, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    LA_CHECK_ARG(em && labels && n_labels && n_frames && dp && bt && scratch_i32 && scratch_f64, "viterbi_core: null pointer");
+    LA_CHECK_ARG(n_labels_host > 0 && n_frames_host > 0 && em_row_stride >= n_labels_host + 1, "viterbi_core: bad sizes");
+    VitPlan pl;
+    if (!plan_viterbi(1, n_frames_host, n_labels_host, &pl)) {
+        la::set_error("viterbi_core: more than 511 labels");
+        return LA_EUNSUPPORTED;
+    }
+    LA_CHECK_ARG(pl.ws_bytes == 0 || (workspace && workspace_bytes >= pl.ws_bytes), "viterbi_core: workspace too small");
+    // scratch_i32: onset[L] | offset[L] | status[1]
+    VitParams p{em, 0, em_row_stride, labels, n_labels_host, n_labels, n_frames, n_frames_host, n_labels_host,
+                scratch_i32, scratch_i32 + n_labels_host, n_labels_host, scratch_f64, scratch_i32 + 2 * n_labels_host,
+                reinterpret_cast<unsigned long long *>(workspace), pl.bt_in_lds ? 1 : 0, dp, bt};
+#define LA_CORE_CASE(NWV)                                                                                           \
+    case NWV: {                                                                                                     \
+        auto kern = viterbi_kernel<NWV, false, true>;                                                               \
+        if (pl.lds_bytes > 48 * 1024)                                                                               \
+            LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                       (int)pl.lds_bytes));                                                         \
+        hipLaunchKernelGGL(kern, dim3(1), dim3(NWV * 64), pl.lds_bytes, stream, p);                                 \
+        break;                                                                                                      \
+    }
+    switch (pl.nw) {
+        LA_CORE_CASE(1) LA_CORE_CASE(2) LA_CORE_CASE(4) LA_CORE_CASE(8) LA_CORE_CASE(16)
+        default: return LA_EUNSUPPORTED;
+    }
+#undef LA_CORE_CASE
+    LA_LAUNCH_CHECK();
+    return LA_OK;
 }

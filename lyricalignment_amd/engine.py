@@ -1,0 +1,231 @@
+"""AlignEngine: the MI355X hot path of AlignModel as a sequence of HIP kernels.
+
+    mel --conv stem--> x --L x {LN, QKV, attention, out-proj(+res), LN, MLP(+res)}--> ln_post
+        --BiGRU x2 (input GEMM + persistent recurrence)--> Mish --fused FC + emission prep--> em
+        --batched Viterbi--> onset / offset frames
+
+Replaces, for inference, whisper_model.embed_audio (module/align_model.py:91,101,112,137),
+align_rnn (module/align_model.py:35-38) and perform_viterbi(_ctc) (utils/alignment.py) of the
+reference.  This file is host plumbing only: weight packing (layout / dtype changes), buffer
+management and kernel sequencing on the current HIP stream; every arithmetic step is a kernel
+in liblyricalign_hip.so, called through the C ABI (lyricalignment_amd.ops).
+
+Data layout in HBM (DESIGN.md "Layout"): activations are token-major rows [clip*1500 + frame][d];
+the residual stream is f32, GEMM operands are in the compute dtype (bf16 or f32); weights keep
+nn.Linear's [out][in] layout (both GEMM operands K-contiguous), q/k/v projections are fused into
+one [3d][d] matrix with head_dim^-0.5 folded into the q rows; conv weights are [out][tap][in].
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib, ops
+from ._lib import LA_VARIANT_CTC, LA_VARIANT_PLAIN
+
+N_FRAMES = 3000   # whisper.audio.N_FRAMES
+N_CTX = 1500      # encoder positions
+C_PAD = 128       # mel channels padded so 3*C is a multiple of the GEMM K tile
+
+
+def _f32(t: torch.Tensor, device) -> torch.Tensor:
+    return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+@dataclass
+class BlockWeights:
+    ln1_g: torch.Tensor; ln1_b: torch.Tensor
+    wqkv: torch.Tensor; bqkv: torch.Tensor
+    wo: torch.Tensor; bo: torch.Tensor
+    ln2_g: torch.Tensor; ln2_b: torch.Tensor
+    w1: torch.Tensor; b1: torch.Tensor
+    w2: torch.Tensor; b2: torch.Tensor
+
+
+@dataclass
+class EncoderWeights:
+    d: int
+    n_head: int
+    n_mels: int
+    dtype: torch.dtype
+    conv1_w: torch.Tensor; conv1_b: torch.Tensor
+    conv2_w: torch.Tensor; conv2_b: torch.Tensor
+    pos: torch.Tensor
+    blocks: List[BlockWeights]
+    lnp_g: torch.Tensor; lnp_b: torch.Tensor
+
+
+@dataclass
+class HeadWeights:
+    hidden: int
+    in_dim: int
+    vocab: int
+    dtype: torch.dtype
+    w_ih: List[torch.Tensor]   # per layer [6H, in] (forward rows then reverse rows)
+    b_ih: List[torch.Tensor]   # per layer [6H] f32
+    w_hh: List[torch.Tensor]   # per layer [2, 3H, H]
+    b_hh: List[torch.Tensor]   # per layer [2, 3H] f32
+    w_fc: torch.Tensor         # [V, 2H]
+    b_fc: torch.Tensor         # [V] f32
+
+
+def pack_encoder(sd: Dict[str, torch.Tensor], n_head: int, dtype: torch.dtype, device, prefix: str = "encoder.") -> EncoderWeights:
+    """openai-whisper AudioEncoder state_dict -> device weights in kernel layout."""
+    g = lambda k: sd[prefix + k]
+    d, n_mels, _ = g("conv1.weight").shape
+    if d % 64 or d // n_head != 64:
+        raise NotImplementedError(f"encoder width {d} / heads {n_head}: kernels are built for head_dim 64")
+    c1 = torch.zeros((d, 3, C_PAD), dtype=torch.float32)
+    c1[:, :, :n_mels] = g("conv1.weight").detach().float().cpu().permute(0, 2, 1)
+    c2 = g("conv2.weight").detach().float().cpu().permute(0, 2, 1).reshape(d, 3 * d)
+    pos = g("positional_embedding")
+    blocks = []
+    i = 0
+    scale = 64 ** -0.5  # (head_dim^-0.25 on q) * (head_dim^-0.25 on k), folded into q: exact power of two
+    while f"{prefix}blocks.{i}.attn.query.weight" in sd:
+        b = f"blocks.{i}."
+        wq, bq = g(b + "attn.query.weight").detach().float() * scale, g(b + "attn.query.bias").detach().float() * scale
+        wk = g(b + "attn.key.weight").detach().float()
+        wv, bv = g(b + "attn.value.weight").detach().float(), g(b + "attn.value.bias").detach().float()
+        wqkv = torch.cat([wq, wk, wv], dim=0)
+        bqkv = torch.cat([bq, torch.zeros_like(bq), bv], dim=0)
+        blocks.append(BlockWeights(
+            _f32(g(b + "attn_ln.weight"), device), _f32(g(b + "attn_ln.bias"), device),
+            wqkv.to(device=device, dtype=dtype).contiguous(), _f32(bqkv, device),
+            g(b + "attn.out.weight").detach().to(device=device, dtype=dtype).contiguous(), _f32(g(b + "attn.out.bias"), device),
+            _f32(g(b + "mlp_ln.weight"), device), _f32(g(b + "mlp_ln.bias"), device),
+            g(b + "mlp.0.weight").detach().to(device=device, dtype=dtype).contiguous(), _f32(g(b + "mlp.0.bias"), device),
+            g(b + "mlp.2.weight").detach().to(device=device, dtype=dtype).contiguous(), _f32(g(b + "mlp.2.bias"), device)))
+        i += 1
+    return EncoderWeights(d, n_head, n_mels, dtype,
+                          c1.reshape(d, 3 * C_PAD).to(device=device, dtype=dtype).contiguous(), _f32(g("conv1.bias"), device),
+                          c2.to(device=device, dtype=dtype).contiguous(), _f32(g("conv2.bias"), device),
+                          _f32(pos, device), blocks, _f32(g("ln_post.weight"), device), _f32(g("ln_post.bias"), device))
+
+
+def pack_head(sd: Dict[str, torch.Tensor], dtype: torch.dtype, device, prefix: str = "align_rnn.") -> HeadWeights:
+    """RNN state_dict (nn.GRU 2 layers bidirectional + nn.Linear, module/align_model.py:23-33) -> kernel layout."""
+    g = lambda k: sd[prefix + k].detach()
+    H = g("rnn.weight_hh_l0").shape[1]
+    if f"{prefix}rnn.weight_ih_l0_reverse" not in sd:
+        raise NotImplementedError("unidirectional head: the kernels implement the bidirectional GRU the reference trains")
+    w_ih, b_ih, w_hh, b_hh = [], [], [], []
+    layer = 0
+    while f"{prefix}rnn.weight_ih_l{layer}" in sd:
+        w_ih.append(torch.cat([g(f"rnn.weight_ih_l{layer}"), g(f"rnn.weight_ih_l{layer}_reverse")], 0).to(device=device, dtype=dtype).contiguous())
+        b_ih.append(_f32(torch.cat([g(f"rnn.bias_ih_l{layer}"), g(f"rnn.bias_ih_l{layer}_reverse")], 0), device))
+        w_hh.append(torch.stack([g(f"rnn.weight_hh_l{layer}"), g(f"rnn.weight_hh_l{layer}_reverse")], 0).to(device=device, dtype=dtype).contiguous())
+        b_hh.append(_f32(torch.stack([g(f"rnn.bias_hh_l{layer}"), g(f"rnn.bias_hh_l{layer}_reverse")], 0), device))
+        layer += 1
+    w_fc = g("fc.weight")
+    return HeadWeights(H, w_ih[0].shape[1], w_fc.shape[0], dtype, w_ih, b_ih, w_hh, b_hh,
+                       w_fc.to(device=device, dtype=dtype).contiguous(), _f32(g("fc.bias"), device))
+
+
+class AlignEngine:
+    """Owns packed weights + scratch buffers for one (model, compute dtype, device)."""
+
+    def __init__(self, enc: EncoderWeights, head: Optional[HeadWeights], device="cuda"):
+        _lib.require_gpu()
+        self.enc, self.head, self.device = enc, head, torch.device(device)
+        self._buf: Dict[Tuple, torch.Tensor] = {}
+
+    # ---- scratch -----------------------------------------------------------------
+    def _get(self, name: str, shape, dtype, zero: bool = False) -> torch.Tensor:
+        key = (name, tuple(shape), dtype)
+        t = self._buf.get(key)
+        if t is None:
+            for k in [k for k in self._buf if k[0] == name]:
+                del self._buf[k]
+            t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
+            self._buf[key] = t
+        return t
+
+    # ---- encoder: Whisper.embed_audio -----------------------------------------------
+    def encode(self, mel: torch.Tensor, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+        """mel [B, n_mels, 3000] f32 (device) -> ln_post output [B*1500, d] in `out_dtype` (default: compute dtype)."""
+        e = self.enc
+        if mel.dim() != 3 or mel.shape[1] != e.n_mels or mel.shape[2] != N_FRAMES:
+            raise AssertionError("incorrect audio shape")  # whisper AudioEncoder asserts the same
+        mel = mel.to(device=self.device, dtype=torch.float32)
+        if mel.stride(2) != 1:
+            mel = mel.contiguous()
+        B, d, dt = mel.shape[0], e.d, e.dtype
+        M = B * N_CTX
+        rows0 = ops.mel_to_rows(mel, C_PAD, dt)                                     # [B, 3002, 128]
+        y1 = self._get("y1", (B, N_FRAMES + 2, d), dt, zero=True)                    # border rows stay zero
+        ops.gemm(rows0, e.conv1_w, y1.view(-1)[d:], bias=e.conv1_b, gelu=True, M=N_FRAMES, lda=C_PAD, batch=B,
+                 stride_a=(N_FRAMES + 2) * C_PAD, stride_c=(N_FRAMES + 2) * d, ldc=d)
+        x = self._get("x", (M, d), torch.float32)
+        ops.gemm(y1, e.conv2_w, x, bias=e.conv2_b, gelu=True, residual=e.pos, out_f32=True, M=N_CTX, lda=2 * d, batch=B,
+                 stride_a=(N_FRAMES + 2) * d, stride_c=N_CTX * d, ldc=d, ldr=d, stride_r=0)
+        h = self._get("h", (M, d), dt)
+        qkv = self._get("qkv", (M, 3 * d), dt)
+        att = self._get("att", (M, d), dt)
+        u = self._get("u", (M, 4 * d), dt)
+        for blk in e.blocks:
+            ops.layernorm(x, blk.ln1_g, blk.ln1_b, dt, out=h)
+            ops.gemm(h, blk.wqkv, qkv, bias=blk.bqkv)
+            ops.attention(qkv, B, N_CTX, e.n_head, out=att)
+            ops.gemm(att, blk.wo, x, bias=blk.bo, residual=x, out_f32=True)          # x += out-proj (in place)
+            ops.layernorm(x, blk.ln2_g, blk.ln2_b, dt, out=h)
+            ops.gemm(h, blk.w1, u, bias=blk.b1, gelu=True)
+            ops.gemm(u, blk.w2, x, bias=blk.b2, residual=x, out_f32=True)            # x += mlp (in place)
+        out_dtype = out_dtype or dt
+        y = self._get("enc_out", (M, d), out_dtype)
+        ops.layernorm(x, e.lnp_g, e.lnp_b, out_dtype, out=y)
+        return y
+
+    # ---- head: align_rnn up to Mish ------------------------------------------------------
+    def head_hidden(self, feats: torch.Tensor, B: int, T: int, feat_clip_stride: int) -> torch.Tensor:
+        """feats: rows [.., d] in compute dtype, clip b at rows b*feat_clip_stride .. +T.  -> Mish(GRU) [B*T, 2H]."""
+        hw = self.head
+        H, dt = hw.hidden, hw.dtype
+        x = feats
+        lda, stride_a = feats.stride(0), feat_clip_stride * feats.stride(0)
+        act = None
+        n_layers = len(hw.w_ih)
+        for layer in range(n_layers):
+            gi = self._get("gi", (B, T, 2, 3 * H), torch.float32)
+            ops.gemm(x, hw.w_ih[layer], gi.view(B * T, 6 * H), bias=hw.b_ih[layer], out_f32=True, M=T, lda=lda, batch=B,
+                     stride_a=stride_a, stride_c=T * 6 * H, ldc=6 * H)
+            out = self._get(f"gru{layer}", (B, T, 2 * H), dt)
+            last = layer == n_layers - 1
+            res = ops.gru_layer(gi, hw.w_hh[layer], hw.b_hh[layer], out=out, want_mish=last)
+            self._last_gru_flag = res[-1]
+            if last:
+                act = res[1]
+            x = out.view(B * T, 2 * H)
+            lda, stride_a = 2 * H, T * 2 * H
+        return act.view(B * T, 2 * H)
+
+    def logits(self, feats: torch.Tensor, B: int, T: int, feat_clip_stride: int) -> torch.Tensor:
+        """Materialised align logits [B, T, V] f32 (the reference's frame_manual_forward output)."""
+        act = self.head_hidden(feats, B, T, feat_clip_stride)
+        out = torch.empty((B * T, self.head.vocab), dtype=torch.float32, device=self.device)
+        ops.gemm(act, self.head.w_fc, out, bias=self.head.b_fc, out_f32=True)
+        return out.view(B, T, self.head.vocab)
+
+    def emissions(self, feats: torch.Tensor, B: int, T: int, feat_clip_stride: int, labels: torch.Tensor,
+                  n_labels: torch.Tensor, variant: int) -> torch.Tensor:
+        act = self.head_hidden(feats, B, T, feat_clip_stride)
+        return ops.fc_emissions(act, self.head.w_fc, self.head.b_fc, B, T, labels, n_labels, variant)
+
+    def check_gru(self) -> None:
+        """Host check of the persistent GRU kernel's bounded waits (synchronises)."""
+        flag = getattr(self, "_last_gru_flag", None)
+        if flag is not None and int(flag.item()) != 0:
+            raise TimeoutError("persistent GRU kernel: a bounded inter-workgroup wait timed out")
+
+    # ---- whole path on a ready mel batch ---------------------------------------------------
+    def align_mel(self, mel: torch.Tensor, labels: torch.Tensor, n_labels: torch.Tensor, n_frames: int = N_CTX,
+                  use_ctc: bool = True):
+        """mel [B,80,3000] -> (onset, offset, final_score, status) device tensors; frames = first n_frames of each clip."""
+        B = mel.shape[0]
+        feats = self.encode(mel)
+        variant = LA_VARIANT_CTC if use_ctc else LA_VARIANT_PLAIN
+        em = self.emissions(feats, B, n_frames, N_CTX, labels, n_labels, variant)
+        nf = torch.full((B,), n_frames, dtype=torch.int32, device=self.device)
+        return ops.viterbi_batch(em, labels, n_labels, nf)

@@ -1,0 +1,203 @@
+"""Drop-in for the reference's module/align_model.py (same class names, constructor and method
+signatures, attribute names and state_dict key layout), with the inference arithmetic on the
+MI355X HIP kernels of liblyricalign_hip.so.
+
+Reference lines mirrored:  RNN  module/align_model.py:11-40;  AlignModel.__init__ :43-70;
+frame_manual_forward :72-123;  forward :126-152.
+
+Differences that are deliberate:
+  * `audios` may be a list OR a tuple and is never mutated (the reference pads the caller's list
+    in place, :78-80, and fails on tuples);
+  * the log-mel runs on the device (the reference computes it on the CPU, :84);
+  * `compute_dtype` (extra keyword, default float32 = the reference's numerics; torch.bfloat16 is
+    the throughput mode) and `align(...)` (the fused, logits-free fast path) are additions.
+There is no PyTorch / CPU fallback: without the HIP library and a gfx950 device these methods raise.
+"""
+from __future__ import annotations
+
+import weakref
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import _lib, ops
+from ..audio_frontend import log_mel_spectrogram
+from ..engine import N_CTX, N_FRAMES, AlignEngine, pack_encoder, pack_head
+from ..whisper_compat import pad_or_trim
+
+
+class RNN(nn.Module):
+    """GRU(2 layers, bidirectional) -> Mish -> Linear; parameters live in nn.GRU / nn.Linear so the
+    state_dict keys are the reference's (align_rnn.rnn.weight_ih_l0 ... align_rnn.fc.bias)."""
+
+    def __init__(self, input_size, hidden_size, output_size, num_layers: int = 2, dropout: float = 0.1,
+                 batch_first: bool = True, bidirectional: bool = True) -> None:
+        super().__init__()
+        self.rnn = nn.GRU(input_size=input_size, hidden_size=hidden_size, num_layers=num_layers, dropout=dropout,
+                          batch_first=batch_first, bidirectional=bidirectional)
+        self.activate = nn.Mish()
+        self.fc = nn.Linear(hidden_size + (bidirectional * hidden_size), output_size)
+        self._owner = None
+
+    def forward(self, x):
+        if self._owner is None or self._owner() is None:
+            raise _lib.LyricAlignHipError("RNN.forward runs through its AlignModel's HIP engine; call it via AlignModel")
+        return self._owner()._head_logits(x)
+
+
+class AlignModel(torch.nn.Module):
+    def __init__(self, whisper_model, embed_dim: int = 1280, hidden_dim: int = 384, dropout: float = 0.15,
+                 output_dim: int = 10000, bidirectional: bool = True, freeze_encoder: bool = False,
+                 train_alignment: bool = True, train_transcript: bool = False, device: str = 'cuda',
+                 compute_dtype: torch.dtype = torch.float32) -> None:
+        super().__init__()
+        self.whisper_model = whisper_model
+        self.align_rnn = RNN(input_size=embed_dim, hidden_size=hidden_dim, output_size=output_dim,
+                             bidirectional=bidirectional, dropout=dropout)
+        self.freeze_encoder = freeze_encoder
+        self.train_alignment = train_alignment
+        self.train_transcript = train_transcript
+        self.device = device
+        self.compute_dtype = compute_dtype
+        self._engine: Optional[AlignEngine] = None
+        self._engine_key = None
+        self.align_rnn._owner = weakref.ref(self)
+        if hasattr(whisper_model, "_engine_owner"):
+            whisper_model._engine_owner = weakref.ref(self)
+
+    # ------------------------------------------------------------------ engine plumbing
+    def _n_head(self) -> int:
+        dims = getattr(self.whisper_model, "dims", None)
+        if dims is not None:
+            return int(dims.n_audio_head)
+        return int(self.whisper_model.encoder.conv1.weight.shape[0]) // 64
+
+    def _weights_version(self):
+        return tuple(p._version for p in self.parameters()) + (str(self.compute_dtype),)
+
+    def engine(self) -> AlignEngine:
+        """Packed device weights; re-packed when parameters were updated (optimizer step, load_state_dict)."""
+        if torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError(
+                "AlignModel training (autograd through the HIP kernels, CTC/CE losses, RCCL data parallel) is the "
+                "fine-tune row that is not built yet (DESIGN.md 'next'); call under torch.no_grad() / model.eval().")
+        key = self._weights_version()
+        if self._engine is None or self._engine_key != key:
+            _lib.require_gpu()
+            dev = torch.device(self.device if self.device != 'cuda' else f'cuda:{torch.cuda.current_device()}')
+            if dev.type != "cuda":
+                raise _lib.LyricAlignHipError("AlignModel runs on the MI355X only (device must be a cuda/HIP device)")
+            enc_sd = {"encoder." + k: v for k, v in self.whisper_model.encoder.state_dict().items()}
+            head_sd = {"align_rnn." + k: v for k, v in self.align_rnn.state_dict().items()}
+            enc = pack_encoder(enc_sd, self._n_head(), self.compute_dtype, dev)
+            head = pack_head(head_sd, self.compute_dtype, dev)
+            self._engine = AlignEngine(enc, head, dev)
+            self._engine_key = key
+        return self._engine
+
+    def _embed_audio(self, mel: torch.Tensor) -> torch.Tensor:
+        """whisper_model.embed_audio: [B,80,3000] -> [B,1500,d] float32."""
+        eng = self.engine()
+        B = mel.shape[0]
+        y = eng.encode(mel, out_dtype=torch.float32)
+        return y.view(B, N_CTX, eng.enc.d).clone()
+
+    def _head_logits(self, embed: torch.Tensor) -> torch.Tensor:
+        """align_rnn(embed): [B,T,d] -> [B,T,output_dim] float32."""
+        eng = self.engine()
+        B, T, d = embed.shape
+        feats = embed.to(device=eng.device, dtype=self.compute_dtype).contiguous().view(B * T, d)
+        out = eng.logits(feats, B, T, T)
+        return out
+
+    # ------------------------------------------------------------------ reference API
+    def _mel_of(self, audios: Sequence[np.ndarray]) -> torch.Tensor:
+        max_audio_len = max(map(len, audios))
+        batch = np.zeros((len(audios), max_audio_len), dtype=np.float32)   # zero-pad to the batch max (:78-82), no mutation
+        for i, a in enumerate(audios):
+            batch[i, : len(a)] = np.asarray(a, dtype=np.float32)
+        return log_mel_spectrogram(batch, device=self.engine().device)     # (:84) on the device
+
+    def _features(self, mel: torch.Tensor, get_orig_len: bool):
+        """-> (feats rows [., d] in compute dtype, B, T, clip stride in rows, embed_pad provider)."""
+        eng = self.engine()
+        B = mel.shape[0]
+        if not get_orig_len:                                                # (:109-115)
+            feats = eng.encode(pad_or_trim(mel, N_FRAMES))
+            return feats, B, N_CTX, N_CTX
+        if mel.shape[-1] <= N_FRAMES:                                       # (:87-92)
+            orig_mel_len = int(round(mel.shape[-1] / 2.0))
+            feats = eng.encode(pad_or_trim(mel, N_FRAMES))
+            return feats, B, orig_mel_len, N_CTX
+        # long form (:94-105): non-overlapping 3000-frame chunks, every chunk of every clip in ONE encoder batch
+        chunks, keep = [], []
+        for start in range(0, mel.shape[-1], N_FRAMES):
+            end = min(start + N_FRAMES, mel.shape[-1])
+            keep.append(int(round((end - start) / 2.0)))
+            chunks.append(pad_or_trim(mel[:, :, start:end], N_FRAMES))
+        enc = eng.encode(torch.cat(chunks, dim=0)).view(len(chunks), B, N_CTX, eng.enc.d)
+        feats = torch.cat([enc[c, :, : keep[c]] for c in range(len(chunks))], dim=1).contiguous()   # [B, sum(keep), d]
+        T = feats.shape[1]
+        return feats.view(B * T, eng.enc.d), B, T, T
+
+    def frame_manual_forward(self, audios: List[np.ndarray], y_in=None, get_orig_len: bool = True):
+        mel = self._mel_of(audios)
+        align_logit = None
+        eng = self.engine()
+        feats, B, T, stride = self._features(mel, get_orig_len)
+        if self.train_alignment:
+            align_logit = eng.logits(feats, B, T, stride)                   # (:106-107, :114-115)
+        transcribe_logit = None
+        if self.train_transcript and y_in is not None:                      # (:118-121)
+            embed_pad = feats.view(B, -1, eng.enc.d)[:, :N_CTX].float()
+            transcribe_logit = self.whisper_model.logits(tokens=y_in, audio_features=embed_pad)
+        return align_logit, transcribe_logit
+
+    def forward(self, mel, y_in=None):
+        eng = self.engine()
+        feats = eng.encode(mel)                                             # (:135-139)
+        B = mel.shape[0]
+        align_logit = eng.logits(feats, B, N_CTX, N_CTX) if self.train_alignment else None
+        transcribe_logit = None
+        if self.train_transcript and y_in is not None:
+            transcribe_logit = self.whisper_model.logits(tokens=y_in, audio_features=feats.view(B, N_CTX, -1).float())
+        return align_logit, transcribe_logit
+
+    # ------------------------------------------------------------------ fused fast path (addition)
+    @torch.no_grad()
+    def align(self, audios: Optional[Sequence[np.ndarray]] = None, labels=None, *, mel: Optional[torch.Tensor] = None,
+              use_ctc: bool = True, hop_size_second: float = 0.02, get_orig_len: bool = True, return_frames: bool = False):
+        """audios (or a ready mel) + class-id labels ([B,Lmax] with -100 padding, or list of lists) ->
+        list[B] of list[L] of [onset_s, offset_s], exactly what perform_viterbi(_ctc)(frame_manual_forward(...))
+        returns in the reference -- but the [B,T,V] logits are never materialised and nothing leaves the GPU
+        except the [L,2] integer frames."""
+        from ..utils.alignment import _labels_to_device, _seconds_from_frames
+        eng = self.engine()
+        if mel is None:
+            mel = self._mel_of(audios)
+        feats, B, T, stride = self._features(mel.to(eng.device), get_orig_len)
+        lab_dev, n_lab, lab_lists = _labels_to_device(labels, B, eng.device)
+        em = eng.emissions(feats, B, T, stride, lab_dev, n_lab, _lib.LA_VARIANT_CTC if use_ctc else _lib.LA_VARIANT_PLAIN)
+        nf = torch.full((B,), T, dtype=torch.int32, device=eng.device)
+        onset, offset, score, status = ops.viterbi_batch(em, lab_dev, n_lab, nf)
+        eng.check_gru()
+        if return_frames:
+            return onset, offset, score, status
+        return _seconds_from_frames(onset, offset, status, lab_lists, hop_size_second)
+
+
+def encoder_only_engine(whisper_model, mel: torch.Tensor) -> torch.Tensor:
+    """embed_audio for a bare whisper_compat.Whisper that is not wrapped in an AlignModel (float32 compute)."""
+    _lib.require_gpu()
+    cache = getattr(whisper_model, "_la_engine", None)
+    key = tuple(p._version for p in whisper_model.encoder.parameters())
+    if cache is None or cache[0] != key:
+        dev = torch.device(f"cuda:{torch.cuda.current_device()}")
+        sd = {"encoder." + k: v for k, v in whisper_model.encoder.state_dict().items()}
+        n_head = int(whisper_model.dims.n_audio_head)
+        cache = (key, AlignEngine(pack_encoder(sd, n_head, torch.float32, dev), None, dev))
+        whisper_model._la_engine = cache
+    eng = cache[1]
+    return eng.encode(mel, out_dtype=torch.float32).view(mel.shape[0], N_CTX, eng.enc.d).clone()
