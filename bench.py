@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""bench.py -- aligned audio-seconds per wall-second of the AlignModel hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+Workload = BASELINE.json configs[1]: Whisper-medium encoder + BiGRU/FC head + CTC forced alignment,
+batch = 32 x 30 s synthetic mel, bf16 operands (f32 accumulate / residual / softmax / DP in f64), one MI355X.
+A "step" is one pass of the whole hot path over one batch already resident in HBM:
+mel [32,80,3000] -> conv stem -> 24 blocks -> ln_post -> 2 x BiGRU -> Mish -> fused FC + emission prep
+-> batched Viterbi -> onset/offset frames (device) -> async D2H of the [32, Lmax] int32 results.
+Multi-GPU: clips are independent, so every rank aligns its own batch with NO data-path collective
+("weak" scaling); torch.distributed (RCCL) is only used for the barrier and the MAX over ranks of the time.
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MODEL = "medium"
+BATCH, CLIP_SECONDS, T_FRAMES = 32, 30.0, 1500
+HIDDEN, VOCAB = 384, 21129
+
+
+def algorithmic_gemm_flops_per_clip(d: int, n_layer: int, H: int = HIDDEN) -> float:
+    """SURVEY.md 2.1 formulae restricted to the launches of the gemm_bf16 kernel family:
+    conv1 + conv2 + per layer (QKV/out 8*T*d^2 + MLP 16*T*d^2) + the GRU input projections + the gathered-column GEMM."""
+    T = T_FRAMES
+    conv = 2 * 3000 * 80 * 3 * d + 2 * T * d * 3 * d
+    layers = n_layer * (8 * T * d * d + 16 * T * d * d)
+    gru_in = 2 * (2 * T * d * 3 * H) + 2 * (2 * T * 2 * H * 3 * H)
+    gather = 2 * T * 2 * H * 27
+    return float(conv + layers + gru_in + gather)
+
+
+def total_flops_per_clip(d: int, n_layer: int, H: int = HIDDEN, V: int = VOCAB) -> float:
+    T = T_FRAMES
+    enc = 2 * 3000 * 80 * 3 * d + 2 * T * d * 3 * d + n_layer * (8 * T * d * d + 4 * T * T * d + 16 * T * d * d)
+    gru = 2 * (2 * T * d * 3 * H + 2 * T * H * 3 * H) + 2 * (2 * T * 2 * H * 3 * H + 2 * T * H * 3 * H)
+    return float(enc + gru + 2 * T * 2 * H * V)
+
+
+def build_inputs(device, seed_offset: int = 0):
+    rs = np.random.RandomState(2 + seed_offset)
+    mel = torch.from_numpy(rs.uniform(-1.0, 1.0, size=(BATCH, 80, 3000)).astype(np.float32)).to(device)
+    Ls = np.random.RandomState(3 + seed_offset).randint(5, 27, size=BATCH)
+    rl = np.random.RandomState(4 + seed_offset)
+    labels = torch.zeros((BATCH, int(Ls.max())), dtype=torch.int32)
+    for b, L in enumerate(Ls):
+        labels[b, :L] = torch.from_numpy(rl.randint(2, 403, size=L).astype(np.int32))
+    return mel, labels.to(device), torch.from_numpy(Ls.astype(np.int32)).to(device), Ls
+
+
+def usable_cores() -> int:
+    """Cores this process may actually use: scheduler affinity capped by the cgroup CPU quota (a container on a
+    256-thread host often owns only a few cores; oversubscribing torch's intra-op pool makes it crawl)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                per = int(f.read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
+def log(msg: str):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def cpu_baseline(model, mel_cpu: np.ndarray, labels_row: np.ndarray, n_head: int):
+    """The oracle (CPU restatement of the reference's fp32 path) timed on this node's host cores on a bounded sample:
+    ONE 30 s clip of the same workload (same weights, first clip of the batch), 1 warm-up + 2 timed passes."""
+    from oracle import alignment_oracle as ao
+    from oracle import model_oracle as mo
+    ao.build()
+    torch.set_num_threads(usable_cores())
+    p = {"encoder." + k: v.detach().float().cpu() for k, v in model.whisper_model.encoder.state_dict().items()}
+    p.update({"align_rnn." + k: v.detach().float().cpu() for k, v in model.align_rnn.state_dict().items()})
+    mel = torch.from_numpy(mel_cpu[None])
+    labels = torch.from_numpy(labels_row[None].astype(np.int64))
+
+    def one():
+        with torch.no_grad():
+            emb = mo.encoder_forward(p, mel, n_head=n_head)
+            logits = mo.gru_head_forward(p, emb)
+            return ao.perform_viterbi_ctc(logits, labels)
+
+    t0 = time.perf_counter()
+    res = one()                      # warm-up (also the first-touch of the weights)
+    warm = time.perf_counter() - t0
+    log(f"cpu baseline warm-up pass {warm:.1f} s on {torch.get_num_threads()} threads")
+    times = []
+    for _ in range(2 if warm < 20 else 1):   # keep the CPU leg bounded
+        t0 = time.perf_counter()
+        res = one()
+        times.append(time.perf_counter() - t0)
+    sec = float(np.median(times))
+    return {"value": CLIP_SECONDS / sec, "unit": "audio-sec/sec", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": f"1 x 30 s clip (first clip of the batch), whisper-{MODEL} fp32 oracle incl. CPU emission prep + C Viterbi, "
+                      f"median of {len(times)} after 1 warm-up, {sec:.2f} s per clip"}, res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    log(f"rank {rank}/{world}: building random-init whisper-{MODEL} weights")
+    from lyricalignment_amd import _lib, whisper_compat as wc
+    from lyricalignment_amd.module.align_model import AlignModel
+    _lib.require_gpu()
+    dims = wc.dims_for(MODEL)
+    wm = wc.build_model(MODEL, seed=0)
+    model = AlignModel(wm, embed_dim=dims.n_audio_state, hidden_dim=HIDDEN, output_dim=VOCAB, device=f"cuda:{local_rank}",
+                       compute_dtype=torch.bfloat16).eval()
+    with torch.no_grad():
+        eng = model.engine()
+    log("weights packed on the device")
+    mel, labels, n_labels, Ls = build_inputs(device, seed_offset=0)   # same synthetic batch on every rank (weak scaling)
+    pinned = [torch.empty((BATCH, labels.shape[1]), dtype=torch.int32).pin_memory() for _ in range(2)]
+    pinned_status = torch.empty((BATCH,), dtype=torch.int32).pin_memory()
+
+    def step():
+        with torch.no_grad():
+            onset, offset, score, status = eng.align_mel(mel, labels, n_labels, n_frames=T_FRAMES, use_ctc=True)
+        pinned[0].copy_(onset, non_blocking=True)
+        pinned[1].copy_(offset, non_blocking=True)
+        pinned_status.copy_(status, non_blocking=True)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for i in range(args.warmup):
+        step()
+        torch.cuda.synchronize()
+        log(f"warm-up step {i} done")
+    eng.check_gru()
+
+    L = _lib.lib()
+    L.la_timer_reset()
+    L.la_timer_enable(b"gemm_bf16")
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    L.la_timer_disable()
+    log(f"timed region: {args.steps} steps in {elapsed:.3f} s")
+    eng.check_gru()
+    if int((pinned_status != 0).sum()) != 0:
+        raise SystemExit("alignment reported non-OK status on the synthetic batch")
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    import ctypes
+    total_ms, launches = ctypes.c_double(0.0), ctypes.c_int64(0)
+    _lib.check(L.la_timer_read(ctypes.byref(total_ms), ctypes.byref(launches)), "timer_read")
+    gemm_flops_step = algorithmic_gemm_flops_per_clip(dims.n_audio_state, dims.n_audio_layer) * BATCH
+    achieved_tf = gemm_flops_step * args.steps / (total_ms.value * 1e-3) / 1e12 if total_ms.value > 0 else 0.0
+
+    if rank == 0:
+        audio_sec = world * BATCH * CLIP_SECONDS * args.steps
+        out = {
+            "metric": "aligned audio-sec/sec (RTF^-1), Whisper-medium 30 s clips",
+            "value": audio_sec / elapsed,
+            "unit": "audio-sec/sec",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16",
+            "data": "synthetic (uniform[-1,1] mel, random class-id labels, random-init weights of the whisper-medium architecture)",
+            "config": {"workload": "whisper-medium encoder + BiGRU/FC head + CTC forced alignment, batch 32 x 30 s mel per GPU "
+                                   "(BASELINE.json configs[1])",
+                       "clips_per_gpu": BATCH, "frames": T_FRAMES, "vocab": VOCAB, "labels_per_clip": "5..26",
+                       "sharding": "clips over ranks, no collective"},
+            "whole_path_tflops": total_flops_per_clip(dims.n_audio_state, dims.n_audio_layer) * BATCH * world * args.steps / elapsed / 1e12,
+            "roofline": {"bound": "mfma", "kernel": "gemm_kernel<bf16> (all linear / conv-as-GEMM launches)",
+                         "achieved": achieved_tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": achieved_tf / 2500.0,
+                         "traffic": None, "launches_per_step": launches.value / max(args.steps, 1),
+                         "avg_launch_ms": total_ms.value / max(launches.value, 1)},
+        }
+        if not args.no_cpu_baseline:
+            base, cpu_res = cpu_baseline(model, mel[0].cpu().numpy(), labels[0, : int(Ls[0])].cpu().numpy(), dims.n_audio_head)
+            out["cpu_baseline"] = base
+            gpu_on = pinned[0][0, : int(Ls[0])].numpy() * 0.02
+            cpu_on = np.array([seg[0] for seg in cpu_res[0]])
+            out["cpu_vs_gpu_onset_mae_s"] = float(np.mean(np.abs(gpu_on - cpu_on)))
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
