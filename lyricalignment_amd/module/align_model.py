@@ -28,6 +28,21 @@ from ..engine import N_CTX, N_FRAMES, AlignEngine, pack_encoder, pack_head
 from ..whisper_compat import pad_or_trim
 
 
+def frame_plan(n_mel: int, get_orig_len: bool = True):
+    """Host bookkeeping of frame_manual_forward (module/align_model.py:86-115): the 3000-frame mel chunks that go
+    through the encoder and how many of each chunk's 1500 output frames are kept.  Python round() = banker's
+    rounding, as in the reference (301 -> 150, 303 -> 152).  -> [(start, end, kept_frames)]"""
+    if not get_orig_len:
+        return [(0, min(n_mel, N_FRAMES), N_CTX)]
+    if n_mel <= N_FRAMES:
+        return [(0, n_mel, int(round(n_mel / 2.0)))]
+    plan = []
+    for start in range(0, n_mel, N_FRAMES):
+        end = min(start + N_FRAMES, n_mel)
+        plan.append((start, end, int(round((end - start) / 2.0))))
+    return plan
+
+
 class RNN(nn.Module):
     """GRU(2 layers, bidirectional) -> Mish -> Linear; parameters live in nn.GRU / nn.Linear so the
     state_dict keys are the reference's (align_rnn.rnn.weight_ih_l0 ... align_rnn.fc.bias)."""
@@ -124,19 +139,13 @@ class AlignModel(torch.nn.Module):
         """-> (feats rows [., d] in compute dtype, B, T, clip stride in rows, embed_pad provider)."""
         eng = self.engine()
         B = mel.shape[0]
-        if not get_orig_len:                                                # (:109-115)
+        plan = frame_plan(mel.shape[-1], get_orig_len)
+        if len(plan) == 1:                                                  # (:87-92) and (:109-115)
             feats = eng.encode(pad_or_trim(mel, N_FRAMES))
-            return feats, B, N_CTX, N_CTX
-        if mel.shape[-1] <= N_FRAMES:                                       # (:87-92)
-            orig_mel_len = int(round(mel.shape[-1] / 2.0))
-            feats = eng.encode(pad_or_trim(mel, N_FRAMES))
-            return feats, B, orig_mel_len, N_CTX
+            return feats, B, plan[0][2], N_CTX
         # long form (:94-105): non-overlapping 3000-frame chunks, every chunk of every clip in ONE encoder batch
-        chunks, keep = [], []
-        for start in range(0, mel.shape[-1], N_FRAMES):
-            end = min(start + N_FRAMES, mel.shape[-1])
-            keep.append(int(round((end - start) / 2.0)))
-            chunks.append(pad_or_trim(mel[:, :, start:end], N_FRAMES))
+        chunks = [pad_or_trim(mel[:, :, s:e], N_FRAMES) for s, e, _ in plan]
+        keep = [k for _, _, k in plan]
         enc = eng.encode(torch.cat(chunks, dim=0)).view(len(chunks), B, N_CTX, eng.enc.d)
         feats = torch.cat([enc[c, :, : keep[c]] for c in range(len(chunks))], dim=1).contiguous()   # [B, sum(keep), d]
         T = feats.shape[1]

@@ -35,7 +35,7 @@ sys.dont_write_bytecode = True
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+REF = next((a for a in sys.argv[1:] if not a.startswith("--")), "/root/reference")
 sys.path.insert(0, ROOT)
 
 import numpy as np
@@ -350,13 +350,69 @@ def gen_losses():
     print("losses", flush=True)
 
 
+# --------------------------------------------------------------------------- #
+# 6. evaluation glue: the reference's align_and_evaluate on fake model + loader  #
+# --------------------------------------------------------------------------- #
+def gen_harness():
+    import contextlib
+    import io
+    import inference_alignment as ref_inf
+
+    class FakeModel(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.zeros(1))
+            self.i = 0
+
+        def frame_manual_forward(self, audios):
+            rs = np.random.RandomState(900 + self.i)
+            self.i += 1
+            return torch.from_numpy((rs.randn(len(audios), 90, 404) * 3).astype(np.float32)), None
+
+    with open(os.path.join(REF, "bert_base_chinese_pronunce_table.json")) as f:
+        token_pinyin, _, lookup = json.load(f)
+    rs = np.random.RandomState(77)
+    ok_ids = [i for i, p in enumerate(token_pinyin) if lookup[p] <= 402 and i not in (0, 102)]
+    batches, raw_tokens = [], []
+    for b in range(5):
+        B = 1 if b % 2 == 0 else 2
+        Ls = [int(rs.randint(3, 9)) for _ in range(B)]
+        tok = torch.full((B, max(Ls)), -100, dtype=torch.long)
+        for i, L in enumerate(Ls):
+            tok[i, :L] = torch.tensor([ok_ids[j] for j in rs.randint(0, len(ok_ids), size=L)])
+        raw_tokens.append(tok.clone())
+        if b == 3:
+            gt = (None,)
+        else:
+            gt = tuple([[float(0.1 * k), float(0.1 * k + 0.08)] for k in range(L)] for L in Ls)
+        batches.append(((np.zeros(16000, dtype=np.float32),) * B, tok, None, gt, None, None))
+    cwd = os.getcwd()
+    os.chdir(REF)  # the reference opens its JSON table relative to the CWD (inference_alignment.py:136)
+    try:
+        with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+            avg = ref_inf.align_and_evaluate(FakeModel(), None, batches, use_ctc_loss=True, device="cpu")
+    finally:
+        os.chdir(cwd)
+    mapped = [b[1] for b in batches]  # the reference maps the token tensors in place (:149-152)
+    pairs = sorted({(int(r), int(m)) for rt, mt in zip(raw_tokens, mapped) for r, m in zip(rt.flatten(), mt.flatten()) if r != -100})
+    with open(os.path.join(HERE, "harness.json"), "w") as f:
+        json.dump(dict(reference="inference_alignment.py:126-180 align_and_evaluate", avg_mae=avg,
+                       logits=dict(seed_base=900, shape_tail=[90, 404], scale=3.0),
+                       raw_tokens=[t.tolist() for t in raw_tokens], mapped_tokens=[t.tolist() for t in mapped],
+                       token_to_class=pairs,
+                       gt=[None if b[3] == (None,) else list(b[3]) for b in batches]), f, indent=1)
+    print("harness", avg, flush=True)
+
+
 if __name__ == "__main__":
-    gen_core()
-    gen_e2e()
-    gen_emission()
-    gen_head()
-    gen_frames()
-    gen_losses()
+    if "--harness-only" not in sys.argv:
+        gen_core()
+        gen_e2e()
+        gen_emission()
+        gen_head()
+        gen_frames()
+        gen_losses()
+    gen_harness()
     leftovers = [d for d, _, fs in os.walk(REF) if d.endswith("__pycache__")]
     assert not leftovers, f"bytecode written into the reference tree: {leftovers}"
     print("done")
