@@ -24,23 +24,23 @@ struct GemmParams {
     const float *residual;
     int64_t ldr, strideR;
     int epilogue;
-    int tiles_m, tiles_n;
+    int tiles_m, tiles_n, group;
 };
 
-template <typename T, bool OUT_F32>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmParams p) {
+template <typename T, bool OUT_F32, typename CF>
+__global__ __launch_bounds__(CF::THREADS, 2) void gemm_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int nwg = p.tiles_m * p.tiles_n;
     const int tile = xcd_remap(blockIdx.x, nwg);
-    const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
+    const TileCoord tc = tile_coord(tile, p.tiles_m, p.tiles_n, p.group);
+    const int m0 = tc.tm * CF::TM, n0 = tc.tn * BN;
     const int z = blockIdx.y;
     const T *A = reinterpret_cast<const T *>(p.A) + (int64_t)z * p.strideA;
     const T *W = reinterpret_cast<const T *>(p.W) + (int64_t)z * p.strideW;
     const float *bias = p.bias ? p.bias + (int64_t)z * p.strideBias : nullptr;
 
     f32x4 acc[4][4];
-    mainloop<T>(A, p.lda, p.M, W, p.K, p.N, p.K, m0, n0, lds, acc);
+    mainloop<T, CF>(A, p.lda, p.M, W, p.K, p.N, p.K, m0, n0, lds, acc);
 
     typedef typename std::conditional<OUT_F32, float, T>::type TC;
     TC *C = reinterpret_cast<TC *>(p.C) + (int64_t)z * p.strideC;
@@ -48,49 +48,80 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmParams p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int r = lane & 15, q = lane >> 4;
-    const bool vec_c = (p.ldc % 4 == 0) && (p.N % 4 == 0);
-    const bool vec_r = R && (p.ldr % 4 == 0) && (p.N % 4 == 0);
     const bool has_bias = (p.epilogue & LA_EPI_BIAS) && bias;
     const bool do_gelu = p.epilogue & LA_EPI_GELU;
     const bool do_mish = p.epilogue & LA_EPI_MISH;
     const bool do_res = (p.epilogue & LA_EPI_RESIDUAL) && R;
 
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-        const int m = m0 + wm * 64 + mi * 16 + r;
-        if (m >= p.M) continue;
+    // bias + activation in registers (lane: 4 consecutive columns n of row m); the activation switches are
+    // wave-uniform and hoisted so each variant is a straight-line pass over the 64 accumulators
+    if (has_bias) {
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
             const int n = n0 + wn * 64 + ni * 16 + q * 4;
-            if (n >= p.N) continue;
-            float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
+            float b4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b4[j] = bias[min(n + j, p.N - 1)];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[mi][ni][j] += b4[j];
+        }
+    }
+    if (do_gelu) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[mi][ni][j] = la::gelu_erf(acc[mi][ni][j]);
+    } else if (do_mish) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[mi][ni][j] = la::mish(acc[mi][ni][j]);
+    }
+
+    // Store path.  Each wave transposes its 64x64 tile through LDS (two passes of 32 rows, f32, row pitch 272 B:
+    // conflict-free b128 writes and reads) so that 16 lanes cover 64 CONSECUTIVE columns of one row: full 128-B
+    // (bf16) / 256-B (f32) line segments per row instead of 32-B pieces scattered over 16 rows (measured: the
+    // scattered form ran the C write at 1.4 TB/s and cost 30-45 % of the kernel).
+    constexpr int PITCH = 272;
+    __syncthreads();  // every wave is done reading the operand stages
+    unsigned char *reg = lds + wave * (32 * PITCH);
+    const int wrow0 = m0 + wm * 64, wcol0 = n0 + wn * 64;
+    const bool fast_c = ((p.ldc * (int64_t)sizeof(TC)) % 16 == 0) && ((uintptr_t)C % 16 == 0);
+    const bool fast_r = do_res && (p.ldr % 4 == 0) && ((uintptr_t)R % 16 == 0);
+    const bool probe_nostore = p.epilogue & 256;  // developer probe: main loop without the C stores
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                *reinterpret_cast<f32x4 *>(reg + (mm * 16 + r) * PITCH + (ni * 16 + q * 4) * 4) = acc[2 * h + mm][ni];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int rl = it * 4 + q;                       // row inside this 32-row pass
+            const int m = wrow0 + h * 32 + rl;
+            const int n = wcol0 + r * 4;                     // 4 consecutive columns
+            f32x4 v = *reinterpret_cast<const f32x4 *>(reg + rl * PITCH + r * 16);
+            if (m >= p.M || n >= p.N) continue;
+            if (probe_nostore && v[0] != 12345.678f) continue;
             const int nv = min(4, p.N - n);
-            if (has_bias) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (j < nv) v[j] += bias[n + j];
-            }
-            if (do_gelu) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = la::gelu_erf(v[j]);
-            }
-            if (do_mish) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = la::mish(v[j]);
-            }
             if (do_res) {
                 const float *rr = R + (int64_t)m * p.ldr + n;
-                if (vec_r) {
+                if (fast_r && nv == 4) {
                     const float4 t = *reinterpret_cast<const float4 *>(rr);
                     v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
                 } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (j < nv) v[j] += rr[j];
+                    for (int j = 0; j < nv; ++j) v[j] += rr[j];
                 }
             }
             TC *c = C + (int64_t)m * p.ldc + n;
-            if (vec_c) {
+            if (fast_c && nv == 4) {
                 if constexpr (sizeof(TC) == 4) {
                     *reinterpret_cast<float4 *>(c) = make_float4(v[0], v[1], v[2], v[3]);
                 } else {
@@ -100,26 +131,33 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmParams p) {
                     *reinterpret_cast<ushort4 *>(c) = pk;
                 }
             } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (j < nv) la::Elem<TC>::store(c + j, v[j]);
+                for (int j = 0; j < nv; ++j) la::Elem<TC>::store(c + j, v[j]);
             }
         }
     }
 }
 
-template <typename T, bool OUT_F32>
-int launch(const GemmParams &p, int batch, hipStream_t stream, const char *family) {
-    auto kern = gemm_kernel<T, OUT_F32>;
+template <typename T, bool OUT_F32, typename CF>
+int launch(GemmParams p, int batch, hipStream_t stream, const char *family) {
+    auto kern = gemm_kernel<T, OUT_F32, CF>;
     static bool attr_done = false;
     if (!attr_done) {
-        LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS));
         attr_done = true;
     }
+    p.tiles_m = la::cdiv(p.M, CF::TM);
     la::TimerScope ts(family, stream);
-    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, batch), dim3(NTHREADS), LDS_BYTES, stream, p);
+    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, batch), dim3(CF::THREADS), CF::LDS, stream, p);
     LA_LAUNCH_CHECK();
     return LA_OK;
+}
+
+// Measured on the config-2 shapes (tools/kbench.py, round 1): the 128x128 / 2-workgroups-per-CU configuration beats the
+// 256x128 / 3-stage / 1-workgroup-per-CU one by 5-15 % on every shape, so it is the default; LA_GEMM_TILE=256 selects
+// the big tile for A/B runs.
+bool use_big_tile(int M, int N, int batch) {
+    static const char *force = getenv("LA_GEMM_TILE");
+    return force && atoi(force) == 256 && (int64_t)la::cdiv(M, 256) * la::cdiv(N, BN) * batch >= 512;
 }
 
 }  // namespace
@@ -140,11 +178,16 @@ int la::gemm_run(int dtype, int M, int N, int K, int batch, const void *A, int64
     LA_CHECK_ARG(!(epilogue & LA_EPI_BIAS) || bias, "gemm: bias epilogue without pointer");
     LA_CHECK_ARG((strideW * es) % 16 == 0, "gemm: W batch stride must be 16-byte aligned");
     GemmParams p{M, N, K, A, lda, strideA, W, strideW, C, ldc, strideC, bias, strideBias, residual, ldr, strideR, epilogue,
-                 la::cdiv(M, BM), la::cdiv(N, BN)};
+                 0, la::cdiv(N, BN), pick_group(K, es, la::cdiv(N, BN))};
     const bool out_f32 = epilogue & LA_EPI_OUT_F32;
-    if (dtype == LA_BF16)
-        return out_f32 ? launch<bf16_t, true>(p, batch, stream, "gemm_bf16") : launch<bf16_t, false>(p, batch, stream, "gemm_bf16");
-    return launch<float, true>(p, batch, stream, "gemm_f32");
+    typedef Cfg<2, 2> Small;
+    typedef Cfg<4, 3> Big;
+    if (dtype == LA_BF16) {
+        if (use_big_tile(M, N, batch))
+            return out_f32 ? launch<bf16_t, true, Big>(p, batch, stream, "gemm_bf16") : launch<bf16_t, false, Big>(p, batch, stream, "gemm_bf16");
+        return out_f32 ? launch<bf16_t, true, Small>(p, batch, stream, "gemm_bf16") : launch<bf16_t, false, Small>(p, batch, stream, "gemm_bf16");
+    }
+    return launch<float, true, Small>(p, batch, stream, "gemm_f32");
 }
 
 extern "C" int la_gemm(int32_t dtype, int32_t M, int32_t N, int32_t K, int32_t batch, const void *A, int64_t lda,

@@ -28,17 +28,18 @@ struct LseParams {
     const float *bias;
     float2 *partials;  // [M][2 * tiles_n]
     int lo, hi;        // inclusive column range of the normaliser
-    int tiles_m, tiles_n;
+    int tiles_m, tiles_n, group;
 };
 
-template <typename T>
-__global__ __launch_bounds__(NTHREADS, 2) void fc_lse_kernel(LseParams p) {
+template <typename T, typename C>
+__global__ __launch_bounds__(C::THREADS, 2) void fc_lse_kernel(LseParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
-    const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
+    const TileCoord tc = tile_coord(tile, p.tiles_m, p.tiles_n, p.group);
+    const int tn = tc.tn;
+    const int m0 = tc.tm * C::TM, n0 = tn * BN;
     f32x4 acc[4][4];
-    mainloop<T>(reinterpret_cast<const T *>(p.A), p.lda, p.M, reinterpret_cast<const T *>(p.W), p.K, p.N, p.K, m0, n0, lds, acc);
+    mainloop<T, C>(reinterpret_cast<const T *>(p.A), p.lda, p.M, reinterpret_cast<const T *>(p.W), p.K, p.N, p.K, m0, n0, lds, acc);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -207,25 +208,38 @@ extern "C" int la_fc_emissions(int32_t dtype, const void *act, int64_t ld_act, c
     // 3. row normaliser partials over the full vocabulary
     LseParams lp{rows, vocab, in_dim, act, ld_act, w_fc, b_fc, partials,
                  variant == LA_VARIANT_CTC ? 1 : 0, variant == LA_VARIANT_CTC ? vocab - 2 : vocab - 1,
-                 la::cdiv(rows, BM), pl.tiles_n};
+                 0, pl.tiles_n, pick_group(in_dim, es, pl.tiles_n)};
     {
-        static bool attr_bf16 = false, attr_f32 = false;
-        if (dtype == LA_BF16) {
+        typedef Cfg<2, 2> Small;
+        typedef Cfg<4, 3> Big;
+        static bool attr_bf16 = false, attr_bf16_big = false, attr_f32 = false;
+        if (dtype == LA_BF16 && rows >= 4096 && getenv("LA_GEMM_TILE") && atoi(getenv("LA_GEMM_TILE")) == 256) {
+            if (!attr_bf16_big) {
+                LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fc_lse_kernel<bf16_t, Big>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, Big::LDS));
+                attr_bf16_big = true;
+            }
+            lp.tiles_m = la::cdiv(rows, Big::TM);
+            la::TimerScope ts("fc_lse_bf16", stream);
+            hipLaunchKernelGGL((fc_lse_kernel<bf16_t, Big>), dim3(lp.tiles_m * lp.tiles_n), dim3(Big::THREADS), Big::LDS, stream, lp);
+        } else if (dtype == LA_BF16) {
             if (!attr_bf16) {
-                LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fc_lse_kernel<bf16_t>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+                LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fc_lse_kernel<bf16_t, Small>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, Small::LDS));
                 attr_bf16 = true;
             }
+            lp.tiles_m = la::cdiv(rows, Small::TM);
             la::TimerScope ts("fc_lse_bf16", stream);
-            hipLaunchKernelGGL((fc_lse_kernel<bf16_t>), dim3(lp.tiles_m * lp.tiles_n), dim3(NTHREADS), LDS_BYTES, stream, lp);
+            hipLaunchKernelGGL((fc_lse_kernel<bf16_t, Small>), dim3(lp.tiles_m * lp.tiles_n), dim3(Small::THREADS), Small::LDS, stream, lp);
         } else {
             if (!attr_f32) {
-                LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fc_lse_kernel<float>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+                LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fc_lse_kernel<float, Small>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, Small::LDS));
                 attr_f32 = true;
             }
+            lp.tiles_m = la::cdiv(rows, Small::TM);
             la::TimerScope ts("fc_lse_f32", stream);
-            hipLaunchKernelGGL((fc_lse_kernel<float>), dim3(lp.tiles_m * lp.tiles_n), dim3(NTHREADS), LDS_BYTES, stream, lp);
+            hipLaunchKernelGGL((fc_lse_kernel<float, Small>), dim3(lp.tiles_m * lp.tiles_n), dim3(Small::THREADS), Small::LDS, stream, lp);
         }
         LA_LAUNCH_CHECK();
     }

@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmarks on the config-2 shapes (developer tool; run on the GPU box).
+    python tools/kbench.py gemm|attn|gru|fc|all [--iters N]
+Interleaved rounds in one process, random operands (cdna guide rules 24/25)."""
+import argparse, os, sys, time
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from lyricalignment_amd import ops
+
+
+def timeit(fn, iters):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for s, e in ev:
+        s.record(); fn(); e.record()
+    torch.cuda.synchronize()
+    t = sorted(s.elapsed_time(e) for s, e in ev)
+    return t[len(t) // 2], t[0]
+
+
+def rnd(*shape, dtype=torch.bfloat16, scale=1.0):
+    return (torch.randn(*shape, device="cuda") * scale).to(dtype)
+
+
+def bench_gemm(iters):
+    M = 48000
+    shapes = [("qkv", 3072, 1024, False), ("mlp_up+gelu", 4096, 1024, False), ("mlp_up_plain", 4096, 1024, False), ("out_proj+res", 1024, 1024, True),
+              ("mlp_down+res", 1024, 4096, True), ("gi0", 2304, 1024, True), ("gi1", 2304, 768, True)]
+    for name, N, K, f32out in shapes:
+        a, w = rnd(M, K), rnd(N, K, scale=K ** -0.5)
+        bias = torch.randn(N, device="cuda")
+        if f32out:
+            res = torch.randn(M, N, device="cuda")
+            out = torch.empty(M, N, device="cuda")
+            fn = lambda: ops.gemm(a, w, out, bias=bias, residual=res if "res" in name else None, out_f32=True)
+        else:
+            out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+            fn = lambda: ops.gemm(a, w, out, bias=bias, gelu="gelu" in name)
+        if os.environ.get("KB_NOSTORE"):
+            from lyricalignment_amd._lib import lib, ptr, stream_ptr
+            epi = 1 | 256 | (8 if f32out else 0) | (2 if "gelu" in name else 0)
+            fn = lambda: lib().la_gemm(1, M, N, K, 1, ptr(a), K, 0, ptr(w), ptr(out), N, 0, ptr(bias), 0, 0, 0, epi, stream_ptr())
+        med, mn = timeit(fn, iters)
+        fl = 2.0 * M * N * K
+        print(f"gemm {name:14s} M={M} N={N} K={K}: median {med*1e3:8.1f} us  min {mn*1e3:8.1f} us  {fl/med/1e9:7.1f} TF/s (min {fl/mn/1e9:7.1f})", flush=True)
+
+
+def bench_attn(iters):
+    B, T, H = 32, 1500, 16
+    qkv = rnd(B * T, 3 * H * 64)
+    out = torch.empty(B * T, H * 64, device="cuda", dtype=torch.bfloat16)
+    med, mn = timeit(lambda: ops.attention(qkv, B, T, H, out=out), iters)
+    fl = 4.0 * T * T * H * 64 * B
+    print(f"attention B={B} T={T} H={H}: median {med*1e3:.1f} us  {fl/med/1e9:.1f} TF/s", flush=True)
+
+
+def bench_gru(iters):
+    B, T, H = 32, 1500, 384
+    gi = torch.randn(B, T, 2, 3 * H, device="cuda") * 0.5
+    w = rnd(2, 3 * H, H, scale=H ** -0.5)
+    b = torch.randn(2, 3 * H, device="cuda") * 0.1
+    out = torch.empty(B, T, 2 * H, device="cuda", dtype=torch.bfloat16)
+    med, mn = timeit(lambda: ops.gru_layer(gi, w, b, out=out, want_mish=True), max(3, iters // 4))
+    print(f"gru layer B={B} T={T} H={H}: median {med:.2f} ms  ({med*1e3/T:.2f} us/step)", flush=True)
+
+
+def bench_fc(iters):
+    B, T, K, V = 32, 1500, 768, 21129
+    act, w = rnd(B * T, K), rnd(V, K, scale=K ** -0.5)
+    bias = torch.randn(V, device="cuda") * 0.1
+    labels = torch.randint(2, 403, (B, 26), device="cuda", dtype=torch.int32)
+    nl = torch.full((B,), 26, device="cuda", dtype=torch.int32)
+    med, mn = timeit(lambda: ops.fc_emissions(act, w, bias, B, T, labels, nl, 1), max(3, iters // 2))
+    print(f"fc_emissions: median {med*1e3:.1f} us  {2.0*B*T*K*V/med/1e9:.1f} TF/s", flush=True)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", nargs="?", default="all")
+    ap.add_argument("--iters", type=int, default=10)
+    a = ap.parse_args()
+    torch.manual_seed(0)
+    if a.what in ("gemm", "all"): bench_gemm(a.iters)
+    if a.what in ("attn", "all"): bench_attn(a.iters)
+    if a.what in ("gru", "all"): bench_gru(a.iters)
+    if a.what in ("fc", "all"): bench_fc(a.iters)
