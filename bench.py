@@ -126,6 +126,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="single stream: no encoder/head overlap across batches")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -156,8 +157,14 @@ def main():
     pinned = [torch.empty((BATCH, labels.shape[1]), dtype=torch.int32).pin_memory() for _ in range(2)]
     pinned_status = torch.empty((BATCH,), dtype=torch.int32).pin_memory()
 
+    from lyricalignment_amd.engine import PipelinedAligner
+    pipe = None if args.no_overlap else PipelinedAligner(eng)
+
     def step():
         with torch.no_grad():
+            if pipe is not None:   # encoder of this batch overlaps the head (GRU/FC/DP) of the previous one
+                pipe.submit(mel, labels, n_labels, n_frames=T_FRAMES, use_ctc=True, host_out=(pinned[0], pinned[1], pinned_status))
+                return
             onset, offset, score, status = eng.align_mel(mel, labels, n_labels, n_frames=T_FRAMES, use_ctc=True)
         pinned[0].copy_(onset, non_blocking=True)
         pinned[1].copy_(offset, non_blocking=True)
@@ -169,8 +176,8 @@ def main():
 
     for i in range(args.warmup):
         step()
-        torch.cuda.synchronize()
-        log(f"warm-up step {i} done")
+    torch.cuda.synchronize()
+    log(f"{args.warmup} warm-up steps done")
     eng.check_gru()
 
     L = _lib.lib()

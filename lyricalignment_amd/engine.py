@@ -144,8 +144,9 @@ class AlignEngine:
         return t
 
     # ---- encoder: Whisper.embed_audio -----------------------------------------------
-    def encode(self, mel: torch.Tensor, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
-        """mel [B, n_mels, 3000] f32 (device) -> ln_post output [B*1500, d] in `out_dtype` (default: compute dtype)."""
+    def encode(self, mel: torch.Tensor, out_dtype: Optional[torch.dtype] = None, slot: int = 0) -> torch.Tensor:
+        """mel [B, n_mels, 3000] f32 (device) -> ln_post output [B*1500, d] in `out_dtype` (default: compute dtype).
+        `slot` names the output buffer (the two-stream pipeline double-buffers it)."""
         e = self.enc
         if mel.dim() != 3 or mel.shape[1] != e.n_mels or mel.shape[2] != N_FRAMES:
             raise AssertionError("incorrect audio shape")  # whisper AudioEncoder asserts the same
@@ -174,7 +175,7 @@ class AlignEngine:
             ops.gemm(h, blk.w1, u, bias=blk.b1, gelu=True)
             ops.gemm(u, blk.w2, x, bias=blk.b2, residual=x, out_f32=True)            # x += mlp (in place)
         out_dtype = out_dtype or dt
-        y = self._get("enc_out", (M, d), out_dtype)
+        y = self._get(f"enc_out{slot}", (M, d), out_dtype)
         ops.layernorm(x, e.lnp_g, e.lnp_b, out_dtype, out=y)
         return y
 
@@ -229,3 +230,54 @@ class AlignEngine:
         em = self.emissions(feats, B, n_frames, N_CTX, labels, n_labels, variant)
         nf = torch.full((B,), n_frames, dtype=torch.int32, device=self.device)
         return ops.viterbi_batch(em, labels, n_labels, nf)
+
+
+class PipelinedAligner:
+    """Two-stream software pipeline over consecutive batches: the encoder of batch i+1 (stream E, GEMM / attention
+    bound, fills the chip) overlaps the head of batch i (stream H: the persistent GRU recurrence occupies 12 CUs for
+    ~25 ms and is latency-bound, then the fused FC and the DP).  The only shared buffer is the encoder output, which is
+    double-buffered and handed over with events; every other scratch buffer belongs to exactly one stream.
+    Clips are independent, so this changes no result -- only which kernels are in flight together."""
+
+    def __init__(self, engine: AlignEngine):
+        self.eng = engine
+        dev = engine.device
+        self.stream_e = torch.cuda.Stream(device=dev)
+        self.stream_h = torch.cuda.Stream(device=dev, priority=-1)   # the GRU's few workgroups should dispatch promptly
+        self.enc_done = [torch.cuda.Event(), torch.cuda.Event()]
+        self.head_done = [torch.cuda.Event(), torch.cuda.Event()]
+        self._head_used = [False, False]
+        self.i = 0
+
+    def submit(self, mel: torch.Tensor, labels: torch.Tensor, n_labels: torch.Tensor, n_frames: int = N_CTX,
+               use_ctc: bool = True, host_out=None):
+        """Enqueue one batch; returns (onset, offset, score, status) device tensors valid after drain() /
+        head_done event.  host_out: optional (onset, offset, status) pinned host tensors for an async D2H."""
+        eng, slot = self.eng, self.i & 1
+        cur = torch.cuda.current_stream(eng.device)
+        self.stream_e.wait_stream(cur)
+        with torch.cuda.stream(self.stream_e):
+            if self._head_used[slot]:
+                self.stream_e.wait_event(self.head_done[slot])       # head of batch i-2 has consumed this slot
+            feats = eng.encode(mel, slot=slot)
+            self.enc_done[slot].record(self.stream_e)
+        with torch.cuda.stream(self.stream_h):
+            self.stream_h.wait_event(self.enc_done[slot])
+            B = mel.shape[0]
+            variant = LA_VARIANT_CTC if use_ctc else LA_VARIANT_PLAIN
+            em = eng.emissions(feats, B, n_frames, N_CTX, labels, n_labels, variant)
+            nf = torch.full((B,), n_frames, dtype=torch.int32, device=eng.device)
+            out = ops.viterbi_batch(em, labels, n_labels, nf)
+            if host_out is not None:
+                host_out[0].copy_(out[0], non_blocking=True)
+                host_out[1].copy_(out[1], non_blocking=True)
+                host_out[2].copy_(out[3], non_blocking=True)
+            self.head_done[slot].record(self.stream_h)
+            self._head_used[slot] = True
+        self.i += 1
+        return out
+
+    def drain(self):
+        self.stream_e.synchronize()
+        self.stream_h.synchronize()
+        self.eng.check_gru()

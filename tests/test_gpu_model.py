@@ -236,3 +236,26 @@ def test_state_dict_layout_and_training_guard():
     model.train()
     with pytest.raises(NotImplementedError):
         model.frame_manual_forward([_wave(16000)])
+
+
+def test_pipelined_aligner_matches_single_stream():
+    """Two-stream encoder/head overlap across consecutive batches changes no result."""
+    from lyricalignment_amd.engine import PipelinedAligner
+    model = _small_model(torch.bfloat16, seed=21)
+    eng = model.engine()
+    pipe = PipelinedAligner(eng)
+    rs = np.random.RandomState(22)
+    batches = []
+    for i in range(5):
+        mel = torch.from_numpy(rs.uniform(-1, 1, size=(3, 80, 3000)).astype(np.float32)).cuda()
+        labels = torch.from_numpy(rs.randint(1, 299, size=(3, 9)).astype(np.int32)).cuda()
+        n_labels = torch.tensor([9, 5, 2], dtype=torch.int32).cuda()
+        batches.append((mel, labels, n_labels))
+    with torch.no_grad():
+        ref = [tuple(t.clone() for t in eng.align_mel(*b, n_frames=700)) for b in batches]
+        torch.cuda.synchronize()
+        outs = [pipe.submit(*b, n_frames=700) for b in batches]
+        pipe.drain()
+    for r, o in zip(ref, outs):
+        assert torch.equal(r[0], o[0]) and torch.equal(r[1], o[1]) and torch.equal(r[3], o[3])
+        assert torch.equal(r[2], o[2])
