@@ -40,8 +40,7 @@ struct AttnParams {
 __device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
 
 __device__ __forceinline__ void glds16(const void *g, void *l) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                     (__attribute__((address_space(3))) void *)l, 16, 0, 0);
+    la::glds16(g, l);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -108,6 +108,35 @@ __device__ __forceinline__ float mish(float x) {
     return x * tanhf(sp);
 }
 
+// global -> LDS DMA, 16 B per lane (global_load_lds_dwordx4): lane i's 16 bytes land at lds_base + 16*i, lds_base wave-uniform.
+// Issued from INLINE ASM on purpose: hipcc models an LDS-DMA issued through the builtin as a pending LDS write and puts
+// s_waitcnt vmcnt(0) in front of the next ds_read of the loop (seen in the ISA of every kernel here), which drains the
+// prefetch it was issued for.  From asm the DMA is invisible to that bookkeeping; completion is OUR job: a counted
+// s_waitcnt vmcnt(N) by the issuing wave, then a barrier, then the ds_read (cdna guide 5.7).  M0 (the LDS base) is
+// saved and restored inside the statement.
+__device__ __forceinline__ void glds16(const void *gsrc, const void *lds_base) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(const __attribute__((address_space(3))) void *)lds_base);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(dst)
+                 : "memory");
+}
+
+// Same DMA with the address split as the hardware wants it in a hot loop: a wave-uniform 64-bit base in SGPRs plus a
+// loop-invariant per-lane 32-bit byte offset in one VGPR, and the LDS destination as a ready M0 value.  Two SALU + the
+// DMA per issue (the generic form above spends ~25 instructions on 64-bit per-lane address arithmetic).  M0 is not
+// restored: nothing else in these kernels reads it (LDS-DMA is its only user on gfx950 besides GWS / sendmsg).
+__device__ __forceinline__ void glds16_so(unsigned voff, const void *sbase, unsigned m0_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :
+                 : "v"(voff), "s"(sbase), "s"(m0_dst)
+                 : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr_u32(const void *p) {
+    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
+}
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 }  // namespace la

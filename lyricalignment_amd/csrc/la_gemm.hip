@@ -5,6 +5,7 @@
 #include <type_traits>
 
 #include "la_gemm_core.h"
+#include "la_gemm_pp.h"
 
 using la::bf16_t;
 using namespace la::gemm;
@@ -137,6 +138,131 @@ __global__ __launch_bounds__(CF::THREADS, 2) void gemm_kernel(GemmParams p) {
     }
 }
 
+// 256x256 ping-pong kernel (bf16 operands only): same epilogue contract as gemm_kernel.
+template <bool OUT_F32, int DBG>
+__global__ __launch_bounds__(PP::THREADS, 2) void gemm_pp_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int tile = xcd_remap(blockIdx.x, nwg);
+    const TileCoord tc = tile_coord(tile, p.tiles_m, p.tiles_n, p.group);
+    const int m0 = tc.tm * PP::TM, n0 = tc.tn * PP::TN;
+    const int z = blockIdx.y;
+    const bf16_t *A = reinterpret_cast<const bf16_t *>(p.A) + (int64_t)z * p.strideA;
+    const bf16_t *W = reinterpret_cast<const bf16_t *>(p.W) + (int64_t)z * p.strideW;
+    const float *bias = p.bias ? p.bias + (int64_t)z * p.strideBias : nullptr;
+
+    f32x4 acc[8][4];
+    mainloop_pp<DBG>(A, p.lda, p.M, W, p.K, p.N, p.K, m0, n0, lds, acc);
+
+    typedef typename std::conditional<OUT_F32, float, bf16_t>::type TC;
+    TC *C = reinterpret_cast<TC *>(p.C) + (int64_t)z * p.strideC;
+    const float *R = p.residual ? p.residual + (int64_t)z * p.strideR : nullptr;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 2, wc = wave & 3;
+    const int r = lane & 15, q = lane >> 4;
+    const bool has_bias = (p.epilogue & LA_EPI_BIAS) && bias;
+    const bool do_gelu = p.epilogue & LA_EPI_GELU;
+    const bool do_res = (p.epilogue & LA_EPI_RESIDUAL) && R;
+    if (has_bias) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int n = n0 + wc * 64 + ni * 16 + q * 4;
+            float b4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b4[j] = bias[min(n + j, p.N - 1)];
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[mi][ni][j] += b4[j];
+        }
+    }
+    if (do_gelu) {
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[mi][ni][j] = la::gelu_erf(acc[mi][ni][j]);
+    }
+    constexpr int PITCH = 272;
+    __syncthreads();
+    unsigned char *reg = lds + wave * (32 * PITCH);
+    const int wrow0 = m0 + wr * 128, wcol0 = n0 + wc * 64;
+    const bool fast_c = ((p.ldc * (int64_t)sizeof(TC)) % 16 == 0) && ((uintptr_t)C % 16 == 0);
+    const bool fast_r = do_res && (p.ldr % 4 == 0) && ((uintptr_t)R % 16 == 0);
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                *reinterpret_cast<f32x4 *>(reg + (mm * 16 + r) * PITCH + (ni * 16 + q * 4) * 4) = acc[2 * h + mm][ni];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int rl = it * 4 + q;
+            const int m = wrow0 + h * 32 + rl;
+            const int n = wcol0 + r * 4;
+            f32x4 v = *reinterpret_cast<const f32x4 *>(reg + rl * PITCH + r * 16);
+            if (m >= p.M || n >= p.N) continue;
+            const int nv = min(4, p.N - n);
+            if (do_res) {
+                const float *rr = R + (int64_t)m * p.ldr + n;
+                if (fast_r && nv == 4) {
+                    const float4 t = *reinterpret_cast<const float4 *>(rr);
+                    v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+                } else {
+                    for (int j = 0; j < nv; ++j) v[j] += rr[j];
+                }
+            }
+            TC *c = C + (int64_t)m * p.ldc + n;
+            if (fast_c && nv == 4) {
+                if constexpr (sizeof(TC) == 4) {
+                    *reinterpret_cast<float4 *>(c) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    ushort4 pk;
+                    pk.x = la::f32_to_bf16(v[0]); pk.y = la::f32_to_bf16(v[1]);
+                    pk.z = la::f32_to_bf16(v[2]); pk.w = la::f32_to_bf16(v[3]);
+                    *reinterpret_cast<ushort4 *>(c) = pk;
+                }
+            } else {
+                for (int j = 0; j < nv; ++j) la::Elem<TC>::store(c + j, v[j]);
+            }
+        }
+    }
+}
+
+template <bool OUT_F32, int DBG>
+int launch_pp_dbg(GemmParams p, int batch, hipStream_t stream);
+
+template <bool OUT_F32>
+int launch_pp(GemmParams p, int batch, hipStream_t stream) {
+    static const int dbg = getenv("LA_PP_DBG") ? atoi(getenv("LA_PP_DBG")) : 0;
+    switch (dbg) {
+        case 1: return launch_pp_dbg<OUT_F32, 1>(p, batch, stream);
+        case 2: return launch_pp_dbg<OUT_F32, 2>(p, batch, stream);
+        case 3: return launch_pp_dbg<OUT_F32, 3>(p, batch, stream);
+        case 4: return launch_pp_dbg<OUT_F32, 4>(p, batch, stream);
+        default: return launch_pp_dbg<OUT_F32, 0>(p, batch, stream);
+    }
+}
+
+template <bool OUT_F32, int DBG>
+int launch_pp_dbg(GemmParams p, int batch, hipStream_t stream) {
+    auto kern = gemm_pp_kernel<OUT_F32, DBG>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, PP::LDS));
+        attr_done = true;
+    }
+    p.tiles_m = la::cdiv(p.M, PP::TM);
+    p.tiles_n = la::cdiv(p.N, PP::TN);
+    p.group = getenv("LA_GEMM_GROUP") ? std::min(p.group, p.tiles_n) : std::max(1, p.group / 2);
+    la::TimerScope ts("gemm_bf16", stream);
+    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, batch), dim3(PP::THREADS), PP::LDS, stream, p);
+    LA_LAUNCH_CHECK();
+    return LA_OK;
+}
+
 template <typename T, bool OUT_F32, typename CF>
 int launch(GemmParams p, int batch, hipStream_t stream, const char *family) {
     auto kern = gemm_kernel<T, OUT_F32, CF>;
@@ -183,6 +309,12 @@ int la::gemm_run(int dtype, int M, int N, int K, int batch, const void *A, int64
     typedef Cfg<2, 2> Small;
     typedef Cfg<4, 3> Big;
     if (dtype == LA_BF16) {
+        // 256x256 ping-pong kernel once it can fill the chip (>= 192 tiles); LA_GEMM_TILE=512 forces it, 128/256 forbid it
+        static const char *force = getenv("LA_GEMM_TILE");
+        const int forced = force ? atoi(force) : 0;
+        const bool pp = forced == 512 || (forced == 0 && (int64_t)la::cdiv(M, 256) * la::cdiv(N, 256) * batch >= 192);
+        if (pp && !(epilogue & LA_EPI_MISH))
+            return out_f32 ? launch_pp<true>(p, batch, stream) : launch_pp<false>(p, batch, stream);
         if (use_big_tile(M, N, batch))
             return out_f32 ? launch<bf16_t, true, Big>(p, batch, stream, "gemm_bf16") : launch<bf16_t, false, Big>(p, batch, stream, "gemm_bf16");
         return out_f32 ? launch<bf16_t, true, Small>(p, batch, stream, "gemm_bf16") : launch<bf16_t, false, Small>(p, batch, stream, "gemm_bf16");

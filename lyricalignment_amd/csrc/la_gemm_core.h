@@ -53,8 +53,7 @@ __device__ __forceinline__ void stage_tile(const unsigned char *src, int64_t ld_
         row = row > last_row ? last_row : row;
         const unsigned char *g = src + (int64_t)row * ld_bytes + ((slot ^ swz(rt)) << 4);
         unsigned char *l = lds_tile + piece * 1024;  // wave-uniform; hardware adds lane*16
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                         (__attribute__((address_space(3))) void *)l, 16, 0, 0);
+        la::glds16(g, l);
     }
 }
 
@@ -196,6 +195,8 @@ __device__ __forceinline__ TileCoord tile_coord(int tile, int tiles_m, int tiles
     return TileCoord{rem / gw, base_n + rem % gw};
 }
 inline int pick_group(int K, int elem_bytes, int tiles_n) {
+    static const char *force = getenv("LA_GEMM_GROUP");   // developer sweep
+    if (force) { const int g = atoi(force); return g < 1 ? 1 : (g > tiles_n ? tiles_n : g); }
     const int64_t tile_bytes = (int64_t)BN * K * elem_bytes;
     int g = (int)((2 << 20) / tile_bytes);
     g = g < 1 ? 1 : (g > 16 ? 16 : g);

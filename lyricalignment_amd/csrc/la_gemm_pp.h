@@ -1,0 +1,196 @@
+// la_gemm_pp.h -- 256x256 "ping-pong" bf16 GEMM main loop for gfx950 (large-M encoder GEMMs).
+//
+// Why: the 128x128 kernel moves 64 flop per byte of L2->LDS traffic and measured ~10 TB/s of that traffic at
+// 650 TFLOP/s -- more than half of what global_load_lds delivers from L2 chip-wide (MI355X_MICROARCH "Indexed rows").
+// A 256x256 tile halves the traffic per flop (128 flop/B).  One 512-thread workgroup per CU (128 KiB LDS):
+//   8 waves = 2 (M) x 4 (N); wave (wr, wc) owns rows wr*128..+127 and columns wc*64..+63 (8 x 4 MFMA 16x16 tiles,
+//   128 accumulator VGPRs).  K advances in tiles of 64 (128 B rows), two LDS buffers of 64 KiB (A 32 KiB | W 32 KiB).
+//
+// Schedule (cdna guide, 8-phase template and "Two waves per SIMD"): each K-tile is four phases, one accumulator
+// quadrant (64 rows x 32 cols, 16 MFMAs) per phase; a phase is  [LOAD segment: ds_read fragments + 2 global_load_lds]
+// s_barrier [COMPUTE segment: 16 MFMAs] s_barrier.  The two wave groups wr=0 / wr=1 (which share SIMDs pairwise) run
+// staggered by one barrier, so one group's LOAD segment sits beside the other group's COMPUTE segment: the matrix pipe
+// sees back-to-back MFMA clusters while LDS reads and DMA issue hide under the partner's MFMAs.
+//   quadrant order per K-tile: (a0,b0) (a0,b1) (a1,b1) (a1,b0)  -> fragment reads: 8+4, 4, 8, 0 ds_read_b128
+// Prefetch: the loads of K-tile t+2 go into the buffer K-tile t occupied, W part first (dead after phase 1 of tile t),
+// then the A part (dead after phase 2), 2 instructions per phase; they are retired by ONE counted s_waitcnt vmcnt per
+// K-tile, placed before the barrier that precedes the first read of that buffer (hazard analysis in DESIGN.md).
+#pragma once
+#include "la_gemm_core.h"
+
+namespace la {
+namespace gemm {
+
+struct PP {
+    static constexpr int TM = 256, TN = 256, THREADS = 512;
+    static constexpr int OPB = 256 * BKB;       // one operand of one K-tile: 32 KiB
+    static constexpr int BUF = 2 * OPB;         // 64 KiB
+    static constexpr int LDS = 2 * BUF;         // 128 KiB
+};
+
+// piece p (0..31) of an operand tile = rows 8p..8p+7; each wave stages 4 pieces of W and 4 of A per K-tile
+__device__ __forceinline__ void pp_stage_piece(const unsigned char *src, int64_t ld_bytes, int row0, int last_row,
+                                               unsigned char *lds_op, int piece, int lane) {
+    const int rt = piece * 8 + (lane >> 3);
+    int row = row0 + rt;
+    row = row > last_row ? last_row : row;
+    const unsigned char *g = src + (int64_t)row * ld_bytes + (((lane & 7) ^ swz(rt)) << 4);
+    la::glds16(g, lds_op + piece * 1024);
+}
+
+// raw barrier fenced for the COMPILER on both sides (memory ops and, via sched_barrier, MFMAs stay in their segment)
+#define LA_PP_BARRIER()                      \
+    do {                                     \
+        __builtin_amdgcn_sched_barrier(0);   \
+        asm volatile("" ::: "memory");       \
+        __builtin_amdgcn_s_barrier();        \
+        asm volatile("" ::: "memory");       \
+        __builtin_amdgcn_sched_barrier(0);   \
+    } while (0)
+
+// acc[mi][ni]: rows m = m0 + wr*128 + mi*16 + (lane & 15); cols n = n0 + wc*64 + ni*16 + (lane >> 4)*4 + reg
+// DBG (developer probes, LA_PP_DBG): bit0 = no in-loop DMA, bit1 = no MFMA, bit2 = s_setprio around the MFMA clusters
+template <int DBG>
+__device__ __forceinline__ void mainloop_pp(const bf16_t *A, int64_t lda, int M, const bf16_t *W, int64_t ldw, int N, int K,
+                                            int m0, int n0, unsigned char *lds, f32x4 (&acc)[8][4]) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: scalar branches, no exec masking
+    const int wr = wave >> 2, wc = wave & 3;       // group = wr: waves 0-3 / 4-7 pair up on the SIMDs
+    const int r = lane & 15, q = lane >> 4;
+    const int nk = K / 64;
+    const unsigned char *Ab = reinterpret_cast<const unsigned char *>(A);
+    const unsigned char *Wb = reinterpret_cast<const unsigned char *>(W);
+    const int64_t lda_b = lda * 2, ldw_b = ldw * 2;
+
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // this wave's 4 pieces of each operand tile: pieces 4*wave .. 4*wave+3, two per issue slot.  Per-lane byte offsets
+    // (row clamp + source-side swizzle) are loop invariant; the K advance lives in the scalar base pointer.
+    unsigned voff_a[4], voff_w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rt = (4 * wave + i) * 8 + (lane >> 3);
+        const int sw = ((lane & 7) ^ swz(rt)) << 4;
+        int ra = m0 + rt; ra = ra > M - 1 ? M - 1 : ra;
+        int rw = n0 + rt; rw = rw > N - 1 ? N - 1 : rw;
+        voff_a[i] = (unsigned)((int64_t)ra * lda_b - (int64_t)m0 * lda_b) + sw;   // relative to row m0: stays < 2^32
+        voff_w[i] = (unsigned)((int64_t)rw * ldw_b - (int64_t)n0 * ldw_b) + sw;
+    }
+    const unsigned char *a_row0 = Ab + (int64_t)m0 * lda_b;
+    const unsigned char *w_row0 = Wb + (int64_t)n0 * ldw_b;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_u32(lds));
+    auto issue_w = [&](int kt, int half) {   // half 0/1 -> pieces 4*wave + 2*half + {0,1} of the W tile of K-tile kt
+        if ((DBG & 1) && kt >= 2) return;
+        const unsigned dst = lds0 + (kt & 1) * PP::BUF + PP::OPB + (4 * wave + 2 * half) * 1024;
+        const unsigned char *src = w_row0 + (int64_t)kt * BKB;
+        glds16_so(voff_w[2 * half], src, dst);
+        glds16_so(voff_w[2 * half + 1], src, dst + 1024);
+    };
+    auto issue_a = [&](int kt, int half) {
+        if ((DBG & 1) && kt >= 2) return;
+        const unsigned dst = lds0 + (kt & 1) * PP::BUF + (4 * wave + 2 * half) * 1024;
+        const unsigned char *src = a_row0 + (int64_t)kt * BKB;
+        glds16_so(voff_a[2 * half], src, dst);
+        glds16_so(voff_a[2 * half + 1], src, dst + 1024);
+    };
+
+    // ---- prologue: K-tiles 0 and 1 completely (the steady-state schedule starts with tile 2) ----
+    issue_w(0, 0); issue_w(0, 1); issue_a(0, 0); issue_a(0, 1);
+    if (nk > 1) { issue_w(1, 0); issue_w(1, 1); issue_a(1, 0); issue_a(1, 1); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    LA_PP_BARRIER();
+    if (wr == 1) LA_PP_BARRIER();   // stagger: group 1 runs one barrier behind group 0
+
+    uint4 af[8], b0f[4], b1f[4];    // a: 4 row tiles x 2 k-steps; b0 / b1: 2 column tiles x 2 k-steps each
+    auto read_a = [&](const unsigned char *abuf, int half) {   // rows wr*128 + half*64 + mi*16 + r
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) af[mi * 2 + ks] = read_frag(abuf, wr * 128 + half * 64 + mi * 16 + r, ks * 4 + q);
+    };
+    auto read_b = [&](const unsigned char *wbuf, int half, uint4 (&bf)[4]) {   // W rows wc*64 + half*32 + ni*16 + r
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) bf[ni * 2 + ks] = read_frag(wbuf, wc * 64 + half * 32 + ni * 16 + r, ks * 4 + q);
+    };
+    auto mma_quadrant = [&](int ah, int bh, const uint4 (&bf)[4]) {
+        if (DBG & 2) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(af[i].x), "v"(af[i].y), "v"(af[i].z), "v"(af[i].w));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(bf[i].x), "v"(bf[i].y), "v"(bf[i].z), "v"(bf[i].w));
+            return;
+        }
+        if (DBG & 4) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    Mma<bf16_t>::run(bf[ni * 2 + ks], af[mi * 2 + ks], acc[ah * 4 + mi][bh * 2 + ni]);
+        if (DBG & 4) __builtin_amdgcn_s_setprio(0);
+    };
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const unsigned char *abuf = lds + (kt & 1) * PP::BUF;
+        const unsigned char *wbuf = abuf + PP::OPB;
+        const bool pf2 = kt + 2 < nk;
+        // Issue slots while tile kt is computed (2 instructions per phase and wave; a buffer half is refilled only
+        // after the barrier that follows the completion of its last fragment read by BOTH groups):
+        //   group 0:  ph0 W half 1 of kt+1 | ph1 A half 0 of kt+1 | ph2 A half 1 of kt+1 | ph3 W half 0 of kt+2
+        //   group 1:  ph0 A half 0 of kt+1 | ph1 A half 1 of kt+1 | ph2 W half 0 of kt+2 | ph3 W half 1 of kt+2
+        // ---------------- phase 0: quadrant (a0, b0) ----------------
+        read_a(abuf, 0);
+        read_b(wbuf, 0, b0f);
+        if (wr == 0) { if (kt >= 1 && kt + 1 < nk) issue_w(kt + 1, 1); }   // g0: 2nd W half of tile kt+1 (buffer of kt-1)
+        else         { if (kt >= 1 && kt + 1 < nk) issue_a(kt + 1, 0); }   // g1: 1st A half of tile kt+1
+        LA_PP_BARRIER();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        mma_quadrant(0, 0, b0f);
+        LA_PP_BARRIER();
+        // ---------------- phase 1: quadrant (a0, b1) ----------------
+        read_b(wbuf, 1, b1f);
+        if (wr == 0) { if (kt >= 1 && kt + 1 < nk) issue_a(kt + 1, 0); }   // g0: 1st A half of tile kt+1
+        else         { if (kt >= 1 && kt + 1 < nk) issue_a(kt + 1, 1); }   // g1: 2nd A half of tile kt+1
+        LA_PP_BARRIER();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        mma_quadrant(0, 1, b1f);
+        LA_PP_BARRIER();
+        // ---------------- phase 2: quadrant (a1, b1) ----------------
+        read_a(abuf, 1);
+        if (wr == 0) { if (kt >= 1 && kt + 1 < nk) issue_a(kt + 1, 1); }   // g0: 2nd A half of tile kt+1
+        else         { if (pf2) issue_w(kt + 2, 0); }                       // g1: 1st W half of tile kt+2 (W of kt dead after phase 1)
+        LA_PP_BARRIER();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        mma_quadrant(1, 1, b1f);
+        LA_PP_BARRIER();
+        // ---------------- phase 3: quadrant (a1, b0) ----------------
+        if (wr == 0) { if (pf2) issue_w(kt + 2, 0); }                       // g0: 1st W half of tile kt+2
+        else {
+            if (pf2) issue_w(kt + 2, 1);                                    // g1: 2nd W half of tile kt+2
+            // g1's LOAD segment closes with the barrier that precedes g0's first read of tile kt+1: retire everything
+            // of tile kt+1 (issued >= 2 segments ago); only tile kt+2's 4 W instructions may stay in flight
+            if (pf2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        LA_PP_BARRIER();
+        __builtin_amdgcn_sched_barrier(0);
+        mma_quadrant(1, 0, b0f);
+        if (wr == 0) {
+            // g0's COMPUTE segment closes with the same barrier: only tile kt+2's 2 W instructions may stay in flight
+            if (pf2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        LA_PP_BARRIER();
+    }
+    if (wr == 0) LA_PP_BARRIER();   // re-align the groups
+}
+
+}  // namespace gemm
+}  // namespace la
