@@ -51,25 +51,38 @@ __device__ __forceinline__ void glds16(const void *g, void *l) {
 __device__ __forceinline__ int kswz(int r) { return (r >> 1) & 7; }
 __device__ __forceinline__ int vswz(int r) { return ((r >> 1) & 1) << 2; }
 
-__device__ __forceinline__ void stage_kv_bf16(const bf16_t *kbase, const bf16_t *vbase, int64_t ld, int key0, int T,
-                                              unsigned char *kl, unsigned char *vl, int wave, int lane) {
+// K/V staging: 2 pieces (8 rows x 128 B) of each per wave and tile.  The per-lane byte offset of a piece (tile row *
+// pitch + source-side swizzled slot) is loop invariant; the tile advance is a scalar base bump.  Rows past the end of
+// the clip (last tile only) are clamped to the last key -- they are masked to -inf in the scores.
+struct KvOff { unsigned k[2], v[2]; };
+__device__ __forceinline__ KvOff kv_offsets_bf16(int64_t ld, int key0, int T, int wave, int lane) {
+    KvOff o;
     const int r8 = lane >> 3, ps = lane & 7;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int piece = wave * 2 + i;
-        const int r = piece * 8 + r8;
-        int key = key0 + r;
-        key = key < T ? key : T - 1;
-        glds16(kbase + (int64_t)key * ld + ((ps ^ kswz(r)) << 3), kl + piece * 1024);
-        glds16(vbase + (int64_t)key * ld + ((ps ^ vswz(r)) << 3), vl + piece * 1024);
+        const int r = (wave * 2 + i) * 8 + r8;
+        int rr = key0 + r < T ? r : T - 1 - key0;
+        o.k[i] = (unsigned)(rr * ld * 2) + ((ps ^ kswz(r)) << 4);
+        o.v[i] = (unsigned)(rr * ld * 2) + ((ps ^ vswz(r)) << 4);
+    }
+    return o;
+}
+__device__ __forceinline__ void stage_kv_bf16(const bf16_t *kbase, const bf16_t *vbase, int64_t ld, int key0, const KvOff &o,
+                                              unsigned kl, unsigned vl, int wave) {
+    const bf16_t *ks = kbase + (int64_t)key0 * ld, *vs = vbase + (int64_t)key0 * ld;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        la::glds16_so(o.k[i], ks, kl + (wave * 2 + i) * 1024);
+        la::glds16_so(o.v[i], vs, vl + (wave * 2 + i) * 1024);
     }
 }
 
-__global__ __launch_bounds__(256) void attention_bf16_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, 2) void attention_bf16_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * KT * 128];  // [buf][K|V][64][128 B] = 32 KiB
     const int T = p.frames;
     const int qt = blockIdx.x, head = blockIdx.y, clip = blockIdx.z;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i32 = lane & 31, h = lane >> 5;
     const int d = p.n_head * 64;
     const bf16_t *base = reinterpret_cast<const bf16_t *>(p.qkv) + (int64_t)clip * T * p.ld_qkv + head * 64;
@@ -91,7 +104,10 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(AttnParams p) {
     float m_run = -INFINITY, l_part = 0.f;
 
     const int nkv = (T + KT - 1) / KT;
-    stage_kv_bf16(kbase, vbase, p.ld_qkv, 0, T, lds, lds + KT * 128, wave, lane);
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(la::lds_addr_u32(lds));
+    const KvOff off_full = kv_offsets_bf16(p.ld_qkv, 0, KT, wave, lane);                 // every row valid
+    const KvOff off_last = kv_offsets_bf16(p.ld_qkv, (nkv - 1) * KT, T, wave, lane);      // rows clamped to key T-1
+    stage_kv_bf16(kbase, vbase, p.ld_qkv, 0, nkv == 1 ? off_last : off_full, lds0, lds0 + KT * 128, wave);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -103,8 +119,8 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(AttnParams p) {
         const unsigned char *kl = lds + cur * (2 * KT * 128);
         const unsigned char *vl = kl + KT * 128;
         if (t + 1 < nkv) {
-            unsigned char *nk = lds + (cur ^ 1) * (2 * KT * 128);
-            stage_kv_bf16(kbase, vbase, p.ld_qkv, (t + 1) * KT, T, nk, nk + KT * 128, wave, lane);
+            const unsigned nk = lds0 + (cur ^ 1) * (2 * KT * 128);
+            stage_kv_bf16(kbase, vbase, p.ld_qkv, (t + 1) * KT, t + 2 == nkv ? off_last : off_full, nk, nk + KT * 128, wave);
         }
         // ---- S^T = K Q^T : two 32-key sub-tiles ----
         f32x16 s[2];
@@ -148,10 +164,12 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(AttnParams p) {
                 psum += pv;
             }
         l_part = l_part * alpha + psum;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {   // wave-uniform; exact: alpha == 1 changes nothing
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+            for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[b][r] *= alpha;
+                for (int r = 0; r < 16; ++r) o[b][r] *= alpha;
+        }
         // ---- O^T += V^T P^T ----
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
@@ -218,7 +236,7 @@ __device__ __forceinline__ void stage_kv_f32(const float *kbase, const float *vb
     }
 }
 
-__global__ __launch_bounds__(256) void attention_f32_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, 2) void attention_f32_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // [buf][K|V][64][256 B] = 64 KiB
     const int T = p.frames;
     const int qt = blockIdx.x, head = blockIdx.y, clip = blockIdx.z;

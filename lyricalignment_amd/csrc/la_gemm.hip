@@ -152,7 +152,8 @@ __global__ __launch_bounds__(PP::THREADS, 2) void gemm_pp_kernel(GemmParams p) {
     const float *bias = p.bias ? p.bias + (int64_t)z * p.strideBias : nullptr;
 
     f32x4 acc[8][4];
-    mainloop_pp<DBG>(A, p.lda, p.M, W, p.K, p.N, p.K, m0, n0, lds, acc);
+    if constexpr (DBG == 8) mainloop_flat256(A, p.lda, p.M, W, p.K, p.N, p.K, m0, n0, lds, acc);
+    else mainloop_pp<DBG>(A, p.lda, p.M, W, p.K, p.N, p.K, m0, n0, lds, acc);
 
     typedef typename std::conditional<OUT_F32, float, bf16_t>::type TC;
     TC *C = reinterpret_cast<TC *>(p.C) + (int64_t)z * p.strideC;
@@ -242,6 +243,7 @@ int launch_pp(GemmParams p, int batch, hipStream_t stream) {
         case 2: return launch_pp_dbg<OUT_F32, 2>(p, batch, stream);
         case 3: return launch_pp_dbg<OUT_F32, 3>(p, batch, stream);
         case 4: return launch_pp_dbg<OUT_F32, 4>(p, batch, stream);
+        case 8: return launch_pp_dbg<OUT_F32, 8>(p, batch, stream);
         default: return launch_pp_dbg<OUT_F32, 0>(p, batch, stream);
     }
 }

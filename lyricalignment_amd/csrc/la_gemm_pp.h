@@ -192,5 +192,63 @@ __device__ __forceinline__ void mainloop_pp(const bf16_t *A, int64_t lda, int M,
     if (wr == 0) LA_PP_BARRIER();   // re-align the groups
 }
 
+// Same 256x256 tile / wave layout with the plain structure: ONE barrier per K-tile, the next tile's 8 DMA pieces per
+// wave issued right after it, fragment reads and MFMAs left to the compiler's interleave (2 waves per SIMD cover each
+// other's LDS latency).  Kept as the A/B partner of the ping-pong schedule (LA_PP_DBG=8).
+__device__ __forceinline__ void mainloop_flat256(const bf16_t *A, int64_t lda, int M, const bf16_t *W, int64_t ldw, int N, int K,
+                                                 int m0, int n0, unsigned char *lds, f32x4 (&acc)[8][4]) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int r = lane & 15, q = lane >> 4;
+    const int nk = K / 64;
+    const int64_t lda_b = lda * 2, ldw_b = ldw * 2;
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    unsigned voff_a[4], voff_w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rt = (4 * wave + i) * 8 + (lane >> 3);
+        const int sw = ((lane & 7) ^ swz(rt)) << 4;
+        int ra = m0 + rt; ra = ra > M - 1 ? M - 1 : ra;
+        int rw = n0 + rt; rw = rw > N - 1 ? N - 1 : rw;
+        voff_a[i] = (unsigned)((int64_t)(ra - m0) * lda_b) + sw;
+        voff_w[i] = (unsigned)((int64_t)(rw - n0) * ldw_b) + sw;
+    }
+    const unsigned char *a_row0 = reinterpret_cast<const unsigned char *>(A) + (int64_t)m0 * lda_b;
+    const unsigned char *w_row0 = reinterpret_cast<const unsigned char *>(W) + (int64_t)n0 * ldw_b;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_u32(lds));
+    auto issue = [&](int kt) {
+        const unsigned da = lds0 + (kt & 1) * PP::BUF + 4 * wave * 1024, dw = da + PP::OPB;
+        const unsigned char *sa = a_row0 + (int64_t)kt * BKB, *sw = w_row0 + (int64_t)kt * BKB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { glds16_so(voff_w[i], sw, dw + i * 1024); glds16_so(voff_a[i], sa, da + i * 1024); }
+    };
+    issue(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // tile kt landed (issued one whole K-tile of MFMAs ago)
+        __builtin_amdgcn_s_barrier();                          // ... for every wave; and every wave is done reading tile kt-1
+        asm volatile("" ::: "memory");
+        if (kt + 1 < nk) issue(kt + 1);
+        const unsigned char *abuf = lds + (kt & 1) * PP::BUF + (wr * 128) * BKB;
+        const unsigned char *wbuf = lds + (kt & 1) * PP::BUF + PP::OPB + (wc * 64) * BKB;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 wf[4];
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) wf[ni] = read_frag(wbuf, ni * 16 + r, ks * 4 + q);
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) {
+                const uint4 af = read_frag(abuf, mi * 16 + r, ks * 4 + q);
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) Mma<bf16_t>::run(wf[ni], af, acc[mi][ni]);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 }  // namespace gemm
 }  // namespace la
