@@ -234,6 +234,40 @@ int la_fc_emissions(int32_t dtype, const void *act, int64_t ld_act, const void *
                     float *em, int64_t em_batch_stride, int64_t em_row_stride,
                     void *workspace, size_t workspace_bytes, void *stream);
 
+/* ------------------------------------------------------------------------- */
+/* fine-tune path: losses on the align logits and the optimizer step          */
+/* ------------------------------------------------------------------------- */
+/*
+ * compute_ce_loss(compute_sil=True) + compute_ctc_loss (train_multitask.py:587-633), forward and gradient with
+ * respect to the logits.  logits [batch][frames][row_stride >= vocab+1] f32: columns 0..vocab-1 are the word classes
+ * (column 0 = CTC blank), column `vocab` the silence logit (vocab = 21128 in the reference).
+ *   frame_labels [batch*frames] i32: class id (>= 1) of the frame or -100 (already trimmed / padded to `frames`,
+ *                train_multitask.py:596-603); the reference's "-1" shift (:607) is folded into the column choice.
+ *   ctc_labels [batch][labels_stride] i32 class ids, n_labels[b] of them valid (target_length, :629).
+ * losses[0] = word CE (mean over frames with a label), losses[1] = silence BCE (mean over all frames),
+ * losses[2] = CTC (mean over the batch of nll_b / n_labels[b]; +inf if an utterance is infeasible).
+ * dlogits (optional, same layout) receives scale * d(losses[0]+losses[1]+losses[2]) / dlogits, restricted to the
+ * requested terms (use_ce / use_ctc).  The alpha/beta lattice runs one workgroup per utterance, one lane per state.
+ */
+int la_multitask_loss_workspace_bytes(int32_t batch, int32_t frames, int32_t max_labels, size_t *bytes);
+int la_multitask_loss(const float *logits, int64_t batch_stride, int64_t row_stride, int32_t batch, int32_t frames,
+                      int32_t vocab, const int32_t *frame_labels, const int32_t *ctc_labels, int32_t labels_stride,
+                      const int32_t *n_labels, int32_t max_labels, int32_t use_ce, int32_t use_ctc, float scale,
+                      float *losses, float *dlogits, int64_t d_batch_stride, int64_t d_row_stride,
+                      void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * clip_grad_norm_(params, max_norm) + AdamW on flat f32 buffers (train_multitask.py:337-340,683-686).
+ * la_grad_sqnorm_f32 ADDS sum(grad^2) into *sum_sq (device double; zero it once, call it per bucket, all-reduce is the
+ * caller's: gradients are already averaged over ranks before this).  la_adamw_step_f32 applies
+ *   g' = g * grad_prescale * min(1, max_norm / (sqrt(*clip_sum_sq) * grad_prescale + 1e-6))    (clip_sum_sq may be NULL)
+ *   p *= 1 - lr*wd;  m = b1 m + (1-b1) g';  v = b2 v + (1-b2) g'^2;  p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+ */
+int la_grad_sqnorm_f32(const float *grad, int64_t n, double *sum_sq, void *stream);
+int la_adamw_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr,
+                      float beta1, float beta2, float eps, float weight_decay, int32_t step,
+                      const double *clip_sum_sq, float max_norm, float grad_prescale, void *stream);
+
 /* elementwise helpers used by the host-side plumbing */
 int la_cast_f32_to_bf16(const float *x, void *y, int64_t n, void *stream);
 int la_cast_bf16_to_f32(const void *x, float *y, int64_t n, void *stream);

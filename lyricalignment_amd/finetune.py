@@ -1,0 +1,108 @@
+"""Host plumbing of the fine-tune row (e): the reference's losses on the align logits
+(train_multitask.py:587-633), clip_grad_norm_ + AdamW (:337-340, 683-686) and -- new in this build -- the data-parallel
+gradient exchange (one flat all-reduce per optimizer step over RCCL / xGMI, placed BEFORE the clip).
+Arithmetic = HIP kernels (la_multitask_loss, la_grad_sqnorm_f32, la_adamw_step_f32) and the collective; nothing here
+computes on tensors.
+
+NOT built yet (DESIGN.md "next"): the backward pass through the head / encoder kernels and the Whisper decoder, so a full
+train_multitask.py step does not run on this engine yet; these pieces are the parts of that step that sit on flat
+buffers and on the logits.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import check, lib, ptr, stream_ptr
+
+
+def pad_frame_labels(frame_labels: torch.Tensor, frames: int) -> torch.Tensor:
+    """train_multitask.py:596-603: trim / right-pad the frame labels with -100 to the logits' frame count (data movement)."""
+    fl = frame_labels[:, :frames]
+    if fl.shape[1] < frames:
+        fl = torch.cat((fl, torch.full((fl.shape[0], frames - fl.shape[1]), -100, dtype=fl.dtype, device=fl.device)), dim=1)
+    return fl
+
+
+def multitask_loss(logits: torch.Tensor, frame_labels: Optional[torch.Tensor], ctc_labels: Optional[torch.Tensor],
+                   vocab_size: int = 21128, scale: float = 1.0, want_grad: bool = True):
+    """logits [B,T,vocab_size+1] f32 (device).  frame_labels [B,<=T] with -100 (or None: no CE/BCE);
+    ctc_labels [B,Lmax] with -100 padding (or None: no CTC).
+    -> (losses f32[3] = [word CE, silence BCE, CTC] on the device, dlogits or None).
+    compute_ce_loss(...) == losses[0] + losses[1]; compute_ctc_loss(...) == losses[2]."""
+    _lib.require_gpu()
+    if not logits.is_cuda or logits.dtype != torch.float32 or logits.dim() != 3 or not logits.is_contiguous():
+        raise ValueError("multitask_loss: logits must be a contiguous float32 device tensor [B,T,V+1]")
+    B, T, W = logits.shape
+    if W < vocab_size + 1:
+        raise ValueError("multitask_loss: logits need vocab_size + 1 columns (word classes + silence)")
+    dev = logits.device
+    fl = None
+    if frame_labels is not None:
+        fl = pad_frame_labels(frame_labels.to(dev), T).to(torch.int32).contiguous()
+    lab = nl = None
+    Lmax = 1
+    if ctc_labels is not None:
+        cl = ctc_labels.to(dev)
+        nl = (cl != -100).sum(dim=1).to(torch.int32).contiguous()          # target_length (:629); data-dependent count, not arithmetic of the path
+        lab = torch.where(cl == -100, torch.zeros_like(cl), cl).to(torch.int32).contiguous()
+        Lmax = max(1, lab.shape[1])
+    losses = torch.empty((3,), dtype=torch.float32, device=dev)
+    dlogits = torch.empty_like(logits) if want_grad else None
+    need = ctypes.c_size_t(0)
+    check(lib().la_multitask_loss_workspace_bytes(B, T, Lmax, ctypes.byref(need)), "multitask_loss_workspace_bytes")
+    ws = torch.empty((need.value,), dtype=torch.uint8, device=dev)
+    check(lib().la_multitask_loss(ptr(logits), logits.stride(0), logits.stride(1), B, T, vocab_size, ptr(fl), ptr(lab),
+                                  lab.stride(0) if lab is not None else 0, ptr(nl), Lmax, 1 if fl is not None else 0,
+                                  1 if lab is not None else 0, float(scale), ptr(losses), ptr(dlogits),
+                                  dlogits.stride(0) if want_grad else 0, dlogits.stride(1) if want_grad else 0, ptr(ws),
+                                  need.value, stream_ptr()), "multitask_loss")
+    return losses, dlogits
+
+
+class FlatAdamW:
+    """clip_grad_norm_(all params, max_norm) + AdamW over flat f32 buckets, one bucket per parameter group
+    (reference: head lr 5e-3, backbone lr 5e-6, weight_decay 1e-5, betas (0.9, 0.999), eps 1e-8)."""
+
+    def __init__(self, groups: Sequence[dict], weight_decay: float = 1e-5, betas=(0.9, 0.999), eps: float = 1e-8):
+        _lib.require_gpu()
+        self.groups = []
+        for g in groups:
+            p = g["params"]
+            if not (p.is_cuda and p.dtype == torch.float32 and p.dim() == 1 and p.is_contiguous()):
+                raise ValueError("FlatAdamW: each group needs a flat contiguous float32 device parameter buffer")
+            self.groups.append(dict(params=p, lr=float(g["lr"]), m=torch.zeros_like(p), v=torch.zeros_like(p)))
+        self.wd, self.betas, self.eps, self.t = weight_decay, betas, eps, 0
+        self._sumsq = torch.zeros((1,), dtype=torch.float64, device=self.groups[0]["params"].device)
+
+    def step(self, grads: Sequence[torch.Tensor], max_norm: Optional[float] = 1.0, grad_prescale: float = 1.0,
+             lr_scale: float = 1.0) -> torch.Tensor:
+        """grads: one flat buffer per group (already averaged over ranks).  Returns the device scalar sum(grad^2)."""
+        self.t += 1
+        L, s = lib(), stream_ptr()
+        self._sumsq.zero_()
+        if max_norm is not None:
+            for g in grads:
+                check(L.la_grad_sqnorm_f32(ptr(g), g.numel(), ptr(self._sumsq), s), "grad_sqnorm")
+        for grp, g in zip(self.groups, grads):
+            if g.numel() != grp["params"].numel() or g.dtype != torch.float32 or not g.is_contiguous():
+                raise ValueError("FlatAdamW.step: gradient bucket does not match its parameter bucket")
+            check(L.la_adamw_step_f32(ptr(grp["params"]), ptr(g), ptr(grp["m"]), ptr(grp["v"]), g.numel(), grp["lr"] * lr_scale,
+                                      self.betas[0], self.betas[1], self.eps, self.wd, self.t,
+                                      ptr(self._sumsq) if max_norm is not None else 0, float(max_norm or 0.0),
+                                      float(grad_prescale), s), "adamw_step")
+        return self._sumsq
+
+
+def allreduce_mean_(buckets: Sequence[torch.Tensor], world: int) -> None:
+    """The data-parallel exchange step: ONE all-reduce (sum) per flat gradient bucket per optimizer step, then the mean is
+    folded into the optimizer's grad_prescale (1/world) by the caller -- or applied here for backends without a fused path.
+    RCCL over xGMI on the GPU box (backend 'nccl'), gloo in the CPU tests.  No-op for world == 1."""
+    if world == 1:
+        return
+    import torch.distributed as dist
+    for b in buckets:
+        dist.all_reduce(b, op=dist.ReduceOp.SUM)

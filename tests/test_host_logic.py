@@ -195,3 +195,42 @@ def test_sharded_evaluation_world_size_2_gloo(tmp_path):
     for o in outs:
         assert o["items"] == list(range(9)) and o["owners"] == [i % 2 for i in range(9)]
         assert abs(o["avg"] - expect) < 1e-15
+
+
+_WORKER_AR = r'''
+import os, sys, json
+sys.path.insert(0, %(root)r)
+import torch, torch.distributed as dist
+from lyricalignment_amd.finetune import allreduce_mean_
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group(backend="gloo", init_method="tcp://127.0.0.1:%(port)d", rank=rank, world_size=world)
+g = torch.Generator().manual_seed(100 + rank)
+head, backbone = torch.randn(1000, generator=g), torch.randn(257, generator=g)
+allreduce_mean_([head, backbone], world)          # ONE collective per flat bucket per optimizer step
+print(json.dumps({"rank": rank, "head": head[:5].tolist(), "hs": float(head.sum()), "bs": float(backbone.sum())}))
+dist.destroy_process_group()
+'''
+
+
+def test_gradient_allreduce_world_size_2_gloo(tmp_path):
+    """Data-parallel exchange of the fine-tune path on CPU/gloo: after the all-reduce both ranks hold the SUM of the
+    two ranks' flat gradient buckets (the 1/world mean is folded into the optimizer's grad_prescale)."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "worker_ar.py"
+    script.write_text(_WORKER_AR % {"root": ROOT, "port": port})
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=180)
+        assert p.returncode == 0, e[-2000:]
+        outs.append(json.loads(o.strip().splitlines()[-1]))
+    g0, g1 = torch.Generator().manual_seed(100), torch.Generator().manual_seed(101)
+    h = torch.randn(1000, generator=g0); b = torch.randn(257, generator=g0)
+    h = h + torch.randn(1000, generator=g1); b = b + torch.randn(257, generator=g1)
+    for o in outs:
+        np.testing.assert_allclose(o["head"], h[:5].numpy(), rtol=1e-6)
+        np.testing.assert_allclose([o["hs"], o["bs"]], [float(h.sum()), float(b.sum())], rtol=1e-5)
