@@ -268,6 +268,14 @@ int la_adamw_step_f32(float *param, const float *grad, float *exp_avg, float *ex
                       float beta1, float beta2, float eps, float weight_decay, int32_t step,
                       const double *clip_sum_sq, float max_norm, float grad_prescale, void *stream);
 
+/*
+ * Polyphase FIR resampling (audio front end, utils/audio.py:3-20: librosa.load(file, sr=16000)):
+ * y[n] = sum_k h[(n + skip)*down - k*up] * x[k], n < n_out.  h is the centred low-pass (host-built Kaiser-windowed sinc,
+ * gain `up`, zero pre-padded so that `skip` whole output samples are dropped), as in scipy.signal.resample_poly.
+ */
+int la_resample_poly_f32(const float *x, int64_t n_in, const float *h, int64_t h_len, int32_t up, int32_t down,
+                         int64_t skip, float *y, int64_t n_out, void *stream);
+
 /* elementwise helpers used by the host-side plumbing */
 int la_cast_f32_to_bf16(const float *x, void *y, int64_t n, void *stream);
 int la_cast_bf16_to_f32(const void *x, float *y, int64_t n, void *stream);

@@ -404,7 +404,28 @@ def gen_harness():
     print("harness", avg, flush=True)
 
 
+# --------------------------------------------------------------------------- #
+# 7. collate-side label builders (dataset.py)                                    #
+# --------------------------------------------------------------------------- #
+def gen_dataset_labels():
+    import dataset as ref_ds
+    cases = []
+    for use_ctc in (True, False):
+        ds = ref_ds.AlignDataset(records=[], hf_tokenizer=None, use_ctc=use_ctc)
+        for toks, oo in (([5, 17, 17, 230], [[0.11, 0.51], [0.51, 0.99], [1.01, 1.49], [1.5, 1.75]]),
+                         ([401], [[0.0, 0.03]]),
+                         ([7, 8, 9], [[0.25, 0.45], [0.45, 0.65], [0.65, 3.756]])):
+            fl = ds._get_frame_label(torch.tensor(toks), oo)
+            cases.append(dict(use_ctc=use_ctc, tokens=toks, on_offset=oo, frame_labels=fl.tolist()))
+    with open(os.path.join(HERE, "frame_labels.json"), "w") as f:
+        json.dump(dict(reference="dataset.py:129-145 AlignDataset._get_frame_label", cases=cases), f, indent=1)
+    print("dataset labels", flush=True)
+
+
 if __name__ == "__main__":
+    if "--labels-only" in sys.argv:
+        gen_dataset_labels()
+        sys.exit(0)
     if "--harness-only" not in sys.argv:
         gen_core()
         gen_e2e()
@@ -412,6 +433,7 @@ if __name__ == "__main__":
         gen_head()
         gen_frames()
         gen_losses()
+        gen_dataset_labels()
     gen_harness()
     leftovers = [d for d, _, fs in os.walk(REF) if d.endswith("__pycache__")]
     assert not leftovers, f"bytecode written into the reference tree: {leftovers}"

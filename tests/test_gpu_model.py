@@ -259,3 +259,30 @@ def test_pipelined_aligner_matches_single_stream():
     for r, o in zip(ref, outs):
         assert torch.equal(r[0], o[0]) and torch.equal(r[1], o[1]) and torch.equal(r[3], o[3])
         assert torch.equal(r[2], o[2])
+
+
+def test_audio_loader_resample_matches_scipy(tmp_path):
+    """utils.audio.load_audio_file: WAV decode + device polyphase resampling vs scipy.signal.resample_poly
+    (the reference's librosa resampler is absent / un-pinned: parity with it is unpinned)."""
+    from scipy.io import wavfile
+    from scipy.signal import resample_poly
+    from lyricalignment_amd.utils.audio import load_audio_file
+    rs = np.random.RandomState(0)
+    for sr, n in ((44100, 44100 * 2 + 17), (48000, 30000), (22050, 9999), (16000, 5000)):
+        t = np.arange(n) / sr
+        stereo = np.stack([0.4 * np.sin(2 * np.pi * 440 * t) + 0.05 * rs.randn(n), 0.3 * np.sin(2 * np.pi * 1000 * t)], axis=1)
+        path = str(tmp_path / f"a{sr}.wav")
+        wavfile.write(path, sr, (stereo * 32767).astype(np.int16))
+        dec = (stereo * 32767).astype(np.int16).astype(np.float32) / 32768.0
+        from fractions import Fraction
+        fr = Fraction(16000, sr)
+        want_mono = resample_poly(dec.mean(axis=1).astype(np.float64), fr.numerator, fr.denominator) if sr != 16000 else dec.mean(axis=1)
+        got = load_audio_file(path, 0)
+        assert got["sampling_rate"] == 16000 and got["speech"].dtype == np.float32
+        np.testing.assert_allclose(got["speech"], want_mono, rtol=0, atol=2e-6)
+        want_ch1 = resample_poly(dec[:, 1].astype(np.float64), fr.numerator, fr.denominator) if sr != 16000 else dec[:, 1]
+        np.testing.assert_allclose(load_audio_file(path, 2)["speech"], want_ch1, rtol=0, atol=2e-6)
+        want_mix = (resample_poly(dec[:, 0].astype(np.float64), fr.numerator, fr.denominator) + want_ch1) / 2 if sr != 16000 else dec.mean(axis=1)
+        np.testing.assert_allclose(load_audio_file(path, 1)["speech"], want_mix, rtol=0, atol=2e-6)
+    with pytest.raises(ValueError):
+        load_audio_file(path, 3)

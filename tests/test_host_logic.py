@@ -234,3 +234,39 @@ def test_gradient_allreduce_world_size_2_gloo(tmp_path):
     for o in outs:
         np.testing.assert_allclose(o["head"], h[:5].numpy(), rtol=1e-6)
         np.testing.assert_allclose([o["hs"], o["bs"]], [float(h.sum()), float(b.sum())], rtol=1e-5)
+
+
+def test_frame_labels_and_records_match_reference(tmp_path):
+    from lyricalignment_amd import data
+    for c in load_json("frame_labels.json")["cases"]:
+        assert data.frame_labels(c["tokens"], c["on_offset"], use_ctc=c["use_ctc"]).tolist() == c["frame_labels"]
+    ids = torch.tensor([[101, 2769, 4638, 102, 0, 0], [101, 872, 102, 0, 0, 0]])
+    assert data.mask_special_tokens(ids).tolist() == [[2769, 4638, -100, -100, -100], [872, -100, -100, -100, -100]]
+    p = tmp_path / "d.json"
+    p.write_text(json.dumps([{"song_path": "/a.wav", "lyric": "abc", "on_offset": [[0, 1]]}, {"song_path": "/b.wav", "lyric": "d"}]))
+    recs = data.read_data(str(p))
+    assert recs[0].lyric_onset_offset == [[0, 1]] and recs[1].lyric_onset_offset is None and recs[1].text == "d"
+
+
+def test_checkpoint_round_trip_reference_layout(tmp_path):
+    """A directory in train_multitask.py's layout (state_dict with the reference's key names + model_args.json) loads into
+    the build's AlignModel, and what the build saves has exactly the reference's keys."""
+    from lyricalignment_amd import data, whisper_compat as wc
+    from lyricalignment_amd.module.align_model import AlignModel
+    dims = wc.ModelDimensions(n_audio_state=128, n_audio_head=2, n_audio_layer=2, n_text_state=128, n_text_head=2, n_text_layer=1, n_vocab=300, n_text_ctx=16)
+    src = AlignModel(wc.build_model(dims=dims, seed=5, with_decoder=True), embed_dim=128, hidden_dim=64, output_dim=77)
+    data.save_align_model(src, str(tmp_path), "best", whisper_model_name="tiny")
+    sd = torch.load(tmp_path / "best_model.pt")
+    head = load_json("head_state_dict_keys.json")
+    assert {k[len("align_rnn."):] for k in sd if k.startswith("align_rnn.")} == set(head)
+    for k in ("whisper_model.encoder.conv1.weight", "whisper_model.encoder.positional_embedding", "whisper_model.encoder.blocks.1.attn.key.weight",
+              "whisper_model.encoder.blocks.0.mlp.2.bias", "whisper_model.encoder.ln_post.weight", "whisper_model.decoder.token_embedding.weight",
+              "whisper_model.decoder.blocks.0.cross_attn.query.weight", "whisper_model.decoder.ln.bias"):
+        assert k in sd, k
+    assert "whisper_model.encoder.blocks.0.attn.key.bias" not in sd
+    sd["whisper_model.decoder.mask"] = torch.zeros(4, 4)          # older openai-whisper checkpoints persist this buffer
+    torch.save(sd, tmp_path / "best_model.pt")
+    dst = data.load_align_model(str(tmp_path), "best", device="cuda")
+    for k, v in src.state_dict().items():
+        assert torch.equal(dst.state_dict()[k], v), k
+    assert json.load(open(tmp_path / "model_args.json"))["output_dim"] == 77
