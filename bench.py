@@ -50,6 +50,31 @@ def total_flops_per_clip(d: int, n_layer: int, H: int = HIDDEN, V: int = VOCAB) 
     return float(enc + gru + 2 * T * 2 * H * V)
 
 
+def measured_gemm_traffic_per_launch():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950, WRITE_SIZE as is; both in KiB), averaged over the
+    encoder's four GEMM shapes weighted by their launches per step.  None if the summary is not there."""
+    path = os.path.join(ROOT, "profiles", "r1c_pmc_gemm_pp.csv")
+    if not os.path.exists(path):
+        return None
+    per_shape = {}
+    with open(path) as f:
+        next(f)
+        for line in f:
+            grid, variant, counter, val = line.strip().split(",")
+            per_shape.setdefault((grid, variant), {})[counter] = float(val)
+    # grid sizes (threads) of the config-2 shapes: QKV, MLP-up, and the two f32-out shapes (out-proj == MLP-down grid)
+    weights = {("1155072", "bf16out"): 24, ("1540096", "bf16out"): 24, ("385024", "f32out"): 48}
+    tot_b, tot_n = 0.0, 0
+    for key, n in weights.items():
+        c = per_shape.get(key)
+        if not c or "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+            return None
+        tot_b += n * (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+        tot_n += n
+    return tot_b / tot_n
+
+
 def build_inputs(device, seed_offset: int = 0):
     rs = np.random.RandomState(2 + seed_offset)
     mel = torch.from_numpy(rs.uniform(-1.0, 1.0, size=(BATCH, 80, 3000)).astype(np.float32)).to(device)
@@ -228,9 +253,10 @@ def main():
                        "clips_per_gpu": BATCH, "frames": T_FRAMES, "vocab": VOCAB, "labels_per_clip": "5..26",
                        "sharding": "clips over ranks, no collective"},
             "whole_path_tflops": total_flops_per_clip(dims.n_audio_state, dims.n_audio_layer) * BATCH * world * args.steps / elapsed / 1e12,
-            "roofline": {"bound": "mfma", "kernel": "gemm_kernel<bf16> (all linear / conv-as-GEMM launches)",
+            "roofline": {"bound": "mfma", "kernel": "gemm_pp_kernel / gemm_kernel <bf16> (every Linear, conv-as-GEMM and GRU input projection launch)",
                          "achieved": achieved_tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": achieved_tf / 2500.0,
-                         "traffic": None, "launches_per_step": launches.value / max(args.steps, 1),
+                         "traffic": measured_gemm_traffic_per_launch(), "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r1c_pmc_gemm_pp.csv)",
+                         "launches_per_step": launches.value / max(args.steps, 1),
                          "avg_launch_ms": total_ms.value / max(launches.value, 1)},
         }
         if not args.no_cpu_baseline:
