@@ -189,3 +189,36 @@ def test_fc_emissions_fused(variant, dtype, B, T, K, V):
         idx = labels[b, :L].long() - 1
         np.testing.assert_allclose(em[b, :, 1:1 + L].numpy(), lp[b][:, idx].numpy(), rtol=0, atol=tol)
         assert torch.equal(em[b, :, 5], em[b, :, 6]) if b == 0 else True  # repeated label -> identical columns
+
+
+@pytest.mark.parametrize("wt", [False, True])
+def test_gru_handoff_under_uneven_load(wt):
+    """The in-launch inter-workgroup hand-off of the persistent GRU must not depend on timing or placement: 12 runs of the
+    config-2 shape while another stream keeps the chip busy with GEMMs of varying size give bit-identical outputs."""
+    if wt:   # the write-through variant is selected per process: run this test body in a child with LA_GRU_WT=1
+        import os, subprocess, sys
+        env = dict(os.environ, LA_GRU_WT="1")
+        r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-m", "gpu", "-k", "test_gru_handoff_under_uneven_load and False"],
+                           env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        return
+    from lyricalignment_amd import ops
+    B, T, H = 32, 400, 384
+    g = torch.Generator().manual_seed(77)
+    gi = (torch.randn(B, T, 2, 3 * H, generator=g) * 0.5).cuda()
+    w = (torch.randn(2, 3 * H, H, generator=g) * H ** -0.5).bfloat16().cuda()
+    b = (torch.randn(2, 3 * H, generator=g) * 0.1).cuda()
+    ref, flag = ops.gru_layer(gi, w, b)
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 0
+    ref = ref.clone()
+    side = torch.cuda.Stream()
+    a = torch.randn(8192, 1024, device="cuda").bfloat16(); ww = torch.randn(4096, 1024, device="cuda").bfloat16()
+    for it in range(12):
+        with torch.cuda.stream(side):
+            for _ in range(1 + it % 4):
+                ops.gemm(a[: 1024 * (1 + it % 8)], ww)
+        out, flag = ops.gru_layer(gi, w, b)
+        torch.cuda.synchronize()
+        assert int(flag.item()) == 0
+        assert torch.equal(out, ref), f"run {it}: hand-off delivered stale or torn data"
