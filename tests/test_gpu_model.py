@@ -286,3 +286,40 @@ def test_audio_loader_resample_matches_scipy(tmp_path):
         np.testing.assert_allclose(load_audio_file(path, 1)["speech"], want_mix, rtol=0, atol=2e-6)
     with pytest.raises(ValueError):
         load_audio_file(path, 3)
+
+
+def test_large_v2_dims_one_layer():
+    """BASELINE configs[3] architecture (d=1280, 20 heads): one block of it through the bf16 and f32 paths vs the oracle."""
+    from lyricalignment_amd import whisper_compat as wc
+    from oracle import model_oracle as mo
+    dims = wc.ModelDimensions(n_audio_state=1280, n_audio_head=20, n_audio_layer=1, n_text_state=1280, n_text_head=20, n_text_layer=0)
+    wm = wc.build_model(dims=dims, seed=31, std=0.02)
+    mel = torch.rand(1, 80, 3000, generator=torch.Generator().manual_seed(32)) * 2 - 1
+    p = {"encoder." + k: v.detach().float() for k, v in wm.encoder.state_dict().items()}
+    ref = mo.encoder_forward(p, mel, n_head=20)
+    with torch.no_grad():
+        out = wm.embed_audio(mel.cuda()).cpu()        # bare Whisper object: float32 engine
+    np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=0, atol=1e-3)
+
+
+def test_long_form_three_minute_song_config5():
+    """BASELINE configs[4] shape: a 3-minute song -> 6 encoder chunks, T = 9000 frames, 150 labels (multi-wave DP with
+    backpointers in the HBM workspace, GRU recurrence over 9000 steps).  Device DP vs the oracle on the device's emissions."""
+    from lyricalignment_amd import _lib
+    from lyricalignment_amd.utils import alignment as ua
+    from oracle import alignment_oracle as ao
+    model = _small_model(torch.bfloat16, seed=41)
+    n = 16000 * 180
+    audio = _wave(n, 42)
+    rs = np.random.RandomState(43)
+    labels = torch.from_numpy(rs.randint(1, 299, size=(1, 150)))
+    with torch.no_grad():
+        on, off, score, status = model.align([audio], labels, use_ctc=True, return_frames=True)
+        eng = model.engine()
+        lab_dev, n_lab, lists = ua._labels_to_device(labels, 1, eng.device)
+        feats, B, T, stride = model._features(model._mel_of([audio]), True)
+        em = eng.emissions(feats, B, T, stride, lab_dev, n_lab, _lib.LA_VARIANT_CTC).cpu().numpy()
+    assert T == 9000 and int(status[0]) == 0
+    rc, on_o, off_o, sc_o = ao.align_frames_compact(em[0], np.array(lists[0]))
+    assert rc == 0 and on.cpu().numpy()[0].tolist() == on_o.tolist() and off.cpu().numpy()[0].tolist() == off_o.tolist()
+    assert float(score[0]) == sc_o
