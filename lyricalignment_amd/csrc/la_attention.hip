@@ -14,6 +14,8 @@
 //         V image; P is rounded to bf16 for the second product (f32 accumulate, f32 softmax).
 //   f32 : v_mfma_f32_32x32x2_f32 (exact fmaf chains): parity mode, P stays f32.
 // Softmax runs in the exp2 domain (v_exp_f32): p = exp2(s*log2e - m*log2e).
+#include <type_traits>
+
 #include "la_common.h"
 
 using la::bf16_t;
@@ -114,8 +116,9 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(AttnParams p) {
     // per-lane constant parts of the V^T transposed-read address
     const int g = lane >> 4, q4 = (lane & 15) >> 2, pp = lane & 3;
 
-    int cur = 0;
-    for (int t = 0; t < nkv; ++t) {
+    // the tile body is instantiated once per LDS buffer so every fragment address is (loop-invariant VGPR) + immediate
+    auto tile = [&](int t, auto curc) {
+        constexpr int cur = decltype(curc)::value;
         const unsigned char *kl = lds + cur * (2 * KT * 128);
         const unsigned char *vl = kl + KT * 128;
         if (t + 1 < nkv) {
@@ -195,7 +198,10 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(AttnParams p) {
             }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        cur ^= 1;
+    };
+    for (int t = 0; t < nkv; t += 2) {
+        tile(t, std::integral_constant<int, 0>{});
+        if (t + 1 < nkv) tile(t + 1, std::integral_constant<int, 1>{});
     }
 
     // ---- epilogue: O[q][dv] = O^T / l ----
