@@ -194,6 +194,18 @@ int la_layernorm(const float *x, int64_t ldx, int32_t M, int32_t d,
 int la_attention(int32_t dtype, const void *qkv, int64_t ld_qkv, void *out, int64_t ld_out,
                  int32_t batch, int32_t frames, int32_t n_head, void *stream);
 
+/* General form for the Whisper text decoder (whisper.model.TextDecoder; module/align_model.py:118-121): separate
+ * q [batch*q_len][>= n_head*64] and k / v [batch*kv_len][>= n_head*64] row sets (k and v share ld_kv), q pre-scaled.
+ * causal != 0: key j is visible to query i iff j <= i (decoder self-attention; requires q_len == kv_len). */
+int la_attention_ex(int32_t dtype, const void *q, int64_t ld_q, const void *k, const void *v, int64_t ld_kv,
+                    void *out, int64_t ld_out, int32_t batch, int32_t q_len, int32_t kv_len, int32_t n_head,
+                    int32_t causal, void *stream);
+
+/* x[b*n_tok + i][:] = token_embedding[tokens[b][i]][:] + positional_embedding[i][:]   (f32 tables, f32 out);
+ * TextDecoder.forward's first line.  tokens int64 [batch][n_tok]. */
+int la_embed_tokens(const int64_t *tokens, int32_t batch, int32_t n_tok, const float *token_embedding, int32_t n_vocab,
+                    const float *positional_embedding, int32_t d, float *x, void *stream);
+
 /* mel [batch][n_mels][frames] f32 -> channels-last zero-padded rows for the conv-as-GEMM view:
  * out[b][1 + t][c] (`dtype`), row pitch `c_pad`, (frames + 2) rows per clip, rows 0 and frames+1
  * and channels >= n_mels zeroed. */

@@ -38,6 +38,8 @@ SYMBOLS = {
     "la_gemm": (c_int32, [_I32, _I32, _I32, _I32, _I32, _P, _I64, _I64, _P, _P, _I64, _I64, _P, _P, _I64, _I64, _I32, _P]),
     "la_layernorm": (c_int32, [_P, _I64, _I32, _I32, _P, _P, _P, _I64, _I32, _P]),
     "la_attention": (c_int32, [_I32, _P, _I64, _P, _I64, _I32, _I32, _I32, _P]),
+    "la_attention_ex": (c_int32, [_I32, _P, _I64, _P, _P, _I64, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P]),
+    "la_embed_tokens": (c_int32, [_P, _I32, _I32, _P, _I32, _P, _I32, _P, _P]),
     "la_mel_to_rows": (c_int32, [_P, _I64, _I64, _I32, _I32, _I32, _P, _I32, _I32, _P]),
     "la_gru_workspace_bytes": (c_int32, [_I32, _I32, _I32, POINTER(_SZ)]),
     "la_gru_layer": (c_int32, [_I32, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _SZ, _P, _P]),

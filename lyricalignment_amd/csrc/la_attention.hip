@@ -31,11 +31,11 @@ constexpr int KT = 64;    // keys per tile
 constexpr float kLog2e = 1.4426950408889634f;
 
 struct AttnParams {
-    const void *qkv;
-    int64_t ld_qkv;
+    const void *q, *k, *v;   // rows [clip*q_len + i][head*64 ..] / [clip*kv_len + j][head*64 ..]
+    int64_t ld_q, ld_kv;
     void *out;
     int64_t ld_out;
-    int frames, n_head;
+    int q_len, kv_len, n_head, causal;
 };
 
 // accumulator register -> row (key / dv index) inside a 32x32 tile for lane half h
@@ -81,22 +81,22 @@ __device__ __forceinline__ void stage_kv_bf16(const bf16_t *kbase, const bf16_t 
 
 __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * KT * 128];  // [buf][K|V][64][128 B] = 32 KiB
-    const int T = p.frames;
+    const int T = p.kv_len;
     const int qt = blockIdx.x, head = blockIdx.y, clip = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i32 = lane & 31, h = lane >> 5;
-    const int d = p.n_head * 64;
-    const bf16_t *base = reinterpret_cast<const bf16_t *>(p.qkv) + (int64_t)clip * T * p.ld_qkv + head * 64;
-    const bf16_t *kbase = base + d, *vbase = base + 2 * d;
+    const bf16_t *base = reinterpret_cast<const bf16_t *>(p.q) + (int64_t)clip * p.q_len * p.ld_q + head * 64;
+    const bf16_t *kbase = reinterpret_cast<const bf16_t *>(p.k) + (int64_t)clip * T * p.ld_kv + head * 64;
+    const bf16_t *vbase = reinterpret_cast<const bf16_t *>(p.v) + (int64_t)clip * T * p.ld_kv + head * 64;
 
     // Q fragments (B operand): lane (q = i32, h) holds Q[q][16c + 8h .. +8], c = 0..3
     int qrow = qt * QT + wave * 32 + i32;
-    const bool q_valid = qrow < T;
-    qrow = q_valid ? qrow : T - 1;
+    const bool q_valid = qrow < p.q_len;
+    qrow = q_valid ? qrow : p.q_len - 1;
     uint4 qf[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) qf[c] = *reinterpret_cast<const uint4 *>(base + (int64_t)qrow * p.ld_qkv + 16 * c + 8 * h);
+    for (int c = 0; c < 4; ++c) qf[c] = *reinterpret_cast<const uint4 *>(base + (int64_t)qrow * p.ld_q + 16 * c + 8 * h);
 
     f32x16 o[2];
 #pragma unroll
@@ -105,11 +105,13 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(AttnParams p) {
         for (int r = 0; r < 16; ++r) o[b][r] = 0.f;
     float m_run = -INFINITY, l_part = 0.f;
 
-    const int nkv = (T + KT - 1) / KT;
+    int nkv = (T + KT - 1) / KT;
+    const int nkv_all = nkv;
+    if (p.causal) nkv = min(nkv, (min(p.q_len, (qt + 1) * QT) - 1) / KT + 1);   // tiles above the block's diagonal are all masked
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(la::lds_addr_u32(lds));
-    const KvOff off_full = kv_offsets_bf16(p.ld_qkv, 0, KT, wave, lane);                 // every row valid
-    const KvOff off_last = kv_offsets_bf16(p.ld_qkv, (nkv - 1) * KT, T, wave, lane);      // rows clamped to key T-1
-    stage_kv_bf16(kbase, vbase, p.ld_qkv, 0, nkv == 1 ? off_last : off_full, lds0, lds0 + KT * 128, wave);
+    const KvOff off_full = kv_offsets_bf16(p.ld_kv, 0, KT, wave, lane);                      // every row valid
+    const KvOff off_last = kv_offsets_bf16(p.ld_kv, (nkv_all - 1) * KT, T, wave, lane);      // rows clamped to key T-1
+    stage_kv_bf16(kbase, vbase, p.ld_kv, 0, nkv_all == 1 ? off_last : off_full, lds0, lds0 + KT * 128, wave);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(AttnParams p) {
         const unsigned char *vl = kl + KT * 128;
         if (t + 1 < nkv) {
             const unsigned nk = lds0 + (cur ^ 1) * (2 * KT * 128);
-            stage_kv_bf16(kbase, vbase, p.ld_qkv, (t + 1) * KT, t + 2 == nkv ? off_last : off_full, nk, nk + KT * 128, wave);
+            stage_kv_bf16(kbase, vbase, p.ld_kv, (t + 1) * KT, t + 2 == nkv_all ? off_last : off_full, nk, nk + KT * 128, wave);
         }
         // ---- S^T = K Q^T : two 32-key sub-tiles ----
         f32x16 s[2];
@@ -139,13 +141,14 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(AttnParams p) {
                                                                  __builtin_bit_cast(bf16x8, qf[c]), s[sub], 0, 0, 0);
             }
         }
-        // ---- mask keys >= T (last tile only) ----
-        if ((t + 1) * KT > T) {
+        // ---- mask keys >= kv_len (last tile) and, for the causal decoder self-attention, keys after the query ----
+        if ((t + 1) * KT > T || p.causal) {
+            const int kmax = p.causal ? min(T - 1, qrow) : T - 1;
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    if (t * KT + sub * 32 + acc_row(r, h) >= T) s[sub][r] = -INFINITY;
+                    if (t * KT + sub * 32 + acc_row(r, h) > kmax) s[sub][r] = -INFINITY;
         }
         // ---- online softmax (exp2 domain) ----
         float mx = -INFINITY;
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(AttnParams p) {
     const float l = l_part + __shfl_xor(l_part, 32);
     const float inv = 1.0f / l;
     if (q_valid) {
-        bf16_t *orow = reinterpret_cast<bf16_t *>(p.out) + ((int64_t)clip * T + qrow) * p.ld_out + head * 64;
+        bf16_t *orow = reinterpret_cast<bf16_t *>(p.out) + ((int64_t)clip * p.q_len + qrow) * p.ld_out + head * 64;
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -244,21 +247,21 @@ __device__ __forceinline__ void stage_kv_f32(const float *kbase, const float *vb
 
 __global__ __launch_bounds__(256, 2) void attention_f32_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // [buf][K|V][64][256 B] = 64 KiB
-    const int T = p.frames;
+    const int T = p.kv_len;
     const int qt = blockIdx.x, head = blockIdx.y, clip = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i32 = lane & 31, h = lane >> 5;
-    const int d = p.n_head * 64;
-    const float *base = reinterpret_cast<const float *>(p.qkv) + (int64_t)clip * T * p.ld_qkv + head * 64;
-    const float *kbase = base + d, *vbase = base + 2 * d;
+    const float *base = reinterpret_cast<const float *>(p.q) + (int64_t)clip * p.q_len * p.ld_q + head * 64;
+    const float *kbase = reinterpret_cast<const float *>(p.k) + (int64_t)clip * T * p.ld_kv + head * 64;
+    const float *vbase = reinterpret_cast<const float *>(p.v) + (int64_t)clip * T * p.ld_kv + head * 64;
 
     int qrow = qt * QT + wave * 32 + i32;
-    const bool q_valid = qrow < T;
-    qrow = q_valid ? qrow : T - 1;
+    const bool q_valid = qrow < p.q_len;
+    qrow = q_valid ? qrow : p.q_len - 1;
     // lane (q, h) holds Q[q][8c + 4h + e], c = 0..7, e = 0..3: element e feeds the e-th MFMA of chunk c
     float4 qf[8];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) qf[c] = *reinterpret_cast<const float4 *>(base + (int64_t)qrow * p.ld_qkv + 8 * c + 4 * h);
+    for (int c = 0; c < 8; ++c) qf[c] = *reinterpret_cast<const float4 *>(base + (int64_t)qrow * p.ld_q + 8 * c + 4 * h);
 
     f32x16 o[2];
 #pragma unroll
@@ -268,8 +271,9 @@ __global__ __launch_bounds__(256, 2) void attention_f32_kernel(AttnParams p) {
     float m_run = -INFINITY, l_part = 0.f;
 
     constexpr int TILE = KT * 256;
-    const int nkv = (T + KT - 1) / KT;
-    stage_kv_f32(kbase, vbase, p.ld_qkv, 0, T, lds, lds + TILE, wave, lane);
+    int nkv = (T + KT - 1) / KT;
+    if (p.causal) nkv = min(nkv, (min(p.q_len, (qt + 1) * QT) - 1) / KT + 1);
+    stage_kv_f32(kbase, vbase, p.ld_kv, 0, T, lds, lds + TILE, wave, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -279,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void attention_f32_kernel(AttnParams p) {
         const unsigned char *vl = kl + TILE;
         if (t + 1 < nkv) {
             unsigned char *nk = lds + (cur ^ 1) * (2 * TILE);
-            stage_kv_f32(kbase, vbase, p.ld_qkv, (t + 1) * KT, T, nk, nk + TILE, wave, lane);
+            stage_kv_f32(kbase, vbase, p.ld_kv, (t + 1) * KT, T, nk, nk + TILE, wave, lane);
         }
         f32x16 s[2];
 #pragma unroll
@@ -296,12 +300,13 @@ __global__ __launch_bounds__(256, 2) void attention_f32_kernel(AttnParams p) {
                 s[sub] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[c].w, s[sub], 0, 0, 0);
             }
         }
-        if ((t + 1) * KT > T) {
+        if ((t + 1) * KT > T || p.causal) {
+            const int kmax = p.causal ? min(T - 1, qrow) : T - 1;
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    if (t * KT + sub * 32 + acc_row(r, h) >= T) s[sub][r] = -INFINITY;
+                    if (t * KT + sub * 32 + acc_row(r, h) > kmax) s[sub][r] = -INFINITY;
         }
         float mx = -INFINITY;
 #pragma unroll
@@ -348,7 +353,7 @@ __global__ __launch_bounds__(256, 2) void attention_f32_kernel(AttnParams p) {
     const float l = l_part + __shfl_xor(l_part, 32);
     const float inv = 1.0f / l;
     if (q_valid) {
-        float *orow = reinterpret_cast<float *>(p.out) + ((int64_t)clip * T + qrow) * p.ld_out + head * 64;
+        float *orow = reinterpret_cast<float *>(p.out) + ((int64_t)clip * p.q_len + qrow) * p.ld_out + head * 64;
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -360,18 +365,8 @@ __global__ __launch_bounds__(256, 2) void attention_f32_kernel(AttnParams p) {
 
 }  // namespace
 
-extern "C" int la_attention(int32_t dtype, const void *qkv, int64_t ld_qkv, void *out, int64_t ld_out, int32_t batch,
-                            int32_t frames, int32_t n_head, void *stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    if (batch == 0 || frames == 0) return LA_OK;
-    LA_CHECK_ARG(qkv && out && batch > 0 && frames > 0 && n_head > 0, "attention: bad arguments");
-    LA_CHECK_ARG(dtype == LA_F32 || dtype == LA_BF16, "attention: bad dtype");
-    const int es = dtype == LA_BF16 ? 2 : 4;
-    LA_CHECK_ARG(ld_qkv >= 3 * n_head * 64 && ld_out >= n_head * 64, "attention: leading dimensions too small");
-    LA_CHECK_ARG((ld_qkv * es) % 16 == 0 && (ld_out * es) % 16 == 0 && (uintptr_t)qkv % 16 == 0 && (uintptr_t)out % 16 == 0,
-                 "attention: rows must be 16-byte aligned");
-    AttnParams p{qkv, ld_qkv, out, ld_out, frames, n_head};
-    const dim3 grid(la::cdiv(frames, QT), n_head, batch), block(256);
+static int attention_launch(int dtype, const AttnParams &p, int batch, hipStream_t stream) {
+    const dim3 grid(la::cdiv(p.q_len, QT), p.n_head, batch), block(256);
     if (dtype == LA_BF16) {
         la::TimerScope ts("attention_bf16", stream);
         hipLaunchKernelGGL(attention_bf16_kernel, grid, block, 0, stream, p);
@@ -387,4 +382,37 @@ extern "C" int la_attention(int32_t dtype, const void *qkv, int64_t ld_qkv, void
     }
     LA_LAUNCH_CHECK();
     return LA_OK;
+}
+
+extern "C" int la_attention(int32_t dtype, const void *qkv, int64_t ld_qkv, void *out, int64_t ld_out, int32_t batch,
+                            int32_t frames, int32_t n_head, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (batch == 0 || frames == 0) return LA_OK;
+    LA_CHECK_ARG(qkv && out && batch > 0 && frames > 0 && n_head > 0, "attention: bad arguments");
+    LA_CHECK_ARG(dtype == LA_F32 || dtype == LA_BF16, "attention: bad dtype");
+    const int es = dtype == LA_BF16 ? 2 : 4;
+    LA_CHECK_ARG(ld_qkv >= 3 * n_head * 64 && ld_out >= n_head * 64, "attention: leading dimensions too small");
+    LA_CHECK_ARG((ld_qkv * es) % 16 == 0 && (ld_out * es) % 16 == 0 && (uintptr_t)qkv % 16 == 0 && (uintptr_t)out % 16 == 0,
+                 "attention: rows must be 16-byte aligned");
+    const char *b = reinterpret_cast<const char *>(qkv);
+    const int d = n_head * 64;
+    AttnParams p{b, b + (int64_t)d * es, b + (int64_t)2 * d * es, ld_qkv, ld_qkv, out, ld_out, frames, frames, n_head, 0};
+    return attention_launch(dtype, p, batch, stream);
+}
+
+extern "C" int la_attention_ex(int32_t dtype, const void *q, int64_t ld_q, const void *k, const void *v, int64_t ld_kv,
+                               void *out, int64_t ld_out, int32_t batch, int32_t q_len, int32_t kv_len, int32_t n_head,
+                               int32_t causal, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (batch == 0 || q_len == 0) return LA_OK;
+    LA_CHECK_ARG(q && k && v && out && batch > 0 && q_len > 0 && kv_len > 0 && n_head > 0, "attention_ex: bad arguments");
+    LA_CHECK_ARG(dtype == LA_F32 || dtype == LA_BF16, "attention_ex: bad dtype");
+    LA_CHECK_ARG(!causal || q_len == kv_len, "attention_ex: causal masking is defined for self-attention (q_len == kv_len)");
+    const int es = dtype == LA_BF16 ? 2 : 4;
+    LA_CHECK_ARG(ld_q >= n_head * 64 && ld_kv >= n_head * 64 && ld_out >= n_head * 64, "attention_ex: leading dimensions too small");
+    LA_CHECK_ARG((ld_q * es) % 16 == 0 && (ld_kv * es) % 16 == 0 && (ld_out * es) % 16 == 0 && (uintptr_t)q % 16 == 0 &&
+                     (uintptr_t)k % 16 == 0 && (uintptr_t)v % 16 == 0 && (uintptr_t)out % 16 == 0,
+                 "attention_ex: rows must be 16-byte aligned");
+    AttnParams p{q, k, v, ld_q, ld_kv, out, ld_out, q_len, kv_len, n_head, causal ? 1 : 0};
+    return attention_launch(dtype, p, batch, stream);
 }

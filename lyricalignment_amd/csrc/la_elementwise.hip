@@ -178,7 +178,33 @@ __global__ __launch_bounds__(256) void mel_to_rows_kernel(const float *mel, int6
     }
 }
 
+__global__ __launch_bounds__(256) void embed_tokens_kernel(const int64_t *tokens, int n_tok, const float *emb, int n_vocab,
+                                                           const float *pos, int d, float *x) {
+    const int row = blockIdx.x;  // b * n_tok + i
+    const int i = row % n_tok;
+    int64_t tk = tokens[row];
+    tk = tk < 0 ? 0 : (tk >= n_vocab ? n_vocab - 1 : tk);
+    const float4 *e = reinterpret_cast<const float4 *>(emb + tk * d);
+    const float4 *pp = reinterpret_cast<const float4 *>(pos + (int64_t)i * d);
+    float4 *o = reinterpret_cast<float4 *>(x + (int64_t)row * d);
+    for (int c = threadIdx.x; c < d / 4; c += 256) {
+        const float4 a = e[c], b = pp[c];
+        o[c] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    }
+}
+
 }  // namespace
+
+extern "C" int la_embed_tokens(const int64_t *tokens, int32_t batch, int32_t n_tok, const float *token_embedding,
+                               int32_t n_vocab, const float *positional_embedding, int32_t d, float *x, void *stream_) {
+    if (batch == 0 || n_tok == 0) return LA_OK;
+    LA_CHECK_ARG(tokens && token_embedding && positional_embedding && x && batch > 0 && n_tok > 0 && n_vocab > 0 && d > 0 && d % 4 == 0,
+                 "embed_tokens: bad arguments");
+    hipLaunchKernelGGL(embed_tokens_kernel, dim3(batch * n_tok), dim3(256), 0, (hipStream_t)stream_, tokens, n_tok,
+                       token_embedding, n_vocab, positional_embedding, d, x);
+    LA_LAUNCH_CHECK();
+    return LA_OK;
+}
 
 extern "C" int la_emissions_from_logits(const float *logits, int64_t batch_stride, int64_t row_stride, int32_t batch,
                                         int32_t frames, int32_t vocab, int32_t variant, const int32_t *labels,

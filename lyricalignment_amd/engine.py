@@ -105,6 +105,62 @@ def pack_encoder(sd: Dict[str, torch.Tensor], n_head: int, dtype: torch.dtype, d
                           _f32(pos, device), blocks, _f32(g("ln_post.weight"), device), _f32(g("ln_post.bias"), device))
 
 
+@dataclass
+class DecoderBlockWeights:
+    ln1_g: torch.Tensor; ln1_b: torch.Tensor
+    wqkv: torch.Tensor; bqkv: torch.Tensor
+    wo: torch.Tensor; bo: torch.Tensor
+    lnc_g: torch.Tensor; lnc_b: torch.Tensor
+    wq_c: torch.Tensor; bq_c: torch.Tensor
+    wkv_c: torch.Tensor; bkv_c: torch.Tensor
+    wo_c: torch.Tensor; bo_c: torch.Tensor
+    ln2_g: torch.Tensor; ln2_b: torch.Tensor
+    w1: torch.Tensor; b1: torch.Tensor
+    w2: torch.Tensor; b2: torch.Tensor
+
+
+@dataclass
+class DecoderWeights:
+    d: int
+    n_head: int
+    dtype: torch.dtype
+    tok_emb_f32: torch.Tensor   # [V, d] f32 (lookup)
+    tok_emb: torch.Tensor       # [V, d] compute dtype (tied output projection)
+    pos: torch.Tensor           # [n_text_ctx, d] f32
+    blocks: List[DecoderBlockWeights]
+    ln_g: torch.Tensor; ln_b: torch.Tensor
+
+
+def pack_decoder(sd: Dict[str, torch.Tensor], n_head: int, dtype: torch.dtype, device, prefix: str = "decoder.") -> DecoderWeights:
+    """openai-whisper TextDecoder state_dict -> device weights (whisper/model.py TextDecoder; module/align_model.py:118-121)."""
+    g = lambda k: sd[prefix + k].detach().float()
+    w = lambda t: t.to(device=device, dtype=dtype).contiguous()
+    d = g("token_embedding.weight").shape[1]
+    if d // n_head != 64:
+        raise NotImplementedError("decoder: kernels are built for head_dim 64")
+    scale = 64 ** -0.5
+    blocks, i = [], 0
+    while f"{prefix}blocks.{i}.attn.query.weight" in sd:
+        b = f"blocks.{i}."
+        bq = g(b + "attn.query.bias") * scale
+        wqkv = torch.cat([g(b + "attn.query.weight") * scale, g(b + "attn.key.weight"), g(b + "attn.value.weight")], 0)
+        bqkv = torch.cat([bq, torch.zeros_like(bq), g(b + "attn.value.bias")], 0)
+        wkv_c = torch.cat([g(b + "cross_attn.key.weight"), g(b + "cross_attn.value.weight")], 0)
+        bkv_c = torch.cat([torch.zeros(d), g(b + "cross_attn.value.bias")], 0)
+        blocks.append(DecoderBlockWeights(
+            _f32(g(b + "attn_ln.weight"), device), _f32(g(b + "attn_ln.bias"), device), w(wqkv), _f32(bqkv, device),
+            w(g(b + "attn.out.weight")), _f32(g(b + "attn.out.bias"), device),
+            _f32(g(b + "cross_attn_ln.weight"), device), _f32(g(b + "cross_attn_ln.bias"), device),
+            w(g(b + "cross_attn.query.weight") * scale), _f32(g(b + "cross_attn.query.bias") * scale, device),
+            w(wkv_c), _f32(bkv_c, device), w(g(b + "cross_attn.out.weight")), _f32(g(b + "cross_attn.out.bias"), device),
+            _f32(g(b + "mlp_ln.weight"), device), _f32(g(b + "mlp_ln.bias"), device),
+            w(g(b + "mlp.0.weight")), _f32(g(b + "mlp.0.bias"), device), w(g(b + "mlp.2.weight")), _f32(g(b + "mlp.2.bias"), device)))
+        i += 1
+    te = g("token_embedding.weight")
+    return DecoderWeights(d, n_head, dtype, _f32(te, device), w(te), _f32(g("positional_embedding"), device), blocks,
+                          _f32(g("ln.weight"), device), _f32(g("ln.bias"), device))
+
+
 def pack_head(sd: Dict[str, torch.Tensor], dtype: torch.dtype, device, prefix: str = "align_rnn.") -> HeadWeights:
     """RNN state_dict (nn.GRU 2 layers bidirectional + nn.Linear, module/align_model.py:23-33) -> kernel layout."""
     g = lambda k: sd[prefix + k].detach()
@@ -127,9 +183,9 @@ def pack_head(sd: Dict[str, torch.Tensor], dtype: torch.dtype, device, prefix: s
 class AlignEngine:
     """Owns packed weights + scratch buffers for one (model, compute dtype, device)."""
 
-    def __init__(self, enc: EncoderWeights, head: Optional[HeadWeights], device="cuda"):
+    def __init__(self, enc: EncoderWeights, head: Optional[HeadWeights], device="cuda", dec: Optional[DecoderWeights] = None):
         _lib.require_gpu()
-        self.enc, self.head, self.device = enc, head, torch.device(device)
+        self.enc, self.head, self.dec, self.device = enc, head, dec, torch.device(device)
         self._buf: Dict[Tuple, torch.Tensor] = {}
 
     # ---- scratch -----------------------------------------------------------------
@@ -178,6 +234,35 @@ class AlignEngine:
         y = self._get(f"enc_out{slot}", (M, d), out_dtype)
         ops.layernorm(x, e.lnp_g, e.lnp_b, out_dtype, out=y)
         return y
+
+    # ---- text decoder: Whisper.logits(tokens, audio_features) --------------------------------
+    def decode(self, tokens: torch.Tensor, xa: torch.Tensor, n_audio: int = N_CTX) -> torch.Tensor:
+        """tokens int64 [B,n]; xa = encoder output rows [B*n_audio, d] in the compute dtype -> logits [B,n,n_vocab] f32
+        (whisper TextDecoder.forward: embeddings, L x {causal self-attention, cross-attention to xa, MLP}, ln, tied projection)."""
+        dw = self.dec
+        if dw is None:
+            raise _lib.LyricAlignHipError("this engine was packed without decoder weights")
+        B, n = tokens.shape
+        d, dt, H = dw.d, dw.dtype, dw.n_head
+        tokens = tokens.to(device=self.device, dtype=torch.int64)
+        x = ops.embed_tokens(tokens, dw.tok_emb_f32, dw.pos)
+        h = torch.empty((B * n, d), dtype=dt, device=self.device)
+        for blk in dw.blocks:
+            ops.layernorm(x, blk.ln1_g, blk.ln1_b, dt, out=h)
+            qkv = ops.gemm(h, blk.wqkv, bias=blk.bqkv)
+            a = ops.attention_ex(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, n, n, H, causal=True)
+            ops.gemm(a, blk.wo, x, bias=blk.bo, residual=x, out_f32=True)
+            ops.layernorm(x, blk.lnc_g, blk.lnc_b, dt, out=h)
+            q = ops.gemm(h, blk.wq_c, bias=blk.bq_c)
+            kv = ops.gemm(xa, blk.wkv_c, bias=blk.bkv_c)
+            a = ops.attention_ex(q, kv[:, :d], kv[:, d:], B, n, n_audio, H, causal=False)
+            ops.gemm(a, blk.wo_c, x, bias=blk.bo_c, residual=x, out_f32=True)
+            ops.layernorm(x, blk.ln2_g, blk.ln2_b, dt, out=h)
+            u = ops.gemm(h, blk.w1, bias=blk.b1, gelu=True)
+            ops.gemm(u, blk.w2, x, bias=blk.b2, residual=x, out_f32=True)
+        ops.layernorm(x, dw.ln_g, dw.ln_b, dt, out=h)
+        logits = ops.gemm(h, dw.tok_emb, out_f32=True)
+        return logits.view(B, n, dw.tok_emb.shape[0])
 
     # ---- head: align_rnn up to Mish ------------------------------------------------------
     def head_hidden(self, feats: torch.Tensor, B: int, T: int, feat_clip_stride: int) -> torch.Tensor:

@@ -24,7 +24,7 @@ from torch import nn
 
 from .. import _lib, ops
 from ..audio_frontend import log_mel_spectrogram
-from ..engine import N_CTX, N_FRAMES, AlignEngine, pack_encoder, pack_head
+from ..engine import N_CTX, N_FRAMES, AlignEngine, pack_decoder, pack_encoder, pack_head
 from ..whisper_compat import pad_or_trim
 
 
@@ -90,7 +90,7 @@ class AlignModel(torch.nn.Module):
         return int(self.whisper_model.encoder.conv1.weight.shape[0]) // 64
 
     def _weights_version(self):
-        return tuple(p._version for p in self.parameters()) + (str(self.compute_dtype),)
+        return tuple(p._version for p in self.parameters()) + (str(self.compute_dtype), bool(self.train_transcript))
 
     def engine(self) -> AlignEngine:
         """Packed device weights; re-packed when parameters were updated (optimizer step, load_state_dict)."""
@@ -108,7 +108,12 @@ class AlignModel(torch.nn.Module):
             head_sd = {"align_rnn." + k: v for k, v in self.align_rnn.state_dict().items()}
             enc = pack_encoder(enc_sd, self._n_head(), self.compute_dtype, dev)
             head = pack_head(head_sd, self.compute_dtype, dev)
-            self._engine = AlignEngine(enc, head, dev)
+            dec = None
+            decoder = getattr(self.whisper_model, "decoder", None)
+            if decoder is not None and self.train_transcript:
+                dec_sd = {"decoder." + k: v for k, v in decoder.state_dict().items()}
+                dec = pack_decoder(dec_sd, int(getattr(self.whisper_model.dims, "n_text_head", self._n_head())), self.compute_dtype, dev)
+            self._engine = AlignEngine(enc, head, dev, dec=dec)
             self._engine_key = key
         return self._engine
 
@@ -159,9 +164,9 @@ class AlignModel(torch.nn.Module):
         if self.train_alignment:
             align_logit = eng.logits(feats, B, T, stride)                   # (:106-107, :114-115)
         transcribe_logit = None
-        if self.train_transcript and y_in is not None:                      # (:118-121)
-            embed_pad = feats.view(B, -1, eng.enc.d)[:, :N_CTX].float()
-            transcribe_logit = self.whisper_model.logits(tokens=y_in, audio_features=embed_pad)
+        if self.train_transcript and y_in is not None:                      # (:118-121): decoder over embed_pad = first 1500 frames
+            embed_pad = feats.view(B, -1, eng.enc.d)[:, :N_CTX].contiguous().view(B * N_CTX, eng.enc.d)
+            transcribe_logit = eng.decode(y_in, embed_pad, N_CTX)
         return align_logit, transcribe_logit
 
     def forward(self, mel, y_in=None):
@@ -171,7 +176,7 @@ class AlignModel(torch.nn.Module):
         align_logit = eng.logits(feats, B, N_CTX, N_CTX) if self.train_alignment else None
         transcribe_logit = None
         if self.train_transcript and y_in is not None:
-            transcribe_logit = self.whisper_model.logits(tokens=y_in, audio_features=feats.view(B, N_CTX, -1).float())
+            transcribe_logit = eng.decode(y_in, feats, N_CTX)
         return align_logit, transcribe_logit
 
     # ------------------------------------------------------------------ fused fast path (addition)
@@ -210,3 +215,22 @@ def encoder_only_engine(whisper_model, mel: torch.Tensor) -> torch.Tensor:
         whisper_model._la_engine = cache
     eng = cache[1]
     return eng.encode(mel, out_dtype=torch.float32).view(mel.shape[0], N_CTX, eng.enc.d).clone()
+
+
+def decoder_engine(whisper_model, tokens: torch.Tensor, audio_features: torch.Tensor) -> torch.Tensor:
+    """Whisper.logits for a bare whisper_compat.Whisper (float32 compute): packs encoder + decoder weights once."""
+    _lib.require_gpu()
+    cache = getattr(whisper_model, "_la_dec_engine", None)
+    key = tuple(p._version for p in whisper_model.parameters())
+    if cache is None or cache[0] != key:
+        dev = torch.device(f"cuda:{torch.cuda.current_device()}")
+        enc_sd = {"encoder." + k: v for k, v in whisper_model.encoder.state_dict().items()}
+        dec_sd = {"decoder." + k: v for k, v in whisper_model.decoder.state_dict().items()}
+        eng = AlignEngine(pack_encoder(enc_sd, int(whisper_model.dims.n_audio_head), torch.float32, dev), None, dev,
+                          dec=pack_decoder(dec_sd, int(whisper_model.dims.n_text_head), torch.float32, dev))
+        cache = (key, eng)
+        whisper_model._la_dec_engine = cache
+    eng = cache[1]
+    B, n_audio, d = audio_features.shape
+    xa = audio_features.to(device=eng.device, dtype=torch.float32).contiguous().view(B * n_audio, d)
+    return eng.decode(tokens, xa, n_audio)

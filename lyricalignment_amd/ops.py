@@ -227,3 +227,38 @@ def fc_emissions(act: torch.Tensor, w_fc: torch.Tensor, b_fc: torch.Tensor, batc
                                 labels.stride(0), ptr(n_labels.contiguous()), Lmax, ptr(em), em.stride(0), em.stride(1),
                                 ptr(ws), need.value, stream_ptr()), "fc_emissions")
     return em
+
+
+def attention_ex(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, q_len: int, kv_len: int, n_head: int,
+                 causal: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """General attention for the text decoder: q [batch*q_len, >=d] / k, v [batch*kv_len, >=d] row views (column slices of
+    packed projections are fine: only the row pitch and the 16-byte alignment matter), q pre-scaled by 1/8."""
+    for name, t in (("q", q), ("k", k), ("v", v)):
+        _dev(t, name)
+        if t.dim() != 2 or t.stride(1) != 1:
+            raise ValueError(f"attention_ex: {name} must be a 2-D row view with unit inner stride")
+    dt = dtype_code(q.dtype)
+    d = n_head * 64
+    if k.dtype != q.dtype or v.dtype != q.dtype or k.stride(0) != v.stride(0):
+        raise ValueError("attention_ex: q/k/v dtypes differ or k and v have different row pitch")
+    if q.shape[0] < batch * q_len or k.shape[0] < batch * kv_len or v.shape[0] < batch * kv_len or min(q.shape[1], k.shape[1], v.shape[1]) < d:
+        raise ValueError("attention_ex: views smaller than batch*len x n_head*64")
+    if out is None:
+        out = torch.empty((batch * q_len, d), dtype=q.dtype, device=q.device)
+    check(lib().la_attention_ex(dt, ptr(q), q.stride(0), ptr(k), ptr(v), k.stride(0), ptr(out), out.stride(0), batch, q_len,
+                                kv_len, n_head, 1 if causal else 0, stream_ptr()), "attention_ex")
+    return out
+
+
+def embed_tokens(tokens: torch.Tensor, token_embedding: torch.Tensor, positional_embedding: torch.Tensor) -> torch.Tensor:
+    """tokens int64 [B,n] -> f32 [B*n, d] = token_embedding[tokens] + positional_embedding[:n]."""
+    _dev(tokens, "tokens", torch.int64); _dev(token_embedding, "token_embedding", torch.float32)
+    _dev(positional_embedding, "positional_embedding", torch.float32)
+    B, n = tokens.shape
+    V, d = token_embedding.shape
+    if positional_embedding.shape[0] < n or positional_embedding.shape[1] != d:
+        raise ValueError("embed_tokens: positional table too short or width mismatch")
+    x = torch.empty((B * n, d), dtype=torch.float32, device=tokens.device)
+    check(lib().la_embed_tokens(ptr(tokens.contiguous()), B, n, ptr(token_embedding.contiguous()), V,
+                                ptr(positional_embedding.contiguous()), d, ptr(x), stream_ptr()), "embed_tokens")
+    return x

@@ -86,7 +86,7 @@ class AudioEncoder(nn.Module):
 
 
 class TextDecoder(nn.Module):
-    """Parameter container (key layout only); the decoder forward belongs to the fine-tune row."""
+    """Parameter container with openai-whisper's names; forward runs on the HIP engine (AlignEngine.decode)."""
 
     def __init__(self, n_vocab: int, n_ctx: int, n_state: int, n_head: int, n_layer: int):
         super().__init__()
@@ -112,7 +112,11 @@ class Whisper(nn.Module):
         return self._engine_owner()._embed_audio(mel)
 
     def logits(self, tokens: torch.Tensor, audio_features: torch.Tensor) -> torch.Tensor:
-        raise NotImplementedError("Whisper text decoder (train_transcript / fine-tune row) is not built yet: DESIGN.md 'next'")
+        """TextDecoder forward on the HIP engine: tokens [B,n], audio_features [B,1500,d] -> [B,n,n_vocab] float32."""
+        if self.decoder is None:
+            raise RuntimeError("this Whisper object was built without a decoder")
+        from .module.align_model import decoder_engine
+        return decoder_engine(self, tokens, audio_features)
 
     def transcribe(self, *a, **k):
         raise NotImplementedError("transcription (beam search) is out of scope of the alignment hot path")

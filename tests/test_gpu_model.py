@@ -323,3 +323,57 @@ def test_long_form_three_minute_song_config5():
     rc, on_o, off_o, sc_o = ao.align_frames_compact(em[0], np.array(lists[0]))
     assert rc == 0 and on.cpu().numpy()[0].tolist() == on_o.tolist() and off.cpu().numpy()[0].tolist() == off_o.tolist()
     assert float(score[0]) == sc_o
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 8e-2)])
+def test_decoder_logits_match_oracle(dtype, tol):
+    """Whisper.logits (text decoder: causal self-attention, cross-attention to the audio features, tied projection)
+    through AlignModel.frame_manual_forward(train_transcript=True) vs the oracle's TextDecoder restatement."""
+    from lyricalignment_amd import whisper_compat as wc
+    from lyricalignment_amd.module.align_model import AlignModel
+    from oracle import model_oracle as mo
+    dims = wc.ModelDimensions(n_audio_state=128, n_audio_head=2, n_audio_layer=2, n_text_state=128, n_text_head=2, n_text_layer=2,
+                              n_vocab=311, n_text_ctx=64)
+    wm = wc.build_model(dims=dims, seed=51, std=0.05, with_decoder=True)
+    model = AlignModel(wm, embed_dim=128, hidden_dim=64, output_dim=300, train_transcript=True, device="cuda", compute_dtype=dtype).eval()
+    audios = [_wave(60096, 52), _wave(48160, 53)]
+    tokens = torch.randint(0, 311, (2, 37), generator=torch.Generator().manual_seed(54))
+    with torch.no_grad():
+        align_logit, tr = model.frame_manual_forward(audios, y_in=tokens)
+    assert tuple(tr.shape) == (2, 37, 311) and tr.dtype == torch.float32 and align_logit.shape[1] == 188
+    p = {"encoder." + k: v.detach().float().cpu() for k, v in wm.encoder.state_dict().items()}
+    p.update({"decoder." + k: v.detach().float().cpu() for k, v in wm.decoder.state_dict().items()})
+    batch = np.zeros((2, 60096), dtype=np.float32); batch[0] = audios[0]; batch[1, :48160] = audios[1]
+    mel = mo.pad_or_trim(mo.log_mel_spectrogram(batch), 3000)
+    xa = mo.encoder_forward(p, mel, n_head=2)
+    ref = mo.decoder_forward(p, tokens, xa, n_head=2)
+    np.testing.assert_allclose(tr.cpu().numpy(), ref.numpy(), rtol=0, atol=tol)
+    if dtype == torch.float32:   # bare Whisper object API: embed_audio + logits
+        with torch.no_grad():
+            feats = wm.embed_audio(mel.cuda())
+            tr2 = wm.logits(tokens=tokens.cuda(), audio_features=feats)
+        np.testing.assert_allclose(tr2.cpu().numpy(), ref.numpy(), rtol=0, atol=tol)
+
+
+def test_attention_ex_causal_and_cross():
+    from lyricalignment_amd import ops
+    g = torch.Generator().manual_seed(60)
+    B, n, m, H = 2, 70, 150, 2
+    d = H * 64
+    for dtype, tol in ((torch.float32, 2e-5), (torch.bfloat16, 2e-2)):
+        qkv = (torch.randn(B * n, 3 * d, generator=g)).to(dtype)
+        qkv[:, :d] *= 0.3
+        x = qkv.cuda()
+        out = ops.attention_ex(x[:, :d], x[:, d:2 * d], x[:, 2 * d:], B, n, n, H, causal=True).float().cpu()
+        xd = qkv.double().reshape(B, n, 3, H, 64)
+        q, k, v = xd[:, :, 0].transpose(1, 2), xd[:, :, 1].transpose(1, 2), xd[:, :, 2].transpose(1, 2)
+        mask = torch.full((n, n), float("-inf"), dtype=torch.float64).triu_(1)
+        ref = (torch.softmax(q @ k.transpose(-1, -2) + mask, dim=-1) @ v).transpose(1, 2).reshape(B * n, d)
+        np.testing.assert_allclose(out.double().numpy(), ref.numpy(), rtol=0, atol=tol)
+        kv = torch.randn(B * m, 2 * d, generator=g).to(dtype)
+        y = kv.cuda()
+        out = ops.attention_ex(x[:, :d], y[:, :d], y[:, d:], B, n, m, H, causal=False).float().cpu()
+        kd = kv.double().reshape(B, m, 2, H, 64)
+        k2, v2 = kd[:, :, 0].transpose(1, 2), kd[:, :, 1].transpose(1, 2)
+        ref = (torch.softmax(q @ k2.transpose(-1, -2), dim=-1) @ v2).transpose(1, 2).reshape(B * n, d)
+        np.testing.assert_allclose(out.double().numpy(), ref.numpy(), rtol=0, atol=tol)

@@ -125,3 +125,42 @@ def test_encoder_matches_hf_whisper_encoder():
     ours = mo.encoder_forward(p, mel, n_head=4)
     assert ours.shape == (2, 1500, 64)
     np.testing.assert_allclose(ours.numpy(), hf.numpy(), rtol=0, atol=2e-5)
+
+
+def test_decoder_matches_hf_whisper_decoder():
+    """Pins the oracle's TextDecoder restatement against the independent HF implementation (same weights)."""
+    from transformers import WhisperConfig
+    from transformers.models.whisper.modeling_whisper import WhisperDecoder
+    d, H, L, V, NCTX = 64, 1, 2, 97, 32
+    cfg = WhisperConfig(vocab_size=V, d_model=d, decoder_layers=L, decoder_attention_heads=H, decoder_ffn_dim=4 * d,
+                        encoder_layers=1, encoder_attention_heads=H, encoder_ffn_dim=4 * d, max_target_positions=NCTX,
+                        pad_token_id=0, bos_token_id=1, eos_token_id=2, decoder_start_token_id=1)
+    cfg._attn_implementation = "eager"
+    dec = WhisperDecoder(cfg).eval()
+    g = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        for p_ in dec.parameters():
+            p_.copy_(torch.randn(p_.shape, generator=g) * 0.1)
+        for lyr in dec.layers:
+            lyr.self_attn.k_proj.bias.zero_() if lyr.self_attn.k_proj.bias is not None else None
+            lyr.encoder_attn.k_proj.bias.zero_() if lyr.encoder_attn.k_proj.bias is not None else None
+    sd = dec.state_dict()
+    p = {"decoder.token_embedding.weight": sd["embed_tokens.weight"], "decoder.positional_embedding": sd["embed_positions.weight"],
+         "decoder.ln.weight": sd["layer_norm.weight"], "decoder.ln.bias": sd["layer_norm.bias"]}
+    names = {"attn.query": "self_attn.q_proj", "attn.key": "self_attn.k_proj", "attn.value": "self_attn.v_proj", "attn.out": "self_attn.out_proj",
+             "attn_ln": "self_attn_layer_norm", "cross_attn.query": "encoder_attn.q_proj", "cross_attn.key": "encoder_attn.k_proj",
+             "cross_attn.value": "encoder_attn.v_proj", "cross_attn.out": "encoder_attn.out_proj", "cross_attn_ln": "encoder_attn_layer_norm",
+             "mlp.0": "fc1", "mlp.2": "fc2", "mlp_ln": "final_layer_norm"}
+    for i in range(L):
+        for ours, hf in names.items():
+            for wb in ("weight", "bias"):
+                k = f"layers.{i}.{hf}.{wb}"
+                if k in sd and not (ours.endswith("key") and wb == "bias"):
+                    p[f"decoder.blocks.{i}.{ours}.{wb}"] = sd[k]
+    tokens = torch.randint(0, V, (2, 9), generator=g)
+    xa = torch.randn(2, 50, d, generator=g)
+    with torch.no_grad():
+        hidden = dec(input_ids=tokens, encoder_hidden_states=xa).last_hidden_state
+        ref = hidden @ sd["embed_tokens.weight"].T
+    ours = mo.decoder_forward(p, tokens, xa, n_head=H)
+    np.testing.assert_allclose(ours.numpy(), ref.numpy(), rtol=0, atol=2e-5)
