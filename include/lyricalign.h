@@ -281,6 +281,28 @@ int la_adamw_step_f32(float *param, const float *grad, float *exp_avg, float *ex
                       const double *clip_sum_sq, float max_norm, float grad_prescale, void *stream);
 
 /*
+ * Backward pass of the head (GRU x2 bidirectional -> Mish -> Linear, module/align_model.py:11-40), float32.
+ * la_gru_layer_train_fwd = la_gru_layer(LA_F32) that also stores, per step, r, z, n and (W_hn h + b_hn) into
+ * gates [batch][frames][2][4H].  la_gru_layer_bwd sweeps the recurrence backwards: dout = gradient w.r.t. the layer
+ * output [batch][frames][2H]; writes dgi / dgh [batch][frames][2][3H], the gradients w.r.t. the input / recurrent gate
+ * pre-activations, from which the weight gradients are plain GEMMs (dW_ih = dgi^T x, dW_hh = dgh^T h_prev, dx = dgi W_ih).
+ * The helpers below express those GEMMs for la_gemm (both operands K-contiguous): zero-padded transposes, column sums
+ * (bias gradients), Mish forward / backward, masked scaling (the inter-layer dropout of nn.GRU in train mode).
+ */
+int la_gru_layer_train_fwd(const float *gi, const float *w_hh, const float *b_hh, float *out, float *gates,
+                           int32_t batch, int32_t frames, int32_t hidden, void *workspace, size_t workspace_bytes,
+                           int32_t *timeout_flag, void *stream);
+int la_gru_layer_bwd(const float *gates, const float *out, const float *dout, const float *w_hh, float *dgi, float *dgh,
+                     int32_t batch, int32_t frames, int32_t hidden, void *workspace, size_t workspace_bytes,
+                     int32_t *timeout_flag, void *stream);
+int la_transpose_pad_f32(const float *in, int64_t ld_in, int32_t rows, int32_t cols, float *out, int64_t ld_out,
+                         int32_t out_rows, int32_t out_cols, void *stream);
+int la_colsum_f32(const float *in, int64_t ld, int32_t rows, int32_t cols, float *out, void *stream);
+int la_mish_f32(const float *x, float *y, int64_t n, void *stream);
+int la_mish_bwd_f32(const float *x, const float *dy, float *dx, int64_t n, void *stream);
+int la_mask_scale_f32(const float *x, const unsigned char *mask, float scale, float *y, int64_t n, void *stream);
+
+/*
  * Polyphase FIR resampling (audio front end, utils/audio.py:3-20: librosa.load(file, sr=16000)):
  * y[n] = sum_k h[(n + skip)*down - k*up] * x[k], n < n_out.  h is the centred low-pass (host-built Kaiser-windowed sinc,
  * gain `up`, zero pre-padded so that `skip` whole output samples are dropped), as in scipy.signal.resample_poly.

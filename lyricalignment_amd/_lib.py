@@ -49,6 +49,13 @@ SYMBOLS = {
     "la_multitask_loss": (c_int32, [_P, _I64, _I64, _I32, _I32, _I32, _P, _P, _I32, _P, _I32, _I32, _I32, ctypes.c_float, _P, _P, _I64, _I64, _P, _SZ, _P]),
     "la_grad_sqnorm_f32": (c_int32, [_P, _I64, _P, _P]),
     "la_adamw_step_f32": (c_int32, [_P, _P, _P, _P, _I64, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _I32, _P, ctypes.c_float, ctypes.c_float, _P]),
+    "la_gru_layer_train_fwd": (c_int32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _SZ, _P, _P]),
+    "la_gru_layer_bwd": (c_int32, [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _SZ, _P, _P]),
+    "la_transpose_pad_f32": (c_int32, [_P, _I64, _I32, _I32, _P, _I64, _I32, _I32, _P]),
+    "la_colsum_f32": (c_int32, [_P, _I64, _I32, _I32, _P, _P]),
+    "la_mish_f32": (c_int32, [_P, _P, _I64, _P]),
+    "la_mish_bwd_f32": (c_int32, [_P, _P, _P, _I64, _P]),
+    "la_mask_scale_f32": (c_int32, [_P, _P, ctypes.c_float, _P, _I64, _P]),
     "la_resample_poly_f32": (c_int32, [_P, _I64, _P, _I64, _I32, _I32, _I64, _P, _I64, _P]),
     "la_cast_f32_to_bf16": (c_int32, [_P, _P, _I64, _P]),
     "la_cast_bf16_to_f32": (c_int32, [_P, _P, _I64, _P]),

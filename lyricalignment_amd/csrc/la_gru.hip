@@ -39,6 +39,7 @@ struct GruParams {
     int *abort_flag;     // workspace word, zeroed per call
     int *timeout_flag;   // caller's (optional)
     int nsplit;
+    float *gates;        // optional [B][T][2][4H] f32: r, z, n, (W_hn h + b_hn) of every step, for the backward sweep
 };
 
 __device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -223,9 +224,17 @@ __global__ __launch_bounds__(GruTraits<T>::NW * 64, 1) void gru_kernel(GruParams
             for (int i = 0; i < 4; ++i) {
                 const float r = sigm(gin[mt][i][0] + (acc[0][mt][i] + bhr));
                 const float z = sigm(gin[mt][i][1] + (acc[1][mt][i] + bhz));
-                const float n = tanhf(gin[mt][i][2] + r * (acc[2][mt][i] + bhn));
+                const float hn = acc[2][mt][i] + bhn;
+                const float n = tanhf(gin[mt][i][2] + r * hn);
                 hnew[mt][i] = (1.0f - z) * n + z * hprev[mt][i];
                 hprev[mt][i] = hnew[mt][i];
+                if (p.gates) {
+                    const int bl = mt * 16 + 4 * q + i;
+                    if (bl < nb) {
+                        float *gp = p.gates + (((int64_t)(b0 + bl) * T_ + t) * 2 + dir) * 4 * H + jcol;
+                        gp[0] = r; gp[H] = z; gp[2 * H] = n; gp[3 * H] = hn;
+                    }
+                }
             }
         // ---- publish h_t into out (and Mish(h_t) into out_mish) ----
 #pragma unroll
@@ -268,6 +277,7 @@ __global__ __launch_bounds__(GruTraits<T>::NW * 64, 1) void gru_kernel(GruParams
 }  // namespace
 
 static int gru_groups(int batch) { return la::cdiv(batch, GROUP); }
+static thread_local float *g_save_gates = nullptr;   // set by la_gru_layer_train for the one launch that follows
 
 extern "C" int la_gru_workspace_bytes(int32_t batch, int32_t frames, int32_t hidden, size_t *bytes) {
     LA_CHECK_ARG(bytes && batch > 0 && frames > 0 && hidden > 0, "gru_workspace_bytes: bad arguments");
@@ -302,7 +312,8 @@ extern "C" int la_gru_layer(int32_t dtype, const float *gi, const void *w_hh, co
     LA_HIP(hipMemsetAsync(workspace, 0, need, stream));
     GruParams p{gi, w_hh, b_hh, out, out_mish, batch, frames, hidden,
                 reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(workspace) + 16),
-                reinterpret_cast<int *>(workspace), timeout_flag, nsplit};
+                reinterpret_cast<int *>(workspace), timeout_flag, nsplit, g_save_gates};
+    g_save_gates = nullptr;
     const dim3 grid(nsplit, 2, groups);
     // measured (tools/kbench.py gru): 14.4 ms write-through vs 14.6 ms fences per layer -- the step is bound by the four
     // serial L2 round trips (store drain, counter add, poll, h loads), not by the fences; keep the architecturally
@@ -327,6 +338,167 @@ extern "C" int la_gru_layer(int32_t dtype, const float *gi, const void *w_hh, co
         if (use_fence) hipLaunchKernelGGL((gru_kernel<float, 24, false>), grid, dim3(128), lds_bytes, stream, p);
         else hipLaunchKernelGGL((gru_kernel<float, 24, true>), grid, dim3(128), lds_bytes, stream, p);
     }
+    LA_LAUNCH_CHECK();
+    return LA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// training face (fine-tune row, float32 like the reference): forward that also stores the gates, and the backward sweep
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int la_gru_layer_train_fwd(const float *gi, const float *w_hh, const float *b_hh, float *out, float *gates,
+                                      int32_t batch, int32_t frames, int32_t hidden, void *workspace, size_t workspace_bytes,
+                                      int32_t *timeout_flag, void *stream) {
+    LA_CHECK_ARG(gates, "gru_layer_train_fwd: gates buffer missing");
+    g_save_gates = gates;
+    return la_gru_layer(LA_F32, gi, w_hh, b_hh, out, nullptr, batch, frames, hidden, workspace, workspace_bytes, timeout_flag, stream);
+}
+
+namespace {
+
+struct GruBwdParams {
+    const float *gates;  // [B][T][2][4H]
+    const float *out;    // [B][T][2H]  h_t of the forward pass
+    const float *dout;   // [B][T][2H]  gradient w.r.t. the layer output
+    const float *w_hh;   // [2][3H][H]
+    float *dgi;          // [B][T][2][3H]  gradient w.r.t. the input projections (W_ih x + b_ih)
+    float *dgh;          // [B][T][2][3H]  gradient w.r.t. the recurrent projections (W_hh h + b_hh); also the exchange buffer
+    int B, T, H;
+    unsigned *counters;
+    int *abort_flag;
+    int *timeout_flag;
+    int nsplit;
+};
+
+// Backward recurrence dh_{t-1} = dh_t * z_t + dgh_t W_hh: the contraction runs over all 3H gate units, so (as in the
+// forward kernel) the H hidden units are split over workgroups, each wave keeps its 16 columns of W_hh (as W_hh^T rows,
+// [16][3H] f32 = 72 KiB) resident in LDS, and dgh of the previous step is exchanged through HBM with the same
+// release / acquire hand-off.  2 waves per workgroup, H/32 workgroups per direction.
+__global__ __launch_bounds__(128, 1) void gru_bwd_kernel(GruBwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int NW = 2;
+    const int slice = blockIdx.x, dir = blockIdx.y, group = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, q = lane >> 4;
+    const int H = p.H, T_ = p.T, K3 = 3 * p.H;
+    const int nks = K3 / 16;
+    const int kcol = (slice * NW + wave) * 16 + r16;   // this lane's hidden unit
+    const int b0 = group * GROUP;
+    const int nb = min(GROUP, p.B - b0);
+    const float *Wd = p.w_hh + (int64_t)dir * K3 * H;
+    const int row_bytes = K3 * 4;
+    const int slots = row_bytes / 16;
+    // W_hh^T image: [wave][16 columns][3H], 16-B slot s of column n stored at s ^ n (low 4 bits)
+    for (int idx = tid; idx < NW * 16 * slots; idx += NW * 64) {
+        const int s4 = idx % slots, n = (idx / slots) % 16, w = idx / (slots * 16);
+        const int k = (slice * NW + w) * 16 + n;
+        float4 v;
+        v.x = Wd[(int64_t)(s4 * 4 + 0) * H + k]; v.y = Wd[(int64_t)(s4 * 4 + 1) * H + k];
+        v.z = Wd[(int64_t)(s4 * 4 + 2) * H + k]; v.w = Wd[(int64_t)(s4 * 4 + 3) * H + k];
+        *reinterpret_cast<float4 *>(lds + 16 + ((int64_t)(w * 16 + n)) * row_bytes + ((s4 ^ n) << 4)) = v;
+    }
+    __syncthreads();
+    int *ok_s = reinterpret_cast<int *>(lds);
+    const unsigned char *wl = lds + 16 + (int64_t)(wave * 16) * row_bytes;
+    unsigned *ctr = p.counters + ((int64_t)group * 2 + dir) * T_;
+    const int64_t g4 = 4 * (int64_t)H, g3 = 3 * (int64_t)H;
+
+    float carry[MT][4];   // dh_t * z_t of the step processed before (the direct path of the recurrence)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) carry[mt][i] = 0.f;
+    int arow[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) arow[mt] = b0 + min(mt * 16 + r16, nb - 1);
+
+    bool alive = true;
+    for (int step = 0; step < T_; ++step) {
+        const int t = dir == 0 ? T_ - 1 - step : step;          // reverse of the forward scan order
+        const int tnext = dir == 0 ? t + 1 : t - 1;              // processed in the previous iteration
+        const int tprev = dir == 0 ? t - 1 : t + 1;              // the forward pass's previous step (h_{t-1})
+        f32x4 acc[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (step > 0) {
+            if (tid == 0) {
+                const bool ok = wait_counter(ctr + (step - 1), (unsigned)p.nsplit, p.abort_flag);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                *ok_s = ok ? 1 : 0;
+            }
+            __syncthreads();
+            alive = *ok_s != 0;
+            if (!alive) break;
+            for (int ks = 0; ks < nks; ++ks) {
+                const uint4 w = *reinterpret_cast<const uint4 *>(wl + (int64_t)r16 * row_bytes + (((ks * 4 + q) ^ r16) << 4));
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const uint4 a = *reinterpret_cast<const uint4 *>(
+                        reinterpret_cast<const unsigned char *>(p.dgh + (((int64_t)arow[mt] * T_ + tnext) * 2 + dir) * g3) + ks * 64 + q * 16);
+                    mma_step(a, w, acc[mt], 0.0f);
+                }
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int bl = mt * 16 + 4 * q + i;
+                const int b = b0 + min(bl, nb - 1);
+                const float *gp = p.gates + (((int64_t)b * T_ + t) * 2 + dir) * g4 + kcol;
+                const float r = gp[0], z = gp[H], n = gp[2 * H], hn = gp[3 * H];
+                const float hp = (tprev >= 0 && tprev < T_) ? p.out[((int64_t)b * T_ + tprev) * 2 * H + dir * H + kcol] : 0.f;
+                const float dh = p.dout[((int64_t)b * T_ + t) * 2 * H + dir * H + kcol] + acc[mt][i] + carry[mt][i];
+                const float dn_pre = dh * (1.0f - z) * (1.0f - n * n);
+                const float dz_pre = dh * (hp - n) * z * (1.0f - z);
+                const float dr_pre = dn_pre * hn * r * (1.0f - r);
+                carry[mt][i] = dh * z;
+                if (bl < nb) {
+                    float *o1 = p.dgi + (((int64_t)b * T_ + t) * 2 + dir) * g3 + kcol;
+                    float *o2 = p.dgh + (((int64_t)b * T_ + t) * 2 + dir) * g3 + kcol;
+                    o1[0] = dr_pre; o1[H] = dz_pre; o1[2 * H] = dn_pre;
+                    o2[0] = dr_pre; o2[H] = dz_pre; o2[2 * H] = dn_pre * r;
+                }
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(ctr + step, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (!alive && tid == 0 && p.timeout_flag) *p.timeout_flag = 1;
+}
+
+}  // namespace
+
+extern "C" int la_gru_layer_bwd(const float *gates, const float *out, const float *dout, const float *w_hh, float *dgi,
+                                float *dgh, int32_t batch, int32_t frames, int32_t hidden, void *workspace,
+                                size_t workspace_bytes, int32_t *timeout_flag, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (batch == 0 || frames == 0) return LA_OK;
+    LA_CHECK_ARG(gates && out && dout && w_hh && dgi && dgh && workspace, "gru_layer_bwd: null pointer");
+    LA_CHECK_ARG(batch > 0 && frames > 0 && hidden > 0 && hidden % 64 == 0 && hidden <= 384, "gru_layer_bwd: hidden must be a multiple of 64, <= 384");
+    size_t need = 0;
+    la_gru_workspace_bytes(batch, frames, hidden, &need);
+    LA_CHECK_ARG(workspace_bytes >= need && (uintptr_t)workspace % 16 == 0, "gru_layer_bwd: workspace too small");
+    const int groups = gru_groups(batch);
+    const int nsplit = hidden / 32;
+    LA_CHECK_ARG(nsplit * 2 * groups <= 224, "gru_layer_bwd: batch too large for one co-resident launch");
+    LA_HIP(hipMemsetAsync(workspace, 0, need, stream));
+    GruBwdParams p{gates, out, dout, w_hh, dgi, dgh, batch, frames, hidden,
+                   reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(workspace) + 16),
+                   reinterpret_cast<int *>(workspace), timeout_flag, nsplit};
+    const size_t lds_bytes = 16 + (size_t)2 * 16 * 3 * hidden * 4;
+    static bool attr_done = false;
+    if (!attr_done) {
+        LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gru_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   16 + 2 * 16 * 3 * 384 * 4));
+        attr_done = true;
+    }
+    la::TimerScope ts("gru_bwd_f32", stream);
+    hipLaunchKernelGGL(gru_bwd_kernel, dim3(nsplit, 2, groups), dim3(128), lds_bytes, stream, p);
     LA_LAUNCH_CHECK();
     return LA_OK;
 }

@@ -1,0 +1,199 @@
+"""Training (forward + backward) of the alignment head -- nn.GRU(2 layers, bidirectional, inter-layer dropout) -> Mish ->
+Linear, module/align_model.py:11-40 -- on the HIP kernels, float32 like the reference's training.
+
+This is the part of the fine-tune step that runs with a frozen encoder (train_multitask.py --freeze-encoder): the encoder is
+forward-only, the head's 18 parameter tensors receive gradients.  The backward pass is a composition of
+  * la_gru_layer_bwd       persistent backward recurrence (gate pre-activation gradients dgi / dgh per step)
+  * la_gemm (float32 MFMA) every weight / input gradient, expressed as K-contiguous "NT" products through
+  * la_transpose_pad_f32   zero-padded transposes,
+  * la_colsum_f32, la_mish_bwd_f32, la_mask_scale_f32.
+Host code here only sequences kernels and moves / pads buffers (torch slicing, zeros, cat).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import _lib, ops
+from ._lib import check, lib, ptr, stream_ptr
+
+_PAD = 32   # float32 GEMM K granule
+
+
+def _rup(x: int, m: int = _PAD) -> int:
+    return (x + m - 1) // m * m
+
+
+def _padK(a: torch.Tensor) -> torch.Tensor:
+    """[M,K] f32 -> contiguous [M,Kp] with zero tail columns (data movement only)."""
+    M, K = a.shape
+    Kp = _rup(K)
+    if Kp == K and a.is_contiguous():
+        return a
+    out = torch.zeros((M, Kp), dtype=torch.float32, device=a.device)
+    out[:, :K] = a
+    return out
+
+
+def transpose_pad(a: torch.Tensor, rows: Optional[int] = None) -> torch.Tensor:
+    """a [R,C] (row view, unit inner stride) -> [C, Rp] f32, Rp = R rounded up to 32, zero padded."""
+    R, C = a.shape
+    Rp = _rup(R)
+    out = torch.empty((C, Rp), dtype=torch.float32, device=a.device)
+    check(lib().la_transpose_pad_f32(ptr(a), a.stride(0), R, C, ptr(out), Rp, C, Rp, stream_ptr()), "transpose_pad")
+    return out
+
+
+def colsum(a: torch.Tensor) -> torch.Tensor:
+    R, C = a.shape
+    out = torch.empty((C,), dtype=torch.float32, device=a.device)
+    check(lib().la_colsum_f32(ptr(a), a.stride(0), R, C, ptr(out), stream_ptr()), "colsum")
+    return out
+
+
+def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """a [M,K] . w [N,K]^T (+ bias) in float32 on the MFMA kernel; K is zero-padded to the kernel's granule when needed."""
+    if a.shape[1] != w.shape[1]:
+        raise ValueError("gemm_nt: K mismatch")
+    return ops.gemm(_padK(a), _padK(w), bias=bias, out_f32=True)
+
+
+def gemm_tn(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """a [M,N]^T . b [M,K] -> [N,K]: the weight-gradient shape (contraction over the rows of both)."""
+    return ops.gemm(transpose_pad(a), transpose_pad(b), out_f32=True)
+
+
+def gemm_nn(a: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """a [M,N] . w [N,K] -> [M,K]: the input-gradient shape."""
+    return ops.gemm(_padK(a), transpose_pad(w), out_f32=True)
+
+
+def _gru_ws(B: int, T: int, H: int, device):
+    need = ctypes.c_size_t(0)
+    check(lib().la_gru_workspace_bytes(B, T, H, ctypes.byref(need)), "gru_workspace_bytes")
+    return torch.empty((need.value,), dtype=torch.uint8, device=device), need.value
+
+
+class HeadFunction(torch.autograd.Function):
+    """logits = Linear(Mish(GRU(x))) with gradients for the head parameters (and for x when it requires grad)."""
+
+    @staticmethod
+    def forward(ctx, x, dropout_p, training, *params):
+        # params: per layer l in (0, 1): w_ih, w_hh, b_ih, b_hh, w_ih_rev, w_hh_rev, b_ih_rev, b_hh_rev ; then fc.weight, fc.bias
+        _lib.require_gpu()
+        B, T, D = x.shape
+        dev = x.device
+        x0 = x.detach().to(torch.float32).contiguous().view(B * T, D)
+        layers = []
+        for l in range(2):
+            w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r = [p.detach().float() for p in params[8 * l: 8 * l + 8]]
+            layers.append(dict(w_ih=torch.cat([w_ih, w_ih_r], 0).contiguous(), b_ih=torch.cat([b_ih, b_ih_r], 0).contiguous(),
+                               w_hh=torch.stack([w_hh, w_hh_r], 0).contiguous(), b_hh=torch.stack([b_hh, b_hh_r], 0).contiguous()))
+        w_fc, b_fc = params[16].detach().float().contiguous(), params[17].detach().float().contiguous()
+        H = layers[0]["w_hh"].shape[2]
+        flag = torch.zeros((1,), dtype=torch.int32, device=dev)
+        saved = []
+        inp = x0
+        mask = None
+        for l, lw in enumerate(layers):
+            gi = gemm_nt(inp, lw["w_ih"], bias=lw["b_ih"]).view(B, T, 2, 3 * H)
+            out = torch.empty((B, T, 2 * H), dtype=torch.float32, device=dev)
+            gates = torch.empty((B, T, 2, 4 * H), dtype=torch.float32, device=dev)
+            ws, nbytes = _gru_ws(B, T, H, dev)
+            check(lib().la_gru_layer_train_fwd(ptr(gi), ptr(lw["w_hh"]), ptr(lw["b_hh"]), ptr(out), ptr(gates), B, T, H, ptr(ws),
+                                               nbytes, ptr(flag), stream_ptr()), "gru_layer_train_fwd")
+            saved.append((inp, out, gates))
+            if l == 0:
+                if training and dropout_p > 0.0:
+                    mask = torch.empty((B * T, 2 * H), dtype=torch.uint8, device=dev).bernoulli_(1.0 - dropout_p)   # RNG draw only
+                    nxt = torch.empty((B * T, 2 * H), dtype=torch.float32, device=dev)
+                    check(lib().la_mask_scale_f32(ptr(out), ptr(mask), 1.0 / (1.0 - dropout_p), ptr(nxt), nxt.numel(), stream_ptr()), "mask_scale")
+                    inp = nxt
+                else:
+                    inp = out.view(B * T, 2 * H)
+        out1 = saved[1][1].view(B * T, 2 * H)
+        act = torch.empty_like(out1)
+        check(lib().la_mish_f32(ptr(out1), ptr(act), act.numel(), stream_ptr()), "mish")
+        logits = gemm_nt(act, w_fc, bias=b_fc)
+        if int(flag.item()) != 0:
+            raise TimeoutError("persistent GRU kernel: a bounded inter-workgroup wait timed out")
+        ctx.layers, ctx.w_fc, ctx.saved, ctx.mask, ctx.act = layers, w_fc, saved, mask, act
+        ctx.dims, ctx.p, ctx.x_needs_grad = (B, T, D, H), float(dropout_p) if training else 0.0, x.requires_grad
+        return logits.view(B, T, -1)
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        B, T, D, H = ctx.dims
+        dev = dlogits.device
+        M = B * T
+        dl = dlogits.to(torch.float32).contiguous().view(M, -1)
+        # ---- Linear ----
+        dact = gemm_nn(dl, ctx.w_fc)                                     # [M, 2H]
+        dw_fc = gemm_tn(dl, ctx.act)                                     # [V, 2H]
+        db_fc = colsum(dl)
+        # ---- Mish ----
+        out1 = ctx.saved[1][1].view(M, 2 * H)
+        dout = torch.empty_like(out1)
+        check(lib().la_mish_bwd_f32(ptr(out1), ptr(dact), ptr(dout), dout.numel(), stream_ptr()), "mish_bwd")
+        grads: List[Optional[torch.Tensor]] = [None] * 18
+        flag = torch.zeros((1,), dtype=torch.int32, device=dev)
+        dx = None
+        for l in (1, 0):
+            lw = ctx.layers[l]
+            inp, out, gates = ctx.saved[l]
+            dgi = torch.empty((B, T, 2, 3 * H), dtype=torch.float32, device=dev)
+            dgh = torch.empty((B, T, 2, 3 * H), dtype=torch.float32, device=dev)
+            ws, nbytes = _gru_ws(B, T, H, dev)
+            check(lib().la_gru_layer_bwd(ptr(gates), ptr(out), ptr(dout), ptr(lw["w_hh"]), ptr(dgi), ptr(dgh), B, T, H, ptr(ws),
+                                         nbytes, ptr(flag), stream_ptr()), "gru_layer_bwd")
+            dgi2, dgh2 = dgi.view(M, 6 * H), dgh.view(M, 6 * H)
+            # layer input as the recurrence saw it
+            if l == 1 and ctx.mask is not None:
+                xin = torch.empty((M, 2 * H), dtype=torch.float32, device=dev)
+                check(lib().la_mask_scale_f32(ptr(ctx.saved[0][1]), ptr(ctx.mask), 1.0 / (1.0 - ctx.p), ptr(xin), xin.numel(), stream_ptr()), "mask_scale")
+            else:
+                xin = inp if l == 0 else ctx.saved[0][1].view(M, 2 * H)
+            dw_ih = gemm_tn(dgi2, xin)                                   # [6H, in]  (forward rows, then reverse rows)
+            db_ih = colsum(dgi2)
+            db_hh = colsum(dgh2)
+            # h_{t-1} as each direction saw it: shift the output sequence by one step, zero at the start (data movement)
+            o = out.view(B, T, 2 * H)
+            hp_f = torch.zeros((B, T, H), dtype=torch.float32, device=dev)
+            hp_r = torch.zeros((B, T, H), dtype=torch.float32, device=dev)
+            if T > 1:
+                hp_f[:, 1:] = o[:, :-1, :H]
+                hp_r[:, :-1] = o[:, 1:, H:]
+            dw_hh_f = gemm_tn(dgh2[:, : 3 * H], hp_f.view(M, H))
+            dw_hh_r = gemm_tn(dgh2[:, 3 * H:], hp_r.view(M, H))
+            base = 8 * l
+            grads[base + 0], grads[base + 4] = dw_ih[: 3 * H], dw_ih[3 * H:]
+            grads[base + 1], grads[base + 5] = dw_hh_f, dw_hh_r
+            grads[base + 2], grads[base + 6] = db_ih[: 3 * H], db_ih[3 * H:]
+            grads[base + 3], grads[base + 7] = db_hh[: 3 * H], db_hh[3 * H:]
+            if l == 1 or ctx.x_needs_grad:
+                dxin = gemm_nn(dgi2, lw["w_ih"])                          # [M, in]
+                if l == 1:
+                    if ctx.mask is not None:
+                        dout = torch.empty_like(dxin)
+                        check(lib().la_mask_scale_f32(ptr(dxin), ptr(ctx.mask), 1.0 / (1.0 - ctx.p), ptr(dout), dout.numel(), stream_ptr()), "mask_scale")
+                    else:
+                        dout = dxin
+                else:
+                    dx = dxin.view(B, T, D)
+        grads[16], grads[17] = dw_fc, db_fc
+        if int(flag.item()) != 0:
+            raise TimeoutError("persistent GRU backward kernel: a bounded inter-workgroup wait timed out")
+        return (dx, None, None, *grads)
+
+
+def head_params(rnn_module) -> List[torch.nn.Parameter]:
+    """The 18 parameter tensors of the reference's RNN module in HeadFunction's order."""
+    g = rnn_module.rnn
+    out = []
+    for l in range(2):
+        for suffix in ("", "_reverse"):
+            out += [getattr(g, f"weight_ih_l{l}{suffix}"), getattr(g, f"weight_hh_l{l}{suffix}"),
+                    getattr(g, f"bias_ih_l{l}{suffix}"), getattr(g, f"bias_hh_l{l}{suffix}")]
+    return out + [rnn_module.fc.weight, rnn_module.fc.bias]

@@ -94,10 +94,11 @@ class AlignModel(torch.nn.Module):
 
     def engine(self) -> AlignEngine:
         """Packed device weights; re-packed when parameters were updated (optimizer step, load_state_dict)."""
-        if torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters()):
+        if self._wants_grad() and not self._encoder_frozen():
             raise NotImplementedError(
-                "AlignModel training (autograd through the HIP kernels, CTC/CE losses, RCCL data parallel) is the "
-                "fine-tune row that is not built yet (DESIGN.md 'next'); call under torch.no_grad() / model.eval().")
+                "AlignModel training with a trainable Whisper backbone needs the backward pass through the encoder / "
+                "decoder kernels, which is not built yet (DESIGN.md 'next').  Head-only fine-tuning works: pass "
+                "freeze_encoder=True (train_multitask.py --freeze-encoder) or set requires_grad=False on whisper_model.")
         key = self._weights_version()
         if self._engine is None or self._engine_key != key:
             _lib.require_gpu()
@@ -116,6 +117,19 @@ class AlignModel(torch.nn.Module):
             self._engine = AlignEngine(enc, head, dev, dec=dec)
             self._engine_key = key
         return self._engine
+
+    def _wants_grad(self) -> bool:
+        return torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters())
+
+    def _encoder_frozen(self) -> bool:
+        return bool(self.freeze_encoder) or not any(p.requires_grad for p in self.whisper_model.parameters())
+
+    def _head_train_logits(self, feats: torch.Tensor, B: int, T: int, stride: int) -> torch.Tensor:
+        """Training-mode head (float32, autograd through the HIP forward/backward kernels, inter-layer dropout active)."""
+        from ..head_train import HeadFunction, head_params
+        d = feats.shape[1]
+        x = feats.view(-1, stride, d)[:, :T] if stride != T else feats.view(B, T, d)
+        return HeadFunction.apply(x.float(), float(self.align_rnn.rnn.dropout), True, *head_params(self.align_rnn))
 
     def _embed_audio(self, mel: torch.Tensor) -> torch.Tensor:
         """whisper_model.embed_audio: [B,80,3000] -> [B,1500,d] float32."""
@@ -157,14 +171,21 @@ class AlignModel(torch.nn.Module):
         return feats.view(B * T, eng.enc.d), B, T, T
 
     def frame_manual_forward(self, audios: List[np.ndarray], y_in=None, get_orig_len: bool = True):
-        mel = self._mel_of(audios)
+        train = self._wants_grad()
+        with torch.no_grad():                                               # frozen encoder: forward only
+            mel = self._mel_of(audios)
+            eng = self.engine()
+            feats, B, T, stride = self._features(mel, get_orig_len)
         align_logit = None
-        eng = self.engine()
-        feats, B, T, stride = self._features(mel, get_orig_len)
         if self.train_alignment:
-            align_logit = eng.logits(feats, B, T, stride)                   # (:106-107, :114-115)
+            if train:
+                align_logit = self._head_train_logits(feats, B, T, stride)
+            else:
+                align_logit = eng.logits(feats, B, T, stride)               # (:106-107, :114-115)
         transcribe_logit = None
         if self.train_transcript and y_in is not None:                      # (:118-121): decoder over embed_pad = first 1500 frames
+            if train:
+                raise NotImplementedError("train_transcript needs the decoder backward pass (not built yet)")
             embed_pad = feats.view(B, -1, eng.enc.d)[:, :N_CTX].contiguous().view(B * N_CTX, eng.enc.d)
             transcribe_logit = eng.decode(y_in, embed_pad, N_CTX)
         return align_logit, transcribe_logit

@@ -72,3 +72,84 @@ def test_fused_clip_adamw_matches_torch():
         np.testing.assert_allclose(float(ss.item()) ** 0.5, float(total), rtol=1e-5)
         np.testing.assert_allclose(mine.groups[0]["params"].cpu().numpy(), ref1.detach().numpy(), rtol=0, atol=2e-6)
         np.testing.assert_allclose(mine.groups[1]["params"].cpu().numpy(), ref2.detach().numpy(), rtol=0, atol=2e-6)
+
+
+def _ref_rnn(D, H, V, seed):
+    torch.manual_seed(seed)
+    gru = torch.nn.GRU(D, H, num_layers=2, batch_first=True, bidirectional=True, dropout=0.0)
+    fc = torch.nn.Linear(2 * H, V)
+    return gru, fc
+
+
+@pytest.mark.parametrize("B,T,D,H,V", [(3, 20, 64, 64, 50), (2, 150, 128, 128, 333), (33, 9, 64, 64, 40)])
+def test_head_backward_matches_torch_autograd(B, T, D, H, V):
+    """HeadFunction (HIP forward + backward of GRUx2 -> Mish -> Linear) vs torch autograd on nn.GRU / nn.Mish / nn.Linear."""
+    from lyricalignment_amd.head_train import HeadFunction
+    gru, fc = _ref_rnn(D, H, V, 70 + T)
+    g = torch.Generator().manual_seed(71)
+    x = torch.randn(B, T, D, generator=g)
+    wgt = torch.randn(B, T, V, generator=g)
+    xr = x.clone().requires_grad_(True)
+    out, _ = gru(xr)
+    ref = fc(torch.nn.functional.mish(out))
+    (ref * wgt).sum().backward()
+    names = []
+    for l in range(2):
+        for sfx in ("", "_reverse"):
+            names += [f"weight_ih_l{l}{sfx}", f"weight_hh_l{l}{sfx}", f"bias_ih_l{l}{sfx}", f"bias_hh_l{l}{sfx}"]
+    params = [getattr(gru, n).detach().clone().cuda().requires_grad_(True) for n in names]
+    params += [fc.weight.detach().clone().cuda().requires_grad_(True), fc.bias.detach().clone().cuda().requires_grad_(True)]
+    xd = x.clone().cuda().requires_grad_(True)
+    logits = HeadFunction.apply(xd, 0.0, True, *params)
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), ref.detach().numpy(), rtol=0, atol=2e-5)
+    (logits * wgt.cuda()).sum().backward()
+    scale = max(1.0, float(T) ** 0.5)
+    for n, p_ in zip(names, params[:16]):
+        want = getattr(gru, n).grad
+        np.testing.assert_allclose(p_.grad.cpu().numpy(), want.numpy(), rtol=0, atol=2e-4 * scale * max(1.0, float(want.abs().max())), err_msg=n)
+    np.testing.assert_allclose(params[16].grad.cpu().numpy(), fc.weight.grad.numpy(), rtol=0, atol=2e-4 * scale)
+    np.testing.assert_allclose(params[17].grad.cpu().numpy(), fc.bias.grad.numpy(), rtol=0, atol=2e-4 * scale)
+    np.testing.assert_allclose(xd.grad.cpu().numpy(), xr.grad.numpy(), rtol=0, atol=2e-4)
+
+
+def test_head_only_finetune_step_through_alignmodel():
+    """Frozen-encoder fine-tune step through the drop-in surface: frame_manual_forward under autograd, the reference's loss
+    formulas (torch ops, as train_multitask.py computes them), backward through the HIP head, fused clip + AdamW.
+    The loss must go down on a fixed tiny batch, and encoder parameters must receive no gradient."""
+    from lyricalignment_amd import finetune as ft, whisper_compat as wc
+    from lyricalignment_amd.head_train import head_params
+    from lyricalignment_amd.module.align_model import AlignModel
+    dims = wc.ModelDimensions(n_audio_state=128, n_audio_head=2, n_audio_layer=1, n_text_state=128, n_text_head=2, n_text_layer=0)
+    model = AlignModel(wc.build_model(dims=dims, seed=81, std=0.05), embed_dim=128, hidden_dim=64, output_dim=41, dropout=0.15,
+                       freeze_encoder=True, device="cuda").to("cuda")
+    for p_ in model.whisper_model.parameters():
+        p_.requires_grad_(False)
+    model.train()
+    rs = np.random.RandomState(82)
+    audios = [(rs.randn(16000) * 0.1).astype(np.float32), (rs.randn(12000) * 0.1).astype(np.float32)]
+    labels = torch.tensor([[3, 7, 7, 12], [5, 9, -100, -100]]).cuda()
+    frame_labels = torch.full((2, 50), -100, dtype=torch.long); frame_labels[0, 5:20] = 3; frame_labels[1, 10:30] = 9
+    V = 40
+    hp = head_params(model.align_rnn)
+    flat = torch.cat([p_.detach().reshape(-1) for p_ in hp]).contiguous()
+    opt = ft.FlatAdamW([{"params": flat, "lr": 5e-3}], weight_decay=1e-5)
+    losses = []
+    for it in range(6):
+        logits, _ = model.frame_manual_forward(audios, get_orig_len=False)
+        assert logits.requires_grad and tuple(logits.shape) == (2, 1500, 41)
+        ce = torch.nn.functional.cross_entropy(logits[:, :, 1:V].transpose(1, 2), torch.where(ft.pad_frame_labels(frame_labels, 1500) == -100, -100, ft.pad_frame_labels(frame_labels, 1500) - 1).cuda())
+        lsm = torch.nn.functional.log_softmax(logits[:, :, :V], dim=2).transpose(0, 1)
+        ctc = torch.nn.functional.ctc_loss(lsm, labels, torch.full((2,), 1500, dtype=torch.long), (labels != -100).sum(1))
+        loss = ce + ctc
+        for p_ in hp:
+            p_.grad = None
+        loss.backward()
+        assert all(p_.grad is not None for p_ in hp) and all(p_.grad is None for p_ in model.whisper_model.parameters())
+        grads = torch.cat([p_.grad.reshape(-1) for p_ in hp]).contiguous()
+        opt.step([grads], max_norm=1.0)
+        with torch.no_grad():                      # scatter the flat bucket back into the module's parameters
+            off = 0
+            for p_ in hp:
+                p_.copy_(flat[off: off + p_.numel()].view_as(p_)); off += p_.numel()
+        losses.append(float(loss.item()))
+    assert losses[-1] < losses[0], losses
