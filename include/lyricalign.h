@@ -302,6 +302,36 @@ int la_mish_f32(const float *x, float *y, int64_t n, void *stream);
 int la_mish_bwd_f32(const float *x, const float *dy, float *dx, int64_t n, void *stream);
 int la_mask_scale_f32(const float *x, const unsigned char *mask, float scale, float *y, int64_t n, void *stream);
 
+/* Backward-pass building blocks of the Whisper encoder (float32): la_gemm with a row pitch for W and per-batch strides
+ * (attention gradients batch over heads inside the packed [T][3d] projections), batched zero-padded transposes, exact-erf
+ * GELU forward / backward, LayerNorm backward (dx and dy*xhat, whose column sum is dgamma), row softmax forward /
+ * backward on materialised score tiles, the overlap-add of the k=3 convolution gradients, elementwise add. */
+int la_gemm_ex(int32_t dtype, int32_t M, int32_t N, int32_t K, int32_t batch, const void *A, int64_t lda, int64_t strideA,
+               const void *W, int64_t ldw, int64_t strideW, void *C, int64_t ldc, int64_t strideC, const float *bias,
+               int32_t epilogue, void *stream);
+int la_transpose_pad_batched_f32(const float *in, int64_t ld_in, int64_t batch_stride_in, int32_t rows, int32_t cols,
+                                 float *out, int64_t ld_out, int64_t batch_stride_out, int32_t out_rows, int32_t out_cols,
+                                 int32_t batch, void *stream);
+int la_gelu_f32(const float *x, float *y, int64_t n, void *stream);
+int la_gelu_bwd_f32(const float *x, const float *dy, float *dx, int64_t n, void *stream);
+int la_add_f32(const float *a, const float *b, float *y, int64_t n, void *stream);
+int la_scale_f32(const float *x, float alpha, float *y, int64_t n, void *stream);
+int la_layernorm_bwd_f32(const float *x, const float *dy, const float *gamma, int32_t M, int32_t d, float *dx, float *dy_xhat,
+                         void *stream);
+/* causal_q_len > 0: row r is query (r mod causal_q_len) and sees keys 0 .. (r mod causal_q_len) + cols - causal_q_len */
+int la_softmax_rows_f32(float *s, int64_t ld, int64_t rows, int32_t cols, int32_t causal_q_len, void *stream);
+int la_softmax_bwd_rows_f32(const float *p, float *dp, int64_t ld, int64_t rows, int32_t cols, void *stream);
+/* Text-decoder training pieces (whisper/model.py TextDecoder; train_multitask.py:285,308 decoder cross-entropy):
+ * gradient of token + learned positional embedding (dtok accumulates, dpos [n][d] is written), and
+ * F.cross_entropy(logits [rows][vocab], target, ignore_index=-100, 'mean'): loss2[0] = loss, loss2[1] = 1/count;
+ * row_ws holds 2*rows floats; dlogits (optional) = scale * dloss/dlogits. */
+int la_embed_tokens_bwd_f32(const float *dx, const int64_t *tokens, int32_t batch, int32_t n, int32_t d, float *dtok, float *dpos,
+                            void *stream);
+int la_cross_entropy_f32(const float *logits, int64_t ld, int32_t rows, int32_t vocab, const int64_t *target, float scale,
+                         float *loss2, float *row_ws, float *dlogits, int64_t ld_d, void *stream);
+int la_col2im3_f32(const float *dcols, int32_t batch, int32_t t_out, int32_t stride, int32_t channels, float *out,
+                   int32_t rows_out, void *stream);
+
 /*
  * Polyphase FIR resampling (audio front end, utils/audio.py:3-20: librosa.load(file, sr=16000)):
  * y[n] = sum_k h[(n + skip)*down - k*up] * x[k], n < n_out.  h is the centred low-pass (host-built Kaiser-windowed sinc,

@@ -56,6 +56,18 @@ SYMBOLS = {
     "la_mish_f32": (c_int32, [_P, _P, _I64, _P]),
     "la_mish_bwd_f32": (c_int32, [_P, _P, _P, _I64, _P]),
     "la_mask_scale_f32": (c_int32, [_P, _P, ctypes.c_float, _P, _I64, _P]),
+    "la_gemm_ex": (c_int32, [_I32, _I32, _I32, _I32, _I32, _P, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _P, _I32, _P]),
+    "la_transpose_pad_batched_f32": (c_int32, [_P, _I64, _I64, _I32, _I32, _P, _I64, _I64, _I32, _I32, _I32, _P]),
+    "la_gelu_f32": (c_int32, [_P, _P, _I64, _P]),
+    "la_gelu_bwd_f32": (c_int32, [_P, _P, _P, _I64, _P]),
+    "la_add_f32": (c_int32, [_P, _P, _P, _I64, _P]),
+    "la_scale_f32": (c_int32, [_P, ctypes.c_float, _P, _I64, _P]),
+    "la_layernorm_bwd_f32": (c_int32, [_P, _P, _P, _I32, _I32, _P, _P, _P]),
+    "la_softmax_rows_f32": (c_int32, [_P, _I64, _I64, _I32, _I32, _P]),
+    "la_embed_tokens_bwd_f32": (c_int32, [_P, _P, _I32, _I32, _I32, _P, _P, _P]),
+    "la_cross_entropy_f32": (c_int32, [_P, _I64, _I32, _I32, _P, ctypes.c_float, _P, _P, _P, _I64, _P]),
+    "la_softmax_bwd_rows_f32": (c_int32, [_P, _P, _I64, _I64, _I32, _P]),
+    "la_col2im3_f32": (c_int32, [_P, _I32, _I32, _I32, _I32, _P, _I32, _P]),
     "la_resample_poly_f32": (c_int32, [_P, _I64, _P, _I64, _I32, _I32, _I64, _P, _I64, _P]),
     "la_cast_f32_to_bf16": (c_int32, [_P, _P, _I64, _P]),
     "la_cast_bf16_to_f32": (c_int32, [_P, _P, _I64, _P]),

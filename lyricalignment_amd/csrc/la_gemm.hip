@@ -17,7 +17,7 @@ struct GemmParams {
     const void *A;
     int64_t lda, strideA;
     const void *W;
-    int64_t strideW;
+    int64_t ldw, strideW;
     void *C;
     int64_t ldc, strideC;
     const float *bias;
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(CF::THREADS, 2) void gemm_kernel(GemmParams p) {
     const float *bias = p.bias ? p.bias + (int64_t)z * p.strideBias : nullptr;
 
     f32x4 acc[4][4];
-    mainloop<T, CF>(A, p.lda, p.M, W, p.K, p.N, p.K, m0, n0, lds, acc);
+    mainloop<T, CF>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
 
     typedef typename std::conditional<OUT_F32, float, T>::type TC;
     TC *C = reinterpret_cast<TC *>(p.C) + (int64_t)z * p.strideC;
@@ -152,8 +152,8 @@ __global__ __launch_bounds__(PP::THREADS, 2) void gemm_pp_kernel(GemmParams p) {
     const float *bias = p.bias ? p.bias + (int64_t)z * p.strideBias : nullptr;
 
     f32x4 acc[8][4];
-    if constexpr (DBG == 8) mainloop_flat256(A, p.lda, p.M, W, p.K, p.N, p.K, m0, n0, lds, acc);
-    else mainloop_pp<DBG>(A, p.lda, p.M, W, p.K, p.N, p.K, m0, n0, lds, acc);
+    if constexpr (DBG == 8) mainloop_flat256(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
+    else mainloop_pp<DBG>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
 
     typedef typename std::conditional<OUT_F32, float, bf16_t>::type TC;
     TC *C = reinterpret_cast<TC *>(p.C) + (int64_t)z * p.strideC;
@@ -290,6 +290,8 @@ bool use_big_tile(int M, int N, int batch) {
 
 }  // namespace
 
+static thread_local int64_t g_ldw = 0;   // row pitch of W for the next gemm_run (0 = dense [N][K]); set by la_gemm_ex
+
 int la::gemm_run(int dtype, int M, int N, int K, int batch, const void *A, int64_t lda, int64_t strideA, const void *W,
                  int64_t strideW, void *C, int64_t ldc, int64_t strideC, const float *bias, int64_t strideBias,
                  const float *residual, int64_t ldr, int64_t strideR, int epilogue, hipStream_t stream) {
@@ -304,8 +306,8 @@ int la::gemm_run(int dtype, int M, int N, int K, int batch, const void *A, int64
                  "gemm: A/W rows must be 16-byte aligned");
     LA_CHECK_ARG(!(epilogue & LA_EPI_RESIDUAL) || residual, "gemm: residual epilogue without pointer");
     LA_CHECK_ARG(!(epilogue & LA_EPI_BIAS) || bias, "gemm: bias epilogue without pointer");
-    LA_CHECK_ARG((strideW * es) % 16 == 0, "gemm: W batch stride must be 16-byte aligned");
-    GemmParams p{M, N, K, A, lda, strideA, W, strideW, C, ldc, strideC, bias, strideBias, residual, ldr, strideR, epilogue,
+    LA_CHECK_ARG((strideW * es) % 16 == 0 && (g_ldw * es) % 16 == 0, "gemm: W batch stride / row pitch must be 16-byte aligned");
+    GemmParams p{M, N, K, A, lda, strideA, W, g_ldw > 0 ? g_ldw : (int64_t)K, strideW, C, ldc, strideC, bias, strideBias, residual, ldr, strideR, epilogue,
                  0, la::cdiv(N, BN), pick_group(K, es, la::cdiv(N, BN))};
     const bool out_f32 = epilogue & LA_EPI_OUT_F32;
     typedef Cfg<2, 2> Small;
@@ -329,4 +331,16 @@ extern "C" int la_gemm(int32_t dtype, int32_t M, int32_t N, int32_t K, int32_t b
                        const float *residual, int64_t ldr, int64_t strideR, int32_t epilogue, void *stream_) {
     return la::gemm_run(dtype, M, N, K, batch, A, lda, strideA, W, 0, C, ldc, strideC, bias, 0, residual, ldr, strideR,
                         epilogue, (hipStream_t)stream_);
+}
+
+// General face used by the backward pass: W rows with their own pitch (ldw >= K) and per-batch strides for A, W, C, bias.
+extern "C" int la_gemm_ex(int32_t dtype, int32_t M, int32_t N, int32_t K, int32_t batch, const void *A, int64_t lda,
+                          int64_t strideA, const void *W, int64_t ldw, int64_t strideW, void *C, int64_t ldc, int64_t strideC,
+                          const float *bias, int32_t epilogue, void *stream_) {
+    LA_CHECK_ARG(ldw >= K, "gemm_ex: ldw < K");
+    g_ldw = ldw;
+    const int rc = la::gemm_run(dtype, M, N, K, batch, A, lda, strideA, W, strideW, C, ldc, strideC, bias, 0, nullptr, 0, 0,
+                                epilogue, (hipStream_t)stream_);
+    g_ldw = 0;
+    return rc;
 }

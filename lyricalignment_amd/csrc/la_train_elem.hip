@@ -7,8 +7,11 @@ namespace {
 
 // out[c][r] = in[r][c] for r < rows, c < cols; out is [cols_pad][ld_out] and everything outside is zero-filled
 __global__ __launch_bounds__(256) void transpose_pad_kernel(const float *in, int64_t ld_in, int rows, int cols, float *out,
-                                                            int64_t ld_out, int out_rows, int out_cols) {
+                                                            int64_t ld_out, int out_rows, int out_cols, int64_t bs_in,
+                                                            int64_t bs_out) {
     __shared__ float tile[32][33];
+    in += (int64_t)blockIdx.z * bs_in;
+    out += (int64_t)blockIdx.z * bs_out;
     const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     for (int i = ty; i < 32; i += 8) {
@@ -56,6 +59,184 @@ __global__ void mask_scale_kernel(const float *x, const unsigned char *mask, flo
         y[i] = mask[i] ? x[i] * scale : 0.f;
 }
 
+// exact-erf GELU forward / backward on float32 buffers (whisper's nn.GELU): gelu'(x) = Phi(x) + x phi(x)
+__global__ void gelu_fwd_kernel(const float *x, float *y, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) y[i] = la::gelu_erf(x[i]);
+}
+__global__ void gelu_bwd_kernel(const float *x, const float *dy, float *dx, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        const float cdf = 0.5f * (1.0f + la::erf_fast(v * 0.70710678118654752440f));
+        const float pdf = 0.3989422804014327f * __expf(-0.5f * v * v);
+        dx[i] = dy[i] * (cdf + v * pdf);
+    }
+}
+__global__ void scale_kernel(const float *x, float alpha, float *y, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) y[i] = alpha * x[i];
+}
+// y = a + b
+__global__ void add_kernel(const float *a, const float *b, float *y, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) y[i] = a[i] + b[i];
+}
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wmax(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// LayerNorm backward, one wave per row (row statistics recomputed):  xhat = (x - mean) rstd,  g = dy * gamma,
+// dx = rstd (g - mean(g) - xhat mean(g xhat));  also writes dy * xhat (its column sum is dgamma; colsum(dy) is dbeta)
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float *x, const float *dy, const float *gamma, int M, int d,
+                                                            float *dx, float *dy_xhat) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const float *xr = x + (int64_t)row * d, *gr = dy + (int64_t)row * d;
+    float s = 0.f;
+    for (int c = lane; c < d; c += 64) s += xr[c];
+    const float mean = wsum(s) / (float)d;
+    float sq = 0.f;
+    for (int c = lane; c < d; c += 64) { const float t = xr[c] - mean; sq += t * t; }
+    const float rstd = 1.0f / sqrtf(wsum(sq) / (float)d + 1e-5f);
+    float sg = 0.f, sgx = 0.f;
+    for (int c = lane; c < d; c += 64) {
+        const float xh = (xr[c] - mean) * rstd, g = gr[c] * gamma[c];
+        sg += g; sgx += g * xh;
+    }
+    const float mg = wsum(sg) / (float)d, mgx = wsum(sgx) / (float)d;
+    for (int c = lane; c < d; c += 64) {
+        const float xh = (xr[c] - mean) * rstd, g = gr[c] * gamma[c];
+        dx[(int64_t)row * d + c] = rstd * (g - mg - xh * mgx);
+        dy_xhat[(int64_t)row * d + c] = gr[c] * xh;
+    }
+}
+
+// in-place row softmax over the first `cols` columns of rows with pitch ld (pad columns are set to 0)
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float *s, int64_t ld, int64_t rows, int cols_all, int causal_q_len) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float *r = s + row * ld;
+    // causal: query i (= row mod q_len) sees keys 0 .. i + (kv_len - q_len); masked entries become exact zeros
+    int cols = cols_all;
+    if (causal_q_len > 0) cols = min(cols_all, max(1, (int)(row % causal_q_len) + 1 + (cols_all - causal_q_len)));
+    float m = -INFINITY;
+    for (int c = lane; c < cols; c += 64) m = fmaxf(m, r[c]);
+    m = wmax(m);
+    float sum = 0.f;
+    for (int c = lane; c < cols; c += 64) { const float e = expf(r[c] - m); r[c] = e; sum += e; }
+    const float inv = 1.0f / wsum(sum);
+    for (int c = lane; c < cols; c += 64) r[c] *= inv;
+    for (int c = cols + lane; c < ld; c += 64) r[c] = 0.f;
+}
+// dS = P * (dP - sum_c dP P), written over dP
+__global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const float *p, float *dp, int64_t ld, int64_t rows, int cols) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float *pr = p + row * ld;
+    float *dr = dp + row * ld;
+    float dot = 0.f;
+    for (int c = lane; c < cols; c += 64) dot += pr[c] * dr[c];
+    dot = wsum(dot);
+    for (int c = lane; c < cols; c += 64) dr[c] = pr[c] * (dr[c] - dot);
+    for (int c = cols + lane; c < ld; c += 64) dr[c] = 0.f;
+}
+
+// overlap-add of the k=3 convolution's column gradients: out[b][r][c] = sum over (t, tap) with t*stride + tap == r of
+// dcols[b][t][tap][c];  out is [B][rows_out][C] (the zero-bordered channels-last input buffer of the conv-as-GEMM view)
+__global__ void col2im3_kernel(const float *dcols, int T_out, int stride, int C, float *out, int rows_out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int r = (int)((i / C) % rows_out);
+        const int64_t b = i / ((int64_t)C * rows_out);
+        float acc = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap) {
+            const int num = r - tap;
+            if (num >= 0 && num % stride == 0) {
+                const int t = num / stride;
+                if (t < T_out) acc += dcols[((b * T_out + t) * 3 + tap) * (int64_t)C + c];
+            }
+        }
+        out[i] = acc;
+    }
+}
+
+// gradient of x[b][i][:] = tok_emb[tokens[b][i]][:] + pos[i][:]:  dtok rows accumulate (atomics: a token may repeat),
+// dpos[i] = sum over the batch (written, deterministic order)
+__global__ void embed_bwd_kernel(const float *dx, const int64_t *tokens, int B, int n, int d, float *dtok, float *dpos) {
+    const int64_t total = (int64_t)n * d;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % d), pos_i = (int)(i / d);
+        float acc = 0.f;
+        for (int b = 0; b < B; ++b) {
+            const float g = dx[((int64_t)b * n + pos_i) * d + c];
+            acc += g;
+            atomicAdd(dtok + tokens[(int64_t)b * n + pos_i] * d + c, g);
+        }
+        dpos[i] = acc;
+    }
+}
+
+// F.cross_entropy(logits [R][V], target [R], ignore_index = -100, reduction = 'mean') -- three small passes
+__global__ __launch_bounds__(256) void ce_row_kernel(const float *logits, int64_t ld, int V, const int64_t *target, float *row_lse,
+                                                      float *row_loss) {
+    __shared__ float red[4];
+    const int r = blockIdx.x;
+    const float *l = logits + (int64_t)r * ld;
+    float m = -INFINITY;
+    for (int c = threadIdx.x; c < V; c += 256) m = fmaxf(m, l[c]);
+    m = wmax(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float s = 0.f;
+    for (int c = threadIdx.x; c < V; c += 256) s += expf(l[c] - m);
+    s = wsum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float lse = m + logf(red[0] + red[1] + red[2] + red[3]);
+        row_lse[r] = lse;
+        const int64_t t = target[r];
+        row_loss[r] = (t >= 0 && t < V) ? lse - l[t] : 0.f;
+    }
+}
+__global__ __launch_bounds__(64) void ce_reduce_kernel(const float *row_loss, const int64_t *target, int R, int V, float *out2) {
+    double s = 0.0;
+    int cnt = 0;
+    for (int r = threadIdx.x; r < R; r += 64) {
+        const int64_t t = target[r];
+        if (t >= 0 && t < V) { s += (double)row_loss[r]; ++cnt; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); cnt += __shfl_xor(cnt, o); }
+    if (threadIdx.x == 0) {
+        out2[0] = cnt > 0 ? (float)(s / cnt) : NAN;      // torch returns nan for an all-ignored batch
+        out2[1] = cnt > 0 ? 1.0f / (float)cnt : 0.f;
+    }
+}
+__global__ void ce_grad_kernel(const float *logits, int64_t ld, int V, const int64_t *target, const float *row_lse, const float *out2,
+                               float scale, float *dlogits, int64_t ld_d, int64_t n) {
+    const float k = out2[1] * scale;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % V);
+        const int64_t r = i / V;
+        const int64_t t = target[r];
+        float g = 0.f;
+        if (t >= 0 && t < V) g = (expf(logits[r * ld + c] - row_lse[r]) - (c == t ? 1.f : 0.f)) * k;
+        dlogits[r * ld_d + c] = g;
+    }
+}
+
 inline int ew_grid(int64_t n) { return (int)std::min<int64_t>(4096, la::cdiv(n, 256)); }
 
 }  // namespace
@@ -64,8 +245,19 @@ extern "C" int la_transpose_pad_f32(const float *in, int64_t ld_in, int32_t rows
                                     int32_t out_rows, int32_t out_cols, void *stream_) {
     LA_CHECK_ARG(in && out && rows > 0 && cols > 0 && out_rows >= cols && out_cols >= rows && ld_out >= out_cols && ld_in >= cols,
                  "transpose_pad: bad arguments");
-    hipLaunchKernelGGL(transpose_pad_kernel, dim3(la::cdiv(out_cols, 32), la::cdiv(out_rows, 32)), dim3(256), 0,
-                       (hipStream_t)stream_, in, ld_in, rows, cols, out, ld_out, out_rows, out_cols);
+    hipLaunchKernelGGL(transpose_pad_kernel, dim3(la::cdiv(out_cols, 32), la::cdiv(out_rows, 32), 1), dim3(256), 0,
+                       (hipStream_t)stream_, in, ld_in, rows, cols, out, ld_out, out_rows, out_cols, (int64_t)0, (int64_t)0);
+    LA_LAUNCH_CHECK();
+    return LA_OK;
+}
+
+extern "C" int la_transpose_pad_batched_f32(const float *in, int64_t ld_in, int64_t batch_stride_in, int32_t rows, int32_t cols,
+                                            float *out, int64_t ld_out, int64_t batch_stride_out, int32_t out_rows,
+                                            int32_t out_cols, int32_t batch, void *stream_) {
+    LA_CHECK_ARG(in && out && rows > 0 && cols > 0 && batch > 0 && out_rows >= cols && out_cols >= rows && ld_out >= out_cols && ld_in >= cols,
+                 "transpose_pad_batched: bad arguments");
+    hipLaunchKernelGGL(transpose_pad_kernel, dim3(la::cdiv(out_cols, 32), la::cdiv(out_rows, 32), batch), dim3(256), 0,
+                       (hipStream_t)stream_, in, ld_in, rows, cols, out, ld_out, out_rows, out_cols, batch_stride_in, batch_stride_out);
     LA_LAUNCH_CHECK();
     return LA_OK;
 }
@@ -97,6 +289,88 @@ extern "C" int la_mask_scale_f32(const float *x, const unsigned char *mask, floa
     if (n == 0) return LA_OK;
     LA_CHECK_ARG(x && mask && y && n > 0, "mask_scale: bad arguments");
     hipLaunchKernelGGL(mask_scale_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream_, x, mask, scale, y, n);
+    LA_LAUNCH_CHECK();
+    return LA_OK;
+}
+
+extern "C" int la_gelu_f32(const float *x, float *y, int64_t n, void *stream_) {
+    if (n == 0) return LA_OK;
+    LA_CHECK_ARG(x && y && n > 0, "gelu: bad arguments");
+    hipLaunchKernelGGL(gelu_fwd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream_, x, y, n);
+    LA_LAUNCH_CHECK();
+    return LA_OK;
+}
+extern "C" int la_gelu_bwd_f32(const float *x, const float *dy, float *dx, int64_t n, void *stream_) {
+    if (n == 0) return LA_OK;
+    LA_CHECK_ARG(x && dy && dx && n > 0, "gelu_bwd: bad arguments");
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream_, x, dy, dx, n);
+    LA_LAUNCH_CHECK();
+    return LA_OK;
+}
+extern "C" int la_add_f32(const float *a, const float *b, float *y, int64_t n, void *stream_) {
+    if (n == 0) return LA_OK;
+    LA_CHECK_ARG(a && b && y && n > 0, "add: bad arguments");
+    hipLaunchKernelGGL(add_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream_, a, b, y, n);
+    LA_LAUNCH_CHECK();
+    return LA_OK;
+}
+extern "C" int la_layernorm_bwd_f32(const float *x, const float *dy, const float *gamma, int32_t M, int32_t d, float *dx,
+                                    float *dy_xhat, void *stream_) {
+    LA_CHECK_ARG(x && dy && gamma && dx && dy_xhat && M > 0 && d > 0, "layernorm_bwd: bad arguments");
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(la::cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream_, x, dy, gamma, M, d, dx, dy_xhat);
+    LA_LAUNCH_CHECK();
+    return LA_OK;
+}
+extern "C" int la_softmax_rows_f32(float *s, int64_t ld, int64_t rows, int32_t cols, int32_t causal_q_len, void *stream_) {
+    LA_CHECK_ARG(s && rows > 0 && cols > 0 && ld >= cols && causal_q_len >= 0, "softmax_rows: bad arguments");
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(la::cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream_, s, ld, rows, cols, causal_q_len);
+    LA_LAUNCH_CHECK();
+    return LA_OK;
+}
+extern "C" int la_softmax_bwd_rows_f32(const float *p, float *dp, int64_t ld, int64_t rows, int32_t cols, void *stream_) {
+    LA_CHECK_ARG(p && dp && rows > 0 && cols > 0 && ld >= cols, "softmax_bwd_rows: bad arguments");
+    hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3(la::cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream_, p, dp, ld, rows, cols);
+    LA_LAUNCH_CHECK();
+    return LA_OK;
+}
+extern "C" int la_col2im3_f32(const float *dcols, int32_t batch, int32_t t_out, int32_t stride, int32_t channels, float *out,
+                              int32_t rows_out, void *stream_) {
+    LA_CHECK_ARG(dcols && out && batch > 0 && t_out > 0 && stride > 0 && channels > 0 && rows_out >= (t_out - 1) * stride + 3,
+                 "col2im3: bad arguments");
+    const int64_t n = (int64_t)batch * rows_out * channels;
+    hipLaunchKernelGGL(col2im3_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream_, dcols, t_out, stride, channels, out, rows_out, n);
+    LA_LAUNCH_CHECK();
+    return LA_OK;
+}
+
+extern "C" int la_scale_f32(const float *x, float alpha, float *y, int64_t n, void *stream_) {
+    if (n == 0) return LA_OK;
+    LA_CHECK_ARG(x && y && n > 0, "scale: bad arguments");
+    hipLaunchKernelGGL(scale_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream_, x, alpha, y, n);
+    LA_LAUNCH_CHECK();
+    return LA_OK;
+}
+
+extern "C" int la_embed_tokens_bwd_f32(const float *dx, const int64_t *tokens, int32_t batch, int32_t n, int32_t d, float *dtok,
+                                       float *dpos, void *stream_) {
+    LA_CHECK_ARG(dx && tokens && dtok && dpos && batch > 0 && n > 0 && d > 0, "embed_tokens_bwd: bad arguments");
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(ew_grid((int64_t)n * d)), dim3(256), 0, (hipStream_t)stream_, dx, tokens, batch, n, d, dtok, dpos);
+    LA_LAUNCH_CHECK();
+    return LA_OK;
+}
+
+extern "C" int la_cross_entropy_f32(const float *logits, int64_t ld, int32_t rows, int32_t vocab, const int64_t *target, float scale,
+                                    float *loss2, float *row_ws, float *dlogits, int64_t ld_d, void *stream_) {
+    LA_CHECK_ARG(logits && target && loss2 && row_ws && rows > 0 && vocab > 0 && ld >= vocab && (!dlogits || ld_d >= vocab),
+                 "cross_entropy: bad arguments");
+    hipStream_t st = (hipStream_t)stream_;
+    float *row_lse = row_ws, *row_loss = row_ws + rows;
+    hipLaunchKernelGGL(ce_row_kernel, dim3(rows), dim3(256), 0, st, logits, ld, vocab, target, row_lse, row_loss);
+    hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(64), 0, st, row_loss, target, rows, vocab, loss2);
+    if (dlogits) {
+        const int64_t n = (int64_t)rows * vocab;
+        hipLaunchKernelGGL(ce_grad_kernel, dim3(ew_grid(n)), dim3(256), 0, st, logits, ld, vocab, target, row_lse, loss2, scale, dlogits, ld_d, n);
+    }
     LA_LAUNCH_CHECK();
     return LA_OK;
 }

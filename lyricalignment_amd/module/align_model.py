@@ -94,17 +94,9 @@ class AlignModel(torch.nn.Module):
 
     def engine(self) -> AlignEngine:
         """Packed device weights; re-packed when parameters were updated (optimizer step, load_state_dict)."""
-        if self._wants_grad() and not self._encoder_frozen():
-            raise NotImplementedError(
-                "AlignModel training with a trainable Whisper backbone needs the backward pass through the encoder / "
-                "decoder kernels, which is not built yet (DESIGN.md 'next').  Head-only fine-tuning works: pass "
-                "freeze_encoder=True (train_multitask.py --freeze-encoder) or set requires_grad=False on whisper_model.")
         key = self._weights_version()
         if self._engine is None or self._engine_key != key:
-            _lib.require_gpu()
-            dev = torch.device(self.device if self.device != 'cuda' else f'cuda:{torch.cuda.current_device()}')
-            if dev.type != "cuda":
-                raise _lib.LyricAlignHipError("AlignModel runs on the MI355X only (device must be a cuda/HIP device)")
+            dev = self._device()
             enc_sd = {"encoder." + k: v for k, v in self.whisper_model.encoder.state_dict().items()}
             head_sd = {"align_rnn." + k: v for k, v in self.align_rnn.state_dict().items()}
             enc = pack_encoder(enc_sd, self._n_head(), self.compute_dtype, dev)
@@ -118,6 +110,13 @@ class AlignModel(torch.nn.Module):
             self._engine_key = key
         return self._engine
 
+    def _device(self) -> torch.device:
+        _lib.require_gpu()
+        dev = torch.device(self.device if self.device != 'cuda' else f'cuda:{torch.cuda.current_device()}')
+        if dev.type != "cuda":
+            raise _lib.LyricAlignHipError("AlignModel runs on the MI355X only (device must be a cuda/HIP device)")
+        return dev
+
     def _wants_grad(self) -> bool:
         return torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters())
 
@@ -130,6 +129,22 @@ class AlignModel(torch.nn.Module):
         d = feats.shape[1]
         x = feats.view(-1, stride, d)[:, :T] if stride != T else feats.view(B, T, d)
         return HeadFunction.apply(x.float(), float(self.align_rnn.rnn.dropout), True, *head_params(self.align_rnn))
+
+    def _encoder_train_features(self, mel: torch.Tensor, get_orig_len: bool) -> torch.Tensor:
+        """Trainable-backbone encoder (float32, autograd through the HIP forward/backward kernels): mel -> [B, T, d] with
+        the same chunking as the forward-only path (:87-115)."""
+        from ..encoder_train import EncoderFunction, encoder_params
+        enc = self.whisper_model.encoder
+        pos = enc.positional_embedding
+        params = encoder_params(enc)
+        plan = frame_plan(mel.shape[-1], get_orig_len)
+        H = self._n_head()
+        if len(plan) == 1:
+            return EncoderFunction.apply(pad_or_trim(mel, N_FRAMES), pos, H, *params)[:, : plan[0][2]]
+        chunks = [pad_or_trim(mel[:, :, s:e], N_FRAMES) for s, e, _ in plan]
+        B = mel.shape[0]
+        y = EncoderFunction.apply(torch.cat(chunks, dim=0), pos, H, *params).view(len(chunks), B, N_CTX, -1)
+        return torch.cat([y[c, :, : plan[c][2]] for c in range(len(chunks))], dim=1)
 
     def _embed_audio(self, mel: torch.Tensor) -> torch.Tensor:
         """whisper_model.embed_audio: [B,80,3000] -> [B,1500,d] float32."""
@@ -152,7 +167,7 @@ class AlignModel(torch.nn.Module):
         batch = np.zeros((len(audios), max_audio_len), dtype=np.float32)   # zero-pad to the batch max (:78-82), no mutation
         for i, a in enumerate(audios):
             batch[i, : len(a)] = np.asarray(a, dtype=np.float32)
-        return log_mel_spectrogram(batch, device=self.engine().device)     # (:84) on the device
+        return log_mel_spectrogram(batch, device=self._device())           # (:84) on the device
 
     def _features(self, mel: torch.Tensor, get_orig_len: bool):
         """-> (feats rows [., d] in compute dtype, B, T, clip stride in rows, embed_pad provider)."""
@@ -172,6 +187,17 @@ class AlignModel(torch.nn.Module):
 
     def frame_manual_forward(self, audios: List[np.ndarray], y_in=None, get_orig_len: bool = True):
         train = self._wants_grad()
+        if train and not self._encoder_frozen():                            # whole-model fine-tune (train_multitask.py default)
+            if self.train_transcript and y_in is not None:
+                raise NotImplementedError("train_transcript needs the decoder backward pass (not built yet)")
+            from ..head_train import HeadFunction, head_params
+            with torch.no_grad():
+                mel = self._mel_of(audios)
+            x = self._encoder_train_features(mel, get_orig_len)
+            align_logit = None
+            if self.train_alignment:
+                align_logit = HeadFunction.apply(x, float(self.align_rnn.rnn.dropout), True, *head_params(self.align_rnn))
+            return align_logit, None
         with torch.no_grad():                                               # frozen encoder: forward only
             mel = self._mel_of(audios)
             eng = self.engine()

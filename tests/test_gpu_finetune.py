@@ -153,3 +153,108 @@ def test_head_only_finetune_step_through_alignmodel():
                 p_.copy_(flat[off: off + p_.numel()].view_as(p_)); off += p_.numel()
         losses.append(float(loss.item()))
     assert losses[-1] < losses[0], losses
+
+
+def _rel(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+@pytest.mark.parametrize("B,T,H", [(1, 96, 2), (2, 1500, 1), (1, 333, 3)])
+def test_attention_backward_matches_torch_autograd(B, T, H):
+    """dQ/dK/dV from recomputed score tiles (batched f32 MFMA GEMMs + row softmax kernels) against torch autograd."""
+    from lyricalignment_amd import encoder_train as et
+    d = 64 * H
+    g = torch.Generator().manual_seed(T)
+    qkv = torch.randn(B * T, 3 * d, generator=g)
+    qkv[:, :d] *= 0.35          # q pre-scaled: logits of a few units, a peaky softmax
+    datt = torch.randn(B * T, d, generator=g)
+    ref_in = qkv.clone().requires_grad_(True)
+    q, k, v = [t.view(B, T, H, 64).permute(0, 2, 1, 3) for t in ref_in.split(d, dim=1)]
+    o = (torch.softmax(q @ k.transpose(-1, -2), dim=-1) @ v).permute(0, 2, 1, 3).reshape(B * T, d)
+    o.backward(datt)
+    got = et.attention_bwd(qkv.cuda(), datt.cuda(), B, T, H).cpu()
+    for name, sl in (("dq", slice(0, d)), ("dk", slice(d, 2 * d)), ("dv", slice(2 * d, 3 * d))):
+        assert _rel(got[:, sl], ref_in.grad[:, sl]) < 2e-4, name     # float32 tolerance (north_star: 1e-3)
+
+
+@pytest.mark.parametrize("d,H,L,B", [(64, 1, 1, 1), (128, 2, 2, 2)])
+def test_encoder_backward_matches_torch_autograd(d, H, L, B):
+    """EncoderFunction (HIP forward + backward) against torch autograd through the oracle's AudioEncoder restatement:
+    output and the gradient of every encoder parameter."""
+    from oracle import model_oracle as mo
+    from lyricalignment_amd import encoder_train as et
+    p = mo.random_encoder_params(d, L, seed=d + L)
+    for i in range(L):                      # sharper attention than the 0.02-std init gives, so softmax' is exercised
+        p[f"encoder.blocks.{i}.attn.query.weight"] *= 12
+        p[f"encoder.blocks.{i}.attn.key.weight"] *= 12
+    names = et.encoder_param_names(L)
+    g = torch.Generator().manual_seed(5)
+    mel = torch.randn(B, 80, 3000, generator=g) * 0.5
+    dy = torch.randn(B, 1500, d, generator=g)
+    ref_p = {k: v.clone().requires_grad_(k != "encoder.positional_embedding") for k, v in p.items()}
+    y_ref = mo.encoder_forward(ref_p, mel, H)
+    y_ref.backward(dy)
+    params = [p["encoder." + n].cuda().requires_grad_(True) for n in names]
+    y = et.EncoderFunction.apply(mel.cuda(), p["encoder.positional_embedding"].cuda(), H, *params)
+    assert _rel(y.detach().cpu(), y_ref.detach()) < 1e-4
+    y.backward(dy.cuda())
+    worst = {}
+    for n, t in zip(names, params):
+        worst[n] = _rel(t.grad.cpu(), ref_p["encoder." + n].grad)
+    bad = {n: e for n, e in worst.items() if e > 1e-3}
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("B,n,Ta,L", [(2, 37, 1500, 2), (1, 5, 100, 1)])
+def test_decoder_backward_matches_torch_autograd(B, n, Ta, L):
+    """DecoderFunction (HIP forward + backward: causal self-attention, cross-attention, tied projection, embeddings)
+    against torch autograd through the oracle's TextDecoder restatement: logits, every parameter gradient, d/d(xa)."""
+    from oracle import model_oracle as mo
+    from lyricalignment_amd import decoder_train as dt, whisper_compat as wc
+    d, H, V = 128, 2, 311
+    dims = wc.ModelDimensions(n_audio_state=d, n_audio_head=H, n_audio_layer=1, n_text_state=d, n_text_head=H, n_text_layer=L,
+                              n_vocab=V, n_text_ctx=64)
+    wm = wc.build_model(dims=dims, seed=60 + n, std=0.05, with_decoder=True)
+    sd = {k: v.detach().float().clone() for k, v in wm.decoder.state_dict().items()}
+    for i in range(L):
+        for a in ("attn", "cross_attn"):
+            sd[f"blocks.{i}.{a}.query.weight"] *= 6
+            sd[f"blocks.{i}.{a}.key.weight"] *= 6
+    names = dt.decoder_param_names(L)
+    g = torch.Generator().manual_seed(61)
+    tokens = torch.randint(0, V, (B, n), generator=g)
+    tokens[0, -1] = tokens[0, 0]                                   # a repeated token: embedding rows accumulate
+    xa = torch.randn(B, Ta, d, generator=g)
+    dlog = torch.randn(B, n, V, generator=g)
+    ref_p = {"decoder." + k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xa_ref = xa.clone().requires_grad_(True)
+    ref = mo.decoder_forward(ref_p, tokens, xa_ref, H)
+    ref.backward(dlog)
+    params = [sd[k].cuda().requires_grad_(True) for k in names]
+    xa_dev = xa.cuda().requires_grad_(True)
+    out = dt.DecoderFunction.apply(tokens.cuda(), xa_dev, H, *params)
+    assert _rel(out.detach().cpu(), ref.detach()) < 1e-4
+    out.backward(dlog.cuda())
+    bad = {}
+    for k, t in zip(names, params):
+        e = _rel(t.grad.cpu(), ref_p["decoder." + k].grad)
+        if e > 1e-3:
+            bad[k] = e
+    e = _rel(xa_dev.grad.cpu(), xa_ref.grad)
+    if e > 1e-3:
+        bad["xa"] = e
+    assert not bad, bad
+
+
+def test_cross_entropy_matches_torch():
+    from lyricalignment_amd import decoder_train as dt
+    g = torch.Generator().manual_seed(70)
+    logits = torch.randn(3, 29, 5187, generator=g) * 3
+    tgt = torch.randint(0, 5187, (3, 29), generator=g)
+    tgt[0, 20:] = -100; tgt[2, :4] = -100
+    ref_in = logits.clone().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(ref_in.permute(0, 2, 1), tgt)           # train_multitask.py:285
+    (ref * 0.125).backward()
+    loss, dl = dt.cross_entropy(logits.cuda(), tgt.cuda(), scale_grad=0.125)
+    np.testing.assert_allclose(float(loss), float(ref.detach()), rtol=2e-6)
+    np.testing.assert_allclose(dl.cpu().numpy(), ref_in.grad.numpy(), rtol=0, atol=1e-8)
