@@ -146,7 +146,8 @@ def pack_decoder(sd: Dict[str, torch.Tensor], n_head: int, dtype: torch.dtype, d
         wqkv = torch.cat([g(b + "attn.query.weight") * scale, g(b + "attn.key.weight"), g(b + "attn.value.weight")], 0)
         bqkv = torch.cat([bq, torch.zeros_like(bq), g(b + "attn.value.bias")], 0)
         wkv_c = torch.cat([g(b + "cross_attn.key.weight"), g(b + "cross_attn.value.weight")], 0)
-        bkv_c = torch.cat([torch.zeros(d), g(b + "cross_attn.value.bias")], 0)
+        bv_c = g(b + "cross_attn.value.bias")
+        bkv_c = torch.cat([torch.zeros_like(bv_c), bv_c], 0)
         blocks.append(DecoderBlockWeights(
             _f32(g(b + "attn_ln.weight"), device), _f32(g(b + "attn_ln.bias"), device), w(wqkv), _f32(bqkv, device),
             w(g(b + "attn.out.weight")), _f32(g(b + "attn.out.bias"), device),

@@ -4,9 +4,8 @@ gradient exchange (one flat all-reduce per optimizer step over RCCL / xGMI, plac
 Arithmetic = HIP kernels (la_multitask_loss, la_grad_sqnorm_f32, la_adamw_step_f32) and the collective; nothing here
 computes on tensors.
 
-NOT built yet (DESIGN.md "next"): the backward pass through the head / encoder kernels and the Whisper decoder, so a full
-train_multitask.py step does not run on this engine yet; these pieces are the parts of that step that sit on flat
-buffers and on the logits.
+FineTuner assembles the whole step: frame_manual_forward under autograd (head_train / encoder_train / decoder_train run
+the forward + backward kernels), the loss kernels on the logits, flat gradient buckets, the all-reduce, clip + AdamW.
 """
 from __future__ import annotations
 
@@ -106,3 +105,109 @@ def allreduce_mean_(buckets: Sequence[torch.Tensor], world: int) -> None:
     import torch.distributed as dist
     for b in buckets:
         dist.all_reduce(b, op=dist.ReduceOp.SUM)
+
+
+def linear_warmup_scale(step: int, warmup_steps: int, train_steps: int) -> float:
+    """transformers.get_linear_schedule_with_warmup's LambdaLR factor (train_multitask.py:688-690): linear 0 -> 1 over the
+    warm-up, then linear 1 -> 0 at train_steps.  `step` counts completed optimizer steps."""
+    if step < warmup_steps:
+        return float(step) / float(max(1, warmup_steps))
+    return max(0.0, float(train_steps - step) / float(max(1, train_steps - warmup_steps)))
+
+
+class FineTuner:
+    """The reference's train_step (train_multitask.py:215-342) on the HIP kernels, one process per GPU.
+
+    micro_step(): frame_manual_forward under autograd (encoder / head / decoder forward + backward kernels), the fused
+    CE + silence-BCE + CTC loss kernel on the alignment logits and the cross-entropy kernel on the decoder logits, each
+    already divided by accum_grad_steps, gradients accumulated into two flat float32 buckets (head, backbone).
+    step(): ONE all-reduce (sum) per bucket over RCCL -- the only exchange of the data-parallel path -- then the fused
+    global-norm clip + AdamW over the buckets (mean over ranks folded into the update), linear warm-up schedule.
+    The module's parameters are views into the flat buckets, so the update is in place and nothing is scattered back."""
+
+    def __init__(self, model, lr: float = 5e-3, backbone_lr: float = 5e-6, weight_decay: float = 1e-5, warmup_steps: int = 0,
+                 train_steps: int = 2000, max_grad_norm: float = 1.0, use_ctc_loss: bool = True, vocab_size: int = 21128,
+                 world: Optional[int] = None):
+        _lib.require_gpu()
+        self.model = model
+        self.use_ctc_loss, self.vocab_size, self.max_grad_norm = use_ctc_loss, vocab_size, max_grad_norm
+        self.warmup_steps, self.train_steps, self.steps_done = warmup_steps, train_steps, 0
+        if world is None:
+            import torch.distributed as dist
+            world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.world = world
+        dev = model._device()
+        self.groups: List[List[torch.nn.Parameter]] = [
+            [p for p in model.align_rnn.parameters() if p.requires_grad],          # lr        (:683)
+            [p for p in model.whisper_model.parameters() if p.requires_grad]]      # backbone_lr (:684)
+        lrs = [lr, backbone_lr]
+        self.flat, self.grad = [], []
+        opt_groups = []
+        for params, group_lr in zip(self.groups, lrs):
+            if not params:
+                continue
+            n = sum(p.numel() for p in params)
+            flat = torch.empty((n,), dtype=torch.float32, device=dev)
+            off = 0
+            for p in params:                                   # parameters become views of the bucket (data movement only)
+                flat[off: off + p.numel()].copy_(p.detach().reshape(-1))
+                p.data = flat[off: off + p.numel()].view_as(p)
+                off += p.numel()
+            self.flat.append(flat)
+            self.grad.append(torch.zeros_like(flat))
+            opt_groups.append({"params": flat, "lr": group_lr})
+        self.groups = [g for g in self.groups if g]
+        self.opt = FlatAdamW(opt_groups, weight_decay=weight_decay)
+        self._dirty = False
+
+    def _accumulate(self) -> None:
+        """p.grad of this micro-batch -> += into the flat buckets (la_add_f32), then dropped."""
+        for params, acc in zip(self.groups, self.grad):
+            g = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params]).contiguous()
+            check(lib().la_add_f32(ptr(acc), ptr(g), ptr(acc), acc.numel(), stream_ptr()), "add")
+            for p in params:
+                p.grad = None
+        self._dirty = True
+
+    def micro_step(self, audios, ctc_labels=None, frame_labels=None, decoder_input=None, decoder_output=None,
+                   accum_grad_steps: int = 1, get_orig_len: bool = False):
+        """One micro-batch: forward, losses, backward.  Labels are pinyin-class ids with -100 padding (the caller maps
+        tokens -> classes as train_step :259-268 does; harness.PinyinClassLUT).  Returns the device loss vector
+        [word CE, silence BCE, CTC, decoder CE] (un-scaled, like the reference's logging)."""
+        m = self.model
+        m.train()
+        if m.train_alignment and not self.use_ctc_loss:
+            raise NotImplementedError("FineTuner: the alignment losses are built for the CTC configuration (output_dim = "
+                                      "vocab_size + 1 with the silence column), the one the reference's scripts train")
+        y_in = decoder_input if (m.train_transcript and decoder_input is not None) else None
+        align_logit, trans_logit = m.frame_manual_forward(audios, y_in, get_orig_len=get_orig_len)
+        out = torch.zeros((4,), dtype=torch.float32, device=self.flat[0].device)
+        roots, grads = [], []
+        s = 1.0 / float(accum_grad_steps)
+        if align_logit is not None and m.train_alignment:
+            logits = align_logit.detach().contiguous()
+            l3, dlog = multitask_loss(logits, frame_labels, ctc_labels if self.use_ctc_loss else None,
+                                      vocab_size=self.vocab_size, scale=s)
+            out[:3] = l3
+            roots.append(align_logit); grads.append(dlog)
+        if trans_logit is not None and decoder_output is not None:
+            from .decoder_train import cross_entropy
+            l, dl = cross_entropy(trans_logit.detach().contiguous(), decoder_output, scale_grad=s)
+            out[3] = l
+            roots.append(trans_logit); grads.append(dl)
+        if roots:
+            torch.autograd.backward(roots, grads)
+            self._accumulate()
+        return out
+
+    def step(self) -> torch.Tensor:
+        """All-reduce + clip + AdamW + schedule; returns the device scalar sum(grad^2) over the summed buckets."""
+        allreduce_mean_(self.grad, self.world)
+        sumsq = self.opt.step(self.grad, max_norm=self.max_grad_norm, grad_prescale=1.0 / self.world,
+                              lr_scale=linear_warmup_scale(self.steps_done, self.warmup_steps, self.train_steps))
+        self.steps_done += 1
+        for g in self.grad:
+            g.zero_()
+        self._dirty = False
+        self.model._engine_key = None        # parameters changed under the packed inference weights: re-pack on next use
+        return sumsq

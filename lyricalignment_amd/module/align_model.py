@@ -121,7 +121,9 @@ class AlignModel(torch.nn.Module):
         return torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters())
 
     def _encoder_frozen(self) -> bool:
-        return bool(self.freeze_encoder) or not any(p.requires_grad for p in self.whisper_model.parameters())
+        """No encoder parameter asks for a gradient.  (The reference's freeze_encoder flag only acts in forward(), :135-139;
+        frame_manual_forward back-propagates into whatever still requires grad, and so does this.)"""
+        return not any(p.requires_grad for p in self.whisper_model.encoder.parameters())
 
     def _head_train_logits(self, feats: torch.Tensor, B: int, T: int, stride: int) -> torch.Tensor:
         """Training-mode head (float32, autograd through the HIP forward/backward kernels, inter-layer dropout active)."""
@@ -131,8 +133,8 @@ class AlignModel(torch.nn.Module):
         return HeadFunction.apply(x.float(), float(self.align_rnn.rnn.dropout), True, *head_params(self.align_rnn))
 
     def _encoder_train_features(self, mel: torch.Tensor, get_orig_len: bool) -> torch.Tensor:
-        """Trainable-backbone encoder (float32, autograd through the HIP forward/backward kernels): mel -> [B, T, d] with
-        the same chunking as the forward-only path (:87-115)."""
+        """Trainable-backbone encoder (float32, autograd through the HIP forward/backward kernels): mel -> (embed [B, T, d],
+        embed_pad [B, 1500, d]) with the same chunking as the forward-only path (:87-115)."""
         from ..encoder_train import EncoderFunction, encoder_params
         enc = self.whisper_model.encoder
         pos = enc.positional_embedding
@@ -140,11 +142,20 @@ class AlignModel(torch.nn.Module):
         plan = frame_plan(mel.shape[-1], get_orig_len)
         H = self._n_head()
         if len(plan) == 1:
-            return EncoderFunction.apply(pad_or_trim(mel, N_FRAMES), pos, H, *params)[:, : plan[0][2]]
+            embed_pad = EncoderFunction.apply(pad_or_trim(mel, N_FRAMES), pos, H, *params)
+            return embed_pad[:, : plan[0][2]], embed_pad
         chunks = [pad_or_trim(mel[:, :, s:e], N_FRAMES) for s, e, _ in plan]
         B = mel.shape[0]
         y = EncoderFunction.apply(torch.cat(chunks, dim=0), pos, H, *params).view(len(chunks), B, N_CTX, -1)
-        return torch.cat([y[c, :, : plan[c][2]] for c in range(len(chunks))], dim=1)
+        embed = torch.cat([y[c, :, : plan[c][2]] for c in range(len(chunks))], dim=1)
+        return embed, embed[:, :N_CTX]
+
+    def _decoder_train_logits(self, y_in: torch.Tensor, embed_pad: torch.Tensor) -> torch.Tensor:
+        """whisper_model.logits(tokens=y_in, audio_features=embed_pad) under autograd (:118-121)."""
+        from ..decoder_train import DecoderFunction, decoder_params
+        dec = self.whisper_model.decoder
+        n_head = int(getattr(self.whisper_model.dims, "n_text_head", self._n_head()))
+        return DecoderFunction.apply(y_in.to(embed_pad.device), embed_pad, n_head, *decoder_params(dec))
 
     def _embed_audio(self, mel: torch.Tensor) -> torch.Tensor:
         """whisper_model.embed_audio: [B,80,3000] -> [B,1500,d] float32."""
@@ -188,16 +199,16 @@ class AlignModel(torch.nn.Module):
     def frame_manual_forward(self, audios: List[np.ndarray], y_in=None, get_orig_len: bool = True):
         train = self._wants_grad()
         if train and not self._encoder_frozen():                            # whole-model fine-tune (train_multitask.py default)
-            if self.train_transcript and y_in is not None:
-                raise NotImplementedError("train_transcript needs the decoder backward pass (not built yet)")
             from ..head_train import HeadFunction, head_params
             with torch.no_grad():
                 mel = self._mel_of(audios)
-            x = self._encoder_train_features(mel, get_orig_len)
-            align_logit = None
+            embed, embed_pad = self._encoder_train_features(mel, get_orig_len)
+            align_logit = transcribe_logit = None
             if self.train_alignment:
-                align_logit = HeadFunction.apply(x, float(self.align_rnn.rnn.dropout), True, *head_params(self.align_rnn))
-            return align_logit, None
+                align_logit = HeadFunction.apply(embed, float(self.align_rnn.rnn.dropout), True, *head_params(self.align_rnn))
+            if self.train_transcript and y_in is not None:
+                transcribe_logit = self._decoder_train_logits(y_in, embed_pad)
+            return align_logit, transcribe_logit
         with torch.no_grad():                                               # frozen encoder: forward only
             mel = self._mel_of(audios)
             eng = self.engine()
@@ -210,13 +221,30 @@ class AlignModel(torch.nn.Module):
                 align_logit = eng.logits(feats, B, T, stride)               # (:106-107, :114-115)
         transcribe_logit = None
         if self.train_transcript and y_in is not None:                      # (:118-121): decoder over embed_pad = first 1500 frames
-            if train:
-                raise NotImplementedError("train_transcript needs the decoder backward pass (not built yet)")
             embed_pad = feats.view(B, -1, eng.enc.d)[:, :N_CTX].contiguous().view(B * N_CTX, eng.enc.d)
-            transcribe_logit = eng.decode(y_in, embed_pad, N_CTX)
+            if train and any(p.requires_grad for p in self.whisper_model.decoder.parameters()):
+                transcribe_logit = self._decoder_train_logits(y_in, embed_pad.view(B, N_CTX, -1).float())
+            else:
+                transcribe_logit = eng.decode(y_in, embed_pad, N_CTX)
         return align_logit, transcribe_logit
 
     def forward(self, mel, y_in=None):
+        if self._wants_grad():                                              # training through forward(): (:135-149)
+            from ..encoder_train import EncoderFunction, encoder_params
+            from ..head_train import HeadFunction, head_params
+            enc = self.whisper_model.encoder
+            mel = mel.to(self._device())
+            if self.freeze_encoder or self._encoder_frozen():
+                with torch.no_grad():
+                    embed = self._embed_audio(mel)
+            else:
+                embed = EncoderFunction.apply(mel, enc.positional_embedding, self._n_head(), *encoder_params(enc))
+            align_logit = transcribe_logit = None
+            if self.train_alignment:
+                align_logit = HeadFunction.apply(embed, float(self.align_rnn.rnn.dropout), True, *head_params(self.align_rnn))
+            if self.train_transcript and y_in is not None:
+                transcribe_logit = self._decoder_train_logits(y_in, embed)
+            return align_logit, transcribe_logit
         eng = self.engine()
         feats = eng.encode(mel)                                             # (:135-139)
         B = mel.shape[0]

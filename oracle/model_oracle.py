@@ -172,7 +172,8 @@ def _mha(p: Dict[str, torch.Tensor], prefix: str, x: torch.Tensor, xa: Optional[
     qk = q @ k
     if mask is not None:
         qk = qk + mask[:n_ctx, :n_ctx]
-    w = F.softmax(qk.float(), dim=-1)
+    # whisper: softmax(qk.float()).to(q.dtype); float64 inputs (the tests' high-precision reference runs) stay float64
+    w = F.softmax(qk if qk.dtype == torch.float64 else qk.float(), dim=-1).to(q.dtype)
     out = (w @ v).permute(0, 2, 1, 3).flatten(start_dim=2)
     return F.linear(out, p[prefix + "out.weight"], p[prefix + "out.bias"])
 
@@ -381,7 +382,7 @@ def ce_loss(logits: torch.Tensor, frame_labels: torch.Tensor, vocab_size: int = 
         fl = torch.cat((fl, torch.full((fl.shape[0], T - fl.shape[1]), -100, dtype=fl.dtype)), dim=1)
     fl[fl != -100] -= 1
     word = F.cross_entropy(logits[:, :, 1:vocab_size].transpose(1, 2), fl)
-    sil_label = torch.where(fl == -100, 1, 0).float()
+    sil_label = torch.where(fl == -100, 1, 0).to(logits.dtype)
     sil = F.binary_cross_entropy_with_logits(logits[:, :, vocab_size], sil_label)
     return word + sil
 

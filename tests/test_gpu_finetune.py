@@ -258,3 +258,90 @@ def test_cross_entropy_matches_torch():
     loss, dl = dt.cross_entropy(logits.cuda(), tgt.cuda(), scale_grad=0.125)
     np.testing.assert_allclose(float(loss), float(ref.detach()), rtol=2e-6)
     np.testing.assert_allclose(dl.cpu().numpy(), ref_in.grad.numpy(), rtol=0, atol=1e-8)
+
+
+def _tiny_full_model(dropout=0.0, seed=90):
+    from lyricalignment_amd import whisper_compat as wc
+    from lyricalignment_amd.module.align_model import AlignModel
+    dims = wc.ModelDimensions(n_audio_state=128, n_audio_head=2, n_audio_layer=1, n_text_state=128, n_text_head=2, n_text_layer=1,
+                              n_vocab=311, n_text_ctx=64)
+    wm = wc.build_model(dims=dims, seed=seed, std=0.05, with_decoder=True)
+    return AlignModel(wm, embed_dim=128, hidden_dim=64, output_dim=41, dropout=dropout, train_transcript=True, device="cuda").to("cuda")
+
+
+def _tiny_batch():
+    rs = np.random.RandomState(91)
+    audios = [(rs.randn(16000) * 0.1).astype(np.float32), (rs.randn(12000) * 0.1).astype(np.float32)]
+    labels = torch.tensor([[3, 7, 7, 12], [5, 9, -100, -100]])
+    frame_labels = torch.full((2, 50), -100, dtype=torch.long); frame_labels[0, 5:20] = 3; frame_labels[1, 10:30] = 9
+    dec_in = torch.tensor([[1, 20, 33, 47, 200], [1, 90, 91, 2, 2]])
+    dec_out = torch.tensor([[20, 33, 47, 200, 2], [90, 91, 2, -100, -100]])
+    return audios, labels, frame_labels, dec_in, dec_out
+
+
+def test_full_finetune_micro_step_gradients_match_torch_autograd():
+    """The whole config-3 micro-step -- log-mel, encoder, BiGRU head, decoder, CE + silence BCE + CTC + decoder CE, backward
+    through every kernel, flat gradient buckets -- against torch autograd through the oracle restatement of the same model
+    with the reference's loss formulas (train_multitask.py:587-633, 285)."""
+    from oracle import model_oracle as mo
+    from lyricalignment_amd import finetune as ft
+    F = torch.nn.functional
+    model = _tiny_full_model(dropout=0.0)
+    sd = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+    audios, labels, frame_labels, dec_in, dec_out = _tiny_batch()
+    tuner = ft.FineTuner(model, vocab_size=40, world=1)
+    losses = tuner.micro_step(audios, labels, frame_labels, dec_in, dec_out, accum_grad_steps=2, get_orig_len=False).cpu()
+    # ---- reference: the same model as torch functional code on the CPU ----
+    p = {}
+    for k, v in sd.items():
+        key = k[len("whisper_model."):] if k.startswith("whisper_model.") else k
+        p[key] = v.double().requires_grad_("encoder.positional_embedding" not in k)     # float64: the truth both sides approximate
+    batch = np.zeros((2, 16000), dtype=np.float32); batch[0] = audios[0]; batch[1, :12000] = audios[1]
+    mel = mo.pad_or_trim(mo.log_mel_spectrogram(batch), 3000).double()
+    xa = mo.encoder_forward(p, mel, n_head=2)
+    logits = mo.gru_head_forward(p, xa)
+    assert logits.dtype == torch.float64
+    ce = mo.ce_loss(logits, frame_labels, vocab_size=40)
+    lsm = F.log_softmax(logits[:, :, :40], dim=2).transpose(0, 1)
+    ctc = F.ctc_loss(lsm, labels, torch.full((2,), 1500, dtype=torch.long), (labels != -100).sum(1))
+    tr = F.cross_entropy(mo.decoder_forward(p, dec_in, xa, n_head=2).permute(0, 2, 1), dec_out)
+    ((ce + ctc + tr) / 2).backward()
+    np.testing.assert_allclose(float(losses[0] + losses[1]), float(ce.detach()), rtol=2e-4)
+    np.testing.assert_allclose(float(losses[2]), float(ctc.detach()), rtol=2e-4)
+    np.testing.assert_allclose(float(losses[3]), float(tr.detach()), rtol=2e-4)
+    for bucket, params, prefix in ((tuner.grad[0], model.align_rnn.named_parameters(), "align_rnn."),
+                                   (tuner.grad[1], model.whisper_model.named_parameters(), "")):
+        got = bucket.cpu()
+        off = 0
+        worst = {}
+        for name, prm in params:
+            if not prm.requires_grad:
+                continue
+            g = got[off: off + prm.numel()].view(prm.shape); off += prm.numel()
+            ref = p[prefix + name].grad
+            worst[name] = float((g - ref).abs().max() / ref.abs().max().clamp_min(1e-12))
+        assert off == got.numel()
+        bad = {k: v for k, v in worst.items() if v > 2e-3}
+        assert not bad, bad
+
+
+def test_full_finetune_steps_reduce_the_loss():
+    """FineTuner: a few optimizer steps (2 micro-batches each) of whole-model fine-tuning on a fixed tiny batch; the
+    parameters are views of the flat buckets, so the fused AdamW updates the module in place and eval re-packs."""
+    from lyricalignment_amd import finetune as ft
+    model = _tiny_full_model(dropout=0.15)
+    audios, labels, frame_labels, dec_in, dec_out = _tiny_batch()
+    tuner = ft.FineTuner(model, lr=5e-3, backbone_lr=2e-4, warmup_steps=1, train_steps=20, vocab_size=40, world=1)
+    totals = []
+    for it in range(5):
+        acc = torch.zeros(4)
+        for _ in range(2):
+            acc += tuner.micro_step(audios, labels, frame_labels, dec_in, dec_out, accum_grad_steps=2).cpu() / 2
+        sumsq = tuner.step()
+        assert float(sumsq) > 0 and torch.isfinite(acc).all()
+        totals.append(float(acc.sum()))
+    assert totals[-1] < totals[1], totals            # step 0 runs at lr 0 (warm-up), like LambdaLR
+    model.eval()
+    with torch.no_grad():
+        logits, _ = model.frame_manual_forward(audios, get_orig_len=True)
+    assert tuple(logits.shape) == (2, 50, 41) and torch.isfinite(logits).all()

@@ -270,3 +270,16 @@ def test_checkpoint_round_trip_reference_layout(tmp_path):
     for k, v in src.state_dict().items():
         assert torch.equal(dst.state_dict()[k], v), k
     assert json.load(open(tmp_path / "model_args.json"))["output_dim"] == 77
+
+
+def test_linear_warmup_scale_matches_transformers_schedule():
+    """FineTuner's LR factor against the scheduler the reference uses (train_multitask.py:688-690)."""
+    import torch
+    from transformers import get_linear_schedule_with_warmup
+    from lyricalignment_amd.finetune import linear_warmup_scale
+    for warm, total in ((0, 10), (3, 17), (100, 2000)):
+        opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1.0)
+        sch = get_linear_schedule_with_warmup(opt, num_warmup_steps=warm, num_training_steps=total)
+        for step in range(min(total + 3, 60)):
+            assert abs(opt.param_groups[0]["lr"] - linear_warmup_scale(step, warm, total)) < 1e-12, (warm, total, step)
+            opt.step(); sch.step()
