@@ -25,17 +25,28 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const float *in, int
     }
 }
 
-// out[c] = sum_r in[r][c]; one workgroup per 64 columns, rows strided over 4 waves, double accumulation
-__global__ __launch_bounds__(256) void colsum_kernel(const float *in, int64_t ld, int rows, int cols, float *out) {
+// out[c] = sum_r in[r][c] in two deterministic passes: (64-column tile x row chunk) workgroups write double partials,
+// then one thread per column adds the chunks in order.  Fills the chip for tall-skinny inputs (3000 x 1024: 752 groups).
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float *in, int64_t ld, int rows, int cols, int rows_per_chunk,
+                                                             double *part) {
     __shared__ double red[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int w = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
     double s = 0.0;
     if (c < cols)
-        for (int r = w; r < rows; r += 4) s += (double)in[(int64_t)r * ld + c];
+        for (int r = r0 + w; r < r1; r += 4) s += (double)in[(int64_t)r * ld + c];
     red[w][threadIdx.x & 63] = s;
     __syncthreads();
-    if (w == 0 && c < cols) out[c] = (float)((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+    if (w == 0 && c < cols)
+        part[(int64_t)blockIdx.y * cols + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+__global__ void colsum_final_kernel(const double *part, int chunks, int cols, float *out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    double s = 0.0;
+    for (int k = 0; k < chunks; ++k) s += part[(int64_t)k * cols + c];
+    out[c] = (float)s;
 }
 
 // dx = dy * mish'(x);  mish(x) = x tanh(sp), sp = softplus(x):  mish' = tanh(sp) + x (1 - tanh(sp)^2) sigmoid(x)
@@ -264,7 +275,14 @@ extern "C" int la_transpose_pad_batched_f32(const float *in, int64_t ld_in, int6
 
 extern "C" int la_colsum_f32(const float *in, int64_t ld, int32_t rows, int32_t cols, float *out, void *stream_) {
     LA_CHECK_ARG(in && out && rows > 0 && cols > 0 && ld >= cols, "colsum: bad arguments");
-    hipLaunchKernelGGL(colsum_kernel, dim3(la::cdiv(cols, 64)), dim3(256), 0, (hipStream_t)stream_, in, ld, rows, cols, out);
+    hipStream_t st = (hipStream_t)stream_;
+    const int chunks = std::max(1, std::min(64, la::cdiv(rows, 64)));
+    const int rows_per_chunk = la::cdiv(rows, chunks);
+    double *part = nullptr;                                   // stream-ordered scratch: safe with concurrent streams
+    LA_HIP(hipMallocAsync((void **)&part, sizeof(double) * (size_t)chunks * cols, st));
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(la::cdiv(cols, 64), chunks), dim3(256), 0, st, in, ld, rows, cols, rows_per_chunk, part);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(la::cdiv(cols, 256)), dim3(256), 0, st, part, chunks, cols, out);
+    LA_HIP(hipFreeAsync(part, st));
     LA_LAUNCH_CHECK();
     return LA_OK;
 }
