@@ -148,7 +148,7 @@ def cpu_baseline(model, mel_cpu: np.ndarray, labels_row: np.ndarray, n_head: int
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="single stream: no encoder/head overlap across batches")

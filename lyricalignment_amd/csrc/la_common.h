@@ -102,6 +102,29 @@ __device__ __forceinline__ float erf_fast(float x) {
 // exact (erf) GELU of whisper's nn.GELU(); abs error of the erf fit <= 1.2e-7
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
 
+// GELU for results that are rounded to bf16 anyway, two values per lane on the packed-FP32 pipe (v_pk_fma_f32 /
+// v_pk_mul_f32 / v_pk_add_f32: 2 lanes per issue).  Same erfc form, degree-5 fit (fractional error of erfc <= 2.8e-5
+// everywhere, i.e. 1/140 of a bf16 ulp; max abs error of gelu 1.3e-6), log2(e) folded into the coefficients so the
+// exponential is a bare v_exp_f32:   gelu(x) = 0.5 (x + |x| (1 - t 2^(q(t) - 0.5 log2e x^2))),  t = 1 / (1 + |x| / (2 sqrt 2)).
+// 15.5 issue slots per value against 32 for gelu_erf: the MLP-up epilogue runs at 1 workgroup per CU with nothing to
+// hide it behind (DESIGN.md "GEMM findings"), so its VALU count is wall time.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_pk(f32x2 x) {
+    const f32x2 ax = __builtin_elementwise_abs(x);
+    const f32x2 d = __builtin_elementwise_fma(ax, f32x2{0.35355339059f, 0.35355339059f}, f32x2{1.f, 1.f});
+    const f32x2 t = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    f32x2 p = f32x2{3.483918905e-01f, 3.483918905e-01f};
+    p = __builtin_elementwise_fma(p, t, f32x2{-1.077869773e+00f, -1.077869773e+00f});
+    p = __builtin_elementwise_fma(p, t, f32x2{7.467902899e-01f, 7.467902899e-01f});
+    p = __builtin_elementwise_fma(p, t, f32x2{3.336617649e-01f, 3.336617649e-01f});
+    p = __builtin_elementwise_fma(p, t, f32x2{1.477083683e+00f, 1.477083683e+00f});
+    p = __builtin_elementwise_fma(p, t, f32x2{-1.828017831e+00f, -1.828017831e+00f});
+    const f32x2 y2 = __builtin_elementwise_fma(x * f32x2{-0.72134752044f, -0.72134752044f}, x, p);
+    const f32x2 e = {__builtin_amdgcn_exp2f(y2.x), __builtin_amdgcn_exp2f(y2.y)};
+    const f32x2 u = __builtin_elementwise_fma(-ax, t * e, ax);          // |x| (1 - erfc(|x| / sqrt 2))
+    return (x + u) * f32x2{0.5f, 0.5f};
+}
+
 // nn.Mish: x * tanh(softplus(x)); softplus with torch's threshold 20
 __device__ __forceinline__ float mish(float x) {
     float sp = x > 20.0f ? x : log1pf(expf(x));

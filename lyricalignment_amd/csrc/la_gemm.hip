@@ -73,9 +73,16 @@ __global__ __launch_bounds__(CF::THREADS, 2) void gemm_kernel(GemmParams p) {
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
+            for (int ni = 0; ni < 4; ++ni) {
+                if constexpr (!OUT_F32 && sizeof(T) == 2) {      // result is rounded to bf16: packed-FP32 form
+                    const la::f32x2 lo = la::gelu_pk(la::f32x2{acc[mi][ni][0], acc[mi][ni][1]});
+                    const la::f32x2 hi = la::gelu_pk(la::f32x2{acc[mi][ni][2], acc[mi][ni][3]});
+                    acc[mi][ni] = f32x4{lo.x, lo.y, hi.x, hi.y};
+                } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[mi][ni][j] = la::gelu_erf(acc[mi][ni][j]);
+                    for (int j = 0; j < 4; ++j) acc[mi][ni][j] = la::gelu_erf(acc[mi][ni][j]);
+                }
+            }
     } else if (do_mish) {
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
@@ -181,9 +188,16 @@ __global__ __launch_bounds__(PP::THREADS, 2) void gemm_pp_kernel(GemmParams p) {
 #pragma unroll
         for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
+            for (int ni = 0; ni < 4; ++ni) {
+                if constexpr (!OUT_F32) {                        // result is rounded to bf16: packed-FP32 form
+                    const la::f32x2 lo = la::gelu_pk(la::f32x2{acc[mi][ni][0], acc[mi][ni][1]});
+                    const la::f32x2 hi = la::gelu_pk(la::f32x2{acc[mi][ni][2], acc[mi][ni][3]});
+                    acc[mi][ni] = f32x4{lo.x, lo.y, hi.x, hi.y};
+                } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[mi][ni][j] = la::gelu_erf(acc[mi][ni][j]);
+                    for (int j = 0; j < 4; ++j) acc[mi][ni][j] = la::gelu_erf(acc[mi][ni][j]);
+                }
+            }
     }
     constexpr int PITCH = 272;
     __syncthreads();

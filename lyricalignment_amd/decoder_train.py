@@ -16,7 +16,7 @@ import torch
 from . import _lib, ops
 from ._lib import check, lib, ptr, stream_ptr
 from .encoder_train import add, attention_bwd, attention_bwd_ex, gelu, gelu_bwd, layernorm_bwd, scale
-from .head_train import colsum, gemm_nn, gemm_tn
+from .head_train import colsum, gemm_nn, gemm_tn, grads_to
 
 PER_BLOCK = ("attn_ln.weight", "attn_ln.bias", "attn.query.weight", "attn.query.bias", "attn.key.weight", "attn.value.weight",
              "attn.value.bias", "attn.out.weight", "attn.out.bias",
@@ -82,6 +82,7 @@ class DecoderFunction(torch.autograd.Function):
         ctx.saved, ctx.packed = saved, packed
         ctx.tail = (tokens, xa2, x, hf, tok_emb, P[-2])
         ctx.xa_needs_grad = xa.requires_grad
+        ctx.param_devices = [p.device for p in params]
         return logits.view(B, n, V)
 
     @staticmethod
@@ -134,7 +135,7 @@ class DecoderFunction(torch.autograd.Function):
         dpos = torch.zeros((n_pos, d), dtype=torch.float32, device=dev)
         check(lib().la_embed_tokens_bwd_f32(ptr(dx), ptr(tokens), B, n, d, ptr(dtok), ptr(dpos), stream_ptr()), "embed_tokens_bwd")
         grads[0], grads[1] = dtok, dpos
-        return (None, dxa.view(B, Ta, d) if dxa is not None else None, None, *grads)
+        return (None, dxa.view(B, Ta, d) if dxa is not None else None, None, *grads_to(grads, ctx.param_devices))
 
 
 def decoder_params(decoder_module, n_layer: Optional[int] = None) -> List[torch.nn.Parameter]:

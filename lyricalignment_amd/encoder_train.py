@@ -21,7 +21,7 @@ import torch
 
 from . import _lib, ops
 from ._lib import check, lib, ptr, stream_ptr
-from .head_train import _rup, colsum, gemm_nn, gemm_tn
+from .head_train import _rup, colsum, gemm_nn, gemm_tn, grads_to
 
 N_FRAMES, N_CTX, C_PAD = 3000, 1500, 128
 LA_F32 = 0
@@ -132,6 +132,8 @@ class EncoderFunction(torch.autograd.Function):
     def forward(ctx, mel, pos, n_head, *params):
         _lib.require_gpu()
         dev = mel.device
+        if dev.type != 'cuda':
+            raise _lib.LyricAlignHipError('EncoderFunction: mel must be a device tensor')
         P = [p.detach().to(device=dev, dtype=torch.float32).contiguous() for p in params]
         n_layer = (len(P) - 6) // len(PER_BLOCK)
         if len(P) != 6 + n_layer * len(PER_BLOCK):
@@ -180,6 +182,7 @@ class EncoderFunction(torch.autograd.Function):
             x = x_next
         y = ops.layernorm(x, P[-2], P[-1], torch.float32)
         ctx.dims = (B, d, H, n_mels, n_layer)
+        ctx.param_devices = [p.device for p in params]
         ctx.stem = (rows0, pre1, y1, pre2, c2w)
         ctx.saved, ctx.packed, ctx.x_last, ctx.lnp_g = saved, packed, x, P[-2]
         return y.view(B, N_CTX, d)
@@ -224,7 +227,7 @@ class EncoderFunction(torch.autograd.Function):
         cols1 = rows0.as_strided((B, N_FRAMES, 3 * C_PAD), ((N_FRAMES + 2) * C_PAD, C_PAD, 1)).contiguous().view(B * N_FRAMES, 3 * C_PAD)
         grads[0] = gemm_tn(dpre1, cols1).view(d, 3, C_PAD)[:, :, :n_mels].permute(0, 2, 1).contiguous()
         grads[1] = colsum(dpre1)
-        return (None, None, None, *grads)
+        return (None, None, None, *grads_to(grads, ctx.param_devices))
 
 
 def encoder_params(encoder_module, n_layer: Optional[int] = None) -> List[torch.nn.Parameter]:

@@ -70,6 +70,11 @@ def gemm_nn(a: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     return ops.gemm(_padK(a), transpose_pad(w), out_f32=True)
 
 
+def grads_to(grads, devices):
+    """Gradients back on the device their parameter lives on (a module kept on the host still trains: a copy per step)."""
+    return [g if (g is None or g.device == d) else g.to(d) for g, d in zip(grads, devices)]
+
+
 def _gru_ws(B: int, T: int, H: int, device):
     need = ctypes.c_size_t(0)
     check(lib().la_gru_workspace_bytes(B, T, H, ctypes.byref(need)), "gru_workspace_bytes")
@@ -88,10 +93,11 @@ class HeadFunction(torch.autograd.Function):
         x0 = x.detach().to(torch.float32).contiguous().view(B * T, D)
         layers = []
         for l in range(2):
-            w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r = [p.detach().float() for p in params[8 * l: 8 * l + 8]]
+            w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r = [p.detach().to(device=dev, dtype=torch.float32) for p in params[8 * l: 8 * l + 8]]
             layers.append(dict(w_ih=torch.cat([w_ih, w_ih_r], 0).contiguous(), b_ih=torch.cat([b_ih, b_ih_r], 0).contiguous(),
                                w_hh=torch.stack([w_hh, w_hh_r], 0).contiguous(), b_hh=torch.stack([b_hh, b_hh_r], 0).contiguous()))
-        w_fc, b_fc = params[16].detach().float().contiguous(), params[17].detach().float().contiguous()
+        w_fc, b_fc = [p.detach().to(device=dev, dtype=torch.float32).contiguous() for p in params[16:18]]
+        ctx.param_devices = [p.device for p in params]
         H = layers[0]["w_hh"].shape[2]
         flag = torch.zeros((1,), dtype=torch.int32, device=dev)
         saved = []
@@ -185,7 +191,7 @@ class HeadFunction(torch.autograd.Function):
         grads[16], grads[17] = dw_fc, db_fc
         if int(flag.item()) != 0:
             raise TimeoutError("persistent GRU backward kernel: a bounded inter-workgroup wait timed out")
-        return (dx, None, None, *grads)
+        return (dx, None, None, *grads_to(grads, ctx.param_devices))
 
 
 def head_params(rnn_module) -> List[torch.nn.Parameter]:

@@ -225,7 +225,7 @@ def test_run_viterbi_core_drop_in_bit_exact():
         assert sha(bt) == case["bt_sha256"] and sha(dp) == case["dp_sha256"], case["seed"]
 
 
-def test_state_dict_layout_and_training_guard():
+def test_state_dict_layout_and_training_mode_forward():
     from conftest import load_json
     model = _small_model(torch.float32)
     keys = load_json("head_state_dict_keys.json")
@@ -233,9 +233,17 @@ def test_state_dict_layout_and_training_guard():
     assert got == set(keys)
     assert any(k.startswith("whisper_model.encoder.blocks.0.attn.query.weight") for k in model.state_dict())
     assert "whisper_model.encoder.blocks.0.attn.key.bias" not in model.state_dict()
-    model.train()
-    with pytest.raises(NotImplementedError):
-        model.frame_manual_forward([_wave(16000)])
+    model.train()                                    # training mode: autograd through the HIP forward / backward kernels
+    logits, _ = model.frame_manual_forward([_wave(16000)])
+    assert logits.requires_grad and logits.shape[1] == 50
+    logits.backward(torch.ones_like(logits))         # the module lives on the host here: gradients come back to it
+    g = model.align_rnn.fc.bias.grad
+    assert g is not None and g.device.type == "cpu" and torch.isfinite(g).all()
+    assert model.whisper_model.encoder.conv1.weight.grad is not None
+    model.eval()
+    with torch.no_grad():
+        ev, _ = model.frame_manual_forward([_wave(16000)])
+    assert not ev.requires_grad and ev.shape == logits.shape
 
 
 def test_pipelined_aligner_matches_single_stream():
