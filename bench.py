@@ -152,6 +152,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="single stream: no encoder/head overlap across batches")
+    ap.add_argument("--head-group", type=int, default=2,
+                    help="batches whose head (GRU / FC / DP) runs as one launch set in the two-stream pipeline")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -183,7 +185,7 @@ def main():
     pinned_status = torch.empty((BATCH,), dtype=torch.int32).pin_memory()
 
     from lyricalignment_amd.engine import PipelinedAligner
-    pipe = None if args.no_overlap else PipelinedAligner(eng)
+    pipe = None if args.no_overlap else PipelinedAligner(eng, head_group=args.head_group)
 
     def step():
         with torch.no_grad():
@@ -201,6 +203,8 @@ def main():
 
     for i in range(args.warmup):
         step()
+    if pipe is not None:
+        pipe.drain()
     torch.cuda.synchronize()
     log(f"{args.warmup} warm-up steps done")
     eng.check_gru()
@@ -213,6 +217,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    if pipe is not None:
+        pipe.drain()                      # flushes a partial head group: every submitted batch is finished inside the timed region
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0

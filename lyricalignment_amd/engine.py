@@ -201,9 +201,11 @@ class AlignEngine:
         return t
 
     # ---- encoder: Whisper.embed_audio -----------------------------------------------
-    def encode(self, mel: torch.Tensor, out_dtype: Optional[torch.dtype] = None, slot: int = 0) -> torch.Tensor:
+    def encode(self, mel: torch.Tensor, out_dtype: Optional[torch.dtype] = None, slot: int = 0,
+               out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """mel [B, n_mels, 3000] f32 (device) -> ln_post output [B*1500, d] in `out_dtype` (default: compute dtype).
-        `slot` names the output buffer (the two-stream pipeline double-buffers it)."""
+        `slot` names the output buffer (the two-stream pipeline double-buffers it); `out` is a caller-owned
+        [B*1500, d] row view to write into instead."""
         e = self.enc
         if mel.dim() != 3 or mel.shape[1] != e.n_mels or mel.shape[2] != N_FRAMES:
             raise AssertionError("incorrect audio shape")  # whisper AudioEncoder asserts the same
@@ -232,7 +234,7 @@ class AlignEngine:
             ops.gemm(h, blk.w1, u, bias=blk.b1, gelu=True)
             ops.gemm(u, blk.w2, x, bias=blk.b2, residual=x, out_f32=True)            # x += mlp (in place)
         out_dtype = out_dtype or dt
-        y = self._get(f"enc_out{slot}", (M, d), out_dtype)
+        y = out if out is not None else self._get(f"enc_out{slot}", (M, d), out_dtype)
         ops.layernorm(x, e.lnp_g, e.lnp_b, out_dtype, out=y)
         return y
 
@@ -319,51 +321,96 @@ class AlignEngine:
 
 
 class PipelinedAligner:
-    """Two-stream software pipeline over consecutive batches: the encoder of batch i+1 (stream E, GEMM / attention
-    bound, fills the chip) overlaps the head of batch i (stream H: the persistent GRU recurrence occupies 12 CUs for
-    ~25 ms and is latency-bound, then the fused FC and the DP).  The only shared buffer is the encoder output, which is
-    double-buffered and handed over with events; every other scratch buffer belongs to exactly one stream.
-    Clips are independent, so this changes no result -- only which kernels are in flight together."""
+    """Two-stream software pipeline over consecutive batches: the encoders of the next batches (stream E, GEMM / attention
+    bound, fill the chip) overlap the head of the previous ones (stream H: the persistent GRU recurrence occupies
+    2 x hidden/64 CUs per 32 clips and is latency-bound, ~13 ms per layer whatever the batch; then the fused FC and the DP).
 
-    def __init__(self, engine: AlignEngine):
+    head_group: the head runs once per `head_group` submitted batches, over all their clips at once (clips are
+    independent: more clips are more workgroup groups of the GRU kernel, not more steps).  While the recurrence is resident
+    the encoder's GEMMs lose CUs and with them whole rounds of 256x256 tiles (752 tiles: 3 rounds on 256 CUs, 4 on 244);
+    running it half / a quarter as often takes that cost off most batches.  Results of a batch arrive when its group is
+    flushed (drain() flushes a partial group).
+
+    The only shared buffers are the encoder outputs of a group, double-buffered and handed over with events; every other
+    scratch buffer belongs to exactly one stream.  This changes no result -- only which kernels are in flight together."""
+
+    def __init__(self, engine: AlignEngine, head_group: int = 2):
+        if head_group < 1:
+            raise ValueError("head_group must be >= 1")
         self.eng = engine
+        self.G = int(head_group)
         dev = engine.device
         self.stream_e = torch.cuda.Stream(device=dev)
         self.stream_h = torch.cuda.Stream(device=dev, priority=-1)   # the GRU's few workgroups should dispatch promptly
         self.enc_done = [torch.cuda.Event(), torch.cuda.Event()]
         self.head_done = [torch.cuda.Event(), torch.cuda.Event()]
         self._head_used = [False, False]
-        self.i = 0
+        self.gi = 0                 # group counter (parity = buffer set)
+        self._pending: List[dict] = []
+        self._key = None
+        self._feats = [None, None]  # per buffer set: [G*B*1500, d] encoder outputs
 
     def submit(self, mel: torch.Tensor, labels: torch.Tensor, n_labels: torch.Tensor, n_frames: int = N_CTX,
                use_ctc: bool = True, host_out=None):
-        """Enqueue one batch; returns (onset, offset, score, status) device tensors valid after drain() /
-        head_done event.  host_out: optional (onset, offset, status) pinned host tensors for an async D2H."""
-        eng, slot = self.eng, self.i & 1
+        """Enqueue one batch; returns (onset, offset, score, status) device tensors that are valid after drain() (or once
+        the batch's group has been flushed and its head_done event has passed).
+        host_out: optional (onset, offset, status) pinned host tensors for an async D2H."""
+        eng = self.eng
+        B = mel.shape[0]
+        key = (B, int(labels.shape[1]), int(n_frames), bool(use_ctc))
+        if self._pending and key != self._key:
+            self._flush()                                            # a group holds batches of one shape
+        self._key = key
+        slot = self.gi & 1
+        j = len(self._pending)
+        d, dt = eng.enc.d, eng.enc.dtype
         cur = torch.cuda.current_stream(eng.device)
         self.stream_e.wait_stream(cur)
         with torch.cuda.stream(self.stream_e):
-            if self._head_used[slot]:
-                self.stream_e.wait_event(self.head_done[slot])       # head of batch i-2 has consumed this slot
-            feats = eng.encode(mel, slot=slot)
-            self.enc_done[slot].record(self.stream_e)
-        with torch.cuda.stream(self.stream_h):
-            self.stream_h.wait_event(self.enc_done[slot])
-            B = mel.shape[0]
-            variant = LA_VARIANT_CTC if use_ctc else LA_VARIANT_PLAIN
-            em = eng.emissions(feats, B, n_frames, N_CTX, labels, n_labels, variant)
-            nf = torch.full((B,), n_frames, dtype=torch.int32, device=eng.device)
-            out = ops.viterbi_batch(em, labels, n_labels, nf)
-            if host_out is not None:
-                host_out[0].copy_(out[0], non_blocking=True)
-                host_out[1].copy_(out[1], non_blocking=True)
-                host_out[2].copy_(out[3], non_blocking=True)
-            self.head_done[slot].record(self.stream_h)
-            self._head_used[slot] = True
-        self.i += 1
+            if j == 0 and self._head_used[slot]:
+                self.stream_e.wait_event(self.head_done[slot])       # the head of group g-2 has consumed this buffer set
+            fb = self._feats[slot]
+            if fb is None or fb.shape[0] != self.G * B * N_CTX or fb.dtype != dt:
+                fb = self._feats[slot] = torch.empty((self.G * B * N_CTX, d), dtype=dt, device=eng.device)
+            eng.encode(mel, out=fb[j * B * N_CTX:(j + 1) * B * N_CTX])
+            self.enc_done[slot].record(self.stream_e)                # re-recorded per batch: the flush waits for the last one
+        Lmax = labels.shape[1]
+        out = (torch.empty((B, Lmax), dtype=torch.int32, device=eng.device), torch.empty((B, Lmax), dtype=torch.int32, device=eng.device),
+               torch.empty((B,), dtype=torch.float64, device=eng.device), torch.empty((B,), dtype=torch.int32, device=eng.device))
+        self._pending.append(dict(labels=labels, n_labels=n_labels, out=out, host_out=host_out))
+        if len(self._pending) == self.G:
+            self._flush()
         return out
 
+    def _flush(self):
+        if not self._pending:
+            return
+        eng, slot = self.eng, self.gi & 1
+        B, _, n_frames, use_ctc = self._key
+        n = len(self._pending)
+        with torch.cuda.stream(self.stream_h):
+            self.stream_h.wait_event(self.enc_done[slot])
+            labels = self._pending[0]["labels"] if n == 1 else torch.cat([q["labels"] for q in self._pending], dim=0)
+            n_labels = self._pending[0]["n_labels"] if n == 1 else torch.cat([q["n_labels"] for q in self._pending], dim=0)
+            variant = LA_VARIANT_CTC if use_ctc else LA_VARIANT_PLAIN
+            feats = self._feats[slot][: n * B * N_CTX]
+            em = eng.emissions(feats, n * B, n_frames, N_CTX, labels, n_labels, variant)
+            nf = torch.full((n * B,), n_frames, dtype=torch.int32, device=eng.device)
+            res = ops.viterbi_batch(em, labels, n_labels, nf)
+            for j, q in enumerate(self._pending):
+                for dst, src in zip(q["out"], res):
+                    dst.copy_(src[j * B:(j + 1) * B], non_blocking=True)
+                if q["host_out"] is not None:
+                    q["host_out"][0].copy_(q["out"][0], non_blocking=True)
+                    q["host_out"][1].copy_(q["out"][1], non_blocking=True)
+                    q["host_out"][2].copy_(q["out"][3], non_blocking=True)
+            self.head_done[slot].record(self.stream_h)
+            self._head_used[slot] = True
+        self._pending = []
+        self.gi += 1
+
     def drain(self):
+        self._flush()
         self.stream_e.synchronize()
         self.stream_h.synchronize()
         self.eng.check_gru()
