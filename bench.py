@@ -211,7 +211,7 @@ def main():
 
     L = _lib.lib()
     L.la_timer_reset()
-    L.la_timer_enable(b"gemm_bf16")
+    L.la_timer_enable(os.environ.get("LA_BENCH_TIMER", "gemm_bf16").encode())
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
