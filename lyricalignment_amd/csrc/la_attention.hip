@@ -128,19 +128,27 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(AttnParams p) {
             stage_kv_bf16(kbase, vbase, p.ld_kv, (t + 1) * KT, t + 2 == nkv_all ? off_last : off_full, nk, nk + KT * 128, wave);
         }
         // ---- S^T = K Q^T : two 32-key sub-tiles ----
+        // all eight K fragments are requested before the first MFMA (32 VGPRs; the kernel has room): the reads return under
+        // the MFMAs instead of one ds_read -> wait -> MFMA round trip per fragment
         f32x16 s[2];
+        uint4 kf[2][4];
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                const int row = sub * 32 + i32;
+                kf[sub][c] = *reinterpret_cast<const uint4 *>(kl + row * 128 + (((2 * c + h) ^ kswz(row)) << 4));
+            }
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[sub][r] = 0.f;
-            const int row = sub * 32 + i32;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const uint4 kf = *reinterpret_cast<const uint4 *>(kl + row * 128 + (((2 * c + h) ^ kswz(row)) << 4));
-                s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf),
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+                s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[sub][c]),
                                                                  __builtin_bit_cast(bf16x8, qf[c]), s[sub], 0, 0, 0);
-            }
-        }
         // ---- mask keys >= kv_len (last tile) and, for the causal decoder self-attention, keys after the query ----
         if ((t + 1) * KT > T || p.causal) {
             const int kmax = p.causal ? min(T - 1, qrow) : T - 1;
