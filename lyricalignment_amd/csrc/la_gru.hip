@@ -254,10 +254,8 @@ __global__ __launch_bounds__(GruTraits<T>::NW * 64, 1) void gru_kernel(GruParams
                         if (bl < nb)
                             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hnew[mt][i]), out_rsrc, (int)(o * 4), 0, 16 /* sc1 */);
                     }
-                    if (bl < nb && outm) la::Elem<T>::store(outm + o, la::mish(hnew[mt][i]));
                 } else if (bl < nb) {
                     la::Elem<T>::store(out + o, hnew[mt][i]);
-                    if (outm) la::Elem<T>::store(outm + o, la::mish(hnew[mt][i]));
                 }
             }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -270,6 +268,20 @@ __global__ __launch_bounds__(GruTraits<T>::NW * 64, 1) void gru_kernel(GruParams
             __hip_atomic_fetch_add(ctr + step, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (step + 1 < T_) load_gi(dir == 0 ? t + 1 : t - 1);  // independent of h: in flight during the next wait
+        // Mish(h_t) for the FC is nobody's input inside the recurrence: computed and stored AFTER the hand-off signal,
+        // under the other slices' step (its libm-grade softplus / tanh took ~0.4 us of every step's critical path before)
+        if (outm) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int bl = mt * 16 + 4 * q + i;
+                    if (bl < nb) {
+                        const int64_t o = (int64_t)(b0 + bl) * out_bs + (int64_t)t * out_ts + dir * H + jcol;
+                        la::Elem<T>::store(outm + o, la::mish(hnew[mt][i]));
+                    }
+                }
+        }
     }
     if (!alive && tid == 0 && p.timeout_flag) *p.timeout_flag = 1;
 }

@@ -11,6 +11,7 @@
 //                    the reference's emission formulas to raw                     (this file)
 // Algorithmic traffic: reads act + W_fc once, writes 8 B per row per 64 columns; 2*M*V*K flops.
 #include "la_gemm_core.h"
+#include "la_gemm_pp.h"
 
 using la::bf16_t;
 using namespace la::gemm;
@@ -26,7 +27,8 @@ struct LseParams {
     int64_t lda;
     const void *W;
     const float *bias;
-    float2 *partials;  // [M][2 * tiles_n]
+    float2 *partials;  // [M][nparts]: one (max, sum exp) pair per row and 64-column strip
+    int nparts;
     int lo, hi;        // inclusive column range of the normaliser
     int tiles_m, tiles_n, group;
 };
@@ -69,7 +71,57 @@ __global__ __launch_bounds__(C::THREADS, 2) void fc_lse_kernel(LseParams p) {
         sum += __shfl_xor(sum, 16);
         sum += __shfl_xor(sum, 32);
         const int m = m0 + wm * 64 + mi * 16 + r;
-        if (q == 0 && m < p.M) p.partials[(int64_t)m * (2 * p.tiles_n) + tn * 2 + wn] = make_float2(mx, sum);
+        if (q == 0 && m < p.M) p.partials[(int64_t)m * p.nparts + tn * 2 + wn] = make_float2(mx, sum);
+    }
+}
+
+// The same reduction on the 256x256 ping-pong main loop (bf16, large row counts): a wave owns 128 rows x one 64-column strip.
+__global__ __launch_bounds__(PP::THREADS, 2) void fc_lse_pp_kernel(LseParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    const TileCoord tc = tile_coord(tile, p.tiles_m, p.tiles_n, p.group);
+    const int tn = tc.tn;
+    const int m0 = tc.tm * PP::TM, n0 = tn * PP::TN;
+    f32x4 acc[8][4];
+    mainloop_pp<0>(reinterpret_cast<const bf16_t *>(p.A), p.lda, p.M, reinterpret_cast<const bf16_t *>(p.W), p.K, p.N, p.K, m0, n0, lds, acc);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 2, wc = wave & 3;
+    const int r = lane & 15, q = lane >> 4;
+    float b4[4][4];
+    bool ok4[4][4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wc * 64 + ni * 16 + q * 4 + j;
+            ok4[ni][j] = n >= p.lo && n <= p.hi;
+            b4[ni][j] = p.bias[n < p.N ? n : p.N - 1];
+        }
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+        float v[16];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float x = ok4[ni][j] ? acc[mi][ni][j] + b4[ni][j] : -INFINITY;
+                v[ni * 4 + j] = x;
+                mx = fmaxf(mx, x);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+        if (mx > -INFINITY) {
+            const float mb = mx * kLog2e;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sum += __builtin_amdgcn_exp2f(fmaf(v[i], kLog2e, -mb));
+        }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const int m = m0 + wr * 128 + mi * 16 + r;
+        if (q == 0 && m < p.M) p.partials[(int64_t)m * p.nparts + tn * 4 + wc] = make_float2(mx, sum);
     }
 }
 
@@ -142,18 +194,19 @@ __global__ __launch_bounds__(256) void merge_emissions_kernel(const float2 *part
 
 struct HeadPlan {
     size_t off_wg, off_bg, off_raw, off_part, total;
-    int tiles_n;
+    int tiles_n, nparts;
 };
 
 HeadPlan plan_head(int batch, int frames, int in_dim, int vocab, int max_labels, int es) {
     HeadPlan pl;
     const int64_t rows = (int64_t)batch * frames, S = max_labels + 1;
     pl.tiles_n = la::cdiv(vocab, BN);
+    pl.nparts = 4 * la::cdiv(vocab, PP::TN);     // 64-column strips, rounded up to whole 256-column tiles (>= 2 * tiles_n)
     size_t o = 0;
     pl.off_wg = o;   o += la::round_up((int64_t)batch * S * in_dim * es, 256);
     pl.off_bg = o;   o += la::round_up((int64_t)batch * S * 4, 256);
     pl.off_raw = o;  o += la::round_up(rows * S * 4, 256);
-    pl.off_part = o; o += la::round_up(rows * 2 * pl.tiles_n * 8, 256);
+    pl.off_part = o; o += la::round_up(rows * pl.nparts * 8, 256);
     pl.total = o;
     return pl;
 }
@@ -206,14 +259,30 @@ extern "C" int la_fc_emissions(int32_t dtype, const void *act, int64_t ld_act, c
                           S, (int64_t)frames * S, bg, S, nullptr, 0, 0, LA_EPI_BIAS | LA_EPI_OUT_F32, stream);
     if (rc != LA_OK) return rc;
     // 3. row normaliser partials over the full vocabulary
-    LseParams lp{rows, vocab, in_dim, act, ld_act, w_fc, b_fc, partials,
+    LseParams lp{rows, vocab, in_dim, act, ld_act, w_fc, b_fc, partials, pl.nparts,
                  variant == LA_VARIANT_CTC ? 1 : 0, variant == LA_VARIANT_CTC ? vocab - 2 : vocab - 1,
                  0, pl.tiles_n, pick_group(in_dim, es, pl.tiles_n)};
     {
         typedef Cfg<2, 2> Small;
         typedef Cfg<4, 3> Big;
-        static bool attr_bf16 = false, attr_bf16_big = false, attr_f32 = false;
-        if (dtype == LA_BF16 && rows >= 4096 && getenv("LA_GEMM_TILE") && atoi(getenv("LA_GEMM_TILE")) == 256) {
+        static bool attr_bf16 = false, attr_bf16_big = false, attr_f32 = false, attr_pp = false;
+        static const char *force_tile = getenv("LA_GEMM_TILE");
+        const bool pp_ok = dtype == LA_BF16 && !force_tile && in_dim % 64 == 0 && in_dim >= 128 && (ld_act * 2) % 16 == 0 &&
+                           (int64_t)la::cdiv(rows, PP::TM) * la::cdiv(vocab, PP::TN) >= 192;
+        if (!pp_ok) lp.nparts = 2 * pl.tiles_n;      // the 128-column kernels write two strips per tile
+        if (pp_ok) {
+            // the strips of the last (partial) 256-column tile that no 128-column tile would have produced must still hold
+            // neutral partials: every strip is written by this kernel, masked columns give (-inf, 0)
+            if (!attr_pp) {
+                LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fc_lse_pp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PP::LDS));
+                attr_pp = true;
+            }
+            lp.tiles_m = la::cdiv(rows, PP::TM);
+            lp.tiles_n = la::cdiv(vocab, PP::TN);
+            lp.group = std::max(1, pick_group(in_dim, es, la::cdiv(vocab, BN)) / 2);
+            la::TimerScope ts("fc_lse_bf16", stream);
+            hipLaunchKernelGGL(fc_lse_pp_kernel, dim3(lp.tiles_m * lp.tiles_n), dim3(PP::THREADS), PP::LDS, stream, lp);
+        } else if (dtype == LA_BF16 && rows >= 4096 && getenv("LA_GEMM_TILE") && atoi(getenv("LA_GEMM_TILE")) == 256) {
             if (!attr_bf16_big) {
                 LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fc_lse_kernel<bf16_t, Big>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, Big::LDS));
@@ -244,7 +313,7 @@ extern "C" int la_fc_emissions(int32_t dtype, const void *act, int64_t ld_act, c
         LA_LAUNCH_CHECK();
     }
     // 4. merge
-    hipLaunchKernelGGL(merge_emissions_kernel, dim3(la::cdiv(rows, 4)), dim3(256), 0, stream, partials, 2 * pl.tiles_n, raw,
+    hipLaunchKernelGGL(merge_emissions_kernel, dim3(la::cdiv(rows, 4)), dim3(256), 0, stream, partials, lp.nparts, raw,
                        frames, rows, variant, vocab, labels, labels_stride, n_labels, max_labels, em, em_batch_stride,
                        em_row_stride);
     LA_LAUNCH_CHECK();
