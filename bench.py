@@ -161,6 +161,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # host threads: the box reports every core of the node, the cgroup quota is what this job may use, and with one rank
+    # per GPU the ranks share it (random-init weight generation runs on the host)
+    torch.set_num_threads(max(1, usable_cores() // max(world, 1)))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None

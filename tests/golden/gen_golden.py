@@ -422,7 +422,46 @@ def gen_dataset_labels():
     print("dataset labels", flush=True)
 
 
+# --------------------------------------------------------------------------- #
+# 7. CER scoring (utils/CER.py): error rate + operation counts on seeded pairs   #
+# --------------------------------------------------------------------------- #
+def gen_cer():
+    from utils import CER as ref_cer
+    rs = np.random.RandomState(4242)
+    cases = []
+
+    def add(hyp, ref):
+        cer, nb = ref_cer.CER(hypothesis=list(hyp), reference=list(ref))
+        cases.append({"hyp": list(hyp), "ref": list(ref), "cer": float(cer), "nb_map": {k: int(v) for k, v in nb.items()}})
+
+    alphabet = [chr(0x4e00 + i) for i in range(12)]          # a small alphabet so that matches are frequent
+    add([], alphabet[:5])                                      # empty hypothesis (evaluate_transcript.py's except branch)
+    add(alphabet[:6], alphabet[:6])                            # identical
+    add(alphabet[:1], alphabet[:1])
+    add(alphabet[:3], alphabet[3:4])                           # all wrong, hypothesis longer
+    for n in range(40):
+        L = int(rs.randint(1, 30))
+        ref = [alphabet[j] for j in rs.randint(0, len(alphabet), size=L)]
+        hyp = list(ref)
+        for _ in range(int(rs.randint(0, 8))):                 # random edits
+            op = rs.randint(0, 3)
+            pos = int(rs.randint(0, len(hyp) + 1))
+            if op == 0 and hyp:
+                hyp[min(pos, len(hyp) - 1)] = alphabet[int(rs.randint(0, len(alphabet)))]
+            elif op == 1:
+                hyp.insert(pos, alphabet[int(rs.randint(0, len(alphabet)))])
+            elif hyp:
+                del hyp[min(pos, len(hyp) - 1)]
+        add(hyp, ref)
+    with open(os.path.join(HERE, "cer.json"), "w") as f:
+        json.dump(cases, f, ensure_ascii=True)
+    print("cer.json", len(cases))
+
+
 if __name__ == "__main__":
+    if "--cer-only" in sys.argv:
+        gen_cer()
+        sys.exit(0)
     if "--labels-only" in sys.argv:
         gen_dataset_labels()
         sys.exit(0)
@@ -434,6 +473,7 @@ if __name__ == "__main__":
         gen_frames()
         gen_losses()
         gen_dataset_labels()
+        gen_cer()
     gen_harness()
     leftovers = [d for d, _, fs in os.walk(REF) if d.endswith("__pycache__")]
     assert not leftovers, f"bytecode written into the reference tree: {leftovers}"

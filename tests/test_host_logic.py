@@ -283,3 +283,16 @@ def test_linear_warmup_scale_matches_transformers_schedule():
         for step in range(min(total + 3, 60)):
             assert abs(opt.param_groups[0]["lr"] - linear_warmup_scale(step, warm, total)) < 1e-12, (warm, total, step)
             opt.step(); sch.step()
+
+
+def test_cer_matches_reference_golden():
+    """utils.CER.CER against error rates and operation counts produced by the reference's own function
+    (tests/golden/gen_golden.py gen_cer): empty hypothesis, identical strings, random edit scripts."""
+    from conftest import load_json
+    from lyricalignment_amd.utils.CER import CER
+    cases = load_json("cer.json")
+    assert len(cases) >= 40
+    for c in cases:
+        cer, nb = CER(hypothesis=c["hyp"], reference=c["ref"])
+        assert float(cer) == c["cer"], c
+        assert {k: int(v) for k, v in nb.items()} == c["nb_map"], c
