@@ -201,6 +201,17 @@ int la_attention_ex(int32_t dtype, const void *q, int64_t ld_q, const void *k, c
                     void *out, int64_t ld_out, int32_t batch, int32_t q_len, int32_t kv_len, int32_t n_head,
                     int32_t causal, void *stream);
 
+/* Attention against a key / value cache (autoregressive decoding: the next row of SURVEY 8f, inference_transcript.py): clip
+ * b's keys / values are rows [b*kv_batch_rows, b*kv_batch_rows + kv_len) of k / v (the cache holds kv_batch_rows >= kv_len
+ * rows per clip), its queries rows [b*q_batch_rows, +q_len) of q, out rows are packed [b*q_len + i].  causal with q_len == 1
+ * (one new token) needs no mask; causal with q_len == kv_len is la_attention_ex's mask. */
+int la_attention_cached(int32_t dtype, const void *q, int64_t ld_q, int64_t q_batch_rows, const void *k, const void *v,
+                        int64_t ld_kv, int64_t kv_batch_rows, void *out, int64_t ld_out, int32_t batch, int32_t q_len,
+                        int32_t kv_len, int32_t n_head, int32_t causal, void *stream);
+
+/* out[r] = argmax_c x[r][c] (first maximum), int64: the greedy token choice over the decoder logits. */
+int la_argmax_rows_f32(const float *x, int64_t ld, int32_t rows, int32_t cols, int64_t *out, void *stream);
+
 /* x[b*n_tok + i][:] = token_embedding[tokens[b][i]][:] + positional_embedding[i][:]   (f32 tables, f32 out);
  * TextDecoder.forward's first line.  tokens int64 [batch][n_tok]. */
 int la_embed_tokens(const int64_t *tokens, int32_t batch, int32_t n_tok, const float *token_embedding, int32_t n_vocab,

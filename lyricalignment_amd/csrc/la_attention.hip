@@ -36,6 +36,7 @@ struct AttnParams {
     void *out;
     int64_t ld_out;
     int q_len, kv_len, n_head, causal;
+    int64_t q_bs, kv_bs, out_bs;   // rows from one clip to the next (== q_len / kv_len / q_len unless the caller says otherwise)
 };
 
 // accumulator register -> row (key / dv index) inside a 32x32 tile for lane half h
@@ -86,9 +87,9 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(AttnParams p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i32 = lane & 31, h = lane >> 5;
-    const bf16_t *base = reinterpret_cast<const bf16_t *>(p.q) + (int64_t)clip * p.q_len * p.ld_q + head * 64;
-    const bf16_t *kbase = reinterpret_cast<const bf16_t *>(p.k) + (int64_t)clip * T * p.ld_kv + head * 64;
-    const bf16_t *vbase = reinterpret_cast<const bf16_t *>(p.v) + (int64_t)clip * T * p.ld_kv + head * 64;
+    const bf16_t *base = reinterpret_cast<const bf16_t *>(p.q) + (int64_t)clip * p.q_bs * p.ld_q + head * 64;
+    const bf16_t *kbase = reinterpret_cast<const bf16_t *>(p.k) + (int64_t)clip * p.kv_bs * p.ld_kv + head * 64;
+    const bf16_t *vbase = reinterpret_cast<const bf16_t *>(p.v) + (int64_t)clip * p.kv_bs * p.ld_kv + head * 64;
 
     // Q fragments (B operand): lane (q = i32, h) holds Q[q][16c + 8h .. +8], c = 0..3
     int qrow = qt * QT + wave * 32 + i32;
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(AttnParams p) {
     const float l = l_part + __shfl_xor(l_part, 32);
     const float inv = 1.0f / l;
     if (q_valid) {
-        bf16_t *orow = reinterpret_cast<bf16_t *>(p.out) + ((int64_t)clip * p.q_len + qrow) * p.ld_out + head * 64;
+        bf16_t *orow = reinterpret_cast<bf16_t *>(p.out) + ((int64_t)clip * p.out_bs + qrow) * p.ld_out + head * 64;
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -259,9 +260,9 @@ __global__ __launch_bounds__(256, 2) void attention_f32_kernel(AttnParams p) {
     const int qt = blockIdx.x, head = blockIdx.y, clip = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i32 = lane & 31, h = lane >> 5;
-    const float *base = reinterpret_cast<const float *>(p.q) + (int64_t)clip * p.q_len * p.ld_q + head * 64;
-    const float *kbase = reinterpret_cast<const float *>(p.k) + (int64_t)clip * T * p.ld_kv + head * 64;
-    const float *vbase = reinterpret_cast<const float *>(p.v) + (int64_t)clip * T * p.ld_kv + head * 64;
+    const float *base = reinterpret_cast<const float *>(p.q) + (int64_t)clip * p.q_bs * p.ld_q + head * 64;
+    const float *kbase = reinterpret_cast<const float *>(p.k) + (int64_t)clip * p.kv_bs * p.ld_kv + head * 64;
+    const float *vbase = reinterpret_cast<const float *>(p.v) + (int64_t)clip * p.kv_bs * p.ld_kv + head * 64;
 
     int qrow = qt * QT + wave * 32 + i32;
     const bool q_valid = qrow < p.q_len;
@@ -361,7 +362,7 @@ __global__ __launch_bounds__(256, 2) void attention_f32_kernel(AttnParams p) {
     const float l = l_part + __shfl_xor(l_part, 32);
     const float inv = 1.0f / l;
     if (q_valid) {
-        float *orow = reinterpret_cast<float *>(p.out) + ((int64_t)clip * p.q_len + qrow) * p.ld_out + head * 64;
+        float *orow = reinterpret_cast<float *>(p.out) + ((int64_t)clip * p.out_bs + qrow) * p.ld_out + head * 64;
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -404,7 +405,7 @@ extern "C" int la_attention(int32_t dtype, const void *qkv, int64_t ld_qkv, void
                  "attention: rows must be 16-byte aligned");
     const char *b = reinterpret_cast<const char *>(qkv);
     const int d = n_head * 64;
-    AttnParams p{b, b + (int64_t)d * es, b + (int64_t)2 * d * es, ld_qkv, ld_qkv, out, ld_out, frames, frames, n_head, 0};
+    AttnParams p{b, b + (int64_t)d * es, b + (int64_t)2 * d * es, ld_qkv, ld_qkv, out, ld_out, frames, frames, n_head, 0, frames, frames, frames};
     return attention_launch(dtype, p, batch, stream);
 }
 
@@ -421,6 +422,29 @@ extern "C" int la_attention_ex(int32_t dtype, const void *q, int64_t ld_q, const
     LA_CHECK_ARG((ld_q * es) % 16 == 0 && (ld_kv * es) % 16 == 0 && (ld_out * es) % 16 == 0 && (uintptr_t)q % 16 == 0 &&
                      (uintptr_t)k % 16 == 0 && (uintptr_t)v % 16 == 0 && (uintptr_t)out % 16 == 0,
                  "attention_ex: rows must be 16-byte aligned");
-    AttnParams p{q, k, v, ld_q, ld_kv, out, ld_out, q_len, kv_len, n_head, causal ? 1 : 0};
+    AttnParams p{q, k, v, ld_q, ld_kv, out, ld_out, q_len, kv_len, n_head, causal ? 1 : 0, q_len, kv_len, q_len};
+    return attention_launch(dtype, p, batch, stream);
+}
+
+// Attention against a key / value CACHE (autoregressive decoding, whisper/decoding.py's kv_cache): clip b's keys are rows
+// [b * kv_batch_rows, b * kv_batch_rows + kv_len) of k / v -- the cache has room for kv_batch_rows >= kv_len rows per clip --
+// and its queries rows [b * q_batch_rows, ... + q_len) of q; out rows are packed [b * q_len + i].  Queries are the LAST q_len
+// positions of the sequence: with causal != 0 query i sees keys 0 .. kv_len - q_len + i.
+extern "C" int la_attention_cached(int32_t dtype, const void *q, int64_t ld_q, int64_t q_batch_rows, const void *k, const void *v,
+                                   int64_t ld_kv, int64_t kv_batch_rows, void *out, int64_t ld_out, int32_t batch, int32_t q_len,
+                                   int32_t kv_len, int32_t n_head, int32_t causal, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (batch == 0 || q_len == 0) return LA_OK;
+    LA_CHECK_ARG(q && k && v && out && batch > 0 && q_len > 0 && kv_len > 0 && n_head > 0, "attention_cached: bad arguments");
+    LA_CHECK_ARG(dtype == LA_F32 || dtype == LA_BF16, "attention_cached: bad dtype");
+    LA_CHECK_ARG(q_batch_rows >= q_len && kv_batch_rows >= kv_len, "attention_cached: batch strides shorter than the lengths");
+    LA_CHECK_ARG(!causal || q_len == 1 || q_len == kv_len, "attention_cached: causal masking needs q_len == 1 or q_len == kv_len");
+    const int es = dtype == LA_BF16 ? 2 : 4;
+    LA_CHECK_ARG(ld_q >= n_head * 64 && ld_kv >= n_head * 64 && ld_out >= n_head * 64, "attention_cached: leading dimensions too small");
+    LA_CHECK_ARG((ld_q * es) % 16 == 0 && (ld_kv * es) % 16 == 0 && (ld_out * es) % 16 == 0 && (uintptr_t)q % 16 == 0 &&
+                     (uintptr_t)k % 16 == 0 && (uintptr_t)v % 16 == 0 && (uintptr_t)out % 16 == 0,
+                 "attention_cached: rows must be 16-byte aligned");
+    // one new token against the whole cache needs no mask at all
+    AttnParams p{q, k, v, ld_q, ld_kv, out, ld_out, q_len, kv_len, n_head, (causal && q_len > 1) ? 1 : 0, q_batch_rows, kv_batch_rows, q_len};
     return attention_launch(dtype, p, batch, stream);
 }

@@ -276,3 +276,39 @@ extern "C" int la_mel_to_rows(const float *mel, int64_t mel_batch_stride, int64_
     LA_LAUNCH_CHECK();
     return LA_OK;
 }
+
+// greedy token choice: out[r] = index of the first maximum of x[r][0..cols)   (torch.argmax semantics on ties: lowest index)
+namespace {
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float *x, int64_t ld, int cols, int64_t *out) {
+    __shared__ float bv[4];
+    __shared__ int bi[4];
+    const float *r = x + (int64_t)blockIdx.x * ld;
+    float best = -INFINITY;
+    int idx = 0x7fffffff;
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        const float v = r[c];
+        if (v > best || idx == 0x7fffffff) { best = v; idx = c; }   // c ascends per thread: strict > keeps the first maximum
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o);
+        const int oi = __shfl_xor(idx, o);
+        if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { bv[threadIdx.x >> 6] = best; bi[threadIdx.x >> 6] = idx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+        out[blockIdx.x] = idx == 0x7fffffff ? 0 : idx;
+    }
+}
+}  // namespace
+
+extern "C" int la_argmax_rows_f32(const float *x, int64_t ld, int32_t rows, int32_t cols, int64_t *out, void *stream_) {
+    if (rows == 0) return LA_OK;
+    LA_CHECK_ARG(x && out && rows > 0 && cols > 0 && ld >= cols, "argmax_rows: bad arguments");
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream_, x, ld, cols, out);
+    LA_LAUNCH_CHECK();
+    return LA_OK;
+}

@@ -267,6 +267,58 @@ class AlignEngine:
         logits = ops.gemm(h, dw.tok_emb, out_f32=True)
         return logits.view(B, n, dw.tok_emb.shape[0])
 
+    # ---- greedy autoregressive decoding with a key / value cache ------------------------------
+    @torch.no_grad()
+    def decode_greedy(self, prompt: torch.Tensor, xa: torch.Tensor, max_new_tokens: int, eot: int, n_audio: int = N_CTX) -> torch.Tensor:
+        """Greedy decoding of the text decoder (the token loop under whisper's transcribe / DecodingTask with
+        temperature 0 and no beam: argmax of Whisper.logits at the last position, fed back, until every sequence has
+        produced `eot` or max_new_tokens are out).  prompt int64 [B, n0] (sot / language / task tokens), xa = encoder output
+        rows [B*n_audio, d] -> tokens int64 [B, n0 + steps]; finished sequences are padded with `eot`.
+        Cross-attention keys / values are projected once per layer; self-attention keys / values go into a per-layer
+        cache, so a step costs one token's worth of projections plus attention over the cache.  No token suppression,
+        timestamp rules or temperature fallback (those live in whisper/decoding.py, outside this path)."""
+        dw = self.dec
+        if dw is None:
+            raise _lib.LyricAlignHipError("this engine was packed without decoder weights")
+        B, n0 = prompt.shape
+        d, dt, H = dw.d, dw.dtype, dw.n_head
+        n_max = n0 + max_new_tokens
+        if n_max > dw.pos.shape[0]:
+            raise ValueError(f"decode_greedy: {n_max} positions exceed the decoder's context ({dw.pos.shape[0]})")
+        dev = self.device
+        tokens = torch.full((B, n_max), int(eot), dtype=torch.int64, device=dev)
+        tokens[:, :n0] = prompt.to(device=dev, dtype=torch.int64)
+        kv_cross = [ops.gemm(xa, blk.wkv_c, bias=blk.bkv_c) for blk in dw.blocks]             # [B*n_audio, 2d] each, once
+        cache = [torch.empty((B * n_max, 2 * d), dtype=dt, device=dev) for _ in dw.blocks]     # k | v rows, n_max per clip
+        finished = torch.zeros((B,), dtype=torch.bool, device=dev)
+        h = torch.empty((B, d), dtype=dt, device=dev)
+        n_out = n0
+        for t in range(n_max - 1):
+            x = ops.embed_tokens(tokens[:, t:t + 1].contiguous(), dw.tok_emb_f32, dw.pos[t:])          # [B, d] f32
+            for blk, kvc, kc in zip(dw.blocks, kv_cross, cache):
+                ops.layernorm(x, blk.ln1_g, blk.ln1_b, dt, out=h)
+                qkv = ops.gemm(h, blk.wqkv, bias=blk.bqkv)                                            # [B, 3d]
+                kc.view(B, n_max, 2 * d)[:, t] = qkv[:, d:]                                           # cache write (copy)
+                a = ops.attention_cached(qkv[:, :d], kc[:, :d], kc[:, d:], B, 1, t + 1, H, q_batch_rows=1, kv_batch_rows=n_max)
+                ops.gemm(a, blk.wo, x, bias=blk.bo, residual=x, out_f32=True)
+                ops.layernorm(x, blk.lnc_g, blk.lnc_b, dt, out=h)
+                q = ops.gemm(h, blk.wq_c, bias=blk.bq_c)
+                a = ops.attention_ex(q, kvc[:, :d], kvc[:, d:], B, 1, n_audio, H, causal=False)
+                ops.gemm(a, blk.wo_c, x, bias=blk.bo_c, residual=x, out_f32=True)
+                ops.layernorm(x, blk.ln2_g, blk.ln2_b, dt, out=h)
+                u = ops.gemm(h, blk.w1, bias=blk.b1, gelu=True)
+                ops.gemm(u, blk.w2, x, bias=blk.b2, residual=x, out_f32=True)
+            if t + 1 < n0:
+                continue                                                   # still consuming the prompt: nothing to choose
+            ops.layernorm(x, dw.ln_g, dw.ln_b, dt, out=h)
+            nxt = ops.argmax_rows(ops.gemm(h, dw.tok_emb, out_f32=True))   # [B]
+            tokens[:, t + 1] = torch.where(finished, tokens[:, t + 1], nxt)   # finished rows keep their eot padding
+            finished |= nxt == eot
+            n_out = t + 2
+            if bool(finished.all()):                                       # one host sync per step: the loop is data dependent
+                break
+        return tokens[:, :n_out]
+
     # ---- head: align_rnn up to Mish ------------------------------------------------------
     def head_hidden(self, feats: torch.Tensor, B: int, T: int, feat_clip_stride: int) -> torch.Tensor:
         """feats: rows [.., d] in compute dtype, clip b at rows b*feat_clip_stride .. +T.  -> Mish(GRU) [B*T, 2H]."""

@@ -292,8 +292,9 @@ def encoder_only_engine(whisper_model, mel: torch.Tensor) -> torch.Tensor:
     return eng.encode(mel, out_dtype=torch.float32).view(mel.shape[0], N_CTX, eng.enc.d).clone()
 
 
-def decoder_engine(whisper_model, tokens: torch.Tensor, audio_features: torch.Tensor) -> torch.Tensor:
-    """Whisper.logits for a bare whisper_compat.Whisper (float32 compute): packs encoder + decoder weights once."""
+def decoder_engine(whisper_model, tokens: torch.Tensor, audio_features: torch.Tensor, greedy=None) -> torch.Tensor:
+    """Whisper.logits for a bare whisper_compat.Whisper (float32 compute): packs encoder + decoder weights once.
+    greedy = (max_new_tokens, eot): run the greedy token loop from the prompt `tokens` instead and return the tokens."""
     _lib.require_gpu()
     cache = getattr(whisper_model, "_la_dec_engine", None)
     key = tuple(p._version for p in whisper_model.parameters())
@@ -308,4 +309,6 @@ def decoder_engine(whisper_model, tokens: torch.Tensor, audio_features: torch.Te
     eng = cache[1]
     B, n_audio, d = audio_features.shape
     xa = audio_features.to(device=eng.device, dtype=torch.float32).contiguous().view(B * n_audio, d)
+    if greedy is not None:
+        return eng.decode_greedy(tokens, xa, greedy[0], greedy[1], n_audio)
     return eng.decode(tokens, xa, n_audio)

@@ -262,3 +262,34 @@ def embed_tokens(tokens: torch.Tensor, token_embedding: torch.Tensor, positional
     check(lib().la_embed_tokens(ptr(tokens.contiguous()), B, n, ptr(token_embedding.contiguous()), V,
                                 ptr(positional_embedding.contiguous()), d, ptr(x), stream_ptr()), "embed_tokens")
     return x
+
+
+def attention_cached(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, q_len: int, kv_len: int, n_head: int,
+                     q_batch_rows: int, kv_batch_rows: int, causal: bool = True, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Attention of the last q_len positions against a key / value cache holding kv_batch_rows (>= kv_len) rows per clip:
+    q [batch*q_batch_rows, >= d], k / v [batch*kv_batch_rows, >= d] row views -> out [batch*q_len, d]."""
+    for name, t in (("q", q), ("k", k), ("v", v)):
+        _dev(t, name)
+        if t.dim() != 2 or t.stride(1) != 1:
+            raise ValueError(f"attention_cached: {name} must be a 2-D row view with unit inner stride")
+    dt = dtype_code(q.dtype)
+    d = n_head * 64
+    if k.dtype != q.dtype or v.dtype != q.dtype or k.stride(0) != v.stride(0):
+        raise ValueError("attention_cached: q/k/v dtypes differ or k and v have different row pitch")
+    if q.shape[0] < (batch - 1) * q_batch_rows + q_len or min(k.shape[0], v.shape[0]) < (batch - 1) * kv_batch_rows + kv_len:
+        raise ValueError("attention_cached: views shorter than the addressed rows")
+    if out is None:
+        out = torch.empty((batch * q_len, d), dtype=q.dtype, device=q.device)
+    check(lib().la_attention_cached(dt, ptr(q), q.stride(0), q_batch_rows, ptr(k), ptr(v), k.stride(0), kv_batch_rows, ptr(out),
+                                    out.stride(0), batch, q_len, kv_len, n_head, 1 if causal else 0, stream_ptr()), "attention_cached")
+    return out
+
+
+def argmax_rows(x: torch.Tensor) -> torch.Tensor:
+    """x [R, C] f32 (row view) -> int64 [R]: index of each row's first maximum."""
+    _dev(x, "x", torch.float32)
+    if x.dim() != 2 or x.stride(1) != 1:
+        raise ValueError("argmax_rows: x must be a 2-D row view with unit inner stride")
+    out = torch.empty((x.shape[0],), dtype=torch.int64, device=x.device)
+    check(lib().la_argmax_rows_f32(ptr(x), x.stride(0), x.shape[0], x.shape[1], ptr(out), stream_ptr()), "argmax_rows")
+    return out

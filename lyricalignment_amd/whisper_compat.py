@@ -118,8 +118,19 @@ class Whisper(nn.Module):
         from .module.align_model import decoder_engine
         return decoder_engine(self, tokens, audio_features)
 
+    def decode_greedy(self, prompt: torch.Tensor, audio_features: torch.Tensor, max_new_tokens: int, eot: int) -> torch.Tensor:
+        """Greedy token loop on the HIP engine with a key / value cache: prompt int64 [B,n0] (sot / language / task tokens),
+        audio_features [B,1500,d] -> tokens int64 [B, n0 + steps] (finished rows padded with `eot`).  This is the device part
+        of the reference's transcript script (inference_transcript.py:72-104 calls whisper's transcribe with beam_size 5);
+        text needs whisper's tiktoken vocabulary, which is not in this image, so the surface stops at token ids."""
+        if self.decoder is None:
+            raise RuntimeError("this Whisper object was built without a decoder")
+        from .module.align_model import decoder_engine
+        return decoder_engine(self, prompt, audio_features, greedy=(int(max_new_tokens), int(eot)))
+
     def transcribe(self, *a, **k):
-        raise NotImplementedError("transcription (beam search) is out of scope of the alignment hot path")
+        raise NotImplementedError("whisper's transcribe (beam search, temperature fallback, timestamp rules, tokenizer) is not "
+                                  "rebuilt here; decode_greedy() runs the decoder's token loop on the device")
 
 
 def dims_for(name: str) -> ModelDimensions:

@@ -387,3 +387,53 @@ def test_attention_ex_causal_and_cross():
         k2, v2 = kd[:, :, 0].transpose(1, 2), kd[:, :, 1].transpose(1, 2)
         ref = (torch.softmax(q @ k2.transpose(-1, -2), dim=-1) @ v2).transpose(1, 2).reshape(B * n, d)
         np.testing.assert_allclose(out.double().numpy(), ref.numpy(), rtol=0, atol=tol)
+
+
+@pytest.mark.parametrize("B,n0,steps", [(2, 3, 12), (1, 1, 20)])
+def test_greedy_decode_with_kv_cache_matches_full_recompute(B, n0, steps):
+    """Whisper.decode_greedy (cross K/V projected once, self K/V cache, one-token attention, device argmax) against the
+    oracle's TextDecoder run from scratch on the growing sequence at every step: same tokens, and the last-step logits of
+    the cached path equal Whisper.logits on the final sequence."""
+    from lyricalignment_amd import whisper_compat as wc
+    from oracle import model_oracle as mo
+    dims = wc.ModelDimensions(n_audio_state=128, n_audio_head=2, n_audio_layer=1, n_text_state=128, n_text_head=2, n_text_layer=2,
+                              n_vocab=97, n_text_ctx=40)
+    wm = wc.build_model(dims=dims, seed=71 + B, std=0.3, with_decoder=True)     # std 0.3: well separated logits
+    p = {"decoder." + k: v.detach().float().cpu() for k, v in wm.decoder.state_dict().items()}
+    g = torch.Generator().manual_seed(72)
+    xa = torch.randn(B, 1500, 128, generator=g)
+    prompt = torch.randint(1, 97, (B, n0), generator=g)
+    eot = 0
+    ref = prompt.clone()
+    done = torch.zeros(B, dtype=torch.bool)
+    for _ in range(steps):
+        nxt = mo.decoder_forward(p, ref, xa, n_head=2)[:, -1].argmax(dim=-1)
+        nxt = torch.where(done, torch.full_like(nxt, eot), nxt)
+        done |= nxt == eot
+        ref = torch.cat([ref, nxt[:, None]], dim=1)
+        if bool(done.all()):
+            break
+    got = wm.decode_greedy(prompt.cuda(), xa.cuda(), max_new_tokens=steps, eot=eot).cpu()
+    assert got.shape == ref.shape and torch.equal(got, ref), (got, ref)
+    full = wm.logits(tokens=got[:, :-1].cuda(), audio_features=xa.cuda())[:, -1].cpu()
+    assert torch.equal(full.argmax(dim=-1), torch.where(done & (got[:, -1] == eot), full.argmax(dim=-1), got[:, -1]))
+
+
+def test_attention_cached_and_argmax_ops():
+    from lyricalignment_amd import ops
+    g = torch.Generator().manual_seed(73)
+    B, H, n_max, n = 3, 2, 24, 17
+    d = 64 * H
+    for dtype, tol in ((torch.float32, 2e-5), (torch.bfloat16, 2e-2)):
+        q = (torch.randn(B, d, generator=g) * 0.3).to(dtype)
+        kv = torch.randn(B, n_max, 2 * d, generator=g).to(dtype)
+        out = ops.attention_cached(q.cuda(), kv.cuda().view(B * n_max, 2 * d)[:, :d], kv.cuda().view(B * n_max, 2 * d)[:, d:],
+                                   B, 1, n, H, q_batch_rows=1, kv_batch_rows=n_max).float().cpu()
+        qd = q.double().view(B, H, 1, 64)
+        kd = kv[:, :n, :d].double().view(B, n, H, 64).transpose(1, 2)
+        vd = kv[:, :n, d:].double().view(B, n, H, 64).transpose(1, 2)
+        ref = (torch.softmax(qd @ kd.transpose(-1, -2), dim=-1) @ vd).transpose(1, 2).reshape(B, d)
+        np.testing.assert_allclose(out.double().numpy(), ref.numpy(), rtol=0, atol=tol)
+    x = torch.randn(5, 3001, generator=g)
+    x[2, 17] = x[2, 2900] = 9.0                                   # tie: the first maximum wins, like torch.argmax
+    assert torch.equal(ops.argmax_rows(x.cuda()).cpu(), torch.tensor([int(r.argmax()) if i != 2 else 17 for i, r in enumerate(x)]))
