@@ -37,7 +37,28 @@ struct AttnParams {
     int64_t ld_out;
     int q_len, kv_len, n_head, causal;
     int64_t q_bs, kv_bs, out_bs;   // rows from one clip to the next (== q_len / kv_len / q_len unless the caller says otherwise)
+    int batch;
 };
+
+// Block -> (query tile, head, clip).  Workgroups are dealt round-robin over the 8 XCDs in launch order and every XCD has its
+// own 4 MiB L2, so with the natural order the query tiles of one (clip, head) -- which all sweep the same 384 KiB of K and V
+// -- land on 8 different L2s and the chip-wide in-flight K/V set (~40 MB) thrashes every one of them.  With (clip, head)
+// pairs a multiple of 8, launch slot L goes to XCD L % 8 and that XCD's slots walk (pair, query tile) with the tile
+// fastest: a pair's tiles share one L2 and ~13 pairs are in flight per XCD.  Otherwise the natural order is kept.
+struct BlockCoord { int qt, head, clip; };
+__device__ __forceinline__ BlockCoord block_coord(int nq, int n_head, int batch) {
+    const int L = blockIdx.x, pairs = n_head * batch;
+    int pair, qt;
+    if ((pairs & 7) == 0) {
+        const int x = L & 7, idx = L >> 3;
+        pair = x + 8 * (idx / nq);
+        qt = idx % nq;
+    } else {
+        pair = L / nq;
+        qt = L % nq;
+    }
+    return BlockCoord{qt, pair % n_head, pair / n_head};
+}
 
 // accumulator register -> row (key / dv index) inside a 32x32 tile for lane half h
 __device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
@@ -83,7 +104,8 @@ __device__ __forceinline__ void stage_kv_bf16(const bf16_t *kbase, const bf16_t 
 __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * KT * 128];  // [buf][K|V][64][128 B] = 32 KiB
     const int T = p.kv_len;
-    const int qt = blockIdx.x, head = blockIdx.y, clip = blockIdx.z;
+    const BlockCoord bc = block_coord((p.q_len + QT - 1) / QT, p.n_head, p.batch);
+    const int qt = bc.qt, head = bc.head, clip = bc.clip;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i32 = lane & 31, h = lane >> 5;
@@ -257,7 +279,8 @@ __device__ __forceinline__ void stage_kv_f32(const float *kbase, const float *vb
 __global__ __launch_bounds__(256, 2) void attention_f32_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // [buf][K|V][64][256 B] = 64 KiB
     const int T = p.kv_len;
-    const int qt = blockIdx.x, head = blockIdx.y, clip = blockIdx.z;
+    const BlockCoord bc = block_coord((p.q_len + QT - 1) / QT, p.n_head, p.batch);
+    const int qt = bc.qt, head = bc.head, clip = bc.clip;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i32 = lane & 31, h = lane >> 5;
     const float *base = reinterpret_cast<const float *>(p.q) + (int64_t)clip * p.q_bs * p.ld_q + head * 64;
@@ -374,8 +397,9 @@ __global__ __launch_bounds__(256, 2) void attention_f32_kernel(AttnParams p) {
 
 }  // namespace
 
-static int attention_launch(int dtype, const AttnParams &p, int batch, hipStream_t stream) {
-    const dim3 grid(la::cdiv(p.q_len, QT), p.n_head, batch), block(256);
+static int attention_launch(int dtype, AttnParams p, int batch, hipStream_t stream) {
+    p.batch = batch;
+    const dim3 grid(la::cdiv(p.q_len, QT) * p.n_head * batch), block(256);
     if (dtype == LA_BF16) {
         la::TimerScope ts("attention_bf16", stream);
         hipLaunchKernelGGL(attention_bf16_kernel, grid, block, 0, stream, p);
@@ -405,7 +429,7 @@ extern "C" int la_attention(int32_t dtype, const void *qkv, int64_t ld_qkv, void
                  "attention: rows must be 16-byte aligned");
     const char *b = reinterpret_cast<const char *>(qkv);
     const int d = n_head * 64;
-    AttnParams p{b, b + (int64_t)d * es, b + (int64_t)2 * d * es, ld_qkv, ld_qkv, out, ld_out, frames, frames, n_head, 0, frames, frames, frames};
+    AttnParams p{b, b + (int64_t)d * es, b + (int64_t)2 * d * es, ld_qkv, ld_qkv, out, ld_out, frames, frames, n_head, 0, frames, frames, frames, 0};
     return attention_launch(dtype, p, batch, stream);
 }
 
@@ -422,7 +446,7 @@ extern "C" int la_attention_ex(int32_t dtype, const void *q, int64_t ld_q, const
     LA_CHECK_ARG((ld_q * es) % 16 == 0 && (ld_kv * es) % 16 == 0 && (ld_out * es) % 16 == 0 && (uintptr_t)q % 16 == 0 &&
                      (uintptr_t)k % 16 == 0 && (uintptr_t)v % 16 == 0 && (uintptr_t)out % 16 == 0,
                  "attention_ex: rows must be 16-byte aligned");
-    AttnParams p{q, k, v, ld_q, ld_kv, out, ld_out, q_len, kv_len, n_head, causal ? 1 : 0, q_len, kv_len, q_len};
+    AttnParams p{q, k, v, ld_q, ld_kv, out, ld_out, q_len, kv_len, n_head, causal ? 1 : 0, q_len, kv_len, q_len, 0};
     return attention_launch(dtype, p, batch, stream);
 }
 
@@ -445,6 +469,6 @@ extern "C" int la_attention_cached(int32_t dtype, const void *q, int64_t ld_q, i
                      (uintptr_t)k % 16 == 0 && (uintptr_t)v % 16 == 0 && (uintptr_t)out % 16 == 0,
                  "attention_cached: rows must be 16-byte aligned");
     // one new token against the whole cache needs no mask at all
-    AttnParams p{q, k, v, ld_q, ld_kv, out, ld_out, q_len, kv_len, n_head, (causal && q_len > 1) ? 1 : 0, q_batch_rows, kv_batch_rows, q_len};
+    AttnParams p{q, k, v, ld_q, ld_kv, out, ld_out, q_len, kv_len, n_head, (causal && q_len > 1) ? 1 : 0, q_batch_rows, kv_batch_rows, q_len, 0};
     return attention_launch(dtype, p, batch, stream);
 }
