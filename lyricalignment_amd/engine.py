@@ -429,6 +429,8 @@ class PipelinedAligner:
         Lmax = labels.shape[1]
         out = (torch.empty((B, Lmax), dtype=torch.int32, device=eng.device), torch.empty((B, Lmax), dtype=torch.int32, device=eng.device),
                torch.empty((B,), dtype=torch.float64, device=eng.device), torch.empty((B,), dtype=torch.int32, device=eng.device))
+        for t_ in out:
+            t_.record_stream(self.stream_h)          # written on stream H: the allocator must not recycle them under it
         self._pending.append(dict(labels=labels, n_labels=n_labels, out=out, host_out=host_out))
         if len(self._pending) == self.G:
             self._flush()
