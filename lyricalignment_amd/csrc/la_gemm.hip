@@ -103,6 +103,44 @@ __global__ __launch_bounds__(CF::THREADS, 2) void gemm_kernel(GemmParams p) {
     const bool fast_c = ((p.ldc * (int64_t)sizeof(TC)) % 16 == 0) && ((uintptr_t)C % 16 == 0);
     const bool fast_r = do_res && (p.ldr % 4 == 0) && ((uintptr_t)R % 16 == 0);
     const bool probe_nostore = p.epilogue & 256;  // developer probe: main loop without the C stores
+    // interior wave tiles: straight-line form (see the ping-pong kernel's epilogue)
+    if (wrow0 + 64 <= p.M && wcol0 + 64 <= p.N && fast_c && (!do_res || fast_r) && !probe_nostore) {
+        TC *cw = C + (int64_t)wrow0 * p.ldc + wcol0 + r * 4;
+        const float *rw = do_res ? R + (int64_t)wrow0 * p.ldr + wcol0 + r * 4 : nullptr;
+        auto fast = [&](auto resc) {
+            constexpr bool RES = decltype(resc)::value;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float4 t[8];
+                if constexpr (RES) {
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) t[it] = *reinterpret_cast<const float4 *>(rw + (int64_t)(h * 32 + it * 4 + q) * p.ldr);
+                }
+#pragma unroll
+                for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni)
+                        *reinterpret_cast<f32x4 *>(reg + (mm * 16 + r) * PITCH + (ni * 16 + q * 4) * 4) = acc[2 * h + mm][ni];
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int rl = it * 4 + q;
+                    f32x4 v = *reinterpret_cast<const f32x4 *>(reg + rl * PITCH + r * 16);
+                    if constexpr (RES) { v[0] += t[it].x; v[1] += t[it].y; v[2] += t[it].z; v[3] += t[it].w; }
+                    TC *c = cw + (int64_t)(h * 32 + rl) * p.ldc;
+                    if constexpr (sizeof(TC) == 4) {
+                        *reinterpret_cast<float4 *>(c) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+                        ushort4 pk;
+                        pk.x = la::f32_to_bf16(v[0]); pk.y = la::f32_to_bf16(v[1]);
+                        pk.z = la::f32_to_bf16(v[2]); pk.w = la::f32_to_bf16(v[3]);
+                        *reinterpret_cast<ushort4 *>(c) = pk;
+                    }
+                }
+            }
+        };
+        if (do_res) fast(std::true_type{}); else fast(std::false_type{});
+        return;
+    }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -205,6 +243,46 @@ __global__ __launch_bounds__(PP::THREADS, 2) void gemm_pp_kernel(GemmParams p) {
     const int wrow0 = m0 + wr * 128, wcol0 = n0 + wc * 64;
     const bool fast_c = ((p.ldc * (int64_t)sizeof(TC)) % 16 == 0) && ((uintptr_t)C % 16 == 0);
     const bool fast_r = do_res && (p.ldr % 4 == 0) && ((uintptr_t)R % 16 == 0);
+    // Interior wave tiles (all but the last row / column of tiles): straight-line code, no bounds or alignment branches, so
+    // the residual loads of four rows are in flight together (the generic loop below waited out one HBM round trip per row:
+    // 32 dependent round trips per wave and tile, most of the 54 us the residual GEMMs lost to their epilogue).
+    if (wrow0 + 128 <= p.M && wcol0 + 64 <= p.N && fast_c && (!do_res || fast_r)) {
+        TC *cw = C + (int64_t)wrow0 * p.ldc + wcol0 + r * 4;
+        const float *rw = do_res ? R + (int64_t)wrow0 * p.ldr + wcol0 + r * 4 : nullptr;
+        auto fast = [&](auto resc) {
+            constexpr bool RES = decltype(resc)::value;
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                float4 t[8];
+                if constexpr (RES) {
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) t[it] = *reinterpret_cast<const float4 *>(rw + (int64_t)(h * 32 + it * 4 + q) * p.ldr);
+                }
+#pragma unroll
+                for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni)
+                        *reinterpret_cast<f32x4 *>(reg + (mm * 16 + r) * PITCH + (ni * 16 + q * 4) * 4) = acc[2 * h + mm][ni];
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int rl = it * 4 + q;
+                    f32x4 v = *reinterpret_cast<const f32x4 *>(reg + rl * PITCH + r * 16);
+                    if constexpr (RES) { v[0] += t[it].x; v[1] += t[it].y; v[2] += t[it].z; v[3] += t[it].w; }
+                    TC *c = cw + (int64_t)(h * 32 + rl) * p.ldc;
+                    if constexpr (sizeof(TC) == 4) {
+                        *reinterpret_cast<float4 *>(c) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+                        ushort4 pk;
+                        pk.x = la::f32_to_bf16(v[0]); pk.y = la::f32_to_bf16(v[1]);
+                        pk.z = la::f32_to_bf16(v[2]); pk.w = la::f32_to_bf16(v[3]);
+                        *reinterpret_cast<ushort4 *>(c) = pk;
+                    }
+                }
+            }
+        };
+        if (do_res) fast(std::true_type{}); else fast(std::false_type{});
+        return;
+    }
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
 #pragma unroll
