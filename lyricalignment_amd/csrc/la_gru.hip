@@ -25,8 +25,9 @@ namespace {
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 
-constexpr int MT = 2;          // 16-row batch tiles per workgroup group (32 clips)
-constexpr int GROUP = 16 * MT;
+constexpr int GROUP = 32;      // clips per workgroup group: up to two 16-row MFMA batch tiles (template parameter MT of the
+                               // kernels: 1 when the whole batch is <= 16 clips -- half the MFMAs of a step, which is what a
+                               // float32 training step with 2 clips, or a single-clip request, spends its time on)
 
 struct GruParams {
     const float *gi;     // [B][T][2][3H]
@@ -100,7 +101,7 @@ __device__ __forceinline__ void mma_step(const uint4 &a, const uint4 &w, f32x4 &
 //     every storing wave drains vmcnt, one lane signals with a relaxed agent-scope add; consumers poll that counter with
 //     an sc1 load, pass a workgroup barrier and read h with sc1 16-byte buffer loads only -> no release / acquire fence
 //     (each costs ~1.7 us per step here).  WT = false is the fence form (default; LA_GRU_WT=1 selects WT).
-template <typename T, int MAXKS, bool WT>
+template <typename T, int MAXKS, bool WT, int MT>
 __global__ __launch_bounds__(GruTraits<T>::NW * 64, 1) void gru_kernel(GruParams p) {
     typedef GruTraits<T> TR;
     constexpr int NW = TR::NW;
@@ -348,21 +349,32 @@ extern "C" int la_gru_layer(int32_t dtype, const float *gi, const void *w_hh, co
     LA_CHECK_ARG((int64_t)batch * frames * 2 * hidden * (dtype == LA_BF16 ? 2 : 4) < (int64_t)2147483647, "gru_layer: out buffer exceeds the 2 GiB buffer-descriptor range");
     if (dtype == LA_BF16) {
         la::TimerScope ts("gru_bf16", stream);
-        if (use_fence) hipLaunchKernelGGL((gru_kernel<bf16_t, 16, false>), grid, dim3(256), 16, stream, p);
-        else hipLaunchKernelGGL((gru_kernel<bf16_t, 16, true>), grid, dim3(256), 16, stream, p);
+        if (batch <= 16) {
+            if (use_fence) hipLaunchKernelGGL((gru_kernel<bf16_t, 16, false, 1>), grid, dim3(256), 16, stream, p);
+            else hipLaunchKernelGGL((gru_kernel<bf16_t, 16, true, 1>), grid, dim3(256), 16, stream, p);
+        } else {
+            if (use_fence) hipLaunchKernelGGL((gru_kernel<bf16_t, 16, false, 2>), grid, dim3(256), 16, stream, p);
+            else hipLaunchKernelGGL((gru_kernel<bf16_t, 16, true, 2>), grid, dim3(256), 16, stream, p);
+        }
     } else {
         const size_t lds_bytes = 16 + (size_t)2 * 3 * 16 * hidden * 4;
         static bool attr_done = false;
         if (!attr_done) {
-            LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gru_kernel<float, 24, false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 16 + 2 * 3 * 16 * 384 * 4));
-            LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gru_kernel<float, 24, true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 16 + 2 * 3 * 16 * 384 * 4));
+            const int max_lds = 16 + 2 * 3 * 16 * 384 * 4;
+            LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gru_kernel<float, 24, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+            LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gru_kernel<float, 24, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+            LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gru_kernel<float, 24, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+            LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gru_kernel<float, 24, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
             attr_done = true;
         }
         la::TimerScope ts("gru_f32", stream);
-        if (use_fence) hipLaunchKernelGGL((gru_kernel<float, 24, false>), grid, dim3(128), lds_bytes, stream, p);
-        else hipLaunchKernelGGL((gru_kernel<float, 24, true>), grid, dim3(128), lds_bytes, stream, p);
+        if (batch <= 16) {
+            if (use_fence) hipLaunchKernelGGL((gru_kernel<float, 24, false, 1>), grid, dim3(128), lds_bytes, stream, p);
+            else hipLaunchKernelGGL((gru_kernel<float, 24, true, 1>), grid, dim3(128), lds_bytes, stream, p);
+        } else {
+            if (use_fence) hipLaunchKernelGGL((gru_kernel<float, 24, false, 2>), grid, dim3(128), lds_bytes, stream, p);
+            else hipLaunchKernelGGL((gru_kernel<float, 24, true, 2>), grid, dim3(128), lds_bytes, stream, p);
+        }
     }
     LA_LAUNCH_CHECK();
     return LA_OK;
@@ -399,6 +411,7 @@ struct GruBwdParams {
 // forward kernel) the H hidden units are split over workgroups, each wave keeps its 16 columns of W_hh (as W_hh^T rows,
 // [16][3H] f32 = 72 KiB) resident in LDS, and dgh of the previous step is exchanged through HBM with the same
 // release / acquire hand-off.  2 waves per workgroup, H/32 workgroups per direction.
+template <int MT>
 __global__ __launch_bounds__(128, 1) void gru_bwd_kernel(GruBwdParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int NW = 2;
@@ -445,6 +458,18 @@ __global__ __launch_bounds__(128, 1) void gru_bwd_kernel(GruBwdParams p) {
         f32x4 acc[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // this step's saved gates, h_{t-1} and upstream gradient do not depend on the hand-off: requested before the wait
+        float g_r[MT][4], g_z[MT][4], g_n[MT][4], g_hn[MT][4], g_hp[MT][4], g_do[MT][4];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int b = b0 + min(mt * 16 + 4 * q + i, nb - 1);
+                const float *gp = p.gates + (((int64_t)b * T_ + t) * 2 + dir) * g4 + kcol;
+                g_r[mt][i] = gp[0]; g_z[mt][i] = gp[H]; g_n[mt][i] = gp[2 * H]; g_hn[mt][i] = gp[3 * H];
+                g_hp[mt][i] = (tprev >= 0 && tprev < T_) ? p.out[((int64_t)b * T_ + tprev) * 2 * H + dir * H + kcol] : 0.f;
+                g_do[mt][i] = p.dout[((int64_t)b * T_ + t) * 2 * H + dir * H + kcol];
+            }
         if (step > 0) {
             if (tid == 0) {
                 const bool ok = wait_counter(ctr + (step - 1), (unsigned)p.nsplit, p.abort_flag);
@@ -455,13 +480,25 @@ __global__ __launch_bounds__(128, 1) void gru_bwd_kernel(GruBwdParams p) {
             __syncthreads();
             alive = *ok_s != 0;
             if (!alive) break;
-            for (int ks = 0; ks < nks; ++ks) {
-                const uint4 w = *reinterpret_cast<const uint4 *>(wl + (int64_t)r16 * row_bytes + (((ks * 4 + q) ^ r16) << 4));
+            // dgh of the step before, 12 k-steps (12 x MT fragments) requested at a time: with one fragment per iteration the
+            // loop was 3H/16 = 72 dependent L2 round trips per step (the whole 22.7 us of it).  3H/16 = 12 (H/64).
+            const unsigned char *arow_ptr[MT];
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const uint4 a = *reinterpret_cast<const uint4 *>(
-                        reinterpret_cast<const unsigned char *>(p.dgh + (((int64_t)arow[mt] * T_ + tnext) * 2 + dir) * g3) + ks * 64 + q * 16);
-                    mma_step(a, w, acc[mt], 0.0f);
+            for (int mt = 0; mt < MT; ++mt)
+                arow_ptr[mt] = reinterpret_cast<const unsigned char *>(p.dgh + (((int64_t)arow[mt] * T_ + tnext) * 2 + dir) * g3) + q * 16;
+            for (int kb = 0; kb < nks; kb += 12) {
+                uint4 a[12][MT];
+#pragma unroll
+                for (int u = 0; u < 12; ++u)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        a[u][mt] = *reinterpret_cast<const uint4 *>(arow_ptr[mt] + (kb + u) * 64);
+#pragma unroll
+                for (int u = 0; u < 12; ++u) {
+                    const int ks = kb + u;
+                    const uint4 w = *reinterpret_cast<const uint4 *>(wl + (int64_t)r16 * row_bytes + (((ks * 4 + q) ^ r16) << 4));
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) mma_step(a[u][mt], w, acc[mt], 0.0f);
                 }
             }
         }
@@ -471,10 +508,8 @@ __global__ __launch_bounds__(128, 1) void gru_bwd_kernel(GruBwdParams p) {
             for (int i = 0; i < 4; ++i) {
                 const int bl = mt * 16 + 4 * q + i;
                 const int b = b0 + min(bl, nb - 1);
-                const float *gp = p.gates + (((int64_t)b * T_ + t) * 2 + dir) * g4 + kcol;
-                const float r = gp[0], z = gp[H], n = gp[2 * H], hn = gp[3 * H];
-                const float hp = (tprev >= 0 && tprev < T_) ? p.out[((int64_t)b * T_ + tprev) * 2 * H + dir * H + kcol] : 0.f;
-                const float dh = p.dout[((int64_t)b * T_ + t) * 2 * H + dir * H + kcol] + acc[mt][i] + carry[mt][i];
+                const float r = g_r[mt][i], z = g_z[mt][i], n = g_n[mt][i], hn = g_hn[mt][i], hp = g_hp[mt][i];
+                const float dh = g_do[mt][i] + acc[mt][i] + carry[mt][i];
                 const float dn_pre = dh * (1.0f - z) * (1.0f - n * n);
                 const float dz_pre = dh * (hp - n) * z * (1.0f - z);
                 const float dr_pre = dn_pre * hn * r * (1.0f - r);
@@ -519,12 +554,15 @@ extern "C" int la_gru_layer_bwd(const float *gates, const float *out, const floa
     const size_t lds_bytes = 16 + (size_t)2 * 16 * 3 * hidden * 4;
     static bool attr_done = false;
     if (!attr_done) {
-        LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gru_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gru_bwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   16 + 2 * 16 * 3 * 384 * 4));
+        LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gru_bwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    16 + 2 * 16 * 3 * 384 * 4));
         attr_done = true;
     }
     la::TimerScope ts("gru_bwd_f32", stream);
-    hipLaunchKernelGGL(gru_bwd_kernel, dim3(nsplit, 2, groups), dim3(128), lds_bytes, stream, p);
+    if (batch <= 16) hipLaunchKernelGGL(gru_bwd_kernel<1>, dim3(nsplit, 2, groups), dim3(128), lds_bytes, stream, p);
+    else hipLaunchKernelGGL(gru_bwd_kernel<2>, dim3(nsplit, 2, groups), dim3(128), lds_bytes, stream, p);
     LA_LAUNCH_CHECK();
     return LA_OK;
 }
