@@ -408,7 +408,8 @@ int la::gemm_run(int dtype, int M, int N, int K, int batch, const void *A, int64
         // 256x256 ping-pong kernel once it can fill the chip (>= 192 tiles); LA_GEMM_TILE=512 forces it, 128/256 forbid it
         static const char *force = getenv("LA_GEMM_TILE");
         const int forced = force ? atoi(force) : 0;
-        const bool pp = forced == 512 || (forced == 0 && (int64_t)la::cdiv(M, 256) * la::cdiv(N, 256) * batch >= 192);
+        // (a 256-column tile on N <= 128 -- the gathered-label logits, N = Lmax + 1 -- would compute mostly padding)
+        const bool pp = forced == 512 || (forced == 0 && N > 128 && (int64_t)la::cdiv(M, 256) * la::cdiv(N, 256) * batch >= 192);
         if (pp && !(epilogue & LA_EPI_MISH))
             return out_f32 ? launch_pp<true>(p, batch, stream) : launch_pp<false>(p, batch, stream);
         if (use_big_tile(M, N, batch))
