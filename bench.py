@@ -152,6 +152,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="single stream: no encoder/head overlap across batches")
+    ap.add_argument("--encoder-streams", type=int, default=1, help="HIP streams the encoders of consecutive batches alternate between")
     ap.add_argument("--head-group", type=int, default=2,
                     help="batches whose head (GRU / FC / DP) runs as one launch set in the two-stream pipeline")
     args = ap.parse_args()
@@ -188,7 +189,7 @@ def main():
     pinned_status = torch.empty((BATCH,), dtype=torch.int32).pin_memory()
 
     from lyricalignment_amd.engine import PipelinedAligner
-    pipe = None if args.no_overlap else PipelinedAligner(eng, head_group=args.head_group)
+    pipe = None if args.no_overlap else PipelinedAligner(eng, head_group=args.head_group, encoder_streams=args.encoder_streams)
 
     def step():
         with torch.no_grad():

@@ -386,13 +386,20 @@ class PipelinedAligner:
     The only shared buffers are the encoder outputs of a group, double-buffered and handed over with events; every other
     scratch buffer belongs to exactly one stream.  This changes no result -- only which kernels are in flight together."""
 
-    def __init__(self, engine: AlignEngine, head_group: int = 2):
+    def __init__(self, engine: AlignEngine, head_group: int = 2, encoder_streams: int = 1):
         if head_group < 1:
             raise ValueError("head_group must be >= 1")
         self.eng = engine
         self.G = int(head_group)
         dev = engine.device
-        self.stream_e = torch.cuda.Stream(device=dev)
+        # encoder_streams = 2: consecutive batches' encoders alternate between two streams (each with its own scratch
+        # buffers, same packed weights), so one batch's kernel tails and launch gaps are filled by the other's kernels
+        self.n_enc = int(encoder_streams)
+        self._enc_engines = [engine] + [AlignEngine(engine.enc, engine.head, dev, dec=engine.dec) for _ in range(self.n_enc - 1)]
+        self._enc_streams = [torch.cuda.Stream(device=dev) for _ in range(self.n_enc)]
+        self._enc_events = [torch.cuda.Event() for _ in range(self.n_enc)]
+        self._enc_i = 0
+        self.stream_e = self._enc_streams[0]
         self.stream_h = torch.cuda.Stream(device=dev, priority=-1)   # the GRU's few workgroups should dispatch promptly
         self.enc_done = [torch.cuda.Event(), torch.cuda.Event()]
         self.head_done = [torch.cuda.Event(), torch.cuda.Event()]
@@ -417,15 +424,24 @@ class PipelinedAligner:
         j = len(self._pending)
         d, dt = eng.enc.d, eng.enc.dtype
         cur = torch.cuda.current_stream(eng.device)
-        self.stream_e.wait_stream(cur)
-        with torch.cuda.stream(self.stream_e):
-            if j == 0 and self._head_used[slot]:
-                self.stream_e.wait_event(self.head_done[slot])       # the head of group g-2 has consumed this buffer set
+        k = self._enc_i % self.n_enc
+        self._enc_i += 1
+        st, enc_eng = self._enc_streams[k], self._enc_engines[k]
+        st.wait_stream(cur)
+        with torch.cuda.stream(st):
+            if self._head_used[slot]:
+                st.wait_event(self.head_done[slot])                  # the head of group g-2 has consumed this buffer set
             fb = self._feats[slot]
             if fb is None or fb.shape[0] != self.G * B * N_CTX or fb.dtype != dt:
                 fb = self._feats[slot] = torch.empty((self.G * B * N_CTX, d), dtype=dt, device=eng.device)
-            eng.encode(mel, out=fb[j * B * N_CTX:(j + 1) * B * N_CTX])
-            self.enc_done[slot].record(self.stream_e)                # re-recorded per batch: the flush waits for the last one
+                fb.record_stream(self.stream_h)
+                for s2 in self._enc_streams:
+                    fb.record_stream(s2)
+            enc_eng.encode(mel, out=fb[j * B * N_CTX:(j + 1) * B * N_CTX])
+            ev = torch.cuda.Event()
+            ev.record(st)
+        self._pending_events = getattr(self, "_pending_events", [])
+        self._pending_events.append(ev)
         Lmax = labels.shape[1]
         out = (torch.empty((B, Lmax), dtype=torch.int32, device=eng.device), torch.empty((B, Lmax), dtype=torch.int32, device=eng.device),
                torch.empty((B,), dtype=torch.float64, device=eng.device), torch.empty((B,), dtype=torch.int32, device=eng.device))
@@ -443,7 +459,9 @@ class PipelinedAligner:
         B, _, n_frames, use_ctc = self._key
         n = len(self._pending)
         with torch.cuda.stream(self.stream_h):
-            self.stream_h.wait_event(self.enc_done[slot])
+            for ev in self._pending_events:                          # every encoder of the group, whichever stream ran it
+                self.stream_h.wait_event(ev)
+            self._pending_events = []
             labels = self._pending[0]["labels"] if n == 1 else torch.cat([q["labels"] for q in self._pending], dim=0)
             n_labels = self._pending[0]["n_labels"] if n == 1 else torch.cat([q["n_labels"] for q in self._pending], dim=0)
             variant = LA_VARIANT_CTC if use_ctc else LA_VARIANT_PLAIN
@@ -465,6 +483,7 @@ class PipelinedAligner:
 
     def drain(self):
         self._flush()
-        self.stream_e.synchronize()
+        for st in self._enc_streams:
+            st.synchronize()
         self.stream_h.synchronize()
         self.eng.check_gru()

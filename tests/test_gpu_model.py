@@ -246,14 +246,14 @@ def test_state_dict_layout_and_training_mode_forward():
     assert not ev.requires_grad and ev.shape == logits.shape
 
 
-@pytest.mark.parametrize("head_group", [1, 2, 3])
-def test_pipelined_aligner_matches_single_stream(head_group):
+@pytest.mark.parametrize("head_group,encoder_streams", [(1, 1), (2, 1), (3, 1), (2, 2)])
+def test_pipelined_aligner_matches_single_stream(head_group, encoder_streams):
     """Two-stream encoder/head overlap across consecutive batches, with the head run once per `head_group` batches,
     changes no result (5 batches: full groups and a partial one flushed by drain())."""
     from lyricalignment_amd.engine import PipelinedAligner
     model = _small_model(torch.bfloat16, seed=21)
     eng = model.engine()
-    pipe = PipelinedAligner(eng, head_group=head_group)
+    pipe = PipelinedAligner(eng, head_group=head_group, encoder_streams=encoder_streams)
     rs = np.random.RandomState(22)
     batches = []
     for i in range(5):
