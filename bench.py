@@ -269,7 +269,9 @@ def main():
                          "launches_per_step": launches.value / max(args.steps, 1),
                          "avg_launch_ms": total_ms.value / max(launches.value, 1)},
         }
-        if not args.no_cpu_baseline:
+        if world > 1:
+            out["cpu_baseline"] = None          # the host baseline is timed on rank 0 of the N = 1 run only
+        elif not args.no_cpu_baseline:
             base, cpu_res = cpu_baseline(model, mel[0].cpu().numpy(), labels[0, : int(Ls[0])].cpu().numpy(), dims.n_audio_head)
             out["cpu_baseline"] = base
             gpu_on = pinned[0][0, : int(Ls[0])].numpy() * 0.02
