@@ -212,6 +212,11 @@ int la_attention_cached(int32_t dtype, const void *q, int64_t ld_q, int64_t q_ba
 /* out[r] = argmax_c x[r][c] (first maximum), int64: the greedy token choice over the decoder logits. */
 int la_argmax_rows_f32(const float *x, int64_t ld, int32_t rows, int32_t cols, int64_t *out, void *stream);
 
+/* The k (<= 8) largest values of each row, their indices (first maximum on ties) and the row's log-sum-exp:
+ * log-probability of candidate j = vals[r][j] - lse[r] (beam search over the decoder logits). */
+int la_topk_rows_f32(const float *x, int64_t ld, int32_t rows, int32_t cols, int32_t k, float *vals, int64_t *idx, float *lse,
+                     void *stream);
+
 /* x[b*n_tok + i][:] = token_embedding[tokens[b][i]][:] + positional_embedding[i][:]   (f32 tables, f32 out);
  * TextDecoder.forward's first line.  tokens int64 [batch][n_tok]. */
 int la_embed_tokens(const int64_t *tokens, int32_t batch, int32_t n_tok, const float *token_embedding, int32_t n_vocab,

@@ -312,3 +312,61 @@ extern "C" int la_argmax_rows_f32(const float *x, int64_t ld, int32_t rows, int3
     LA_LAUNCH_CHECK();
     return LA_OK;
 }
+
+// top-k of each row plus the row's log-sum-exp (beam search: log-probabilities of the k best next tokens are
+// value - lse).  k <= 8; one workgroup per row, k rounds of a masked arg-max (first maximum on ties).
+namespace {
+__global__ __launch_bounds__(256) void topk_rows_kernel(const float *x, int64_t ld, int cols, int k, float *vals, int64_t *idx,
+                                                       float *lse) {
+    __shared__ float bv[4];
+    __shared__ int bi[4];
+    __shared__ int chosen[8];
+    __shared__ float red[4];
+    const float *r = x + (int64_t)blockIdx.x * ld;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int round = 0; round < k; ++round) {
+        float best = -INFINITY;
+        int at = 0x7fffffff;
+        for (int c = threadIdx.x; c < cols; c += 256) {
+            bool taken = false;
+            for (int j = 0; j < round; ++j) taken |= chosen[j] == c;
+            const float v = r[c];
+            if (!taken && (v > best || at == 0x7fffffff)) { best = v; at = c; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o);
+            const int oi = __shfl_xor(at, o);
+            if (oi != 0x7fffffff && (at == 0x7fffffff || ov > best || (ov == best && oi < at))) { best = ov; at = oi; }
+        }
+        if (lane == 0) { bv[wave] = best; bi[wave] = at; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < 4; ++w)
+                if (bi[w] != 0x7fffffff && (at == 0x7fffffff || bv[w] > best || (bv[w] == best && bi[w] < at))) { best = bv[w]; at = bi[w]; }
+            chosen[round] = at;
+            vals[(int64_t)blockIdx.x * k + round] = best;
+            idx[(int64_t)blockIdx.x * k + round] = at == 0x7fffffff ? 0 : at;
+        }
+        __syncthreads();
+    }
+    // log-sum-exp around the row maximum (= the first chosen value)
+    const float m = vals[(int64_t)blockIdx.x * k];
+    float s = 0.f;
+    for (int c = threadIdx.x; c < cols; c += 256) s += expf(r[c] - m);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) lse[blockIdx.x] = m + logf((red[0] + red[1]) + (red[2] + red[3]));
+}
+}  // namespace
+
+extern "C" int la_topk_rows_f32(const float *x, int64_t ld, int32_t rows, int32_t cols, int32_t k, float *vals, int64_t *idx,
+                                float *lse, void *stream_) {
+    if (rows == 0) return LA_OK;
+    LA_CHECK_ARG(x && vals && idx && lse && rows > 0 && cols > 0 && ld >= cols && k >= 1 && k <= 8 && k <= cols, "topk_rows: bad arguments");
+    hipLaunchKernelGGL(topk_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream_, x, ld, cols, k, vals, idx, lse);
+    LA_LAUNCH_CHECK();
+    return LA_OK;
+}

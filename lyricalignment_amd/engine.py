@@ -267,7 +267,49 @@ class AlignEngine:
         logits = ops.gemm(h, dw.tok_emb, out_f32=True)
         return logits.view(B, n, dw.tok_emb.shape[0])
 
-    # ---- greedy autoregressive decoding with a key / value cache ------------------------------
+    # ---- autoregressive decoding with a key / value cache --------------------------------------
+    def _token_step(self, tok: torch.Tensor, t: int, caches, kv_cross, n_audio_clips: int, rows_per_clip: int, n_max: int,
+                    n_audio: int) -> torch.Tensor:
+        """One decoder position for N = n_audio_clips * rows_per_clip sequences (clip-major): tok int64 [N] at position t ->
+        the residual stream x [N, d] f32 after all blocks.  Self-attention keys / values of this position are appended to
+        `caches`; cross-attention treats a clip's rows_per_clip sequences as the query rows of one clip (no mask), so the
+        audio keys / values are projected and stored once per clip whatever the beam width."""
+        dw = self.dec
+        d, dt, H = dw.d, dw.dtype, dw.n_head
+        N = tok.shape[0]
+        x = ops.embed_tokens(tok.view(N, 1).contiguous(), dw.tok_emb_f32, dw.pos[t:])                    # [N, d] f32
+        h = torch.empty((N, d), dtype=dt, device=self.device)
+        for blk, kvc, kc in zip(dw.blocks, kv_cross, caches):
+            ops.layernorm(x, blk.ln1_g, blk.ln1_b, dt, out=h)
+            qkv = ops.gemm(h, blk.wqkv, bias=blk.bqkv)                                                  # [N, 3d]
+            kc.view(N, n_max, 2 * d)[:, t] = qkv[:, d:]                                                 # cache write (copy)
+            a = ops.attention_cached(qkv[:, :d], kc[:, :d], kc[:, d:], N, 1, t + 1, H, q_batch_rows=1, kv_batch_rows=n_max)
+            ops.gemm(a, blk.wo, x, bias=blk.bo, residual=x, out_f32=True)
+            ops.layernorm(x, blk.lnc_g, blk.lnc_b, dt, out=h)
+            q = ops.gemm(h, blk.wq_c, bias=blk.bq_c)
+            a = ops.attention_ex(q, kvc[:, :d], kvc[:, d:], n_audio_clips, rows_per_clip, n_audio, H, causal=False)
+            ops.gemm(a, blk.wo_c, x, bias=blk.bo_c, residual=x, out_f32=True)
+            ops.layernorm(x, blk.ln2_g, blk.ln2_b, dt, out=h)
+            u = ops.gemm(h, blk.w1, bias=blk.b1, gelu=True)
+            ops.gemm(u, blk.w2, x, bias=blk.b2, residual=x, out_f32=True)
+        return x
+
+    def _last_logits(self, x: torch.Tensor) -> torch.Tensor:
+        dw = self.dec
+        h = ops.layernorm(x, dw.ln_g, dw.ln_b, dw.dtype)
+        return ops.gemm(h, dw.tok_emb, out_f32=True)                                                    # [N, V] f32
+
+    def _decode_setup(self, B: int, n0: int, max_new_tokens: int, xa: torch.Tensor, rows_per_clip: int):
+        dw = self.dec
+        if dw is None:
+            raise _lib.LyricAlignHipError("this engine was packed without decoder weights")
+        n_max = n0 + max_new_tokens
+        if n_max > dw.pos.shape[0]:
+            raise ValueError(f"decoding: {n_max} positions exceed the decoder's context ({dw.pos.shape[0]})")
+        kv_cross = [ops.gemm(xa, blk.wkv_c, bias=blk.bkv_c) for blk in dw.blocks]                        # [B*n_audio, 2d], once
+        caches = [torch.empty((B * rows_per_clip * n_max, 2 * dw.d), dtype=dw.dtype, device=self.device) for _ in dw.blocks]
+        return n_max, kv_cross, caches
+
     @torch.no_grad()
     def decode_greedy(self, prompt: torch.Tensor, xa: torch.Tensor, max_new_tokens: int, eot: int, n_audio: int = N_CTX) -> torch.Tensor:
         """Greedy decoding of the text decoder (the token loop under whisper's transcribe / DecodingTask with
@@ -277,47 +319,105 @@ class AlignEngine:
         Cross-attention keys / values are projected once per layer; self-attention keys / values go into a per-layer
         cache, so a step costs one token's worth of projections plus attention over the cache.  No token suppression,
         timestamp rules or temperature fallback (those live in whisper/decoding.py, outside this path)."""
-        dw = self.dec
-        if dw is None:
-            raise _lib.LyricAlignHipError("this engine was packed without decoder weights")
         B, n0 = prompt.shape
-        d, dt, H = dw.d, dw.dtype, dw.n_head
-        n_max = n0 + max_new_tokens
-        if n_max > dw.pos.shape[0]:
-            raise ValueError(f"decode_greedy: {n_max} positions exceed the decoder's context ({dw.pos.shape[0]})")
+        n_max, kv_cross, caches = self._decode_setup(B, n0, max_new_tokens, xa, 1)
         dev = self.device
         tokens = torch.full((B, n_max), int(eot), dtype=torch.int64, device=dev)
         tokens[:, :n0] = prompt.to(device=dev, dtype=torch.int64)
-        kv_cross = [ops.gemm(xa, blk.wkv_c, bias=blk.bkv_c) for blk in dw.blocks]             # [B*n_audio, 2d] each, once
-        cache = [torch.empty((B * n_max, 2 * d), dtype=dt, device=dev) for _ in dw.blocks]     # k | v rows, n_max per clip
         finished = torch.zeros((B,), dtype=torch.bool, device=dev)
-        h = torch.empty((B, d), dtype=dt, device=dev)
         n_out = n0
         for t in range(n_max - 1):
-            x = ops.embed_tokens(tokens[:, t:t + 1].contiguous(), dw.tok_emb_f32, dw.pos[t:])          # [B, d] f32
-            for blk, kvc, kc in zip(dw.blocks, kv_cross, cache):
-                ops.layernorm(x, blk.ln1_g, blk.ln1_b, dt, out=h)
-                qkv = ops.gemm(h, blk.wqkv, bias=blk.bqkv)                                            # [B, 3d]
-                kc.view(B, n_max, 2 * d)[:, t] = qkv[:, d:]                                           # cache write (copy)
-                a = ops.attention_cached(qkv[:, :d], kc[:, :d], kc[:, d:], B, 1, t + 1, H, q_batch_rows=1, kv_batch_rows=n_max)
-                ops.gemm(a, blk.wo, x, bias=blk.bo, residual=x, out_f32=True)
-                ops.layernorm(x, blk.lnc_g, blk.lnc_b, dt, out=h)
-                q = ops.gemm(h, blk.wq_c, bias=blk.bq_c)
-                a = ops.attention_ex(q, kvc[:, :d], kvc[:, d:], B, 1, n_audio, H, causal=False)
-                ops.gemm(a, blk.wo_c, x, bias=blk.bo_c, residual=x, out_f32=True)
-                ops.layernorm(x, blk.ln2_g, blk.ln2_b, dt, out=h)
-                u = ops.gemm(h, blk.w1, bias=blk.b1, gelu=True)
-                ops.gemm(u, blk.w2, x, bias=blk.b2, residual=x, out_f32=True)
+            x = self._token_step(tokens[:, t].contiguous(), t, caches, kv_cross, B, 1, n_max, n_audio)
             if t + 1 < n0:
                 continue                                                   # still consuming the prompt: nothing to choose
-            ops.layernorm(x, dw.ln_g, dw.ln_b, dt, out=h)
-            nxt = ops.argmax_rows(ops.gemm(h, dw.tok_emb, out_f32=True))   # [B]
+            nxt = ops.argmax_rows(self._last_logits(x))                    # [B]
             tokens[:, t + 1] = torch.where(finished, tokens[:, t + 1], nxt)   # finished rows keep their eot padding
             finished |= nxt == eot
             n_out = t + 2
             if bool(finished.all()):                                       # one host sync per step: the loop is data dependent
                 break
         return tokens[:, :n_out]
+
+    @torch.no_grad()
+    def decode_beam(self, prompt: torch.Tensor, xa: torch.Tensor, beam_size: int, max_new_tokens: int, eot: int,
+                    patience: float = 1.0, n_audio: int = N_CTX):
+        """Beam search over the text decoder (what inference_transcript.py:88-91 asks whisper's transcribe for with
+        beam_size=5): per step the beam_size + 1 best continuations of every live sequence (la_topk_rows_f32 on the device:
+        values and the row log-sum-exp), candidates ranked per clip by summed log-probability, sequences ending in `eot`
+        moved to the clip's finished set (at most round(beam_size * patience) kept), the key / value caches re-gathered to
+        follow their source sequences, until every clip has its finished set or max_new_tokens are out; the returned
+        sequence per clip is the finished one with the highest summed log-probability per generated token.
+        Follows the published algorithm of whisper/decoding.py (BeamSearchDecoder + MaximumLikelihoodRanker without
+        length penalty); openai-whisper is not in this image, so this is NOT pinned to it -- the tests pin the device
+        path (cache gather, top-k, log-sum-exp) to a plain restatement run on the oracle's decoder.
+        prompt int64 [B, n0]; xa [B*n_audio, d] -> (list of B int64 tensors (prompt + generated, without eot),
+        list of B summed log-probabilities)."""
+        B, n0 = prompt.shape
+        beam = int(beam_size)
+        if not 1 <= beam <= 7:
+            raise ValueError("decode_beam: beam_size must be in 1..7")
+        n_max, kv_cross, caches = self._decode_setup(B, n0, max_new_tokens, xa, beam)
+        dev = self.device
+        N = B * beam
+        seqs = [[int(v) for v in prompt[i].tolist()] for i in range(B) for _ in range(beam)]     # clip-major, beam-minor
+        sum_lp = [0.0] * N
+        finished = [dict() for _ in range(B)]
+        max_cand = max(1, round(beam * patience))
+        cur = torch.tensor([s_[0] for s_ in seqs], dtype=torch.int64, device=dev)
+        for t in range(n_max - 1):
+            x = self._token_step(cur, t, caches, kv_cross, B, beam, n_max, n_audio)
+            if t + 1 < n0:
+                cur = torch.tensor([s_[t + 1] for s_ in seqs], dtype=torch.int64, device=dev)
+                continue
+            vals, idx, lse = ops.topk_rows(self._last_logits(x), beam + 1)
+            lp = (vals - lse[:, None]).cpu().tolist()                                             # [N][beam+1] log-probabilities
+            ix = idx.cpu().tolist()
+            new_seqs, new_lp, src = [], [], []
+            for i in range(B):
+                scores, sources = {}, {}
+                for j in range(beam):
+                    r = i * beam + j
+                    for c in range(beam + 1):
+                        key = tuple(seqs[r] + [ix[r][c]])
+                        scores[key] = sum_lp[r] + lp[r][c]
+                        sources[key] = r
+                saved = 0
+                for key in sorted(scores, key=scores.get, reverse=True):
+                    if key[-1] == eot:
+                        finished[i][key] = scores[key]
+                    else:
+                        new_seqs.append(list(key)); new_lp.append(scores[key]); src.append(sources[key])
+                        saved += 1
+                        if saved == beam:
+                            break
+                while saved < beam:                                  # fewer live continuations than beams: repeat the best
+                    new_seqs.append(list(new_seqs[-1]) if saved else seqs[i * beam] + [eot])
+                    new_lp.append(new_lp[-1] if saved else -float("inf")); src.append(src[-1] if saved else i * beam)
+                    saved += 1
+                if len(finished[i]) > max_cand:                      # keep the best max_cand finished sequences
+                    keep = sorted(finished[i], key=finished[i].get, reverse=True)[:max_cand]
+                    finished[i] = {k_: finished[i][k_] for k_ in keep}
+            seqs, sum_lp = new_seqs, new_lp
+            src_dev = torch.tensor(src, dtype=torch.int64, device=dev)
+            for li in range(len(caches)):                            # caches follow their source sequences (gather = data movement)
+                kc = caches[li].view(N, n_max, -1)
+                caches[li] = kc.index_select(0, src_dev).view(N * n_max, -1)
+            if all(len(f) >= max_cand for f in finished) or t + 2 >= n_max:
+                break
+            cur = torch.tensor([s_[t + 1] for s_ in seqs], dtype=torch.int64, device=dev)
+        out_tokens, out_lp = [], []
+        for i in range(B):
+            cands = dict(finished[i])
+            if len(cands) < beam:                                    # not enough finished: the live beams count as ended here
+                order = sorted(range(beam), key=lambda j: sum_lp[i * beam + j], reverse=True)
+                for j in order:
+                    if len(cands) >= beam:
+                        break
+                    cands[tuple(seqs[i * beam + j] + [eot])] = sum_lp[i * beam + j]
+            best = max(cands, key=lambda k_: cands[k_] / max(1, len(k_) - n0 - 1))
+            out_tokens.append(torch.tensor(list(best[:-1]), dtype=torch.int64))
+            out_lp.append(float(cands[best]))
+        return out_tokens, out_lp
 
     # ---- head: align_rnn up to Mish ------------------------------------------------------
     def head_hidden(self, feats: torch.Tensor, B: int, T: int, feat_clip_stride: int) -> torch.Tensor:

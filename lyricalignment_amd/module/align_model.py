@@ -309,6 +309,8 @@ def decoder_engine(whisper_model, tokens: torch.Tensor, audio_features: torch.Te
     eng = cache[1]
     B, n_audio, d = audio_features.shape
     xa = audio_features.to(device=eng.device, dtype=torch.float32).contiguous().view(B * n_audio, d)
+    if greedy is not None and len(greedy) == 3:
+        return eng.decode_beam(tokens, xa, greedy[2], greedy[0], greedy[1], n_audio=n_audio)
     if greedy is not None:
         return eng.decode_greedy(tokens, xa, greedy[0], greedy[1], n_audio)
     return eng.decode(tokens, xa, n_audio)

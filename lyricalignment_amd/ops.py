@@ -293,3 +293,17 @@ def argmax_rows(x: torch.Tensor) -> torch.Tensor:
     out = torch.empty((x.shape[0],), dtype=torch.int64, device=x.device)
     check(lib().la_argmax_rows_f32(ptr(x), x.stride(0), x.shape[0], x.shape[1], ptr(out), stream_ptr()), "argmax_rows")
     return out
+
+
+def topk_rows(x: torch.Tensor, k: int):
+    """x [R, C] f32 row view -> (values [R,k] f32, indices [R,k] int64, lse [R] f32): the k largest entries of each row in
+    descending order and the row's log-sum-exp (log-probability = value - lse)."""
+    _dev(x, "x", torch.float32)
+    if x.dim() != 2 or x.stride(1) != 1 or not 1 <= k <= min(8, x.shape[1]):
+        raise ValueError("topk_rows: x must be a 2-D row view and 1 <= k <= min(8, columns)")
+    R = x.shape[0]
+    vals = torch.empty((R, k), dtype=torch.float32, device=x.device)
+    idx = torch.empty((R, k), dtype=torch.int64, device=x.device)
+    lse = torch.empty((R,), dtype=torch.float32, device=x.device)
+    check(lib().la_topk_rows_f32(ptr(x), x.stride(0), R, x.shape[1], k, ptr(vals), ptr(idx), ptr(lse), stream_ptr()), "topk_rows")
+    return vals, idx, lse

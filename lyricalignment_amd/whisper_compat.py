@@ -128,9 +128,16 @@ class Whisper(nn.Module):
         from .module.align_model import decoder_engine
         return decoder_engine(self, prompt, audio_features, greedy=(int(max_new_tokens), int(eot)))
 
+    def decode_beam(self, prompt: torch.Tensor, audio_features: torch.Tensor, beam_size: int, max_new_tokens: int, eot: int):
+        """Beam search on the HIP engine (AlignEngine.decode_beam): -> (list of token tensors, list of summed log-probs)."""
+        if self.decoder is None:
+            raise RuntimeError("this Whisper object was built without a decoder")
+        from .module.align_model import decoder_engine
+        return decoder_engine(self, prompt, audio_features, greedy=(int(max_new_tokens), int(eot), int(beam_size)))
+
     def transcribe(self, *a, **k):
-        raise NotImplementedError("whisper's transcribe (beam search, temperature fallback, timestamp rules, tokenizer) is not "
-                                  "rebuilt here; decode_greedy() runs the decoder's token loop on the device")
+        raise NotImplementedError("whisper's transcribe (temperature fallback, timestamp rules, token suppression, tokenizer) is "
+                                  "not rebuilt here; decode_greedy() / decode_beam() run the decoder's token loop on the device")
 
 
 def dims_for(name: str) -> ModelDimensions:

@@ -437,3 +437,75 @@ def test_attention_cached_and_argmax_ops():
     x = torch.randn(5, 3001, generator=g)
     x[2, 17] = x[2, 2900] = 9.0                                   # tie: the first maximum wins, like torch.argmax
     assert torch.equal(ops.argmax_rows(x.cuda()).cpu(), torch.tensor([int(r.argmax()) if i != 2 else 17 for i, r in enumerate(x)]))
+
+
+def _reference_beam_search(p, prompt_row, xa_row, beam, max_new, eot, n_head):
+    """Plain restatement of the beam search of whisper/decoding.py (BeamSearchDecoder.update / finalize + the
+    maximum-likelihood ranker without length penalty) on the oracle's decoder, re-run from scratch on every hypothesis."""
+    from oracle import model_oracle as mo
+    n0 = len(prompt_row)
+    seqs = [list(prompt_row)] * beam
+    sums = [0.0] * beam
+    finished = {}
+    for _ in range(max_new):
+        toks = torch.tensor(seqs)
+        logits = mo.decoder_forward(p, toks, xa_row[None].expand(beam, -1, -1), n_head=n_head)[:, -1]
+        logp = torch.log_softmax(logits.double(), dim=-1)
+        scores, sources = {}, {}
+        for j in range(beam):
+            v, ix = logp[j].topk(beam + 1)
+            for lp, tk in zip(v.tolist(), ix.tolist()):
+                key = tuple(seqs[j] + [tk])
+                scores[key] = sums[j] + lp
+                sources[key] = j
+        new_seqs, new_sums = [], []
+        for key in sorted(scores, key=scores.get, reverse=True):
+            if key[-1] == eot:
+                finished[key] = scores[key]
+            else:
+                new_seqs.append(list(key)); new_sums.append(scores[key])
+                if len(new_seqs) == beam:
+                    break
+        seqs, sums = new_seqs, new_sums
+        if len(finished) > beam:
+            keep = sorted(finished, key=finished.get, reverse=True)[:beam]
+            finished = {k: finished[k] for k in keep}
+        if len(finished) >= beam:
+            break
+    cands = dict(finished)
+    for j in sorted(range(beam), key=lambda j: sums[j], reverse=True):
+        if len(cands) >= beam:
+            break
+        cands[tuple(seqs[j] + [eot])] = sums[j]
+    best = max(cands, key=lambda k: cands[k] / max(1, len(k) - n0 - 1))
+    return list(best[:-1]), cands[best]
+
+
+@pytest.mark.parametrize("beam,eot", [(3, 0), (5, 7)])
+def test_beam_search_matches_plain_restatement(beam, eot):
+    """AlignEngine.decode_beam (device top-k + log-sum-exp, K/V cache gathered along the surviving hypotheses,
+    cross-attention shared by a clip's beams) against the plain restatement above: same winning tokens, same score."""
+    from lyricalignment_amd import whisper_compat as wc
+    dims = wc.ModelDimensions(n_audio_state=128, n_audio_head=2, n_audio_layer=1, n_text_state=128, n_text_head=2, n_text_layer=2,
+                              n_vocab=61, n_text_ctx=32)
+    wm = wc.build_model(dims=dims, seed=80 + beam, std=0.25, with_decoder=True)
+    p = {"decoder." + k: v.detach().float().cpu() for k, v in wm.decoder.state_dict().items()}
+    g = torch.Generator().manual_seed(81)
+    B, n0, max_new = 2, 2, 9
+    xa = torch.randn(B, 1500, 128, generator=g)
+    prompt = torch.randint(1, 61, (B, n0), generator=g)
+    toks, lps = wm.decode_beam(prompt.cuda(), xa.cuda(), beam_size=beam, max_new_tokens=max_new, eot=eot)
+    for i in range(B):
+        ref_t, ref_lp = _reference_beam_search(p, prompt[i].tolist(), xa[i], beam, max_new, eot, 2)
+        assert toks[i].tolist() == ref_t, (i, toks[i].tolist(), ref_t)
+        assert abs(lps[i] - ref_lp) < 2e-3 * max(1.0, abs(ref_lp))
+
+
+def test_topk_rows_matches_torch():
+    from lyricalignment_amd import ops
+    g = torch.Generator().manual_seed(82)
+    x = torch.randn(7, 51865, generator=g) * 3
+    v, i, lse = ops.topk_rows(x.cuda(), 6)
+    rv, ri = x.topk(6, dim=1)
+    assert torch.equal(i.cpu(), ri) and torch.equal(v.cpu(), rv)
+    np.testing.assert_allclose(lse.cpu().numpy(), torch.logsumexp(x.double(), dim=1).numpy(), rtol=2e-6)
