@@ -382,10 +382,9 @@ bool use_big_tile(int M, int N, int batch) {
 
 }  // namespace
 
-static thread_local int64_t g_ldw = 0;   // row pitch of W for the next gemm_run (0 = dense [N][K]); set by la_gemm_ex
-
-int la::gemm_run(int dtype, int M, int N, int K, int batch, const void *A, int64_t lda, int64_t strideA, const void *W,
-                 int64_t strideW, void *C, int64_t ldc, int64_t strideC, const float *bias, int64_t strideBias,
+// ldw: row pitch of W in elements (0 = dense [N][K])
+static int gemm_run_ldw(int dtype, int M, int N, int K, int batch, const void *A, int64_t lda, int64_t strideA, const void *W,
+                        int64_t ldw_arg, int64_t strideW, void *C, int64_t ldc, int64_t strideC, const float *bias, int64_t strideBias,
                  const float *residual, int64_t ldr, int64_t strideR, int epilogue, hipStream_t stream) {
     if (M == 0 || N == 0 || batch == 0) return LA_OK;
     LA_CHECK_ARG(A && W && C, "gemm: null pointer");
@@ -398,8 +397,8 @@ int la::gemm_run(int dtype, int M, int N, int K, int batch, const void *A, int64
                  "gemm: A/W rows must be 16-byte aligned");
     LA_CHECK_ARG(!(epilogue & LA_EPI_RESIDUAL) || residual, "gemm: residual epilogue without pointer");
     LA_CHECK_ARG(!(epilogue & LA_EPI_BIAS) || bias, "gemm: bias epilogue without pointer");
-    LA_CHECK_ARG((strideW * es) % 16 == 0 && (g_ldw * es) % 16 == 0, "gemm: W batch stride / row pitch must be 16-byte aligned");
-    GemmParams p{M, N, K, A, lda, strideA, W, g_ldw > 0 ? g_ldw : (int64_t)K, strideW, C, ldc, strideC, bias, strideBias, residual, ldr, strideR, epilogue,
+    LA_CHECK_ARG((strideW * es) % 16 == 0 && (ldw_arg * es) % 16 == 0, "gemm: W batch stride / row pitch must be 16-byte aligned");
+    GemmParams p{M, N, K, A, lda, strideA, W, ldw_arg > 0 ? ldw_arg : (int64_t)K, strideW, C, ldc, strideC, bias, strideBias, residual, ldr, strideR, epilogue,
                  0, la::cdiv(N, BN), pick_group(K, es, la::cdiv(N, BN))};
     const bool out_f32 = epilogue & LA_EPI_OUT_F32;
     typedef Cfg<2, 2> Small;
@@ -419,6 +418,13 @@ int la::gemm_run(int dtype, int M, int N, int K, int batch, const void *A, int64
     return launch<float, true, Small>(p, batch, stream, "gemm_f32");
 }
 
+int la::gemm_run(int dtype, int M, int N, int K, int batch, const void *A, int64_t lda, int64_t strideA, const void *W,
+                 int64_t strideW, void *C, int64_t ldc, int64_t strideC, const float *bias, int64_t strideBias,
+                 const float *residual, int64_t ldr, int64_t strideR, int epilogue, hipStream_t stream) {
+    return gemm_run_ldw(dtype, M, N, K, batch, A, lda, strideA, W, 0, strideW, C, ldc, strideC, bias, strideBias, residual, ldr,
+                        strideR, epilogue, stream);
+}
+
 extern "C" int la_gemm(int32_t dtype, int32_t M, int32_t N, int32_t K, int32_t batch, const void *A, int64_t lda,
                        int64_t strideA, const void *W, void *C, int64_t ldc, int64_t strideC, const float *bias,
                        const float *residual, int64_t ldr, int64_t strideR, int32_t epilogue, void *stream_) {
@@ -431,9 +437,6 @@ extern "C" int la_gemm_ex(int32_t dtype, int32_t M, int32_t N, int32_t K, int32_
                           int64_t strideA, const void *W, int64_t ldw, int64_t strideW, void *C, int64_t ldc, int64_t strideC,
                           const float *bias, int32_t epilogue, void *stream_) {
     LA_CHECK_ARG(ldw >= K, "gemm_ex: ldw < K");
-    g_ldw = ldw;
-    const int rc = la::gemm_run(dtype, M, N, K, batch, A, lda, strideA, W, strideW, C, ldc, strideC, bias, 0, nullptr, 0, 0,
-                                epilogue, (hipStream_t)stream_);
-    g_ldw = 0;
-    return rc;
+    return gemm_run_ldw(dtype, M, N, K, batch, A, lda, strideA, W, ldw, strideW, C, ldc, strideC, bias, 0, nullptr, 0, 0, epilogue,
+                        (hipStream_t)stream_);
 }

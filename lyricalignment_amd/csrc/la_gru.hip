@@ -302,7 +302,6 @@ __global__ __launch_bounds__(GruTraits<T>::NW * 64, 1) void gru_kernel(GruParams
 }  // namespace
 
 static int gru_groups(int batch) { return la::cdiv(batch, GROUP); }
-static thread_local float *g_save_gates = nullptr;   // set by la_gru_layer_train for the one launch that follows
 
 extern "C" int la_gru_workspace_bytes(int32_t batch, int32_t frames, int32_t hidden, size_t *bytes) {
     LA_CHECK_ARG(bytes && batch > 0 && frames > 0 && hidden > 0, "gru_workspace_bytes: bad arguments");
@@ -311,9 +310,10 @@ extern "C" int la_gru_workspace_bytes(int32_t batch, int32_t frames, int32_t hid
     return LA_OK;
 }
 
-extern "C" int la_gru_layer(int32_t dtype, const float *gi, const void *w_hh, const float *b_hh, void *out, void *out_mish,
-                            int32_t batch, int32_t frames, int32_t hidden, void *workspace, size_t workspace_bytes,
-                            int32_t *timeout_flag, void *stream_) {
+// gates != nullptr: the training forward (float32) also stores r, z, n and W_hn h + b_hn of every step
+static int gru_forward(int32_t dtype, const float *gi, const void *w_hh, const float *b_hh, void *out, void *out_mish,
+                       int32_t batch, int32_t frames, int32_t hidden, void *workspace, size_t workspace_bytes,
+                       int32_t *timeout_flag, float *gates, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (batch == 0 || frames == 0) return LA_OK;
     LA_CHECK_ARG(gi && w_hh && b_hh && out && workspace, "gru_layer: null pointer");
@@ -337,8 +337,7 @@ extern "C" int la_gru_layer(int32_t dtype, const float *gi, const void *w_hh, co
     LA_HIP(hipMemsetAsync(workspace, 0, need, stream));
     GruParams p{gi, w_hh, b_hh, out, out_mish, batch, frames, hidden,
                 reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(workspace) + 16),
-                reinterpret_cast<int *>(workspace), timeout_flag, nsplit, g_save_gates};
-    g_save_gates = nullptr;
+                reinterpret_cast<int *>(workspace), timeout_flag, nsplit, gates};
     const dim3 grid(nsplit, 2, groups);
     // measured (tools/kbench.py gru, after the fast gate math): 9.1 ms write-through vs 9.5 ms fences per layer; a third
     // form that polls the data itself (out pre-filled with NaN, no counter, no barrier) ran 9.9 ms, and requesting all h
@@ -380,6 +379,12 @@ extern "C" int la_gru_layer(int32_t dtype, const float *gi, const void *w_hh, co
     return LA_OK;
 }
 
+extern "C" int la_gru_layer(int32_t dtype, const float *gi, const void *w_hh, const float *b_hh, void *out, void *out_mish,
+                            int32_t batch, int32_t frames, int32_t hidden, void *workspace, size_t workspace_bytes,
+                            int32_t *timeout_flag, void *stream) {
+    return gru_forward(dtype, gi, w_hh, b_hh, out, out_mish, batch, frames, hidden, workspace, workspace_bytes, timeout_flag, nullptr, stream);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // training face (fine-tune row, float32 like the reference): forward that also stores the gates, and the backward sweep
 // ---------------------------------------------------------------------------------------------------------------
@@ -387,8 +392,7 @@ extern "C" int la_gru_layer_train_fwd(const float *gi, const float *w_hh, const 
                                       int32_t batch, int32_t frames, int32_t hidden, void *workspace, size_t workspace_bytes,
                                       int32_t *timeout_flag, void *stream) {
     LA_CHECK_ARG(gates, "gru_layer_train_fwd: gates buffer missing");
-    g_save_gates = gates;
-    return la_gru_layer(LA_F32, gi, w_hh, b_hh, out, nullptr, batch, frames, hidden, workspace, workspace_bytes, timeout_flag, stream);
+    return gru_forward(LA_F32, gi, w_hh, b_hh, out, nullptr, batch, frames, hidden, workspace, workspace_bytes, timeout_flag, gates, stream);
 }
 
 namespace {
