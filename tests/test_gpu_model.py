@@ -509,3 +509,43 @@ def test_topk_rows_matches_torch():
     rv, ri = x.topk(6, dim=1)
     assert torch.equal(i.cpu(), ri) and torch.equal(v.cpu(), rv)
     np.testing.assert_allclose(lse.cpu().numpy(), torch.logsumexp(x.double(), dim=1).numpy(), rtol=2e-6)
+
+
+def test_full_size_medium_batch_properties():
+    """BASELINE configs[1] at full size (Whisper-medium, 32 x 30 s, bf16, T = 1500): size-independent properties of the
+    whole path.  (1) every alignment is well formed: status OK, onset <= offset - 1, segments ordered and inside [0, T];
+    (2) sharding invariance: aligning the two halves of the batch separately gives bit-identical frames and scores (clips
+    are independent -- the multi-GPU path shards them with no collective); (3) the two-stream pipeline changes nothing;
+    (4) idempotence: a second pass over the same batch reproduces the first bit for bit."""
+    from lyricalignment_amd import whisper_compat as wc
+    from lyricalignment_amd.engine import PipelinedAligner
+    from lyricalignment_amd.module.align_model import AlignModel
+    wm = wc.build_model("medium", seed=3)
+    model = AlignModel(wm, embed_dim=1024, hidden_dim=384, output_dim=21129, device="cuda", compute_dtype=torch.bfloat16).eval()
+    eng = model.engine()
+    rs = np.random.RandomState(5)
+    B, T, Lmax = 32, 1500, 26
+    mel = torch.from_numpy(rs.uniform(-1, 1, size=(B, 80, 3000)).astype(np.float32)).cuda()
+    Ls = rs.randint(5, Lmax + 1, size=B)
+    labels = torch.zeros((B, Lmax), dtype=torch.int32)
+    for b in range(B):
+        labels[b, : Ls[b]] = torch.from_numpy(rs.randint(2, 403, size=Ls[b]).astype(np.int32))
+    labels, n_labels = labels.cuda(), torch.from_numpy(Ls.astype(np.int32)).cuda()
+    with torch.no_grad():
+        on, off, score, status = [t.clone() for t in eng.align_mel(mel, labels, n_labels, n_frames=T, use_ctc=True)]
+        on2, off2, score2, _ = [t.clone() for t in eng.align_mel(mel, labels, n_labels, n_frames=T, use_ctc=True)]
+        halves = [[t.clone() for t in eng.align_mel(mel[s], labels[s], n_labels[s], n_frames=T, use_ctc=True)] for s in (slice(0, 16), slice(16, 32))]
+        pipe = PipelinedAligner(eng, head_group=2)
+        outs = [pipe.submit(mel, labels, n_labels, n_frames=T) for _ in range(3)]
+        pipe.drain()
+    assert int((status != 0).sum()) == 0
+    onc, offc = on.cpu().numpy(), off.cpu().numpy()
+    for b in range(B):
+        L = int(Ls[b])
+        o, f = onc[b, :L], offc[b, :L]
+        assert (o >= 0).all() and (f <= T).all() and (f > o).all() and (o[1:] >= f[:-1]).all(), b
+    assert torch.equal(on, on2) and torch.equal(off, off2) and torch.equal(score, score2)
+    assert torch.equal(torch.cat([halves[0][0], halves[1][0]]), on) and torch.equal(torch.cat([halves[0][1], halves[1][1]]), off)
+    assert torch.equal(torch.cat([halves[0][2], halves[1][2]]), score)
+    for o in outs:
+        assert torch.equal(o[0], on) and torch.equal(o[1], off) and torch.equal(o[2], score)
