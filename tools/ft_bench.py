@@ -2,7 +2,11 @@
 one MI355X: micro-step (forward + losses + backward) and optimizer step.  Synthetic audio / labels, random-init weights."""
 import argparse
 import json
+import os
+import sys
 import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 import numpy as np
 import torch
