@@ -202,29 +202,63 @@ __global__ __launch_bounds__(GruTraits<T>::NW * 64, 1) void gru_kernel(GruParams
             alive = *ok_s != 0;
             if (!alive) break;
             // ---- gh = h_{t-1} W_hh^T for this wave's 48 gate columns ----
-#pragma unroll
-            for (int ks = 0; ks < MAXKS; ++ks) {
-                if (ks < nks) {
-                    uint4 a[MT];
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        const int64_t eoff = (int64_t)arow[mt] * out_bs + (int64_t)tprev * out_ts + dir * H;
-                        if constexpr (WT) {
-                            typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-                            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(
-                                out_rsrc, (int)(eoff * (int64_t)sizeof(T)) + ks * 64 + q * 16, 0, 16 /* sc1 */);
-                            a[mt] = make_uint4(v[0], v[1], v[2], v[3]);
-                        } else {
-                            a[mt] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(out + eoff) + ks * 64 + q * 16);
-                        }
+            if constexpr (TR::W_IN_REGS) {
+                // Every wave needs ALL of h_{t-1} (16*MT clips x H): fetched once per workgroup into LDS, 16 B per thread and
+                // request, then read as MFMA A fragments from there.  (Each wave loading its own copy made the loads 4x
+                // redundant: 96 KB per CU and step from beyond this XCD's L2 -- measured 3.7 us of a 6.4 us step at 32 clips.)
+                // Row pitch H*2 + 16 B: the 16 rows of an m-tile start 16 B apart modulo 256 B -> conflict-free b128 reads.
+                const int chunks = row_bytes >> 4, pitch = row_bytes + 16;
+                unsigned char *hl = lds + 16;
+                for (int idx = tid; idx < 16 * MT * chunks; idx += NW * 64) {
+                    const int row = idx / chunks, c = idx - row * chunks;
+                    const int64_t eoff = (int64_t)(b0 + min(row, nb - 1)) * out_bs + (int64_t)tprev * out_ts + dir * H;
+                    uint4 v;
+                    if constexpr (WT) {
+                        typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+                        const u32x4 t4 = __builtin_amdgcn_raw_buffer_load_b128(out_rsrc, (int)(eoff * (int64_t)sizeof(T)) + c * 16, 0, 16 /* sc1 */);
+                        v = make_uint4(t4[0], t4[1], t4[2], t4[3]);
+                    } else {
+                        v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(out + eoff) + c * 16);
                     }
+                    *reinterpret_cast<uint4 *>(hl + row * pitch + c * 16) = v;
+                }
+                __syncthreads();
 #pragma unroll
-                    for (int g = 0; g < 3; ++g) {
-                        uint4 w;
-                        if constexpr (TR::W_IN_REGS) w = wreg[g][ks];
-                        else w = *reinterpret_cast<const uint4 *>(wl + (int64_t)(g * 16 + r16) * row_bytes + (((ks * 4 + q) ^ r16) << 4));
+                for (int ks = 0; ks < MAXKS; ++ks) {
+                    if (ks < nks) {
+                        uint4 a[MT];
 #pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) mma_step(a[mt], w, acc[g][mt], T{});
+                        for (int mt = 0; mt < MT; ++mt)
+                            a[mt] = *reinterpret_cast<const uint4 *>(hl + (mt * 16 + r16) * pitch + ks * 64 + q * 16);
+#pragma unroll
+                        for (int g = 0; g < 3; ++g)
+#pragma unroll
+                            for (int mt = 0; mt < MT; ++mt) mma_step(a[mt], wreg[g][ks], acc[g][mt], T{});
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < MAXKS; ++ks) {
+                    if (ks < nks) {
+                        uint4 a[MT];
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) {
+                            const int64_t eoff = (int64_t)arow[mt] * out_bs + (int64_t)tprev * out_ts + dir * H;
+                            if constexpr (WT) {
+                                typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+                                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(
+                                    out_rsrc, (int)(eoff * (int64_t)sizeof(T)) + ks * 64 + q * 16, 0, 16 /* sc1 */);
+                                a[mt] = make_uint4(v[0], v[1], v[2], v[3]);
+                            } else {
+                                a[mt] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(out + eoff) + ks * 64 + q * 16);
+                            }
+                        }
+#pragma unroll
+                        for (int g = 0; g < 3; ++g) {
+                            const uint4 w = *reinterpret_cast<const uint4 *>(wl + (int64_t)(g * 16 + r16) * row_bytes + (((ks * 4 + q) ^ r16) << 4));
+#pragma unroll
+                            for (int mt = 0; mt < MT; ++mt) mma_step(a[mt], w, acc[g][mt], T{});
+                        }
                     }
                 }
             }
@@ -349,11 +383,13 @@ static int gru_forward(int32_t dtype, const float *gi, const void *w_hh, const f
     if (dtype == LA_BF16) {
         la::TimerScope ts("gru_bf16", stream);
         if (batch <= 16) {
-            if (use_fence) hipLaunchKernelGGL((gru_kernel<bf16_t, 16, false, 1>), grid, dim3(256), 16, stream, p);
-            else hipLaunchKernelGGL((gru_kernel<bf16_t, 16, true, 1>), grid, dim3(256), 16, stream, p);
+            const size_t lds_b = 16 + (size_t)16 * (hidden * 2 + 16);          // flag + the staged h rows of one m-tile
+            if (use_fence) hipLaunchKernelGGL((gru_kernel<bf16_t, 16, false, 1>), grid, dim3(256), lds_b, stream, p);
+            else hipLaunchKernelGGL((gru_kernel<bf16_t, 16, true, 1>), grid, dim3(256), lds_b, stream, p);
         } else {
-            if (use_fence) hipLaunchKernelGGL((gru_kernel<bf16_t, 16, false, 2>), grid, dim3(256), 16, stream, p);
-            else hipLaunchKernelGGL((gru_kernel<bf16_t, 16, true, 2>), grid, dim3(256), 16, stream, p);
+            const size_t lds_b = 16 + (size_t)32 * (hidden * 2 + 16);
+            if (use_fence) hipLaunchKernelGGL((gru_kernel<bf16_t, 16, false, 2>), grid, dim3(256), lds_b, stream, p);
+            else hipLaunchKernelGGL((gru_kernel<bf16_t, 16, true, 2>), grid, dim3(256), lds_b, stream, p);
         }
     } else {
         const size_t lds_bytes = 16 + (size_t)2 * 3 * 16 * hidden * 4;
