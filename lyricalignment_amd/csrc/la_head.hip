@@ -19,7 +19,6 @@ using namespace la::gemm;
 namespace {
 
 constexpr float kLog2e = 1.4426950408889634f;
-constexpr float kLn2 = 0.6931471805599453f;
 
 struct LseParams {
     int M, N, K;
