@@ -350,7 +350,10 @@ int launch_pp_dbg(GemmParams p, int batch, hipStream_t stream) {
     }
     p.tiles_m = la::cdiv(p.M, PP::TM);
     p.tiles_n = la::cdiv(p.N, PP::TN);
-    p.group = getenv("LA_GEMM_GROUP") ? std::min(p.group, p.tiles_n) : std::max(1, p.group / 2);
+    // column tiles that walk the M dimension together (their W panels share the XCD's L2 with the streaming A panel).
+    // At least 4: with fewer, the K=4096 GEMM (N = 4 tiles) re-reads its 2 MB-per-row-block A panel once per column tile
+    // (in-pipeline sweep: 1 -> 46.1 ms/step, 4 -> 45.7, 8 -> 45.9, 16 -> 46.4).
+    p.group = getenv("LA_GEMM_GROUP") ? std::min(p.group, p.tiles_n) : std::min(p.tiles_n, std::max(4, p.group / 2));
     la::TimerScope ts("gemm_bf16", stream);
     hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, batch), dim3(PP::THREADS), PP::LDS, stream, p);
     LA_LAUNCH_CHECK();
