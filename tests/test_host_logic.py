@@ -45,6 +45,16 @@ def test_argument_validation_without_gpu():
     assert L.la_viterbi_workspace_bytes(1, 9000, 238, ctypes.byref(need)) == _lib.LA_OK and need.value == 9000 * 8 * 16
     assert L.la_viterbi_workspace_bytes(1, 100, 600, ctypes.byref(need)) == _lib.LA_EUNSUPPORTED
     assert L.la_gru_workspace_bytes(32, 1500, 384, ctypes.byref(need)) == _lib.LA_OK and need.value == 16 + 2 * 1500 * 4
+    # entry points added for the training / decoding rows: the same host-side rejection before any HIP call
+    P = 16                                                            # a non-null, 16-byte aligned stand-in pointer
+    assert L.la_gemm_ex(_lib.LA_F32, 64, 64, 64, 1, P, 64, 0, P, 32, 0, P, 64, 0, 0, 0, 0) == _lib.LA_EINVAL       # ldw < K
+    assert "ldw" in _lib.last_error()
+    assert L.la_topk_rows_f32(P, 100, 4, 100, 9, P, P, P, 0) == _lib.LA_EINVAL                                        # k > 8
+    assert L.la_attention_cached(_lib.LA_BF16, P, 128, 1, P, P, 128, 4, P, 128, 2, 1, 9, 2, 1, 0) == _lib.LA_EINVAL   # cache shorter than kv_len
+    assert L.la_attention_cached(_lib.LA_BF16, P, 128, 3, P, P, 128, 16, P, 128, 2, 3, 9, 2, 1, 0) == _lib.LA_EINVAL  # causal needs q_len 1 or == kv_len
+    assert L.la_softmax_rows_f32(P, 8, 4, 16, 0, 0) == _lib.LA_EINVAL                                                  # ld < cols
+    assert L.la_col2im3_f32(P, 1, 10, 2, 8, P, 5, 0) == _lib.LA_EINVAL                                                 # output rows too few
+    assert L.la_cross_entropy_f32(P, 4, 2, 8, P, 1.0, P, P, 0, 0, 0) == _lib.LA_EINVAL                                 # ld < vocab
     with pytest.raises(ValueError):
         _lib.check(_lib.LA_EINVAL, "x")
     with pytest.raises(NotImplementedError):
