@@ -152,6 +152,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="single stream: no encoder/head overlap across batches")
+    ap.add_argument("--dtype", choices=["bf16", "f16"], default="bf16",
+                    help="16-bit operand type of the throughput kernels (BASELINE configs[1] is quoted on bf16)")
     ap.add_argument("--encoder-streams", type=int, default=1, help="HIP streams the encoders of consecutive batches alternate between")
     ap.add_argument("--head-group", type=int, default=2,
                     help="batches whose head (GRU / FC / DP) runs as one launch set in the two-stream pipeline")
@@ -180,7 +182,7 @@ def main():
     dims = wc.dims_for(MODEL)
     wm = wc.build_model(MODEL, seed=0)
     model = AlignModel(wm, embed_dim=dims.n_audio_state, hidden_dim=HIDDEN, output_dim=VOCAB, device=f"cuda:{local_rank}",
-                       compute_dtype=torch.bfloat16).eval()
+                       compute_dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float16).eval()
     with torch.no_grad():
         eng = model.engine()
     log("weights packed on the device")
@@ -256,7 +258,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "bf16",
+            "dtype": args.dtype,
             "data": "synthetic (uniform[-1,1] mel, random class-id labels, random-init weights of the whisper-medium architecture)",
             "config": {"workload": "whisper-medium encoder + BiGRU/FC head + CTC forced alignment, batch 32 x 30 s mel per GPU "
                                    "(BASELINE.json configs[1])",

@@ -51,7 +51,9 @@ typedef enum la_status {
 
 typedef enum la_dtype {
     LA_F32 = 0,  /* parity mode: f32 storage, f32-input MFMA (exact fmaf chains)      */
-    LA_BF16 = 1  /* throughput mode: bf16 operands, f32 accumulate, f32 residual      */
+    LA_BF16 = 1, /* throughput mode: bf16 operands, f32 accumulate, f32 residual      */
+    LA_F16 = 2   /* the same kernels on IEEE half operands (BASELINE configs[3]: "fp16 MFMA"); 10-bit mantissa, range
+                    +-65504 -- Whisper was trained in fp16, so its activations fit                                   */
 } la_dtype;
 
 typedef enum la_variant {

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "liblyricalign_hip.so")
 
 LA_OK, LA_EINVAL, LA_EINFEASIBLE, LA_EEMPTY, LA_EHIP, LA_ETIMEOUT, LA_EUNSUPPORTED = range(7)
-LA_F32, LA_BF16 = 0, 1
+LA_F32, LA_BF16, LA_F16 = 0, 1, 2
 LA_VARIANT_PLAIN, LA_VARIANT_CTC = 0, 1
 EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_OUT_F32, EPI_MISH = 1, 2, 4, 8, 16
 
@@ -134,7 +134,9 @@ def dtype_code(dt: torch.dtype) -> int:
         return LA_F32
     if dt == torch.bfloat16:
         return LA_BF16
-    raise ValueError(f"unsupported compute dtype {dt} (float32 or bfloat16)")
+    if dt == torch.float16:
+        return LA_F16
+    raise ValueError(f"unsupported compute dtype {dt} (float32, bfloat16 or float16)")
 
 
 def require_gpu() -> None:

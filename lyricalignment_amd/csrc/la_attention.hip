@@ -24,6 +24,20 @@ namespace {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+
+// the two 16-bit operand types of the "throughput" kernels: same kernel text, different MFMA / conversion
+template <typename T16> struct Half16;
+template <> struct Half16<bf16_t> {
+    typedef bf16x8 vec8;
+    typedef __bf16 elem;
+    __device__ static __forceinline__ f32x16 mfma32(vec8 a, vec8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct Half16<la::f16_t> {
+    typedef f16x8 vec8;
+    typedef _Float16 elem;
+    __device__ static __forceinline__ f32x16 mfma32(vec8 a, vec8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 constexpr int QT = 128;   // queries per workgroup (4 waves x 32)
@@ -101,7 +115,10 @@ __device__ __forceinline__ void stage_kv_bf16(const bf16_t *kbase, const bf16_t 
     }
 }
 
+template <typename T16>
 __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(AttnParams p) {
+    typedef Half16<T16> HT;
+    typedef typename HT::vec8 vec8;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * KT * 128];  // [buf][K|V][64][128 B] = 32 KiB
     const int T = p.kv_len;
     const BlockCoord bc = block_coord((p.q_len + QT - 1) / QT, p.n_head, p.batch);
@@ -109,6 +126,7 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(AttnParams p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i32 = lane & 31, h = lane >> 5;
+    // (pointer arithmetic in 16-bit elements; bf16_t stands for either storage type here)
     const bf16_t *base = reinterpret_cast<const bf16_t *>(p.q) + (int64_t)clip * p.q_bs * p.ld_q + head * 64;
     const bf16_t *kbase = reinterpret_cast<const bf16_t *>(p.k) + (int64_t)clip * p.kv_bs * p.ld_kv + head * 64;
     const bf16_t *vbase = reinterpret_cast<const bf16_t *>(p.v) + (int64_t)clip * p.kv_bs * p.ld_kv + head * 64;
@@ -170,8 +188,7 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(AttnParams p) {
         for (int c = 0; c < 4; ++c)
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub)
-                s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[sub][c]),
-                                                                 __builtin_bit_cast(bf16x8, qf[c]), s[sub], 0, 0, 0);
+                s[sub] = HT::mfma32(__builtin_bit_cast(vec8, kf[sub][c]), __builtin_bit_cast(vec8, qf[c]), s[sub]);
         // ---- mask keys >= kv_len (last tile) and, for the causal decoder self-attention, keys after the query ----
         if ((t + 1) * KT > T || p.causal) {
             const int kmax = p.causal ? min(T - 1, qrow) : T - 1;
@@ -212,9 +229,9 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(AttnParams p) {
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 pf;  // element j <-> accumulator register 8*ks + j <-> key sub*32 + 16ks + 8(j>>2) + 4h + (j&3)
+                vec8 pf;  // element j <-> accumulator register 8*ks + j <-> key sub*32 + 16ks + 8(j>>2) + 4h + (j&3)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) pf[j] = (__bf16)s[sub][8 * ks + j];
+                for (int j = 0; j < 8; ++j) pf[j] = (typename HT::elem)s[sub][8 * ks + j];
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
                     // lane (dv = 32b + 16(g&1) + (lane&15), half h = g>>1): 4 keys key0 .. key0+3 per read
@@ -227,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(AttnParams p) {
                         (__attribute__((address_space(3))) s16x4 *)(vl + r1 * 128 + ((slot ^ vswz(r1)) << 4) + (pp & 1) * 8));
                     typedef __attribute__((ext_vector_type(8))) short s16x8;
                     const s16x8 vf = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
-                    o[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), pf, o[b], 0, 0, 0);
+                    o[b] = HT::mfma32(__builtin_bit_cast(vec8, vf), pf, o[b]);
                 }
             }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -247,12 +264,8 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(AttnParams p) {
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
-                ushort4 pk;
-                pk.x = la::f32_to_bf16(o[b][4 * r4 + 0] * inv);
-                pk.y = la::f32_to_bf16(o[b][4 * r4 + 1] * inv);
-                pk.z = la::f32_to_bf16(o[b][4 * r4 + 2] * inv);
-                pk.w = la::f32_to_bf16(o[b][4 * r4 + 3] * inv);
-                *reinterpret_cast<ushort4 *>(orow + 32 * b + 8 * r4 + 4 * h) = pk;
+                *reinterpret_cast<ushort4 *>(orow + 32 * b + 8 * r4 + 4 * h) =
+                    la::Pack4<T16>::run(o[b][4 * r4 + 0] * inv, o[b][4 * r4 + 1] * inv, o[b][4 * r4 + 2] * inv, o[b][4 * r4 + 3] * inv);
             }
     }
 }
@@ -400,9 +413,10 @@ __global__ __launch_bounds__(256, 2) void attention_f32_kernel(AttnParams p) {
 static int attention_launch(int dtype, AttnParams p, int batch, hipStream_t stream) {
     p.batch = batch;
     const dim3 grid(la::cdiv(p.q_len, QT) * p.n_head * batch), block(256);
-    if (dtype == LA_BF16) {
+    if (dtype == LA_BF16 || dtype == LA_F16) {
         la::TimerScope ts("attention_bf16", stream);
-        hipLaunchKernelGGL(attention_bf16_kernel, grid, block, 0, stream, p);
+        if (dtype == LA_F16) hipLaunchKernelGGL(attention_bf16_kernel<la::f16_t>, grid, block, 0, stream, p);
+        else hipLaunchKernelGGL(attention_bf16_kernel<bf16_t>, grid, block, 0, stream, p);
     } else {
         static bool attr_done = false;
         if (!attr_done) {
@@ -422,8 +436,8 @@ extern "C" int la_attention(int32_t dtype, const void *qkv, int64_t ld_qkv, void
     hipStream_t stream = (hipStream_t)stream_;
     if (batch == 0 || frames == 0) return LA_OK;
     LA_CHECK_ARG(qkv && out && batch > 0 && frames > 0 && n_head > 0, "attention: bad arguments");
-    LA_CHECK_ARG(dtype == LA_F32 || dtype == LA_BF16, "attention: bad dtype");
-    const int es = dtype == LA_BF16 ? 2 : 4;
+    LA_CHECK_ARG(dtype == LA_F32 || dtype == LA_BF16 || dtype == LA_F16, "attention: bad dtype");
+    const int es = dtype == LA_F32 ? 4 : 2;
     LA_CHECK_ARG(ld_qkv >= 3 * n_head * 64 && ld_out >= n_head * 64, "attention: leading dimensions too small");
     LA_CHECK_ARG((ld_qkv * es) % 16 == 0 && (ld_out * es) % 16 == 0 && (uintptr_t)qkv % 16 == 0 && (uintptr_t)out % 16 == 0,
                  "attention: rows must be 16-byte aligned");
@@ -439,9 +453,9 @@ extern "C" int la_attention_ex(int32_t dtype, const void *q, int64_t ld_q, const
     hipStream_t stream = (hipStream_t)stream_;
     if (batch == 0 || q_len == 0) return LA_OK;
     LA_CHECK_ARG(q && k && v && out && batch > 0 && q_len > 0 && kv_len > 0 && n_head > 0, "attention_ex: bad arguments");
-    LA_CHECK_ARG(dtype == LA_F32 || dtype == LA_BF16, "attention_ex: bad dtype");
+    LA_CHECK_ARG(dtype == LA_F32 || dtype == LA_BF16 || dtype == LA_F16, "attention_ex: bad dtype");
     LA_CHECK_ARG(!causal || q_len == kv_len, "attention_ex: causal masking is defined for self-attention (q_len == kv_len)");
-    const int es = dtype == LA_BF16 ? 2 : 4;
+    const int es = dtype == LA_F32 ? 4 : 2;
     LA_CHECK_ARG(ld_q >= n_head * 64 && ld_kv >= n_head * 64 && ld_out >= n_head * 64, "attention_ex: leading dimensions too small");
     LA_CHECK_ARG((ld_q * es) % 16 == 0 && (ld_kv * es) % 16 == 0 && (ld_out * es) % 16 == 0 && (uintptr_t)q % 16 == 0 &&
                      (uintptr_t)k % 16 == 0 && (uintptr_t)v % 16 == 0 && (uintptr_t)out % 16 == 0,
@@ -460,10 +474,10 @@ extern "C" int la_attention_cached(int32_t dtype, const void *q, int64_t ld_q, i
     hipStream_t stream = (hipStream_t)stream_;
     if (batch == 0 || q_len == 0) return LA_OK;
     LA_CHECK_ARG(q && k && v && out && batch > 0 && q_len > 0 && kv_len > 0 && n_head > 0, "attention_cached: bad arguments");
-    LA_CHECK_ARG(dtype == LA_F32 || dtype == LA_BF16, "attention_cached: bad dtype");
+    LA_CHECK_ARG(dtype == LA_F32 || dtype == LA_BF16 || dtype == LA_F16, "attention_cached: bad dtype");
     LA_CHECK_ARG(q_batch_rows >= q_len && kv_batch_rows >= kv_len, "attention_cached: batch strides shorter than the lengths");
     LA_CHECK_ARG(!causal || q_len == 1 || q_len == kv_len, "attention_cached: causal masking needs q_len == 1 or q_len == kv_len");
-    const int es = dtype == LA_BF16 ? 2 : 4;
+    const int es = dtype == LA_F32 ? 4 : 2;
     LA_CHECK_ARG(ld_q >= n_head * 64 && ld_kv >= n_head * 64 && ld_out >= n_head * 64, "attention_cached: leading dimensions too small");
     LA_CHECK_ARG((ld_q * es) % 16 == 0 && (ld_kv * es) % 16 == 0 && (ld_out * es) % 16 == 0 && (uintptr_t)q % 16 == 0 &&
                      (uintptr_t)k % 16 == 0 && (uintptr_t)v % 16 == 0 && (uintptr_t)out % 16 == 0,

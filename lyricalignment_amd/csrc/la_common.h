@@ -66,6 +66,27 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
     return __builtin_bit_cast(unsigned short, b);
 }
 
+// IEEE half: a distinct fundamental type, so the 16-bit kernels specialise on it beside bf16_t
+typedef _Float16 f16_t;
+
+// four f32 -> four 16-bit (or f32) storage elements, packed for one 8-byte (16-byte) store
+template <typename T> struct Pack4;
+template <> struct Pack4<bf16_t> {
+    typedef ushort4 type;
+    __device__ static __forceinline__ ushort4 run(float a, float b, float c, float d) {
+        ushort4 r; r.x = f32_to_bf16(a); r.y = f32_to_bf16(b); r.z = f32_to_bf16(c); r.w = f32_to_bf16(d); return r;
+    }
+};
+template <> struct Pack4<_Float16> {
+    typedef ushort4 type;
+    __device__ static __forceinline__ ushort4 run(float a, float b, float c, float d) {
+        ushort4 r;
+        r.x = __builtin_bit_cast(unsigned short, (_Float16)a); r.y = __builtin_bit_cast(unsigned short, (_Float16)b);
+        r.z = __builtin_bit_cast(unsigned short, (_Float16)c); r.w = __builtin_bit_cast(unsigned short, (_Float16)d);
+        return r;
+    }
+};
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
     static constexpr int kDtype = LA_F32;
@@ -76,6 +97,11 @@ template <> struct Elem<bf16_t> {
     static constexpr int kDtype = LA_BF16;
     __device__ static __forceinline__ float load(const bf16_t *p) { return bf16_to_f32(*p); }
     __device__ static __forceinline__ void store(bf16_t *p, float v) { *p = f32_to_bf16(v); }
+};
+template <> struct Elem<_Float16> {
+    static constexpr int kDtype = LA_F16;
+    __device__ static __forceinline__ float load(const _Float16 *p) { return (float)*p; }
+    __device__ static __forceinline__ void store(_Float16 *p, float v) { *p = (_Float16)v; }
 };
 
 // erfc(|z|) = t exp(-z^2 + P(t)), t = 1/(1 + z/2): Chebyshev fit with fractional error < 1.2e-7 everywhere

@@ -122,10 +122,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *x, int64_t 
             if constexpr (sizeof(TOut) == 4) {
                 *reinterpret_cast<float4 *>(yr + c) = make_float4(o0, o1, o2, o3);
             } else {
-                ushort4 pk;
-                pk.x = la::f32_to_bf16(o0); pk.y = la::f32_to_bf16(o1);
-                pk.z = la::f32_to_bf16(o2); pk.w = la::f32_to_bf16(o3);
-                *reinterpret_cast<ushort4 *>(yr + c) = pk;
+                *reinterpret_cast<ushort4 *>(yr + c) = la::Pack4<TOut>::run(o0, o1, o2, o3);
             }
         }
     }
@@ -230,11 +227,13 @@ extern "C" int la_layernorm(const float *x, int64_t ldx, int32_t M, int32_t d, c
     if (M == 0) return LA_OK;
     LA_CHECK_ARG(x && gamma && beta && y, "layernorm: null pointer");
     LA_CHECK_ARG(d > 0 && d % 4 == 0 && d <= 64 * 4 * 8 && ldx % 4 == 0 && ldy % 4 == 0, "layernorm: d=%d unsupported", d);
-    LA_CHECK_ARG(out_dtype == LA_F32 || out_dtype == LA_BF16, "layernorm: bad dtype");
+    LA_CHECK_ARG(out_dtype == LA_F32 || out_dtype == LA_BF16 || out_dtype == LA_F16, "layernorm: bad dtype");
     la::TimerScope ts("layernorm", stream);
     const dim3 grid(la::cdiv(M, 4)), block(256);
     if (out_dtype == LA_F32)
         hipLaunchKernelGGL((layernorm_kernel<float, 8>), grid, block, 0, stream, x, ldx, M, d, gamma, beta, (float *)y, ldy);
+    else if (out_dtype == LA_F16)
+        hipLaunchKernelGGL((layernorm_kernel<la::f16_t, 8>), grid, block, 0, stream, x, ldx, M, d, gamma, beta, (la::f16_t *)y, ldy);
     else
         hipLaunchKernelGGL((layernorm_kernel<bf16_t, 8>), grid, block, 0, stream, x, ldx, M, d, gamma, beta, (bf16_t *)y, ldy);
     LA_LAUNCH_CHECK();
@@ -264,12 +263,15 @@ extern "C" int la_mel_to_rows(const float *mel, int64_t mel_batch_stride, int64_
                               int32_t n_mels, int32_t frames, void *out, int32_t c_pad, int32_t dtype, void *stream_) {
     if (batch == 0) return LA_OK;
     LA_CHECK_ARG(mel && out && batch > 0 && n_mels > 0 && frames > 0 && c_pad >= n_mels, "mel_to_rows: bad arguments");
-    LA_CHECK_ARG(dtype == LA_F32 || dtype == LA_BF16, "mel_to_rows: bad dtype");
+    LA_CHECK_ARG(dtype == LA_F32 || dtype == LA_BF16 || dtype == LA_F16, "mel_to_rows: bad dtype");
     const dim3 grid(la::cdiv(frames + 2, 32), la::cdiv(c_pad, 32), batch), block(256);
     hipStream_t stream = (hipStream_t)stream_;
     if (dtype == LA_F32)
         hipLaunchKernelGGL((mel_to_rows_kernel<float>), grid, block, 0, stream, mel, mel_batch_stride, mel_row_stride,
                            n_mels, frames, (float *)out, c_pad);
+    else if (dtype == LA_F16)
+        hipLaunchKernelGGL((mel_to_rows_kernel<la::f16_t>), grid, block, 0, stream, mel, mel_batch_stride, mel_row_stride,
+                           n_mels, frames, (la::f16_t *)out, c_pad);
     else
         hipLaunchKernelGGL((mel_to_rows_kernel<bf16_t>), grid, block, 0, stream, mel, mel_batch_stride, mel_row_stride,
                            n_mels, frames, (bf16_t *)out, c_pad);

@@ -130,10 +130,7 @@ __global__ __launch_bounds__(CF::THREADS, 2) void gemm_kernel(GemmParams p) {
                     if constexpr (sizeof(TC) == 4) {
                         *reinterpret_cast<float4 *>(c) = make_float4(v[0], v[1], v[2], v[3]);
                     } else {
-                        ushort4 pk;
-                        pk.x = la::f32_to_bf16(v[0]); pk.y = la::f32_to_bf16(v[1]);
-                        pk.z = la::f32_to_bf16(v[2]); pk.w = la::f32_to_bf16(v[3]);
-                        *reinterpret_cast<ushort4 *>(c) = pk;
+                        *reinterpret_cast<ushort4 *>(c) = la::Pack4<TC>::run(v[0], v[1], v[2], v[3]);
                     }
                 }
             }
@@ -171,10 +168,7 @@ __global__ __launch_bounds__(CF::THREADS, 2) void gemm_kernel(GemmParams p) {
                 if constexpr (sizeof(TC) == 4) {
                     *reinterpret_cast<float4 *>(c) = make_float4(v[0], v[1], v[2], v[3]);
                 } else {
-                    ushort4 pk;
-                    pk.x = la::f32_to_bf16(v[0]); pk.y = la::f32_to_bf16(v[1]);
-                    pk.z = la::f32_to_bf16(v[2]); pk.w = la::f32_to_bf16(v[3]);
-                    *reinterpret_cast<ushort4 *>(c) = pk;
+                    *reinterpret_cast<ushort4 *>(c) = la::Pack4<TC>::run(v[0], v[1], v[2], v[3]);
                 }
             } else {
                 for (int j = 0; j < nv; ++j) la::Elem<TC>::store(c + j, v[j]);
@@ -184,7 +178,7 @@ __global__ __launch_bounds__(CF::THREADS, 2) void gemm_kernel(GemmParams p) {
 }
 
 // 256x256 ping-pong kernel (bf16 operands only): same epilogue contract as gemm_kernel.
-template <bool OUT_F32, int DBG>
+template <bool OUT_F32, int DBG, typename T16>
 __global__ __launch_bounds__(PP::THREADS, 2) void gemm_pp_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int nwg = p.tiles_m * p.tiles_n;
@@ -192,15 +186,15 @@ __global__ __launch_bounds__(PP::THREADS, 2) void gemm_pp_kernel(GemmParams p) {
     const TileCoord tc = tile_coord(tile, p.tiles_m, p.tiles_n, p.group);
     const int m0 = tc.tm * PP::TM, n0 = tc.tn * PP::TN;
     const int z = blockIdx.y;
-    const bf16_t *A = reinterpret_cast<const bf16_t *>(p.A) + (int64_t)z * p.strideA;
-    const bf16_t *W = reinterpret_cast<const bf16_t *>(p.W) + (int64_t)z * p.strideW;
+    const T16 *A = reinterpret_cast<const T16 *>(p.A) + (int64_t)z * p.strideA;
+    const T16 *W = reinterpret_cast<const T16 *>(p.W) + (int64_t)z * p.strideW;
     const float *bias = p.bias ? p.bias + (int64_t)z * p.strideBias : nullptr;
 
     f32x4 acc[8][4];
-    if constexpr (DBG == 8) mainloop_flat256(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
-    else mainloop_pp<DBG>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
+    if constexpr (DBG == 8 && std::is_same<T16, bf16_t>::value) mainloop_flat256(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
+    else mainloop_pp<DBG, T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
 
-    typedef typename std::conditional<OUT_F32, float, bf16_t>::type TC;
+    typedef typename std::conditional<OUT_F32, float, T16>::type TC;
     TC *C = reinterpret_cast<TC *>(p.C) + (int64_t)z * p.strideC;
     const float *R = p.residual ? p.residual + (int64_t)z * p.strideR : nullptr;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -272,10 +266,7 @@ __global__ __launch_bounds__(PP::THREADS, 2) void gemm_pp_kernel(GemmParams p) {
                     if constexpr (sizeof(TC) == 4) {
                         *reinterpret_cast<float4 *>(c) = make_float4(v[0], v[1], v[2], v[3]);
                     } else {
-                        ushort4 pk;
-                        pk.x = la::f32_to_bf16(v[0]); pk.y = la::f32_to_bf16(v[1]);
-                        pk.z = la::f32_to_bf16(v[2]); pk.w = la::f32_to_bf16(v[3]);
-                        *reinterpret_cast<ushort4 *>(c) = pk;
+                        *reinterpret_cast<ushort4 *>(c) = la::Pack4<TC>::run(v[0], v[1], v[2], v[3]);
                     }
                 }
             }
@@ -312,10 +303,7 @@ __global__ __launch_bounds__(PP::THREADS, 2) void gemm_pp_kernel(GemmParams p) {
                 if constexpr (sizeof(TC) == 4) {
                     *reinterpret_cast<float4 *>(c) = make_float4(v[0], v[1], v[2], v[3]);
                 } else {
-                    ushort4 pk;
-                    pk.x = la::f32_to_bf16(v[0]); pk.y = la::f32_to_bf16(v[1]);
-                    pk.z = la::f32_to_bf16(v[2]); pk.w = la::f32_to_bf16(v[3]);
-                    *reinterpret_cast<ushort4 *>(c) = pk;
+                    *reinterpret_cast<ushort4 *>(c) = la::Pack4<TC>::run(v[0], v[1], v[2], v[3]);
                 }
             } else {
                 for (int j = 0; j < nv; ++j) la::Elem<TC>::store(c + j, v[j]);
@@ -324,25 +312,28 @@ __global__ __launch_bounds__(PP::THREADS, 2) void gemm_pp_kernel(GemmParams p) {
     }
 }
 
-template <bool OUT_F32, int DBG>
+template <bool OUT_F32, int DBG, typename T16>
 int launch_pp_dbg(GemmParams p, int batch, hipStream_t stream);
 
-template <bool OUT_F32>
+template <bool OUT_F32, typename T16>
 int launch_pp(GemmParams p, int batch, hipStream_t stream) {
     static const int dbg = getenv("LA_PP_DBG") ? atoi(getenv("LA_PP_DBG")) : 0;
-    switch (dbg) {
-        case 1: return launch_pp_dbg<OUT_F32, 1>(p, batch, stream);
-        case 2: return launch_pp_dbg<OUT_F32, 2>(p, batch, stream);
-        case 3: return launch_pp_dbg<OUT_F32, 3>(p, batch, stream);
-        case 4: return launch_pp_dbg<OUT_F32, 4>(p, batch, stream);
-        case 8: return launch_pp_dbg<OUT_F32, 8>(p, batch, stream);
-        default: return launch_pp_dbg<OUT_F32, 0>(p, batch, stream);
+    if constexpr (std::is_same<T16, bf16_t>::value) {       // the developer probes exist for the bf16 instantiation
+        switch (dbg) {
+            case 1: return launch_pp_dbg<OUT_F32, 1, T16>(p, batch, stream);
+            case 2: return launch_pp_dbg<OUT_F32, 2, T16>(p, batch, stream);
+            case 3: return launch_pp_dbg<OUT_F32, 3, T16>(p, batch, stream);
+            case 4: return launch_pp_dbg<OUT_F32, 4, T16>(p, batch, stream);
+            case 8: return launch_pp_dbg<OUT_F32, 8, T16>(p, batch, stream);
+            default: break;
+        }
     }
+    return launch_pp_dbg<OUT_F32, 0, T16>(p, batch, stream);
 }
 
-template <bool OUT_F32, int DBG>
+template <bool OUT_F32, int DBG, typename T16>
 int launch_pp_dbg(GemmParams p, int batch, hipStream_t stream) {
-    auto kern = gemm_pp_kernel<OUT_F32, DBG>;
+    auto kern = gemm_pp_kernel<OUT_F32, DBG, T16>;
     static bool attr_done = false;
     if (!attr_done) {
         LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, PP::LDS));
@@ -392,9 +383,9 @@ static int gemm_run_ldw(int dtype, int M, int N, int K, int batch, const void *A
     if (M == 0 || N == 0 || batch == 0) return LA_OK;
     LA_CHECK_ARG(A && W && C, "gemm: null pointer");
     LA_CHECK_ARG(M > 0 && N > 0 && K > 0 && batch > 0, "gemm: bad sizes");
-    LA_CHECK_ARG(dtype == LA_F32 || dtype == LA_BF16, "gemm: bad dtype");
-    const int ke = dtype == LA_BF16 ? 64 : 32;
-    const int es = dtype == LA_BF16 ? 2 : 4;
+    LA_CHECK_ARG(dtype == LA_F32 || dtype == LA_BF16 || dtype == LA_F16, "gemm: bad dtype");
+    const int ke = dtype == LA_F32 ? 32 : 64;
+    const int es = dtype == LA_F32 ? 4 : 2;
     LA_CHECK_ARG(K % ke == 0, "gemm: K=%d must be a multiple of %d", K, ke);
     LA_CHECK_ARG((lda * es) % 16 == 0 && (strideA * es) % 16 == 0 && ((uintptr_t)A % 16 == 0) && ((uintptr_t)W % 16 == 0),
                  "gemm: A/W rows must be 16-byte aligned");
@@ -406,16 +397,20 @@ static int gemm_run_ldw(int dtype, int M, int N, int K, int batch, const void *A
     const bool out_f32 = epilogue & LA_EPI_OUT_F32;
     typedef Cfg<2, 2> Small;
     typedef Cfg<4, 3> Big;
-    if (dtype == LA_BF16) {
+    if (dtype == LA_BF16 || dtype == LA_F16) {
         // 256x256 ping-pong kernel once it can fill the chip (>= 192 tiles); LA_GEMM_TILE=512 forces it, 128/256 forbid it
+        // (a 256-column tile on N <= 128 -- the gathered-label logits, N = Lmax + 1 -- would compute mostly padding)
         static const char *force = getenv("LA_GEMM_TILE");
         const int forced = force ? atoi(force) : 0;
-        // (a 256-column tile on N <= 128 -- the gathered-label logits, N = Lmax + 1 -- would compute mostly padding)
         const bool pp = forced == 512 || (forced == 0 && N > 128 && (int64_t)la::cdiv(M, 256) * la::cdiv(N, 256) * batch >= 192);
-        if (pp && !(epilogue & LA_EPI_MISH))
-            return out_f32 ? launch_pp<true>(p, batch, stream) : launch_pp<false>(p, batch, stream);
-        if (use_big_tile(M, N, batch))
+        const bool half = dtype == LA_F16;
+        if (pp && !(epilogue & LA_EPI_MISH)) {
+            if (half) return out_f32 ? launch_pp<true, la::f16_t>(p, batch, stream) : launch_pp<false, la::f16_t>(p, batch, stream);
+            return out_f32 ? launch_pp<true, bf16_t>(p, batch, stream) : launch_pp<false, bf16_t>(p, batch, stream);
+        }
+        if (!half && use_big_tile(M, N, batch))
             return out_f32 ? launch<bf16_t, true, Big>(p, batch, stream, "gemm_bf16") : launch<bf16_t, false, Big>(p, batch, stream, "gemm_bf16");
+        if (half) return out_f32 ? launch<la::f16_t, true, Small>(p, batch, stream, "gemm_bf16") : launch<la::f16_t, false, Small>(p, batch, stream, "gemm_bf16");
         return out_f32 ? launch<bf16_t, true, Small>(p, batch, stream, "gemm_bf16") : launch<bf16_t, false, Small>(p, batch, stream, "gemm_bf16");
     }
     return launch<float, true, Small>(p, batch, stream, "gemm_f32");

@@ -33,6 +33,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 template <typename T> struct KElems;
 template <> struct KElems<bf16_t> { static constexpr int v = BKB / 2; };
 template <> struct KElems<float> { static constexpr int v = BKB / 4; };
+template <> struct KElems<_Float16> { static constexpr int v = BKB / 2; };
 
 __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 
@@ -65,6 +66,12 @@ template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
     __device__ static __forceinline__ void run(const uint4 &w, const uint4 &a, f32x4 &acc) {
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, a), acc, 0, 0, 0);
+    }
+};
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+template <> struct Mma<_Float16> {
+    __device__ static __forceinline__ void run(const uint4 &w, const uint4 &a, f32x4 &acc) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, a), acc, 0, 0, 0);
     }
 };
 template <> struct Mma<float> {

@@ -50,8 +50,8 @@ __device__ __forceinline__ void pp_stage_piece(const unsigned char *src, int64_t
 
 // acc[mi][ni]: rows m = m0 + wr*128 + mi*16 + (lane & 15); cols n = n0 + wc*64 + ni*16 + (lane >> 4)*4 + reg
 // DBG (developer probes, LA_PP_DBG): bit0 = no in-loop DMA, bit1 = no MFMA, bit2 = s_setprio around the MFMA clusters
-template <int DBG>
-__device__ __forceinline__ void mainloop_pp(const bf16_t *A, int64_t lda, int M, const bf16_t *W, int64_t ldw, int N, int K,
+template <int DBG, typename T16 = bf16_t>
+__device__ __forceinline__ void mainloop_pp(const T16 *A, int64_t lda, int M, const T16 *W, int64_t ldw, int N, int K,
                                             int m0, int n0, unsigned char *lds, f32x4 (&acc)[8][4]) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: scalar branches, no exec masking
@@ -132,7 +132,7 @@ __device__ __forceinline__ void mainloop_pp(const bf16_t *A, int64_t lda, int M,
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
-                    Mma<bf16_t>::run(bf[ni * 2 + ks], af[mi * 2 + ks], acc[ah * 4 + mi][bh * 2 + ni]);
+                    Mma<T16>::run(bf[ni * 2 + ks], af[mi * 2 + ks], acc[ah * 4 + mi][bh * 2 + ni]);
         if (DBG & 4) __builtin_amdgcn_s_setprio(0);
     };
 

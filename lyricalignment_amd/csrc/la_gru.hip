@@ -80,6 +80,11 @@ template <> struct GruTraits<bf16_t> {
     static constexpr int KSTEP = 32;    // k elements per 16-byte-per-lane fragment step
     static constexpr bool W_IN_REGS = true;
 };
+template <> struct GruTraits<la::f16_t> {
+    static constexpr int NW = 4;
+    static constexpr int KSTEP = 32;
+    static constexpr bool W_IN_REGS = true;
+};
 template <> struct GruTraits<float> {
     static constexpr int NW = 2;
     static constexpr int KSTEP = 16;
@@ -88,6 +93,10 @@ template <> struct GruTraits<float> {
 
 __device__ __forceinline__ void mma_step(const uint4 &a, const uint4 &w, f32x4 &acc, bf16_t) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, w), acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma_step(const uint4 &a, const uint4 &w, f32x4 &acc, la::f16_t) {
+    typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, w), acc, 0, 0, 0);
 }
 __device__ __forceinline__ void mma_step(const uint4 &a, const uint4 &w, f32x4 &acc, float) {
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(w.x), acc, 0, 0, 0);
@@ -293,7 +302,9 @@ __global__ __launch_bounds__(GruTraits<T>::NW * 64, 1) void gru_kernel(GruParams
                 if constexpr (WT) {
                     if constexpr (sizeof(T) == 2) {
                         // pair (jcol, jcol+1) -> one 4-byte write-through store by the even lane (neighbour = lane + 1)
-                        const unsigned mine = la::f32_to_bf16(hnew[mt][i]);
+                        T h16;
+                        la::Elem<T>::store(&h16, hnew[mt][i]);
+                        const unsigned mine = __builtin_bit_cast(unsigned short, h16);
                         const unsigned nb_bits = (unsigned)__shfl_down((int)mine, 1);
                         if (bl < nb && (r16 & 1) == 0)
                             __builtin_amdgcn_raw_buffer_store_b32(mine | (nb_bits << 16), out_rsrc, (int)(o * 2), 0, 16 /* sc1 */);
@@ -351,15 +362,15 @@ static int gru_forward(int32_t dtype, const float *gi, const void *w_hh, const f
     hipStream_t stream = (hipStream_t)stream_;
     if (batch == 0 || frames == 0) return LA_OK;
     LA_CHECK_ARG(gi && w_hh && b_hh && out && workspace, "gru_layer: null pointer");
-    LA_CHECK_ARG(dtype == LA_F32 || dtype == LA_BF16, "gru_layer: bad dtype");
+    LA_CHECK_ARG(dtype == LA_F32 || dtype == LA_BF16 || dtype == LA_F16, "gru_layer: bad dtype");
     LA_CHECK_ARG(batch > 0 && frames > 0 && hidden > 0, "gru_layer: bad sizes");
     LA_CHECK_ARG((uintptr_t)w_hh % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)workspace % 16 == 0, "gru_layer: alignment");
     size_t need = 0;
     la_gru_workspace_bytes(batch, frames, hidden, &need);
     LA_CHECK_ARG(workspace_bytes >= need, "gru_layer: workspace too small (%zu < %zu)", workspace_bytes, need);
     const int groups = gru_groups(batch);
-    const int nw = dtype == LA_BF16 ? 4 : 2;
-    if (hidden % 64 != 0 || (dtype == LA_BF16 && hidden > 512) || (dtype == LA_F32 && hidden > 384)) {
+    const int nw = dtype == LA_F32 ? 2 : 4;
+    if (hidden % 64 != 0 || (dtype != LA_F32 && hidden > 512) || (dtype == LA_F32 && hidden > 384)) {
         la::set_error("gru_layer: hidden=%d unsupported (multiple of 64; bf16 <= 512, f32 <= 384)", hidden);
         return LA_EUNSUPPORTED;
     }
@@ -379,18 +390,23 @@ static int gru_forward(int32_t dtype, const float *gi, const void *w_hh, const f
     // (~5 us) however it is signalled.  The architecturally guaranteed release/acquire form stays the default,
     // LA_GRU_WT=1 selects the write-through form.
     static const bool use_fence = getenv("LA_GRU_WT") == nullptr;
-    LA_CHECK_ARG((int64_t)batch * frames * 2 * hidden * (dtype == LA_BF16 ? 2 : 4) < (int64_t)2147483647, "gru_layer: out buffer exceeds the 2 GiB buffer-descriptor range");
-    if (dtype == LA_BF16) {
+    LA_CHECK_ARG((int64_t)batch * frames * 2 * hidden * (dtype == LA_F32 ? 4 : 2) < (int64_t)2147483647, "gru_layer: out buffer exceeds the 2 GiB buffer-descriptor range");
+    if (dtype == LA_BF16 || dtype == LA_F16) {
         la::TimerScope ts("gru_bf16", stream);
-        if (batch <= 16) {
-            const size_t lds_b = 16 + (size_t)16 * (hidden * 2 + 16);          // flag + the staged h rows of one m-tile
-            if (use_fence) hipLaunchKernelGGL((gru_kernel<bf16_t, 16, false, 1>), grid, dim3(256), lds_b, stream, p);
-            else hipLaunchKernelGGL((gru_kernel<bf16_t, 16, true, 1>), grid, dim3(256), lds_b, stream, p);
-        } else {
-            const size_t lds_b = 16 + (size_t)32 * (hidden * 2 + 16);
-            if (use_fence) hipLaunchKernelGGL((gru_kernel<bf16_t, 16, false, 2>), grid, dim3(256), lds_b, stream, p);
-            else hipLaunchKernelGGL((gru_kernel<bf16_t, 16, true, 2>), grid, dim3(256), lds_b, stream, p);
-        }
+        const int mt = batch <= 16 ? 1 : 2;
+        const size_t lds_b = 16 + (size_t)16 * mt * (hidden * 2 + 16);          // flag + the staged h rows of the batch tiles
+#define LA_GRU_LAUNCH16(T_)                                                                                                \
+    do {                                                                                                                   \
+        if (mt == 1) {                                                                                                     \
+            if (use_fence) hipLaunchKernelGGL((gru_kernel<T_, 16, false, 1>), grid, dim3(256), lds_b, stream, p);          \
+            else hipLaunchKernelGGL((gru_kernel<T_, 16, true, 1>), grid, dim3(256), lds_b, stream, p);                     \
+        } else {                                                                                                           \
+            if (use_fence) hipLaunchKernelGGL((gru_kernel<T_, 16, false, 2>), grid, dim3(256), lds_b, stream, p);          \
+            else hipLaunchKernelGGL((gru_kernel<T_, 16, true, 2>), grid, dim3(256), lds_b, stream, p);                     \
+        }                                                                                                                  \
+    } while (0)
+        if (dtype == LA_F16) LA_GRU_LAUNCH16(la::f16_t); else LA_GRU_LAUNCH16(bf16_t);
+#undef LA_GRU_LAUNCH16
     } else {
         const size_t lds_bytes = 16 + (size_t)2 * 3 * 16 * hidden * 4;
         static bool attr_done = false;

@@ -75,6 +75,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void fc_lse_kernel(LseParams p) {
 }
 
 // The same reduction on the 256x256 ping-pong main loop (bf16, large row counts): a wave owns 128 rows x one 64-column strip.
+template <typename T16>
 __global__ __launch_bounds__(PP::THREADS, 2) void fc_lse_pp_kernel(LseParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(PP::THREADS, 2) void fc_lse_pp_kernel(LseParams p) 
     const int tn = tc.tn;
     const int m0 = tc.tm * PP::TM, n0 = tn * PP::TN;
     f32x4 acc[8][4];
-    mainloop_pp<0>(reinterpret_cast<const bf16_t *>(p.A), p.lda, p.M, reinterpret_cast<const bf16_t *>(p.W), p.K, p.N, p.K, m0, n0, lds, acc);
+    mainloop_pp<0, T16>(reinterpret_cast<const T16 *>(p.A), p.lda, p.M, reinterpret_cast<const T16 *>(p.W), p.K, p.N, p.K, m0, n0, lds, acc);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave >> 2, wc = wave & 3;
@@ -215,7 +216,7 @@ HeadPlan plan_head(int batch, int frames, int in_dim, int vocab, int max_labels,
 extern "C" int la_fc_emissions_workspace_bytes(int32_t dtype, int32_t batch, int32_t frames, int32_t in_dim, int32_t vocab,
                                                int32_t max_labels, size_t *bytes) {
     LA_CHECK_ARG(bytes && batch > 0 && frames > 0 && in_dim > 0 && vocab > 0 && max_labels > 0, "fc_emissions_workspace_bytes: bad arguments");
-    *bytes = plan_head(batch, frames, in_dim, vocab, max_labels, dtype == LA_BF16 ? 2 : 4).total;
+    *bytes = plan_head(batch, frames, in_dim, vocab, max_labels, dtype == LA_F32 ? 4 : 2).total;
     return LA_OK;
 }
 
@@ -227,11 +228,11 @@ extern "C" int la_fc_emissions(int32_t dtype, const void *act, int64_t ld_act, c
     hipStream_t stream = (hipStream_t)stream_;
     if (batch == 0 || frames == 0) return LA_OK;
     LA_CHECK_ARG(act && w_fc && b_fc && labels && n_labels && em && workspace, "fc_emissions: null pointer");
-    LA_CHECK_ARG(dtype == LA_F32 || dtype == LA_BF16, "fc_emissions: bad dtype");
+    LA_CHECK_ARG(dtype == LA_F32 || dtype == LA_BF16 || dtype == LA_F16, "fc_emissions: bad dtype");
     LA_CHECK_ARG(batch > 0 && frames > 0 && max_labels > 0, "fc_emissions: bad sizes");
     LA_CHECK_ARG(variant == LA_VARIANT_CTC ? vocab >= 3 : vocab >= 2, "fc_emissions: vocab too small");
     LA_CHECK_ARG(em_row_stride >= max_labels + 1 && labels_stride >= max_labels, "fc_emissions: strides smaller than max_labels");
-    const int es = dtype == LA_BF16 ? 2 : 4, ke = dtype == LA_BF16 ? 64 : 32;
+    const int es = dtype == LA_F32 ? 4 : 2, ke = dtype == LA_F32 ? 32 : 64;
     LA_CHECK_ARG(in_dim % ke == 0, "fc_emissions: in_dim=%d must be a multiple of %d", in_dim, ke);
     LA_CHECK_ARG((ld_act * es) % 16 == 0 && (uintptr_t)act % 16 == 0 && (uintptr_t)w_fc % 16 == 0 && (uintptr_t)workspace % 256 == 0,
                  "fc_emissions: alignment");
@@ -246,7 +247,7 @@ extern "C" int la_fc_emissions(int32_t dtype, const void *act, int64_t ld_act, c
     const int rows = batch * frames;
 
     // 1. gather
-    if (dtype == LA_BF16)
+    if (dtype != LA_F32)       // 16-bit rows are copied as raw bits: one instantiation serves bf16 and half
         hipLaunchKernelGGL((gather_rows_kernel<bf16_t>), dim3(S, batch), dim3(128), 0, stream, (const bf16_t *)w_fc, b_fc,
                            in_dim, vocab, variant, labels, labels_stride, n_labels, max_labels, (bf16_t *)wg, bg);
     else
@@ -266,21 +267,23 @@ extern "C" int la_fc_emissions(int32_t dtype, const void *act, int64_t ld_act, c
         typedef Cfg<4, 3> Big;
         static bool attr_bf16 = false, attr_bf16_big = false, attr_f32 = false, attr_pp = false;
         static const char *force_tile = getenv("LA_GEMM_TILE");
-        const bool pp_ok = dtype == LA_BF16 && !force_tile && in_dim % 64 == 0 && in_dim >= 128 && (ld_act * 2) % 16 == 0 &&
+        const bool pp_ok = dtype != LA_F32 && !force_tile && in_dim % 64 == 0 && in_dim >= 128 && (ld_act * 2) % 16 == 0 &&
                            (int64_t)la::cdiv(rows, PP::TM) * la::cdiv(vocab, PP::TN) >= 192;
         if (!pp_ok) lp.nparts = 2 * pl.tiles_n;      // the 128-column kernels write two strips per tile
         if (pp_ok) {
             // the strips of the last (partial) 256-column tile that no 128-column tile would have produced must still hold
             // neutral partials: every strip is written by this kernel, masked columns give (-inf, 0)
             if (!attr_pp) {
-                LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fc_lse_pp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PP::LDS));
+                LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fc_lse_pp_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, PP::LDS));
+                LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fc_lse_pp_kernel<la::f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, PP::LDS));
                 attr_pp = true;
             }
             lp.tiles_m = la::cdiv(rows, PP::TM);
             lp.tiles_n = la::cdiv(vocab, PP::TN);
             lp.group = std::max(1, pick_group(in_dim, es, la::cdiv(vocab, BN)) / 2);
             la::TimerScope ts("fc_lse_bf16", stream);
-            hipLaunchKernelGGL(fc_lse_pp_kernel, dim3(lp.tiles_m * lp.tiles_n), dim3(PP::THREADS), PP::LDS, stream, lp);
+            if (dtype == LA_F16) hipLaunchKernelGGL(fc_lse_pp_kernel<la::f16_t>, dim3(lp.tiles_m * lp.tiles_n), dim3(PP::THREADS), PP::LDS, stream, lp);
+            else hipLaunchKernelGGL(fc_lse_pp_kernel<bf16_t>, dim3(lp.tiles_m * lp.tiles_n), dim3(PP::THREADS), PP::LDS, stream, lp);
         } else if (dtype == LA_BF16 && rows >= 4096 && getenv("LA_GEMM_TILE") && atoi(getenv("LA_GEMM_TILE")) == 256) {
             if (!attr_bf16_big) {
                 LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fc_lse_kernel<bf16_t, Big>),
@@ -290,15 +293,18 @@ extern "C" int la_fc_emissions(int32_t dtype, const void *act, int64_t ld_act, c
             lp.tiles_m = la::cdiv(rows, Big::TM);
             la::TimerScope ts("fc_lse_bf16", stream);
             hipLaunchKernelGGL((fc_lse_kernel<bf16_t, Big>), dim3(lp.tiles_m * lp.tiles_n), dim3(Big::THREADS), Big::LDS, stream, lp);
-        } else if (dtype == LA_BF16) {
+        } else if (dtype == LA_BF16 || dtype == LA_F16) {
             if (!attr_bf16) {
                 LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fc_lse_kernel<bf16_t, Small>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, Small::LDS));
+                LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fc_lse_kernel<la::f16_t, Small>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, Small::LDS));
                 attr_bf16 = true;
             }
             lp.tiles_m = la::cdiv(rows, Small::TM);
             la::TimerScope ts("fc_lse_bf16", stream);
-            hipLaunchKernelGGL((fc_lse_kernel<bf16_t, Small>), dim3(lp.tiles_m * lp.tiles_n), dim3(Small::THREADS), Small::LDS, stream, lp);
+            if (dtype == LA_F16) hipLaunchKernelGGL((fc_lse_kernel<la::f16_t, Small>), dim3(lp.tiles_m * lp.tiles_n), dim3(Small::THREADS), Small::LDS, stream, lp);
+            else hipLaunchKernelGGL((fc_lse_kernel<bf16_t, Small>), dim3(lp.tiles_m * lp.tiles_n), dim3(Small::THREADS), Small::LDS, stream, lp);
         } else {
             if (!attr_f32) {
                 LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fc_lse_kernel<float, Small>),

@@ -9,7 +9,7 @@ Differences that are deliberate:
   * `audios` may be a list OR a tuple and is never mutated (the reference pads the caller's list
     in place, :78-80, and fails on tuples);
   * the log-mel runs on the device (the reference computes it on the CPU, :84);
-  * `compute_dtype` (extra keyword, default float32 = the reference's numerics; torch.bfloat16 is
+  * `compute_dtype` (extra keyword, default float32 = the reference's numerics; torch.bfloat16 / torch.float16 are
     the throughput mode) and `align(...)` (the fused, logits-free fast path) are additions.
 There is no PyTorch / CPU fallback: without the HIP library and a gfx950 device these methods raise.
 """

@@ -119,7 +119,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None, *
         epi |= EPI_GELU
     if mish:
         epi |= EPI_MISH
-    if c_dtype == torch.float32 and dt == LA_BF16:
+    if c_dtype == torch.float32 and dt != LA_F32:
         epi |= EPI_OUT_F32
     check(lib().la_gemm(dt, M, N, K, batch, ptr(a), lda, stride_a, ptr(w), ptr(out), ldc, stride_c, ptr(bias),
                         ptr(residual), ldr or 0, stride_r, epi, stream_ptr()), "gemm")

@@ -48,7 +48,7 @@ def test_log_mel_matches_oracle():
     np.testing.assert_allclose(one.numpy(), mo.log_mel_spectrogram(_wave(480000, 3)).numpy(), rtol=0, atol=2e-4)
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 6e-2)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 6e-2), (torch.float16, 8e-3)])
 def test_encoder_matches_oracle(dtype, tol):
     from oracle import model_oracle as mo
     model = _small_model(dtype)
@@ -549,3 +549,35 @@ def test_full_size_medium_batch_properties():
     assert torch.equal(torch.cat([halves[0][2], halves[1][2]]), score)
     for o in outs:
         assert torch.equal(o[0], on) and torch.equal(o[1], off) and torch.equal(o[2], score)
+
+
+def test_large_v2_fp16_alignment_config4():
+    """BASELINE configs[3]: Whisper-large-v2 shape (d = 1280, 20 heads; two blocks here), float16 MFMA path, fused
+    align: emissions within the float16 tolerance of the fp32 oracle and frames bit-exact given the device emissions."""
+    from lyricalignment_amd import _lib, whisper_compat as wc
+    from lyricalignment_amd.module.align_model import AlignModel
+    from lyricalignment_amd.utils.alignment import _labels_to_device
+    from oracle import alignment_oracle as ao, model_oracle as mo
+    dims = wc.ModelDimensions(n_audio_state=1280, n_audio_head=20, n_audio_layer=2, n_text_state=1280, n_text_head=20, n_text_layer=0)
+    wm = wc.build_model(dims=dims, seed=131, std=0.02)
+    model = AlignModel(wm, embed_dim=1280, hidden_dim=384, output_dim=420, device="cuda", compute_dtype=torch.float16).eval()
+    audio = _wave(60096, 132)
+    lists = [[3, 17, 17, 250, 9, 401, 44, 2, 90, 91, 300]]
+    with torch.no_grad():
+        on, off, score, status = model.align([audio], lists, use_ctc=True, return_frames=True)
+        eng = model.engine()
+        lab_dev, n_lab, _ = _labels_to_device(lists, 1, eng.device)
+        feats, B, T, stride = model._features(model._mel_of([audio]), True)
+        em = eng.emissions(feats, B, T, stride, lab_dev, n_lab, _lib.LA_VARIANT_CTC).cpu().numpy()
+    assert int(status[0]) == 0 and T == 188
+    rc, on_o, off_o, sc_o = ao.align_frames_compact(em[0], np.array(lists[0]))
+    assert rc == 0 and on.cpu().numpy()[0, :11].tolist() == on_o.tolist() and off.cpu().numpy()[0, :11].tolist() == off_o.tolist()
+    # emissions vs the fp32 oracle of the same weights
+    p = {"encoder." + k: v.detach().float().cpu() for k, v in wm.encoder.state_dict().items()}
+    p.update({"align_rnn." + k: v.detach().float().cpu() for k, v in model.align_rnn.state_dict().items()})
+    mel = mo.pad_or_trim(mo.log_mel_spectrogram(audio[None]), 3000)
+    logits = mo.gru_head_forward(p, mo.encoder_forward(p, mel, n_head=20)[:, :188])
+    lp, ls = mo.emission_prep_ctc(logits)
+    np.testing.assert_allclose(em[0, :, 0], ls[0, :, 0].numpy(), rtol=0, atol=2e-2)
+    idx = torch.tensor(lists[0]) - 1
+    np.testing.assert_allclose(em[0, :, 1:12], lp[0][:, idx].numpy(), rtol=0, atol=2e-2)

@@ -13,7 +13,7 @@ def _rand(*shape, seed=0, scale=1.0):
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 128), (1500, 1152, 384), (257, 21129 // 8, 768), (48, 36, 1024)])
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_gemm_plain(M, N, K, dtype):
     from lyricalignment_amd import ops
     a = _rand(M, K, seed=1, scale=0.5); w = _rand(N, K, seed=2, scale=0.5)
@@ -36,7 +36,7 @@ def test_gemm_asymmetric_identity():
     assert torch.equal(outb.cpu(), w.bfloat16().float().T.contiguous())
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_gemm_epilogues(dtype):
     from lyricalignment_amd import ops
     M, N, K = 200, 136, 192
@@ -50,10 +50,12 @@ def test_gemm_epilogues(dtype):
     np.testing.assert_allclose(out.numpy(), (base + res).numpy(), rtol=0, atol=tol)
     out = ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda(), mish=True, out_f32=True).cpu()
     np.testing.assert_allclose(out.numpy(), torch.nn.functional.mish(base).numpy(), rtol=0, atol=tol)
-    if dtype == torch.bfloat16:
+    if dtype != torch.float32:
         out = ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda()).cpu()
-        assert out.dtype == torch.bfloat16
+        assert out.dtype == dtype
         np.testing.assert_allclose(out.float().numpy(), base.numpy(), rtol=1e-2, atol=1e-2)
+        out = ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda(), gelu=True).cpu()          # packed-FP32 GELU, 16-bit out
+        np.testing.assert_allclose(out.float().numpy(), torch.nn.functional.gelu(base).numpy(), rtol=1e-2, atol=1e-2)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -102,7 +104,7 @@ def test_mel_to_rows_and_cast():
 
 
 @pytest.mark.parametrize("B,T,H", [(1, 5, 1), (2, 64, 2), (1, 200, 3), (2, 1500, 2), (1, 129, 1)])
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_attention(B, T, H, dtype):
     """softmax(q k^T) v per head, q pre-scaled; fp64 reference on the host over the FULL tensor."""
     from lyricalignment_amd import ops
@@ -136,7 +138,7 @@ def test_attention_online_rescale_spike():
 
 
 @pytest.mark.parametrize("B,T,H", [(1, 1, 64), (3, 7, 64), (32, 50, 128), (40, 23, 384), (2, 300, 384)])
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_gru_layer(B, T, H, dtype):
     """Persistent bidirectional GRU recurrence vs torch.nn.GRU (CPU fp32) fed the same input projections."""
     from lyricalignment_amd import ops
@@ -147,8 +149,8 @@ def test_gru_layer(B, T, H, dtype):
         for prm in gru.parameters():
             prm.copy_((torch.rand(prm.shape, generator=g) * 2 - 1) * (1.0 / H ** 0.5))
         w_hh = torch.stack([gru.weight_hh_l0, gru.weight_hh_l0_reverse])
-        if dtype == torch.bfloat16:  # the reference net uses the same (rounded) recurrent weights
-            gru.weight_hh_l0.copy_(w_hh[0].bfloat16().float()); gru.weight_hh_l0_reverse.copy_(w_hh[1].bfloat16().float())
+        if dtype != torch.float32:  # the reference net uses the same (rounded) recurrent weights
+            gru.weight_hh_l0.copy_(w_hh[0].to(dtype).float()); gru.weight_hh_l0_reverse.copy_(w_hh[1].to(dtype).float())
         x = torch.randn(B, T, I, generator=g)
         ref, _ = gru(x)
         gi = torch.stack([x @ gru.weight_ih_l0.T + gru.bias_ih_l0, x @ gru.weight_ih_l0_reverse.T + gru.bias_ih_l0_reverse], dim=2)
@@ -156,13 +158,13 @@ def test_gru_layer(B, T, H, dtype):
     out, out_mish, flag = ops.gru_layer(gi.contiguous().cuda(), w_hh.to(dtype).contiguous().cuda(), b_hh.contiguous().cuda(), want_mish=True)
     torch.cuda.synchronize()
     assert int(flag.item()) == 0, "bounded wait in the persistent GRU kernel timed out"
-    tol = 2e-5 if dtype == torch.float32 else 2e-2  # bf16: h is rounded to bf16 before every recurrent product
+    tol = {torch.float32: 2e-5, torch.bfloat16: 2e-2, torch.float16: 3e-3}[dtype]  # 16-bit: h is rounded before every recurrent product
     np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), rtol=0, atol=tol)
     np.testing.assert_allclose(out_mish.float().cpu().numpy(), torch.nn.functional.mish(ref).numpy(), rtol=0, atol=tol)
 
 
 @pytest.mark.parametrize("variant", ["ctc", "plain"])
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("B,T,K,V", [(2, 37, 128, 300), (3, 150, 768, 21129)])
 def test_fc_emissions_fused(variant, dtype, B, T, K, V):
     """Fused FC + row normaliser + gather vs (fp64 logits of the same rounded operands) -> the oracle's emission prep."""
