@@ -28,6 +28,7 @@ from ._lib import LA_VARIANT_CTC, LA_VARIANT_PLAIN
 N_FRAMES = 3000   # whisper.audio.N_FRAMES
 N_CTX = 1500      # encoder positions
 C_PAD = 128       # mel channels padded so 3*C is a multiple of the GEMM K tile
+HEAD_CLIPS_MAX = 512   # clips per head launch set (GRU: 16 workgroup groups of 32 clips co-resident, out buffer < 2 GiB)
 
 
 def _f32(t: torch.Tensor, device) -> torch.Tensor:
@@ -467,9 +468,20 @@ class AlignEngine:
         B = mel.shape[0]
         feats = self.encode(mel)
         variant = LA_VARIANT_CTC if use_ctc else LA_VARIANT_PLAIN
-        em = self.emissions(feats, B, n_frames, N_CTX, labels, n_labels, variant)
-        nf = torch.full((B,), n_frames, dtype=torch.int32, device=self.device)
-        return ops.viterbi_batch(em, labels, n_labels, nf)
+        if B <= HEAD_CLIPS_MAX:
+            em = self.emissions(feats, B, n_frames, N_CTX, labels, n_labels, variant)
+            nf = torch.full((B,), n_frames, dtype=torch.int32, device=self.device)
+            return ops.viterbi_batch(em, labels, n_labels, nf)
+        # Very large batches (BASELINE configs[3]: "batch sized to fill 288 GB"): the encoder takes them whole, the head runs
+        # over slices of clips -- the persistent GRU recurrence needs all its workgroups resident (one group of 12 per 32
+        # clips) and addresses its exchange buffer through a 2 GiB buffer descriptor.
+        outs = []
+        for b0 in range(0, B, HEAD_CLIPS_MAX):
+            b1 = min(B, b0 + HEAD_CLIPS_MAX)
+            em = self.emissions(feats[b0 * N_CTX: b1 * N_CTX], b1 - b0, n_frames, N_CTX, labels[b0:b1], n_labels[b0:b1].contiguous(), variant)
+            nf = torch.full((b1 - b0,), n_frames, dtype=torch.int32, device=self.device)
+            outs.append(ops.viterbi_batch(em, labels[b0:b1], n_labels[b0:b1].contiguous(), nf))
+        return tuple(torch.cat([o[i] for o in outs], dim=0) for i in range(4))
 
 
 class PipelinedAligner:

@@ -581,3 +581,21 @@ def test_large_v2_fp16_alignment_config4():
     np.testing.assert_allclose(em[0, :, 0], ls[0, :, 0].numpy(), rtol=0, atol=2e-2)
     idx = torch.tensor(lists[0]) - 1
     np.testing.assert_allclose(em[0, :, 1:12], lp[0][:, idx].numpy(), rtol=0, atol=2e-2)
+
+
+def test_head_chunking_for_huge_batches(monkeypatch):
+    """align_mel slices the head over clips when a batch exceeds HEAD_CLIPS_MAX (BASELINE configs[3] batches): same result."""
+    from lyricalignment_amd import engine as eng_mod
+    model = _small_model(torch.bfloat16, seed=141)
+    eng = model.engine()
+    rs = np.random.RandomState(142)
+    B = 5
+    mel = torch.from_numpy(rs.uniform(-1, 1, size=(B, 80, 3000)).astype(np.float32)).cuda()
+    labels = torch.from_numpy(rs.randint(1, 299, size=(B, 9)).astype(np.int32)).cuda()
+    n_labels = torch.tensor([9, 5, 2, 7, 1], dtype=torch.int32).cuda()
+    with torch.no_grad():
+        ref = [t.clone() for t in eng.align_mel(mel, labels, n_labels, n_frames=700)]
+        monkeypatch.setattr(eng_mod, "HEAD_CLIPS_MAX", 2)
+        got = eng.align_mel(mel, labels, n_labels, n_frames=700)
+    for r, g in zip(ref, got):
+        assert torch.equal(r, g)
