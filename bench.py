@@ -167,13 +167,21 @@ def main():
     # host threads: the box reports every core of the node, the cgroup quota is what this job may use, and with one rank
     # per GPU the ranks share it (random-init weight generation runs on the host)
     torch.set_num_threads(max(1, usable_cores() // max(world, 1)))
+    # test knobs (exercise the multi-rank control flow on a one-GPU box): all ranks on device 0 over gloo
+    same_device = os.environ.get("LA_BENCH_SAME_DEVICE") == "1"
+    backend = os.environ.get("LA_BENCH_DIST_BACKEND", "nccl")
+    if same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend=backend)
 
     log(f"rank {rank}/{world}: building random-init whisper-{MODEL} weights")
     from lyricalignment_amd import _lib, whisper_compat as wc
