@@ -157,6 +157,10 @@ class FineTuner:
             self.grad.append(torch.zeros_like(flat))
             opt_groups.append({"params": flat, "lr": group_lr})
         self.groups = [g for g in self.groups if g]
+        if self.world > 1:                                     # replicas start from rank 0's parameters (the head's initialisation
+            import torch.distributed as dist                   # is drawn per process), one broadcast per bucket
+            for flat in self.flat:
+                dist.broadcast(flat, src=0)
         self.opt = FlatAdamW(opt_groups, weight_decay=weight_decay)
         self._dirty = False
 

@@ -1,5 +1,6 @@
 """GPU parity of the fine-tune pieces: CE / BCE / CTC losses (forward + gradient w.r.t. the logits) against the
 reference's own functions (golden) and torch; fused clip + AdamW against torch.optim.AdamW + clip_grad_norm_."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -345,3 +346,49 @@ def test_full_finetune_steps_reduce_the_loss():
     with torch.no_grad():
         logits, _ = model.frame_manual_forward(audios, get_orig_len=True)
     assert tuple(logits.shape) == (2, 50, 41) and torch.isfinite(logits).all()
+
+
+def _dp_worker(rank, world, port, out_dir):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)      # RCCL on a multi-GPU node; gloo here (one GPU)
+    from lyricalignment_amd import finetune as ft
+    torch.manual_seed(95)                                                      # the head's torch-default initialisation
+    model = _tiny_full_model(dropout=0.0, seed=95)
+    audios, labels, frame_labels, dec_in, dec_out = _tiny_batch()
+    if rank == 1:                                                              # a replica that starts elsewhere: the constructor's
+        with torch.no_grad():                                                  # broadcast must bring it to rank 0's parameters
+            for p in model.align_rnn.parameters():
+                p.add_(0.01)
+    tuner = ft.FineTuner(model, lr=5e-3, backbone_lr=2e-4, vocab_size=40)      # world from the process group
+    assert tuner.world == world
+    sl = slice(rank, rank + 1)                                                   # one clip per rank
+    tuner.micro_step([audios[rank]], labels[sl], frame_labels[sl], dec_in[sl], dec_out[sl], accum_grad_steps=1)
+    tuner.step()
+    torch.save([f.cpu() for f in tuner.flat], os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_step_equals_accumulated_single_process(tmp_path):
+    """The data-parallel fine-tune step (one flat gradient all-reduce per bucket before the clip, mean folded into the
+    update) on 2 ranks with one clip each == one process accumulating the same two clips (each scaled by 1/2): identical
+    parameters on both ranks, and equal to the single-process result."""
+    import torch.multiprocessing as mp
+    from lyricalignment_amd import finetune as ft
+    port = 29600 + (os.getpid() % 200)
+    mp.spawn(_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / "rank0.pt"); r1 = torch.load(tmp_path / "rank1.pt")
+    for a, b in zip(r0, r1):
+        assert torch.equal(a, b)
+    torch.manual_seed(95)
+    model = _tiny_full_model(dropout=0.0, seed=95)
+    audios, labels, frame_labels, dec_in, dec_out = _tiny_batch()
+    tuner = ft.FineTuner(model, lr=5e-3, backbone_lr=2e-4, vocab_size=40, world=1)
+    for r in range(2):
+        sl = slice(r, r + 1)
+        tuner.micro_step([audios[r]], labels[sl], frame_labels[sl], dec_in[sl], dec_out[sl], accum_grad_steps=2)
+    tuner.step()
+    for a, b in zip(r0, tuner.flat):
+        np.testing.assert_allclose(a.numpy(), b.cpu().numpy(), rtol=0, atol=2e-6)
