@@ -523,12 +523,30 @@ class PipelinedAligner:
 
     def submit(self, mel: torch.Tensor, labels: torch.Tensor, n_labels: torch.Tensor, n_frames: int = N_CTX,
                use_ctc: bool = True, host_out=None):
-        """Enqueue one batch; returns (onset, offset, score, status) device tensors that are valid after drain() (or once
-        the batch's group has been flushed and its head_done event has passed).
+        """Enqueue one batch of <= 30 s clips (mel [B,80,3000]); returns (onset, offset, score, status) device tensors that
+        are valid after drain() (or once the batch's group has been flushed and its head_done event has passed).
         host_out: optional (onset, offset, status) pinned host tensors for an async D2H."""
+        return self._submit(mel, mel.shape[0], int(n_frames), N_CTX, labels, n_labels, use_ctc, host_out)
+
+    def submit_songs(self, mel: torch.Tensor, labels: torch.Tensor, n_labels: torch.Tensor, get_orig_len: bool = True,
+                     use_ctc: bool = True, host_out=None):
+        """Long form (BASELINE configs[4]; reference chunking module/align_model.py:94-105): mel [S,80,n] of whole songs.
+        The songs' 30 s chunks go through the encoder as ONE song-major batch on the encoder stream; the recurrence over
+        the T = n/2 frames of each song, the fused FC and the DP run on the head stream under the next batch's encoder
+        (T sequential GRU steps per layer whatever S is: songs are the GRU's batch rows / workgroup groups)."""
+        from .module.align_model import frame_plan, song_major_chunks      # host bookkeeping shared with AlignModel
+        from .whisper_compat import pad_or_trim
+        plan = frame_plan(mel.shape[-1], get_orig_len)
+        S = mel.shape[0]
+        if len(plan) == 1:
+            return self._submit(pad_or_trim(mel, N_FRAMES), S, plan[0][2], N_CTX, labels, n_labels, use_ctc, host_out)
+        return self._submit(song_major_chunks(mel, plan), S, sum(k for _, _, k in plan), len(plan) * N_CTX, labels, n_labels,
+                            use_ctc, host_out)
+
+    def _submit(self, mel: torch.Tensor, B: int, n_frames: int, clip_rows: int, labels, n_labels, use_ctc: bool, host_out):
+        """mel: [B * clip_rows / 1500, 80, 3000] encoder clips, clip-major; clip b owns encoder rows b*clip_rows .. +n_frames."""
         eng = self.eng
-        B = mel.shape[0]
-        key = (B, int(labels.shape[1]), int(n_frames), bool(use_ctc))
+        key = (B, int(labels.shape[1]), int(n_frames), bool(use_ctc), int(clip_rows))
         if self._pending and key != self._key:
             self._flush()                                            # a group holds batches of one shape
         self._key = key
@@ -540,16 +558,18 @@ class PipelinedAligner:
         self._enc_i += 1
         st, enc_eng = self._enc_streams[k], self._enc_engines[k]
         st.wait_stream(cur)
+        rows = B * clip_rows
         with torch.cuda.stream(st):
             if self._head_used[slot]:
                 st.wait_event(self.head_done[slot])                  # the head of group g-2 has consumed this buffer set
             fb = self._feats[slot]
-            if fb is None or fb.shape[0] != self.G * B * N_CTX or fb.dtype != dt:
-                fb = self._feats[slot] = torch.empty((self.G * B * N_CTX, d), dtype=dt, device=eng.device)
+            if fb is None or fb.shape[0] != self.G * rows or fb.dtype != dt:
+                fb = self._feats[slot] = torch.empty((self.G * rows, d), dtype=dt, device=eng.device)
                 fb.record_stream(self.stream_h)
                 for s2 in self._enc_streams:
                     fb.record_stream(s2)
-            enc_eng.encode(mel, out=fb[j * B * N_CTX:(j + 1) * B * N_CTX])
+            mel.record_stream(st)
+            enc_eng.encode(mel, out=fb[j * rows:(j + 1) * rows])
             ev = torch.cuda.Event()
             ev.record(st)
         self._pending_events = getattr(self, "_pending_events", [])
@@ -568,7 +588,7 @@ class PipelinedAligner:
         if not self._pending:
             return
         eng, slot = self.eng, self.gi & 1
-        B, _, n_frames, use_ctc = self._key
+        B, _, n_frames, use_ctc, clip_rows = self._key
         n = len(self._pending)
         with torch.cuda.stream(self.stream_h):
             for ev in self._pending_events:                          # every encoder of the group, whichever stream ran it
@@ -577,8 +597,8 @@ class PipelinedAligner:
             labels = self._pending[0]["labels"] if n == 1 else torch.cat([q["labels"] for q in self._pending], dim=0)
             n_labels = self._pending[0]["n_labels"] if n == 1 else torch.cat([q["n_labels"] for q in self._pending], dim=0)
             variant = LA_VARIANT_CTC if use_ctc else LA_VARIANT_PLAIN
-            feats = self._feats[slot][: n * B * N_CTX]
-            em = eng.emissions(feats, n * B, n_frames, N_CTX, labels, n_labels, variant)
+            feats = self._feats[slot][: n * B * clip_rows]
+            em = eng.emissions(feats, n * B, n_frames, clip_rows, labels, n_labels, variant)
             nf = torch.full((n * B,), n_frames, dtype=torch.int32, device=eng.device)
             res = ops.viterbi_batch(em, labels, n_labels, nf)
             for j, q in enumerate(self._pending):

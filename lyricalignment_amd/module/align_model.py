@@ -43,6 +43,18 @@ def frame_plan(n_mel: int, get_orig_len: bool = True):
     return plan
 
 
+def song_major_chunks(mel: torch.Tensor, plan) -> torch.Tensor:
+    """Long form (:94-105): mel [S,80,n] -> zero-padded 3000-frame chunks ordered song-major, [S*C, 80, 3000].  Every chunk
+    but a song's last keeps all of its 1500 output frames, so with this order song s's frames are the contiguous encoder
+    output rows s*C*1500 .. +T: the head reads them in place (clip stride C*1500), nothing is concatenated."""
+    S, C = mel.shape[0], len(plan)
+    assert all(k == N_CTX for _, _, k in plan[:-1])
+    out = torch.zeros((S, C, mel.shape[1], N_FRAMES), dtype=mel.dtype, device=mel.device)
+    for c, (s0, e0, _) in enumerate(plan):
+        out[:, c, :, : e0 - s0] = mel[:, :, s0:e0]
+    return out.view(S * C, mel.shape[1], N_FRAMES)
+
+
 class RNN(nn.Module):
     """GRU(2 layers, bidirectional) -> Mish -> Linear; parameters live in nn.GRU / nn.Linear so the
     state_dict keys are the reference's (align_rnn.rnn.weight_ih_l0 ... align_rnn.fc.bias)."""
@@ -189,12 +201,8 @@ class AlignModel(torch.nn.Module):
             feats = eng.encode(pad_or_trim(mel, N_FRAMES))
             return feats, B, plan[0][2], N_CTX
         # long form (:94-105): non-overlapping 3000-frame chunks, every chunk of every clip in ONE encoder batch
-        chunks = [pad_or_trim(mel[:, :, s:e], N_FRAMES) for s, e, _ in plan]
-        keep = [k for _, _, k in plan]
-        enc = eng.encode(torch.cat(chunks, dim=0)).view(len(chunks), B, N_CTX, eng.enc.d)
-        feats = torch.cat([enc[c, :, : keep[c]] for c in range(len(chunks))], dim=1).contiguous()   # [B, sum(keep), d]
-        T = feats.shape[1]
-        return feats.view(B * T, eng.enc.d), B, T, T
+        feats = eng.encode(song_major_chunks(mel, plan))
+        return feats, B, sum(k for _, _, k in plan), len(plan) * N_CTX
 
     def frame_manual_forward(self, audios: List[np.ndarray], y_in=None, get_orig_len: bool = True):
         train = self._wants_grad()

@@ -271,6 +271,38 @@ def test_pipelined_aligner_matches_single_stream(head_group, encoder_streams):
         assert torch.equal(r[2], o[2])
 
 
+@pytest.mark.parametrize("head_group", [1, 2])
+def test_pipelined_long_form_songs_match_single_stream(head_group):
+    """BASELINE configs[4]: whole songs (73 s -> two full 30 s chunks + a partial one, T = 3651 frames) through
+    PipelinedAligner.submit_songs -- song-major chunk batch on the encoder stream, recurrence + FC + DP of the previous
+    songs on the head stream -- give exactly AlignModel.align's frames; and a batch of <= 30 s songs takes the short branch."""
+    from lyricalignment_amd.engine import PipelinedAligner
+    model = _small_model(torch.bfloat16, seed=23)
+    eng = model.engine()
+    pipe = PipelinedAligner(eng, head_group=head_group)
+    rs = np.random.RandomState(24)
+    batches = []
+    for i in range(3):
+        n_mel = 7302 if i < 2 else 2001                      # 2001 mel frames -> short branch, round(2001 / 2) = 1000 frames
+        mel = torch.from_numpy(rs.uniform(-1, 1, size=(2, 80, n_mel)).astype(np.float32)).cuda()
+        labels = torch.from_numpy(rs.randint(1, 299, size=(2, 40)).astype(np.int64))
+        labels[1, 25:] = -100
+        batches.append((mel, labels))
+    from lyricalignment_amd.utils.alignment import _labels_to_device
+    with torch.no_grad():
+        ref = [tuple(t.clone() for t in model.align(mel=m, labels=l, return_frames=True)) for m, l in batches]
+        torch.cuda.synchronize()
+        outs = []
+        for m, l in batches:
+            lab_dev, n_lab, _ = _labels_to_device(l, 2, eng.device)
+            outs.append(pipe.submit_songs(m, lab_dev, n_lab))
+        pipe.drain()
+    assert int(ref[0][3].abs().sum()) == 0
+    for r, o in zip(ref, outs):
+        for a, b in zip(r, o):
+            assert torch.equal(a, b)
+
+
 def test_audio_loader_resample_matches_scipy(tmp_path):
     """utils.audio.load_audio_file: WAV decode + device polyphase resampling vs scipy.signal.resample_poly
     (the reference's librosa resampler is absent / un-pinned: parity with it is unpinned)."""
