@@ -25,9 +25,10 @@ namespace {
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 
-constexpr int GROUP = 32;      // clips per workgroup group: up to two 16-row MFMA batch tiles (template parameter MT of the
-                               // kernels: 1 when the whole batch is <= 16 clips -- half the MFMAs of a step, which is what a
-                               // float32 training step with 2 clips, or a single-clip request, spends its time on)
+constexpr int GROUP = 16;      // clips per workgroup group = one 16-row MFMA batch tile (MT = 1).  32-clip groups (MT = 2: two batch
+                               // tiles per workgroup, kept as a template parameter) halve the workgroups but every step then does
+                               // twice the MFMAs, gates and exchange bytes on its critical path: 4.40 vs 3.62 us per step at 32
+                               // clips.  More clips = more groups running side by side on other CUs, not longer steps.
 
 struct GruParams {
     const float *gi;     // [B][T][2][3H]
@@ -109,7 +110,7 @@ __device__ __forceinline__ void mma_step(const uint4 &a, const uint4 &w, f32x4 &
 // WT: write-through hand-off (cdna guide G16, valid-forms row 1): h is stored with sc1 (write-through) 4-byte stores,
 //     every storing wave drains vmcnt, one lane signals with a relaxed agent-scope add; consumers poll that counter with
 //     an sc1 load, pass a workgroup barrier and read h with sc1 16-byte buffer loads only -> no release / acquire fence
-//     (each costs ~1.7 us per step here).  WT = false is the fence form (default; LA_GRU_WT=1 selects WT).
+//     (each costs ~1.7 us per step here).  WT = true is the default; LA_GRU_FENCE=1 selects the fence form (WT = false).
 template <typename T, int MAXKS, bool WT, int MT>
 __global__ __launch_bounds__(GruTraits<T>::NW * 64, 1) void gru_kernel(GruParams p) {
     typedef GruTraits<T> TR;
@@ -218,18 +219,32 @@ __global__ __launch_bounds__(GruTraits<T>::NW * 64, 1) void gru_kernel(GruParams
                 // Row pitch H*2 + 16 B: the 16 rows of an m-tile start 16 B apart modulo 256 B -> conflict-free b128 reads.
                 const int chunks = row_bytes >> 4, pitch = row_bytes + 16;
                 unsigned char *hl = lds + 16;
-                for (int idx = tid; idx < 16 * MT * chunks; idx += NW * 64) {
-                    const int row = idx / chunks, c = idx - row * chunks;
-                    const int64_t eoff = (int64_t)(b0 + min(row, nb - 1)) * out_bs + (int64_t)tprev * out_ts + dir * H;
-                    uint4 v;
-                    if constexpr (WT) {
-                        typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-                        const u32x4 t4 = __builtin_amdgcn_raw_buffer_load_b128(out_rsrc, (int)(eoff * (int64_t)sizeof(T)) + c * 16, 0, 16 /* sc1 */);
-                        v = make_uint4(t4[0], t4[1], t4[2], t4[3]);
-                    } else {
-                        v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(out + eoff) + c * 16);
+                // all of this thread's requests go out before the first one is waited for (a rolled load -> LDS-store loop
+                // serialised 3 / 6 memory round trips: that, not the distance to the other XCDs, was the 2.7-3.7 us fetch)
+                constexpr int NREQ = (16 * MT * MAXKS * 4) / (NW * 64);
+                uint4 hv[NREQ];
+#pragma unroll
+                for (int k = 0; k < NREQ; ++k) {
+                    const int idx = tid + k * NW * 64;
+                    if (idx < 16 * MT * chunks) {
+                        const int row = idx / chunks, c = idx - row * chunks;
+                        const int64_t eoff = (int64_t)(b0 + min(row, nb - 1)) * out_bs + (int64_t)tprev * out_ts + dir * H;
+                        if constexpr (WT) {
+                            typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+                            const u32x4 t4 = __builtin_amdgcn_raw_buffer_load_b128(out_rsrc, (int)(eoff * (int64_t)sizeof(T)) + c * 16, 0, 16 /* sc1 */);
+                            hv[k] = make_uint4(t4[0], t4[1], t4[2], t4[3]);
+                        } else {
+                            hv[k] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(out + eoff) + c * 16);
+                        }
                     }
-                    *reinterpret_cast<uint4 *>(hl + row * pitch + c * 16) = v;
+                }
+#pragma unroll
+                for (int k = 0; k < NREQ; ++k) {
+                    const int idx = tid + k * NW * 64;
+                    if (idx < 16 * MT * chunks) {
+                        const int row = idx / chunks, c = idx - row * chunks;
+                        *reinterpret_cast<uint4 *>(hl + row * pitch + c * 16) = hv[k];
+                    }
                 }
                 __syncthreads();
 #pragma unroll
@@ -347,11 +362,12 @@ __global__ __launch_bounds__(GruTraits<T>::NW * 64, 1) void gru_kernel(GruParams
 }  // namespace
 
 static int gru_groups(int batch) { return la::cdiv(batch, GROUP); }
+static size_t gru_ctr_bytes(int batch, int frames) { return (size_t)la::round_up(16 + (int64_t)gru_groups(batch) * 2 * frames * 4, 256); }
 
 extern "C" int la_gru_workspace_bytes(int32_t batch, int32_t frames, int32_t hidden, size_t *bytes) {
     LA_CHECK_ARG(bytes && batch > 0 && frames > 0 && hidden > 0, "gru_workspace_bytes: bad arguments");
-    // [16 B header: abort flag] + counters [groups][2][frames] u32, padded to 16 B
-    *bytes = 16 + (size_t)la::round_up((int64_t)gru_groups(batch) * 2 * frames * 4, 16);
+    // [16 B header: abort flag] + counters [groups][2][frames] u32, padded to 256 B
+    *bytes = gru_ctr_bytes(batch, frames);
     return LA_OK;
 }
 
@@ -384,16 +400,14 @@ static int gru_forward(int32_t dtype, const float *gi, const void *w_hh, const f
                 reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(workspace) + 16),
                 reinterpret_cast<int *>(workspace), timeout_flag, nsplit, gates};
     const dim3 grid(nsplit, 2, groups);
-    // measured (tools/kbench.py gru, after the fast gate math): 9.1 ms write-through vs 9.5 ms fences per layer; a third
-    // form that polls the data itself (out pre-filled with NaN, no counter, no barrier) ran 9.9 ms, and requesting all h
-    // fragments before the first MFMA changed nothing: a step is one cross-XCD store -> load hand-off through memory
-    // (~5 us) however it is signalled.  The architecturally guaranteed release/acquire form stays the default,
-    // LA_GRU_WT=1 selects the write-through form.
-    static const bool use_fence = getenv("LA_GRU_WT") == nullptr;
+    // Hand-off forms (tools/kbench.py gru, 32 clips, T=1500, H=384; tools/handoff_bench.hip for the bare protocol costs):
+    // write-through (sc1 stores, drained; relaxed counter; sc1 loads) 5.4 ms per layer, release / acquire fences 9.0 ms.
+    // The write-through form is the default; LA_GRU_FENCE=1 selects the fence form.
+    static const bool use_fence = getenv("LA_GRU_FENCE") != nullptr;
     LA_CHECK_ARG((int64_t)batch * frames * 2 * hidden * (dtype == LA_F32 ? 4 : 2) < (int64_t)2147483647, "gru_layer: out buffer exceeds the 2 GiB buffer-descriptor range");
     if (dtype == LA_BF16 || dtype == LA_F16) {
         la::TimerScope ts("gru_bf16", stream);
-        const int mt = batch <= 16 ? 1 : 2;
+        const int mt = (batch <= 16 || GROUP == 16) ? 1 : 2;
         const size_t lds_b = 16 + (size_t)16 * mt * (hidden * 2 + 16);          // flag + the staged h rows of the batch tiles
 #define LA_GRU_LAUNCH16(T_)                                                                                                \
     do {                                                                                                                   \
@@ -419,7 +433,7 @@ static int gru_forward(int32_t dtype, const float *gi, const void *w_hh, const f
             attr_done = true;
         }
         la::TimerScope ts("gru_f32", stream);
-        if (batch <= 16) {
+        if (batch <= 16 || GROUP == 16) {
             if (use_fence) hipLaunchKernelGGL((gru_kernel<float, 24, false, 1>), grid, dim3(128), lds_bytes, stream, p);
             else hipLaunchKernelGGL((gru_kernel<float, 24, true, 1>), grid, dim3(128), lds_bytes, stream, p);
         } else {
@@ -617,7 +631,7 @@ extern "C" int la_gru_layer_bwd(const float *gates, const float *out, const floa
         attr_done = true;
     }
     la::TimerScope ts("gru_bwd_f32", stream);
-    if (batch <= 16) hipLaunchKernelGGL(gru_bwd_kernel<1>, dim3(nsplit, 2, groups), dim3(128), lds_bytes, stream, p);
+    if (batch <= 16 || GROUP == 16) hipLaunchKernelGGL(gru_bwd_kernel<1>, dim3(nsplit, 2, groups), dim3(128), lds_bytes, stream, p);
     else hipLaunchKernelGGL(gru_bwd_kernel<2>, dim3(nsplit, 2, groups), dim3(128), lds_bytes, stream, p);
     LA_LAUNCH_CHECK();
     return LA_OK;

@@ -28,7 +28,7 @@ from ._lib import LA_VARIANT_CTC, LA_VARIANT_PLAIN
 N_FRAMES = 3000   # whisper.audio.N_FRAMES
 N_CTX = 1500      # encoder positions
 C_PAD = 128       # mel channels padded so 3*C is a multiple of the GEMM K tile
-HEAD_CLIPS_MAX = 512   # clips per head launch set (GRU: 16 workgroup groups of 32 clips co-resident, out buffer < 2 GiB)
+HEAD_CLIPS_MAX = 256   # clips per head launch set (GRU: 16 workgroup groups of 16 clips co-resident = 192 CUs, out buffer < 2 GiB)
 
 
 def _f32(t: torch.Tensor, device) -> torch.Tensor:

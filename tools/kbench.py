@@ -59,7 +59,8 @@ def bench_attn(iters):
 
 
 def bench_gru(iters):
-    B, T, H = 32, 1500, 384
+    import os
+    B, T, H = int(os.environ.get("KB_GRU_B", "32")), 1500, 384
     gi = torch.randn(B, T, 2, 3 * H, device="cuda") * 0.5
     w = rnd(2, 3 * H, H, scale=H ** -0.5)
     b = torch.randn(2, 3 * H, device="cuda") * 0.1
