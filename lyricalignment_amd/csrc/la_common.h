@@ -13,6 +13,10 @@ namespace la {
 char *err_buf();
 void set_error(const char *fmt, ...);
 
+// library-owned scratch for one (device, stream, purpose); nullptr on allocation failure (la_runtime.cpp)
+enum { SCRATCH_SPLITK = 0, SCRATCH_COLSUM = 1 };
+void *stream_scratch(hipStream_t stream, int purpose, size_t bytes);
+
 #define LA_CHECK_ARG(cond, ...)                \
     do {                                       \
         if (!(cond)) {                         \

@@ -377,6 +377,22 @@ bool use_big_tile(int M, int N, int batch) {
 }  // namespace
 
 // ldw: row pitch of W in elements (0 = dense [N][K])
+// Split-K tail: C[m][n] = epilogue(sum_s P[s][m][n]) in a fixed order (deterministic), same epilogue order as the GEMM kernels
+// (bias, activation, residual).
+__global__ void splitk_reduce_kernel(const float *P, int S, int M, int N, float *C, int64_t ldc, const float *bias,
+                                     const float *residual, int64_t ldr, int epilogue) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)M * N) return;
+    const int m = (int)(i / N), n = (int)(i - (int64_t)m * N);
+    float v = 0.f;
+    for (int s = 0; s < S; ++s) v += P[(int64_t)s * M * N + i];
+    if ((epilogue & LA_EPI_BIAS) && bias) v += bias[n];
+    if (epilogue & LA_EPI_GELU) v = la::gelu_erf(v);
+    else if (epilogue & LA_EPI_MISH) v = la::mish(v);
+    if ((epilogue & LA_EPI_RESIDUAL) && residual) v += residual[(int64_t)m * ldr + n];
+    C[(int64_t)m * ldc + n] = v;
+}
+
 static int gemm_run_ldw(int dtype, int M, int N, int K, int batch, const void *A, int64_t lda, int64_t strideA, const void *W,
                         int64_t ldw_arg, int64_t strideW, void *C, int64_t ldc, int64_t strideC, const float *bias, int64_t strideBias,
                  const float *residual, int64_t ldr, int64_t strideR, int epilogue, hipStream_t stream) {
@@ -412,6 +428,31 @@ static int gemm_run_ldw(int dtype, int M, int N, int K, int batch, const void *A
             return out_f32 ? launch<bf16_t, true, Big>(p, batch, stream, "gemm_bf16") : launch<bf16_t, false, Big>(p, batch, stream, "gemm_bf16");
         if (half) return out_f32 ? launch<la::f16_t, true, Small>(p, batch, stream, "gemm_bf16") : launch<la::f16_t, false, Small>(p, batch, stream, "gemm_bf16");
         return out_f32 ? launch<bf16_t, true, Small>(p, batch, stream, "gemm_bf16") : launch<bf16_t, false, Small>(p, batch, stream, "gemm_bf16");
+    }
+    // float32 (training / parity mode) with few tiles and a long K -- the text decoder's 80-row GEMMs are 8 tiles on 256 CUs,
+    // each a serial K = 1024..4096 walk: K is cut into S equal chunks that run as S batch slots of the same kernel into a
+    // partial-sum buffer, and a second kernel adds them in a fixed order and applies the epilogue.
+    if (batch == 1) {
+        const int tiles = la::cdiv(M, Small::TM) * la::cdiv(N, BN);
+        int S = 1;
+        while (S < 16 && tiles * S * 2 <= 256 && K % (S * 2 * 32) == 0 && K / (S * 2) >= 128) S *= 2;
+        static const bool no_split = getenv("LA_GEMM_NO_SPLITK") != nullptr;
+        if (S > 1 && !no_split && !(epilogue & 256)) {
+            float *part = static_cast<float *>(la::stream_scratch(stream, la::SCRATCH_SPLITK, (size_t)S * M * N * sizeof(float)));
+            if (!part) { la::set_error("gemm: split-K scratch allocation failed"); return LA_EHIP; }
+            const int Kc = K / S;
+            GemmParams ps{M, N, Kc, A, lda, (int64_t)Kc, W, p.ldw, (int64_t)Kc, part, (int64_t)N, (int64_t)M * N, nullptr, 0, nullptr, 0, 0,
+                          LA_EPI_OUT_F32, 0, la::cdiv(N, BN), pick_group(Kc, es, la::cdiv(N, BN))};
+            const int rc = launch<float, true, Small>(ps, S, stream, "gemm_f32");
+            if (rc == LA_OK) {
+                const int64_t total = (int64_t)M * N;
+                hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)la::cdiv(total, (int64_t)256)), dim3(256), 0, stream, part, S, M, N,
+                                   reinterpret_cast<float *>(C), ldc, bias, residual, ldr, epilogue);
+            }
+            if (rc != LA_OK) return rc;
+            LA_LAUNCH_CHECK();
+            return LA_OK;
+        }
     }
     return launch<float, true, Small>(p, batch, stream, "gemm_f32");
 }

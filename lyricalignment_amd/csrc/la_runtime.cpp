@@ -21,6 +21,33 @@ void set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
+// ---- per-stream scratch -------------------------------------------------------
+// Small internal scratch (split-K partial sums, column-sum partials): one buffer per (device, stream, purpose), grown on demand
+// and kept.  Uses on one stream are ordered, so a buffer is never shared by kernels that can overlap.  (hipMallocAsync /
+// hipFreeAsync per call cost ~50 us of host time each on this stack: more than the kernels they served.)
+void *stream_scratch(hipStream_t stream, int purpose, size_t bytes) {
+    struct Slot { int dev; hipStream_t stream; int purpose; void *ptr; size_t bytes; };
+    static std::mutex mu;
+    static std::vector<Slot> slots;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    for (Slot &sl : slots)
+        if (sl.dev == dev && sl.stream == stream && sl.purpose == purpose) {
+            if (sl.bytes >= bytes) return sl.ptr;
+            if (hipStreamSynchronize(stream) != hipSuccess) return nullptr;      // earlier users of the small buffer
+            (void)hipFree(sl.ptr);
+            sl.ptr = nullptr; sl.bytes = 0;
+            if (hipMalloc(&sl.ptr, bytes) != hipSuccess) return nullptr;
+            sl.bytes = bytes;
+            return sl.ptr;
+        }
+    Slot sl{dev, stream, purpose, nullptr, bytes < ((size_t)1 << 20) ? ((size_t)1 << 20) : bytes};
+    if (hipMalloc(&sl.ptr, sl.bytes) != hipSuccess) return nullptr;
+    slots.push_back(sl);
+    return sl.ptr;
+}
+
 // ---- kernel-family timer ------------------------------------------------------
 namespace {
 struct TimerState {

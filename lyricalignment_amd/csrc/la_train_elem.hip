@@ -278,11 +278,10 @@ extern "C" int la_colsum_f32(const float *in, int64_t ld, int32_t rows, int32_t 
     hipStream_t st = (hipStream_t)stream_;
     const int chunks = std::max(1, std::min(64, la::cdiv(rows, 64)));
     const int rows_per_chunk = la::cdiv(rows, chunks);
-    double *part = nullptr;                                   // stream-ordered scratch: safe with concurrent streams
-    LA_HIP(hipMallocAsync((void **)&part, sizeof(double) * (size_t)chunks * cols, st));
+    double *part = static_cast<double *>(la::stream_scratch(st, la::SCRATCH_COLSUM, sizeof(double) * (size_t)chunks * cols));   // per stream
+    if (!part) { la::set_error("colsum: scratch allocation failed"); return LA_EHIP; }
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(la::cdiv(cols, 64), chunks), dim3(256), 0, st, in, ld, rows, cols, rows_per_chunk, part);
     hipLaunchKernelGGL(colsum_final_kernel, dim3(la::cdiv(cols, 256)), dim3(256), 0, st, part, chunks, cols, out);
-    LA_HIP(hipFreeAsync(part, st));
     LA_LAUNCH_CHECK();
     return LA_OK;
 }

@@ -518,6 +518,7 @@ class PipelinedAligner:
         self._head_used = [False, False]
         self.gi = 0                 # group counter (parity = buffer set)
         self._pending: List[dict] = []
+        self._pending_events: List[torch.cuda.Event] = []   # one per submitted batch of the open group (its encoder is done)
         self._key = None
         self._feats = [None, None]  # per buffer set: [G*B*1500, d] encoder outputs
 
@@ -572,7 +573,6 @@ class PipelinedAligner:
             enc_eng.encode(mel, out=fb[j * rows:(j + 1) * rows])
             ev = torch.cuda.Event()
             ev.record(st)
-        self._pending_events = getattr(self, "_pending_events", [])
         self._pending_events.append(ev)
         Lmax = labels.shape[1]
         out = (torch.empty((B, Lmax), dtype=torch.int32, device=eng.device), torch.empty((B, Lmax), dtype=torch.int32, device=eng.device),

@@ -58,6 +58,29 @@ def test_gemm_epilogues(dtype):
         np.testing.assert_allclose(out.float().numpy(), torch.nn.functional.gelu(base).numpy(), rtol=1e-2, atol=1e-2)
 
 
+@pytest.mark.parametrize("M,N,K", [(80, 1024, 4096), (80, 1000, 1024), (129, 260, 3072)])
+def test_gemm_f32_split_k_small_grids(M, N, K):
+    """float32 GEMMs with few output tiles and a long K (the text decoder's 80-row GEMMs in the fine-tune step) run as S
+    K-chunks + a fixed-order reduction that applies the epilogue: same results as the one-pass kernel within f32 rounding,
+    run-to-run identical (no atomics)."""
+    from lyricalignment_amd import ops
+    a = _rand(M, K, seed=13, scale=0.3); w = _rand(N, K, seed=14, scale=0.3)
+    bias = _rand(N, seed=15); res = _rand(M, N, seed=16)
+    base = (a.double() @ w.double().T + bias.double())
+    tol = 2e-4 * (K / 64) ** 0.5
+    out = ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda(), out_f32=True).cpu()
+    np.testing.assert_allclose(out.double().numpy(), base.numpy(), rtol=0, atol=tol)
+    again = ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda(), out_f32=True).cpu()
+    assert torch.equal(out, again)
+    out = ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda(), gelu=True, out_f32=True).cpu()
+    np.testing.assert_allclose(out.double().numpy(), torch.nn.functional.gelu(base).numpy(), rtol=0, atol=tol)
+    out = ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda(), residual=res.cuda(), out_f32=True).cpu()
+    np.testing.assert_allclose(out.double().numpy(), (base + res.double()).numpy(), rtol=0, atol=tol)
+    x = res.clone().cuda()                                   # in-place residual (C aliases the residual), as the encoder uses it
+    ops.gemm(a.cuda(), w.cuda(), x, bias=bias.cuda(), residual=x, out_f32=True)
+    np.testing.assert_allclose(x.cpu().double().numpy(), (base + res.double()).numpy(), rtol=0, atol=tol)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_conv_as_gemm_views(dtype):
     """Conv1d(k=3, pad=1, stride s) on channels-last rows == GEMM over overlapping row views."""
