@@ -44,7 +44,8 @@ def test_argument_validation_without_gpu():
     assert L.la_viterbi_workspace_bytes(32, 1500, 26, ctypes.byref(need)) == _lib.LA_OK and need.value == 0      # backpointers fit LDS
     assert L.la_viterbi_workspace_bytes(1, 9000, 238, ctypes.byref(need)) == _lib.LA_OK and need.value == 9000 * 8 * 16
     assert L.la_viterbi_workspace_bytes(1, 100, 600, ctypes.byref(need)) == _lib.LA_EUNSUPPORTED
-    assert L.la_gru_workspace_bytes(32, 1500, 384, ctypes.byref(need)) == _lib.LA_OK and need.value == 16 + 2 * 1500 * 4
+    # header + arrival counters [groups of 16 clips][2 directions][frames] u32, padded to 256 B
+    assert L.la_gru_workspace_bytes(32, 1500, 384, ctypes.byref(need)) == _lib.LA_OK and need.value == (16 + 2 * 2 * 1500 * 4 + 255) // 256 * 256
     # entry points added for the training / decoding rows: the same host-side rejection before any HIP call
     P = 16                                                            # a non-null, 16-byte aligned stand-in pointer
     assert L.la_gemm_ex(_lib.LA_F32, 64, 64, 64, 1, P, 64, 0, P, 32, 0, P, 64, 0, 0, 0, 0) == _lib.LA_EINVAL       # ldw < K
