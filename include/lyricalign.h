@@ -321,6 +321,24 @@ int la_mish_f32(const float *x, float *y, int64_t n, void *stream);
 int la_mish_bwd_f32(const float *x, const float *dy, float *dx, int64_t n, void *stream);
 int la_mask_scale_f32(const float *x, const unsigned char *mask, float scale, float *y, int64_t n, void *stream);
 
+/*
+ * LayerNorm folded into the GEMMs on either side of it -- whisper's ResidualAttentionBlock computes
+ * x = x + attn(attn_ln(x)); x = x + mlp(mlp_ln(x)) (third-party whisper/model.py; call module/align_model.py:91,101,112,137).
+ * In the 16-bit modes, for shapes that run on the 256x256 kernel:
+ *   producer  (la_gemm_fused_ln with C2 != NULL, LA_EPI_OUT_F32): the GEMM that writes the f32 residual stream also stores
+ *             the same rows rounded to `dtype` into C2 [M][ldc2] -- the RAW operand of the next GEMM;
+ *   la_row_stats16: stats[m] = (mean, 1/sqrt(var + eps)) of those raw rows;
+ *   consumer  (ln_stats != NULL): A = raw rows, W = gamma-folded weights W'[n][k] = gamma[k] W[n][k], ln_csum[n] = sum_k W'[n][k],
+ *             bias[n] = b[n] + sum_k beta[k] W[n][k]:   LN(x) W^T + b = rstd (x W'^T - mean c) + bias.
+ * Replaces the separate LayerNorm pass (read f32, write 16-bit) between them.  LA_EUNSUPPORTED for f32 and for shapes
+ * the 256x256 kernel does not take (callers fall back to la_layernorm + la_gemm).
+ */
+int la_gemm_fused_ln(int32_t dtype, int32_t M, int32_t N, int32_t K, int32_t batch, const void *A, int64_t lda, int64_t strideA,
+                     const void *W, void *C, int64_t ldc, int64_t strideC, const float *bias, const float *residual, int64_t ldr,
+                     int64_t strideR, int32_t epilogue, void *C2, int64_t ldc2, int64_t strideC2, const float *ln_stats,
+                     const float *ln_csum, void *stream);
+int la_row_stats16(int32_t dtype, const void *x, int64_t ldx, int32_t M, int32_t d, float eps, float *stats, void *stream);
+
 /* Backward-pass building blocks of the Whisper encoder (float32): la_gemm with a row pitch for W and per-batch strides
  * (attention gradients batch over heads inside the packed [T][3d] projections), batched zero-padded transposes, exact-erf
  * GELU forward / backward, LayerNorm backward (dx and dy*xhat, whose column sum is dgamma), row softmax forward /

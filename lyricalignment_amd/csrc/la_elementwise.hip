@@ -128,6 +128,43 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *x, int64_t 
     }
 }
 
+// Row statistics of 16-bit rows (the raw copy of the residual stream that the LayerNorm-folded GEMMs consume):
+// stats[row] = (mean, 1 / sqrt(var + eps)), two-pass on the row held in registers.  One wave per row, d <= 64*8*MAXV.
+template <typename T16, int MAXV>
+__global__ __launch_bounds__(256) void row_stats16_kernel(const T16 *x, int64_t ldx, int M, int d, float eps, float2 *stats) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const T16 *xr = x + (int64_t)row * ldx;
+    float v[MAXV][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (lane + 64 * i) * 8;
+        if (c < d) {
+            const uint4 raw = *reinterpret_cast<const uint4 *>(xr + c);
+            const T16 *e = reinterpret_cast<const T16 *>(&raw);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { v[i][j] = la::Elem<T16>::load(e + j); sum += v[i][j]; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+        }
+    }
+    const float mean = wave_sum(sum) / (float)d;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (lane + 64 * i) * 8;
+        if (c < d) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float a = v[i][j] - mean; sq = fmaf(a, a, sq); }
+        }
+    }
+    const float var = wave_sum(sq) / (float)d;
+    if (lane == 0) stats[row] = make_float2(mean, 1.0f / sqrtf(var + eps));
+}
+
 __global__ void cast_f32_bf16_kernel(const float *x, bf16_t *y, int64_t n) {
     int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
@@ -236,6 +273,23 @@ extern "C" int la_layernorm(const float *x, int64_t ldx, int32_t M, int32_t d, c
         hipLaunchKernelGGL((layernorm_kernel<la::f16_t, 8>), grid, block, 0, stream, x, ldx, M, d, gamma, beta, (la::f16_t *)y, ldy);
     else
         hipLaunchKernelGGL((layernorm_kernel<bf16_t, 8>), grid, block, 0, stream, x, ldx, M, d, gamma, beta, (bf16_t *)y, ldy);
+    LA_LAUNCH_CHECK();
+    return LA_OK;
+}
+
+extern "C" int la_row_stats16(int32_t dtype, const void *x, int64_t ldx, int32_t M, int32_t d, float eps, float *stats, void *stream_) {
+    if (M == 0) return LA_OK;
+    LA_CHECK_ARG(x && stats && M > 0 && d > 0, "row_stats16: bad arguments");
+    LA_CHECK_ARG(dtype == LA_BF16 || dtype == LA_F16, "row_stats16: 16-bit rows only");
+    LA_CHECK_ARG(d % 8 == 0 && d <= 64 * 8 * 4 && ldx % 8 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)stats % 8 == 0),
+                 "row_stats16: d must be a multiple of 8 and <= 2048, rows 16-byte aligned");
+    hipStream_t stream = (hipStream_t)stream_;
+    la::TimerScope ts("layernorm", stream);
+    const dim3 grid(la::cdiv(M, 4)), block(256);
+    if (dtype == LA_F16)
+        hipLaunchKernelGGL((row_stats16_kernel<la::f16_t, 4>), grid, block, 0, stream, (const la::f16_t *)x, ldx, M, d, eps, (float2 *)stats);
+    else
+        hipLaunchKernelGGL((row_stats16_kernel<bf16_t, 4>), grid, block, 0, stream, (const bf16_t *)x, ldx, M, d, eps, (float2 *)stats);
     LA_LAUNCH_CHECK();
     return LA_OK;
 }

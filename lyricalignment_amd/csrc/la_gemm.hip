@@ -26,6 +26,11 @@ struct GemmParams {
     int64_t ldr, strideR;
     int epilogue;
     int tiles_m, tiles_n, group;
+    // LayerNorm folded into the GEMMs around it (ping-pong kernel only; la_gemm_fused_ln):
+    void *C2 = nullptr;                // producer: second, 16-bit copy of the f32 result rows (the next GEMM's raw A operand)
+    int64_t ldc2 = 0, strideC2 = 0;
+    const float *ln_stats = nullptr;   // consumer: per-row (mean, rstd) of the raw A rows, [M][2]
+    const float *ln_csum = nullptr;    // consumer: c[n] = sum_k W'[n][k] of the gamma-folded weights, [N]
 };
 
 template <typename T, bool OUT_F32, typename CF>
@@ -203,6 +208,32 @@ __global__ __launch_bounds__(PP::THREADS, 2) void gemm_pp_kernel(GemmParams p) {
     const bool has_bias = (p.epilogue & LA_EPI_BIAS) && bias;
     const bool do_gelu = p.epilogue & LA_EPI_GELU;
     const bool do_res = (p.epilogue & LA_EPI_RESIDUAL) && R;
+    if (p.ln_stats) {
+        // A held the RAW rows x (16-bit copy of the residual stream) and W the gamma-folded weights W' = gamma o W:
+        // LN(x) W^T + b = rstd (x W'^T - mean c) + b'.  acc row = mi*16 + r, col = ni*16 + 4q + j.  Statistics, column sums
+        // and bias are requested together (one exposed round trip per tile, not three) and applied as two FMAs per element.
+        float rs[8], bm[8];
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            const float2 st = reinterpret_cast<const float2 *>(p.ln_stats)[min(m0 + wr * 128 + mi * 16 + r, p.M - 1)];
+            rs[mi] = st.y; bm[mi] = -st.x * st.y;
+        }
+        float c4[4][4], b4[4][4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = min(n0 + wc * 64 + ni * 16 + q * 4 + j, p.N - 1);
+                c4[ni][j] = p.ln_csum[n];
+                b4[ni][j] = has_bias ? bias[n] : 0.f;
+            }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[mi][ni][j] = fmaf(acc[mi][ni][j], rs[mi], fmaf(bm[mi], c4[ni][j], b4[ni][j]));
+    } else
     if (has_bias) {
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
@@ -243,6 +274,11 @@ __global__ __launch_bounds__(PP::THREADS, 2) void gemm_pp_kernel(GemmParams p) {
     if (wrow0 + 128 <= p.M && wcol0 + 64 <= p.N && fast_c && (!do_res || fast_r)) {
         TC *cw = C + (int64_t)wrow0 * p.ldc + wcol0 + r * 4;
         const float *rw = do_res ? R + (int64_t)wrow0 * p.ldr + wcol0 + r * 4 : nullptr;
+        T16 *c2w = nullptr;
+        if constexpr (OUT_F32) {
+            if (p.C2 && (p.ldc2 % 4 == 0))
+                c2w = reinterpret_cast<T16 *>(p.C2) + (int64_t)z * p.strideC2 + (int64_t)wrow0 * p.ldc2 + wcol0 + r * 4;
+        }
         auto fast = [&](auto resc) {
             constexpr bool RES = decltype(resc)::value;
 #pragma unroll
@@ -265,6 +301,7 @@ __global__ __launch_bounds__(PP::THREADS, 2) void gemm_pp_kernel(GemmParams p) {
                     TC *c = cw + (int64_t)(h * 32 + rl) * p.ldc;
                     if constexpr (sizeof(TC) == 4) {
                         *reinterpret_cast<float4 *>(c) = make_float4(v[0], v[1], v[2], v[3]);
+                        if (c2w) *reinterpret_cast<ushort4 *>(c2w + (int64_t)(h * 32 + rl) * p.ldc2) = la::Pack4<T16>::run(v[0], v[1], v[2], v[3]);
                     } else {
                         *reinterpret_cast<ushort4 *>(c) = la::Pack4<TC>::run(v[0], v[1], v[2], v[3]);
                     }
@@ -273,6 +310,10 @@ __global__ __launch_bounds__(PP::THREADS, 2) void gemm_pp_kernel(GemmParams p) {
         };
         if (do_res) fast(std::true_type{}); else fast(std::false_type{});
         return;
+    }
+    T16 *C2 = nullptr;
+    if constexpr (OUT_F32) {
+        if (p.C2) C2 = reinterpret_cast<T16 *>(p.C2) + (int64_t)z * p.strideC2;
     }
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
@@ -308,6 +349,8 @@ __global__ __launch_bounds__(PP::THREADS, 2) void gemm_pp_kernel(GemmParams p) {
             } else {
                 for (int j = 0; j < nv; ++j) la::Elem<TC>::store(c + j, v[j]);
             }
+            if (C2)
+                for (int j = 0; j < nv; ++j) la::Elem<T16>::store(C2 + (int64_t)m * p.ldc2 + n + j, v[j]);
         }
     }
 }
@@ -393,9 +436,14 @@ __global__ void splitk_reduce_kernel(const float *P, int S, int M, int N, float 
     C[(int64_t)m * ldc + n] = v;
 }
 
+struct LnFuse {
+    void *C2; int64_t ldc2, strideC2;
+    const float *stats, *csum;
+};
+
 static int gemm_run_ldw(int dtype, int M, int N, int K, int batch, const void *A, int64_t lda, int64_t strideA, const void *W,
                         int64_t ldw_arg, int64_t strideW, void *C, int64_t ldc, int64_t strideC, const float *bias, int64_t strideBias,
-                 const float *residual, int64_t ldr, int64_t strideR, int epilogue, hipStream_t stream) {
+                 const float *residual, int64_t ldr, int64_t strideR, int epilogue, hipStream_t stream, const LnFuse *ln = nullptr) {
     if (M == 0 || N == 0 || batch == 0) return LA_OK;
     LA_CHECK_ARG(A && W && C, "gemm: null pointer");
     LA_CHECK_ARG(M > 0 && N > 0 && K > 0 && batch > 0, "gemm: bad sizes");
@@ -420,6 +468,16 @@ static int gemm_run_ldw(int dtype, int M, int N, int K, int batch, const void *A
         const int forced = force ? atoi(force) : 0;
         const bool pp = forced == 512 || (forced == 0 && N > 128 && (int64_t)la::cdiv(M, 256) * la::cdiv(N, 256) * batch >= 192);
         const bool half = dtype == LA_F16;
+        if (ln) {
+            if (!pp || (epilogue & LA_EPI_MISH)) {
+                la::set_error("gemm_fused_ln: shape M=%d N=%d batch=%d does not run on the 256x256 kernel the fusion is built into", M, N, batch);
+                return LA_EUNSUPPORTED;
+            }
+            LA_CHECK_ARG(!ln->C2 || (out_f32 && ln->ldc2 >= N), "gemm_fused_ln: the 16-bit copy accompanies an f32 result");
+            LA_CHECK_ARG((ln->stats == nullptr) == (ln->csum == nullptr), "gemm_fused_ln: stats and csum go together");
+            LA_CHECK_ARG(!ln->stats || batch == 1, "gemm_fused_ln: the LayerNorm epilogue takes batch 1");
+            p.C2 = ln->C2; p.ldc2 = ln->ldc2; p.strideC2 = ln->strideC2; p.ln_stats = ln->stats; p.ln_csum = ln->csum;
+        }
         if (pp && !(epilogue & LA_EPI_MISH)) {
             if (half) return out_f32 ? launch_pp<true, la::f16_t>(p, batch, stream) : launch_pp<false, la::f16_t>(p, batch, stream);
             return out_f32 ? launch_pp<true, bf16_t>(p, batch, stream) : launch_pp<false, bf16_t>(p, batch, stream);
@@ -455,6 +513,24 @@ static int gemm_run_ldw(int dtype, int M, int N, int K, int batch, const void *A
         }
     }
     return launch<float, true, Small>(p, batch, stream, "gemm_f32");
+}
+
+// LayerNorm folded into the GEMMs on either side of it (encoder blocks, 16-bit modes, shapes that run on the 256x256 kernel):
+//   producer  (C2 != null): besides the f32 result rows (residual stream) also stores them rounded to `dtype` into C2;
+//   consumer  (ln_stats != null): A = those raw rows, W = gamma-folded weights, ln_stats [M][2] = (mean, rstd) per row,
+//             ln_csum [N] = row sums of W; bias must already hold b + W beta.  LA_EUNSUPPORTED for other shapes / f32.
+extern "C" int la_gemm_fused_ln(int32_t dtype, int32_t M, int32_t N, int32_t K, int32_t batch, const void *A, int64_t lda,
+                                int64_t strideA, const void *W, void *C, int64_t ldc, int64_t strideC, const float *bias,
+                                const float *residual, int64_t ldr, int64_t strideR, int32_t epilogue, void *C2, int64_t ldc2,
+                                int64_t strideC2, const float *ln_stats, const float *ln_csum, void *stream_) {
+    if (dtype != LA_BF16 && dtype != LA_F16) {
+        la::set_error("gemm_fused_ln: 16-bit compute dtypes only");
+        return LA_EUNSUPPORTED;
+    }
+    LA_CHECK_ARG(C2 || ln_stats, "gemm_fused_ln: neither a second output nor row statistics given");
+    const LnFuse ln{C2, ldc2, strideC2, ln_stats, ln_csum};
+    return gemm_run_ldw(dtype, M, N, K, batch, A, lda, strideA, W, 0, 0, C, ldc, strideC, bias, 0, residual, ldr, strideR, epilogue,
+                        (hipStream_t)stream_, &ln);
 }
 
 int la::gemm_run(int dtype, int M, int N, int K, int batch, const void *A, int64_t lda, int64_t strideA, const void *W,

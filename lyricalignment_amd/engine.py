@@ -20,6 +20,8 @@ from __future__ import annotations
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 
+import os
+
 import torch
 
 from . import _lib, ops
@@ -28,6 +30,7 @@ from ._lib import LA_VARIANT_CTC, LA_VARIANT_PLAIN
 N_FRAMES = 3000   # whisper.audio.N_FRAMES
 N_CTX = 1500      # encoder positions
 C_PAD = 128       # mel channels padded so 3*C is a multiple of the GEMM K tile
+LN_FUSION = os.environ.get("LA_LN_FUSION", "1") != "0"   # developer switch: 0 = always the separate LayerNorm pass
 HEAD_CLIPS_MAX = 256   # clips per head launch set (GRU: 16 workgroup groups of 16 clips co-resident = 192 CUs, out buffer < 2 GiB)
 
 
@@ -43,6 +46,17 @@ class BlockWeights:
     ln2_g: torch.Tensor; ln2_b: torch.Tensor
     w1: torch.Tensor; b1: torch.Tensor
     w2: torch.Tensor; b2: torch.Tensor
+    # LayerNorm folded into the QKV / MLP-up GEMMs (16-bit modes): W' = gamma o W, c = row sums of the ROUNDED W', b' = b + W beta
+    wqkv_ln: Optional[torch.Tensor] = None; cqkv: Optional[torch.Tensor] = None; bqkv_ln: Optional[torch.Tensor] = None
+    w1_ln: Optional[torch.Tensor] = None; c1: Optional[torch.Tensor] = None; b1_ln: Optional[torch.Tensor] = None
+
+
+def _fold_ln(w: torch.Tensor, b: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, dtype: torch.dtype, device):
+    """LN(x) W^T + b = rstd (x W'^T - mean c) + b'   with W' = gamma o W (rounded to `dtype`), c = W'.sum(1), b' = b + W beta."""
+    w, b, gamma, beta = (t.detach().double().cpu() for t in (w, b, gamma, beta))
+    wl = (w * gamma[None, :]).to(dtype)
+    return (wl.to(device).contiguous(), wl.double().sum(dim=1).float().to(device).contiguous(),
+            (b + w @ beta).float().to(device).contiguous())
 
 
 @dataclass
@@ -92,13 +106,18 @@ def pack_encoder(sd: Dict[str, torch.Tensor], n_head: int, dtype: torch.dtype, d
         wv, bv = g(b + "attn.value.weight").detach().float(), g(b + "attn.value.bias").detach().float()
         wqkv = torch.cat([wq, wk, wv], dim=0)
         bqkv = torch.cat([bq, torch.zeros_like(bq), bv], dim=0)
-        blocks.append(BlockWeights(
+        blk = BlockWeights(
             _f32(g(b + "attn_ln.weight"), device), _f32(g(b + "attn_ln.bias"), device),
             wqkv.to(device=device, dtype=dtype).contiguous(), _f32(bqkv, device),
             g(b + "attn.out.weight").detach().to(device=device, dtype=dtype).contiguous(), _f32(g(b + "attn.out.bias"), device),
             _f32(g(b + "mlp_ln.weight"), device), _f32(g(b + "mlp_ln.bias"), device),
             g(b + "mlp.0.weight").detach().to(device=device, dtype=dtype).contiguous(), _f32(g(b + "mlp.0.bias"), device),
-            g(b + "mlp.2.weight").detach().to(device=device, dtype=dtype).contiguous(), _f32(g(b + "mlp.2.bias"), device)))
+            g(b + "mlp.2.weight").detach().to(device=device, dtype=dtype).contiguous(), _f32(g(b + "mlp.2.bias"), device))
+        if dtype == torch.bfloat16:
+            blk.wqkv_ln, blk.cqkv, blk.bqkv_ln = _fold_ln(wqkv, bqkv, g(b + "attn_ln.weight"), g(b + "attn_ln.bias"), dtype, device)
+            blk.w1_ln, blk.c1, blk.b1_ln = _fold_ln(g(b + "mlp.0.weight"), g(b + "mlp.0.bias"), g(b + "mlp_ln.weight"),
+                                                    g(b + "mlp_ln.bias"), dtype, device)
+        blocks.append(blk)
         i += 1
     return EncoderWeights(d, n_head, n_mels, dtype,
                           c1.reshape(d, 3 * C_PAD).to(device=device, dtype=dtype).contiguous(), _f32(g("conv1.bias"), device),
@@ -220,13 +239,29 @@ class AlignEngine:
         ops.gemm(rows0, e.conv1_w, y1.view(-1)[d:], bias=e.conv1_b, gelu=True, M=N_FRAMES, lda=C_PAD, batch=B,
                  stride_a=(N_FRAMES + 2) * C_PAD, stride_c=(N_FRAMES + 2) * d, ldc=d)
         x = self._get("x", (M, d), torch.float32)
-        ops.gemm(y1, e.conv2_w, x, bias=e.conv2_b, gelu=True, residual=e.pos, out_f32=True, M=N_CTX, lda=2 * d, batch=B,
-                 stride_a=(N_FRAMES + 2) * d, stride_c=N_CTX * d, ldc=d, ldr=d, stride_r=0)
         h = self._get("h", (M, d), dt)
         qkv = self._get("qkv", (M, 3 * d), dt)
         att = self._get("att", (M, d), dt)
         u = self._get("u", (M, 4 * d), dt)
-        for blk in e.blocks:
+        # LayerNorm folded into the GEMMs around it: the GEMMs that write the f32 residual stream x also store it rounded to
+        # bf16 (h = raw x), a small kernel takes the row statistics of h, and the QKV / MLP-up GEMMs apply
+        # rstd (acc - mean c) + b' in their epilogue on gamma-folded weights.  Only where every GEMM of a block runs on the
+        # 256x256 kernel (>= 192 tiles, i.e. >= 9 clips at d = 1024) and in bfloat16; otherwise the separate LayerNorm pass.
+        fused = (LN_FUSION and dt == torch.bfloat16 and e.blocks and e.blocks[0].wqkv_ln is not None and d > 128
+                 and -(-M // 256) * -(-d // 256) >= 192 and -(-N_CTX // 256) * -(-d // 256) * B >= 192)
+        ops.gemm(y1, e.conv2_w, x, bias=e.conv2_b, gelu=True, residual=e.pos, out_f32=True, M=N_CTX, lda=2 * d, batch=B,
+                 stride_a=(N_FRAMES + 2) * d, stride_c=N_CTX * d, ldc=d, ldr=d, stride_r=0, out16=h if fused else None)
+        if fused:
+            stats = self._get("ln_stats", (M, 2), torch.float32)
+            for blk in e.blocks:
+                ops.row_stats16(h, out=stats)
+                ops.gemm(h, blk.wqkv_ln, qkv, bias=blk.bqkv_ln, ln_stats=stats, ln_csum=blk.cqkv)
+                ops.attention(qkv, B, N_CTX, e.n_head, out=att)
+                ops.gemm(att, blk.wo, x, bias=blk.bo, residual=x, out_f32=True, out16=h)     # x += out-proj; h = bf16(x)
+                ops.row_stats16(h, out=stats)
+                ops.gemm(h, blk.w1_ln, u, bias=blk.b1_ln, gelu=True, ln_stats=stats, ln_csum=blk.c1)
+                ops.gemm(u, blk.w2, x, bias=blk.b2, residual=x, out_f32=True, out16=h)       # x += mlp; h = bf16(x)
+        for blk in (() if fused else e.blocks):
             ops.layernorm(x, blk.ln1_g, blk.ln1_b, dt, out=h)
             ops.gemm(h, blk.wqkv, qkv, bias=blk.bqkv)
             ops.attention(qkv, B, N_CTX, e.n_head, out=att)

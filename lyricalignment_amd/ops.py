@@ -77,9 +77,12 @@ def emissions_from_logits(logits: torch.Tensor, labels: torch.Tensor, n_labels: 
 def gemm(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None, *, bias: Optional[torch.Tensor] = None,
          residual: Optional[torch.Tensor] = None, gelu: bool = False, mish: bool = False, out_f32: bool = False,
          M: Optional[int] = None, lda: Optional[int] = None, batch: int = 1, stride_a: int = 0, stride_c: int = 0,
-         stride_r: int = 0, ldc: Optional[int] = None, ldr: Optional[int] = None) -> torch.Tensor:
+         stride_r: int = 0, ldc: Optional[int] = None, ldr: Optional[int] = None, out16: Optional[torch.Tensor] = None,
+         ln_stats: Optional[torch.Tensor] = None, ln_csum: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[z][m][n] = epi(sum_k a[z][m][k] w[n][k]).  `a` may be a flat buffer addressed through
-    (M, lda, stride_a): that is how the conv-as-GEMM views (overlapping rows) are expressed."""
+    (M, lda, stride_a): that is how the conv-as-GEMM views (overlapping rows) are expressed.
+    LayerNorm folded into the neighbouring GEMMs (la_gemm_fused_ln): `out16` = a second, 16-bit copy of the f32 result rows
+    (same row pitch / batch stride as out); `ln_stats` [M,2] + `ln_csum` [N] = apply rstd (acc - mean c) before the bias."""
     _dev(a, "a"); _dev(w, "w")
     dt = dtype_code(w.dtype)
     if a.dtype != w.dtype:
@@ -121,8 +124,35 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None, *
         epi |= EPI_MISH
     if c_dtype == torch.float32 and dt != LA_F32:
         epi |= EPI_OUT_F32
+    if out16 is not None or ln_stats is not None:
+        if out16 is not None:
+            _dev(out16, "out16", w.dtype)
+            if c_dtype != torch.float32 or _capacity(out16) < (batch - 1) * stride_c + (M - 1) * ldc + N:
+                raise ValueError("gemm: out16 accompanies an f32 out of the same layout")
+        if ln_stats is not None:
+            _dev(ln_stats, "ln_stats", torch.float32); _dev(ln_csum, "ln_csum", torch.float32)
+            if ln_stats.numel() < 2 * M or ln_csum.numel() < N or batch != 1 or not ln_stats.is_contiguous():
+                raise ValueError("gemm: ln_stats [M,2] / ln_csum [N] expected (batch 1)")
+        check(lib().la_gemm_fused_ln(dt, M, N, K, batch, ptr(a), lda, stride_a, ptr(w), ptr(out), ldc, stride_c, ptr(bias),
+                                     ptr(residual), ldr or 0, stride_r, epi, ptr(out16), ldc, stride_c, ptr(ln_stats), ptr(ln_csum),
+                                     stream_ptr()), "gemm_fused_ln")
+        return out
     check(lib().la_gemm(dt, M, N, K, batch, ptr(a), lda, stride_a, ptr(w), ptr(out), ldc, stride_c, ptr(bias),
                         ptr(residual), ldr or 0, stride_r, epi, stream_ptr()), "gemm")
+    return out
+
+
+def row_stats16(x: torch.Tensor, out: Optional[torch.Tensor] = None, eps: float = 1e-5) -> torch.Tensor:
+    """x [M,d] bf16 / f16 rows -> [M,2] f32 (mean, 1/sqrt(var + eps)) per row (two-pass, biased variance like LayerNorm)."""
+    _dev(x, "x")
+    if x.dim() != 2 or x.stride(1) != 1 or x.dtype not in (torch.bfloat16, torch.float16):
+        raise ValueError("row_stats16: [M,d] 16-bit rows expected")
+    M, d = x.shape
+    if out is None:
+        out = torch.empty((M, 2), dtype=torch.float32, device=x.device)
+    if out.shape != (M, 2) or out.dtype != torch.float32 or not out.is_contiguous():
+        raise ValueError("row_stats16: bad out buffer")
+    check(lib().la_row_stats16(dtype_code(x.dtype), ptr(x), x.stride(0), M, d, float(eps), ptr(out), stream_ptr()), "row_stats16")
     return out
 
 

@@ -631,3 +631,38 @@ def test_head_chunking_for_huge_batches(monkeypatch):
         got = eng.align_mel(mel, labels, n_labels, n_frames=700)
     for r, g in zip(ref, got):
         assert torch.equal(r, g)
+
+
+def test_layernorm_folded_into_gemms_matches_separate_pass(monkeypatch):
+    """Encoder blocks at a size where every GEMM runs on the 256x256 kernel (d = 1024, 9 clips): the LayerNorm-folded path
+    (GEMMs that write the f32 residual stream also emit its bf16 copy, row statistics, rstd (acc - mean c) + b' epilogue on
+    gamma-folded weights) against the separate LayerNorm pass and against the float32 engine.  Same function, different
+    rounding points: the folded path must be as close to float32 as the separate pass is."""
+    from lyricalignment_amd import engine as eng_mod, whisper_compat as wc
+    dims = wc.ModelDimensions(n_audio_state=1024, n_audio_head=16, n_audio_layer=2, n_text_state=1024, n_text_head=16, n_text_layer=0)
+    wm = wc.build_model(dims=dims, seed=77, std=0.02)
+    with torch.no_grad():                                   # a mean offset and a few large channels in the residual stream
+        wm.encoder.conv2.bias.add_(0.3)
+        wm.encoder.conv2.bias[::97].mul_(8.0)
+    sd = {"encoder." + k: v for k, v in wm.encoder.state_dict().items()}
+    dev = torch.device("cuda")
+    e16 = eng_mod.AlignEngine(eng_mod.pack_encoder(sd, 16, torch.bfloat16, dev), None, dev)
+    e32 = eng_mod.AlignEngine(eng_mod.pack_encoder(sd, 16, torch.float32, dev), None, dev)
+    mel = torch.from_numpy(np.random.RandomState(78).uniform(-1, 1, size=(9, 80, 3000)).astype(np.float32)).cuda()
+    with torch.no_grad():
+        ref = e32.encode(mel).float().clone()
+        monkeypatch.setattr(eng_mod, "LN_FUSION", True)
+        fused = e16.encode(mel, out_dtype=torch.float32).clone()
+        monkeypatch.setattr(eng_mod, "LN_FUSION", False)
+        plain = e16.encode(mel, out_dtype=torch.float32).clone()
+    assert not torch.equal(fused, plain)                    # the folded path did run
+    err_f = (fused - ref).abs()
+    err_p = (plain - ref).abs()
+    assert float(err_p.max()) < 0.1 and float(err_f.max()) < 0.1
+    assert float(err_f.mean()) < 1.3 * float(err_p.mean()) + 1e-4, (float(err_f.mean()), float(err_p.mean()))
+    assert float(err_f.max()) < 1.5 * float(err_p.max()) + 1e-3, (float(err_f.max()), float(err_p.max()))
+    # fewer than 9 clips: the GEMMs leave the 256x256 kernel, encode() takes the separate pass by itself
+    monkeypatch.setattr(eng_mod, "LN_FUSION", True)
+    with torch.no_grad():
+        small = e16.encode(mel[:2], out_dtype=torch.float32)
+    assert torch.equal(small, plain[: 2 * 1500])

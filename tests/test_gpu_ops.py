@@ -247,3 +247,37 @@ def test_gru_handoff_under_uneven_load(wt):
         torch.cuda.synchronize()
         assert int(flag.item()) == 0
         assert torch.equal(out, ref), f"run {it}: hand-off delivered stale or torn data"
+
+
+def test_gemm_fused_layernorm_pieces():
+    """la_row_stats16 and the two faces of la_gemm_fused_ln against torch: (a) the 16-bit copy of an f32 result,
+    (b) LN(x) W^T + b computed from raw rows, gamma-folded weights, row statistics and column sums."""
+    from lyricalignment_amd import ops, _lib
+    M, d, N = 256 * 48 + 40, 1024, 1024                      # 49 x 4 tiles (>= 192: the 256x256 kernel), last row of tiles ragged
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(M, d, generator=g) * 1.5 + 0.4)
+    x[:, 7] *= 20.0
+    xb = x.bfloat16().cuda()
+    st = ops.row_stats16(xb).cpu()
+    xf = xb.float().cpu().double()
+    np.testing.assert_allclose(st[:, 0].numpy(), xf.mean(1).numpy(), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(st[:, 1].numpy(), (1.0 / torch.sqrt(xf.var(1, unbiased=False) + 1e-5)).numpy(), rtol=2e-5)
+    gamma = 1.0 + 0.1 * torch.randn(d, generator=g); beta = 0.1 * torch.randn(d, generator=g)
+    w = torch.randn(N, d, generator=g) * 0.03; b = torch.randn(N, generator=g) * 0.1
+    wl = (w.double() * gamma.double()[None, :]).bfloat16()
+    csum = wl.double().sum(1).float().cuda()
+    bl = (b.double() + w.double() @ beta.double()).float().cuda()
+    out = ops.gemm(xb, wl.cuda(), bias=bl, ln_stats=st.cuda(), ln_csum=csum, out_f32=True).cpu()
+    want = torch.nn.functional.layer_norm(xf, (d,), gamma.double(), beta.double(), 1e-5) @ w.double().T + b.double()
+    np.testing.assert_allclose(out.double().numpy(), want.numpy(), rtol=0, atol=3e-2)    # bf16 operands, |want| ~ 1
+    assert float((out.double() - want).abs().mean()) < 3e-3
+    # (a) producer face: f32 result + residual, and its bf16 copy
+    a = (torch.randn(M, d, generator=g) * 0.3).bfloat16().cuda()
+    res = torch.randn(M, N, generator=g).cuda()
+    c = res.clone(); c16 = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+    ops.gemm(a, wl.cuda(), c, bias=bl, residual=c, out_f32=True, out16=c16)
+    c_ref = ops.gemm(a, wl.cuda(), bias=bl, residual=res, out_f32=True)
+    assert torch.equal(c, c_ref) and torch.equal(c16, c_ref.bfloat16())
+    # shapes that do not run on the 256x256 kernel are refused loudly
+    with pytest.raises(NotImplementedError):
+        ops.gemm(xb[:300], wl.cuda(), bias=bl, ln_stats=st[:300].contiguous().cuda(), ln_csum=csum, out_f32=True)
