@@ -183,7 +183,9 @@ __global__ __launch_bounds__(CF::THREADS, 2) void gemm_kernel(GemmParams p) {
 }
 
 // 256x256 ping-pong kernel (bf16 operands only): same epilogue contract as gemm_kernel.
-template <bool OUT_F32, int DBG, typename T16>
+// LNM: 0 = plain; 1 = producer of the LayerNorm fold (second, 16-bit copy of the f32 rows); 2 = consumer (LayerNorm epilogue).
+// Separate instantiations: one body with run-time switches for all three spilled 40-48 VGPRs in every mode.
+template <bool OUT_F32, int DBG, typename T16, int LNM = 0>
 __global__ __launch_bounds__(PP::THREADS, 2) void gemm_pp_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int nwg = p.tiles_m * p.tiles_n;
@@ -195,6 +197,18 @@ __global__ __launch_bounds__(PP::THREADS, 2) void gemm_pp_kernel(GemmParams p) {
     const T16 *W = reinterpret_cast<const T16 *>(p.W) + (int64_t)z * p.strideW;
     const float *bias = p.bias ? p.bias + (int64_t)z * p.strideBias : nullptr;
 
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 2, wc = wave & 3;
+    const int r = lane & 15, q = lane >> 4;
+    const bool has_bias = (p.epilogue & LA_EPI_BIAS) && bias;
+    // Per-column epilogue operands are requested BEFORE the main loop, one column per lane (this wave's 64 columns), and
+    // handed to the accumulator layout with ds_bpermute afterwards: all eight waves reach the epilogue together, so a load
+    // issued there is a fully exposed L2 round trip per tile.
+    const int ncol = min(n0 + wc * 64 + lane, p.N - 1);
+    const float bias_l = has_bias ? bias[ncol] : 0.f;
+    float csum_l = 0.f;
+    if constexpr (LNM == 2) csum_l = p.ln_csum[ncol];
+
     f32x4 acc[8][4];
     if constexpr (DBG == 8 && std::is_same<T16, bf16_t>::value) mainloop_flat256(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
     else mainloop_pp<DBG, T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
@@ -202,13 +216,11 @@ __global__ __launch_bounds__(PP::THREADS, 2) void gemm_pp_kernel(GemmParams p) {
     typedef typename std::conditional<OUT_F32, float, T16>::type TC;
     TC *C = reinterpret_cast<TC *>(p.C) + (int64_t)z * p.strideC;
     const float *R = p.residual ? p.residual + (int64_t)z * p.strideR : nullptr;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wr = wave >> 2, wc = wave & 3;
-    const int r = lane & 15, q = lane >> 4;
-    const bool has_bias = (p.epilogue & LA_EPI_BIAS) && bias;
     const bool do_gelu = p.epilogue & LA_EPI_GELU;
     const bool do_res = (p.epilogue & LA_EPI_RESIDUAL) && R;
-    if (p.ln_stats) {
+    const int q16 = q * 16;                                   // byte address of lane 4q for ds_bpermute
+    auto lane_bcast = [](float v, int byte_addr) { return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_addr, __float_as_int(v))); };
+    if constexpr (LNM == 2) {
         // A held the RAW rows x (16-bit copy of the residual stream) and W the gamma-folded weights W' = gamma o W:
         // LN(x) W^T + b = rstd (x W'^T - mean c) + b'.  acc row = mi*16 + r, col = ni*16 + 4q + j.  Statistics, column sums
         // and bias are requested together (one exposed round trip per tile, not three) and applied as two FMAs per element.
@@ -218,34 +230,23 @@ __global__ __launch_bounds__(PP::THREADS, 2) void gemm_pp_kernel(GemmParams p) {
             const float2 st = reinterpret_cast<const float2 *>(p.ln_stats)[min(m0 + wr * 128 + mi * 16 + r, p.M - 1)];
             rs[mi] = st.y; bm[mi] = -st.x * st.y;
         }
-        float c4[4][4], b4[4][4];
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int n = min(n0 + wc * 64 + ni * 16 + q * 4 + j, p.N - 1);
-                c4[ni][j] = p.ln_csum[n];
-                b4[ni][j] = has_bias ? bias[n] : 0.f;
+                const float c = lane_bcast(csum_l, q16 + (ni * 16 + j) * 4), b = lane_bcast(bias_l, q16 + (ni * 16 + j) * 4);
+#pragma unroll
+                for (int mi = 0; mi < 8; ++mi) acc[mi][ni][j] = fmaf(acc[mi][ni][j], rs[mi], fmaf(bm[mi], c, b));
             }
+    } else if (has_bias) {
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-            for (int mi = 0; mi < 8; ++mi)
+            for (int j = 0; j < 4; ++j) {
+                const float b = lane_bcast(bias_l, q16 + (ni * 16 + j) * 4);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[mi][ni][j] = fmaf(acc[mi][ni][j], rs[mi], fmaf(bm[mi], c4[ni][j], b4[ni][j]));
-    } else
-    if (has_bias) {
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            const int n = n0 + wc * 64 + ni * 16 + q * 4;
-            float b4[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) b4[j] = bias[min(n + j, p.N - 1)];
-#pragma unroll
-            for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[mi][ni][j] += b4[j];
-        }
+                for (int mi = 0; mi < 8; ++mi) acc[mi][ni][j] += b;
+            }
     }
     if (do_gelu) {
 #pragma unroll
@@ -274,11 +275,9 @@ __global__ __launch_bounds__(PP::THREADS, 2) void gemm_pp_kernel(GemmParams p) {
     if (wrow0 + 128 <= p.M && wcol0 + 64 <= p.N && fast_c && (!do_res || fast_r)) {
         TC *cw = C + (int64_t)wrow0 * p.ldc + wcol0 + r * 4;
         const float *rw = do_res ? R + (int64_t)wrow0 * p.ldr + wcol0 + r * 4 : nullptr;
+        // producer: the 16-bit copy has the row pitch and batch stride of C (checked on the host), so one element offset serves both
         T16 *c2w = nullptr;
-        if constexpr (OUT_F32) {
-            if (p.C2 && (p.ldc2 % 4 == 0))
-                c2w = reinterpret_cast<T16 *>(p.C2) + (int64_t)z * p.strideC2 + (int64_t)wrow0 * p.ldc2 + wcol0 + r * 4;
-        }
+        if constexpr (LNM == 1 && OUT_F32) c2w = reinterpret_cast<T16 *>(p.C2) + (int64_t)z * p.strideC + (int64_t)wrow0 * p.ldc + wcol0 + r * 4;
         auto fast = [&](auto resc) {
             constexpr bool RES = decltype(resc)::value;
 #pragma unroll
@@ -298,10 +297,11 @@ __global__ __launch_bounds__(PP::THREADS, 2) void gemm_pp_kernel(GemmParams p) {
                     const int rl = it * 4 + q;
                     f32x4 v = *reinterpret_cast<const f32x4 *>(reg + rl * PITCH + r * 16);
                     if constexpr (RES) { v[0] += t[it].x; v[1] += t[it].y; v[2] += t[it].z; v[3] += t[it].w; }
-                    TC *c = cw + (int64_t)(h * 32 + rl) * p.ldc;
+                    const int64_t off = (int64_t)(h * 32 + rl) * p.ldc;
+                    TC *c = cw + off;
                     if constexpr (sizeof(TC) == 4) {
                         *reinterpret_cast<float4 *>(c) = make_float4(v[0], v[1], v[2], v[3]);
-                        if (c2w) *reinterpret_cast<ushort4 *>(c2w + (int64_t)(h * 32 + rl) * p.ldc2) = la::Pack4<T16>::run(v[0], v[1], v[2], v[3]);
+                        if constexpr (LNM == 1) *reinterpret_cast<ushort4 *>(c2w + off) = la::Pack4<T16>::run(v[0], v[1], v[2], v[3]);
                     } else {
                         *reinterpret_cast<ushort4 *>(c) = la::Pack4<TC>::run(v[0], v[1], v[2], v[3]);
                     }
@@ -312,9 +312,7 @@ __global__ __launch_bounds__(PP::THREADS, 2) void gemm_pp_kernel(GemmParams p) {
         return;
     }
     T16 *C2 = nullptr;
-    if constexpr (OUT_F32) {
-        if (p.C2) C2 = reinterpret_cast<T16 *>(p.C2) + (int64_t)z * p.strideC2;
-    }
+    if constexpr (LNM == 1 && OUT_F32) C2 = reinterpret_cast<T16 *>(p.C2) + (int64_t)z * p.strideC;
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
 #pragma unroll
@@ -349,13 +347,14 @@ __global__ __launch_bounds__(PP::THREADS, 2) void gemm_pp_kernel(GemmParams p) {
             } else {
                 for (int j = 0; j < nv; ++j) la::Elem<TC>::store(c + j, v[j]);
             }
-            if (C2)
-                for (int j = 0; j < nv; ++j) la::Elem<T16>::store(C2 + (int64_t)m * p.ldc2 + n + j, v[j]);
+            if constexpr (LNM == 1) {
+                for (int j = 0; j < nv; ++j) la::Elem<T16>::store(C2 + (int64_t)m * p.ldc + n + j, v[j]);
+            }
         }
     }
 }
 
-template <bool OUT_F32, int DBG, typename T16>
+template <bool OUT_F32, int DBG, typename T16, int LNM = 0>
 int launch_pp_dbg(GemmParams p, int batch, hipStream_t stream);
 
 template <bool OUT_F32, typename T16>
@@ -371,12 +370,16 @@ int launch_pp(GemmParams p, int batch, hipStream_t stream) {
             default: break;
         }
     }
+    if (p.ln_stats) return launch_pp_dbg<OUT_F32, 0, T16, 2>(p, batch, stream);
+    if constexpr (OUT_F32) {
+        if (p.C2) return launch_pp_dbg<OUT_F32, 0, T16, 1>(p, batch, stream);
+    }
     return launch_pp_dbg<OUT_F32, 0, T16>(p, batch, stream);
 }
 
-template <bool OUT_F32, int DBG, typename T16>
+template <bool OUT_F32, int DBG, typename T16, int LNM>
 int launch_pp_dbg(GemmParams p, int batch, hipStream_t stream) {
-    auto kern = gemm_pp_kernel<OUT_F32, DBG, T16>;
+    auto kern = gemm_pp_kernel<OUT_F32, DBG, T16, LNM>;
     static bool attr_done = false;
     if (!attr_done) {
         LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, PP::LDS));
@@ -473,7 +476,9 @@ static int gemm_run_ldw(int dtype, int M, int N, int K, int batch, const void *A
                 la::set_error("gemm_fused_ln: shape M=%d N=%d batch=%d does not run on the 256x256 kernel the fusion is built into", M, N, batch);
                 return LA_EUNSUPPORTED;
             }
-            LA_CHECK_ARG(!ln->C2 || (out_f32 && ln->ldc2 >= N), "gemm_fused_ln: the 16-bit copy accompanies an f32 result");
+            LA_CHECK_ARG(!ln->C2 || (out_f32 && ln->ldc2 == ldc && ln->strideC2 == strideC && ldc % 4 == 0 && (uintptr_t)ln->C2 % 8 == 0),
+                         "gemm_fused_ln: the 16-bit copy accompanies an f32 result and shares its row pitch / batch stride");
+            LA_CHECK_ARG(!(ln->C2 && ln->stats), "gemm_fused_ln: a GEMM is the producer or the consumer of a folded LayerNorm, not both");
             LA_CHECK_ARG((ln->stats == nullptr) == (ln->csum == nullptr), "gemm_fused_ln: stats and csum go together");
             LA_CHECK_ARG(!ln->stats || batch == 1, "gemm_fused_ln: the LayerNorm epilogue takes batch 1");
             p.C2 = ln->C2; p.ldc2 = ln->ldc2; p.strideC2 = ln->strideC2; p.ln_stats = ln->stats; p.ln_csum = ln->csum;
