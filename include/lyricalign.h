@@ -327,7 +327,7 @@ int la_mask_scale_f32(const float *x, const unsigned char *mask, float scale, fl
  * In the 16-bit modes, for shapes that run on the 256x256 kernel:
  *   producer  (la_gemm_fused_ln with C2 != NULL, LA_EPI_OUT_F32): the GEMM that writes the f32 residual stream also stores
  *             the same rows rounded to `dtype` into C2 [M][ldc2] -- the RAW operand of the next GEMM;
- *   la_row_stats16: stats[m] = (mean, 1/sqrt(var + eps)) of those raw rows;
+ *   la_row_stats16 (or ln_part + la_ln_stats_finalize): stats[m] = (mean, 1/sqrt(var + eps)) of those raw rows;
  *   consumer  (ln_stats != NULL): A = raw rows, W = gamma-folded weights W'[n][k] = gamma[k] W[n][k], ln_csum[n] = sum_k W'[n][k],
  *             bias[n] = b[n] + sum_k beta[k] W[n][k]:   LN(x) W^T + b = rstd (x W'^T - mean c) + bias.
  * Replaces the separate LayerNorm pass (read f32, write 16-bit) between them.  LA_EUNSUPPORTED for f32 and for shapes
@@ -336,7 +336,11 @@ int la_mask_scale_f32(const float *x, const unsigned char *mask, float scale, fl
 int la_gemm_fused_ln(int32_t dtype, int32_t M, int32_t N, int32_t K, int32_t batch, const void *A, int64_t lda, int64_t strideA,
                      const void *W, void *C, int64_t ldc, int64_t strideC, const float *bias, const float *residual, int64_t ldr,
                      int64_t strideR, int32_t epilogue, void *C2, int64_t ldc2, int64_t strideC2, const float *ln_stats,
-                     const float *ln_csum, void *stream);
+                     const float *ln_csum, float *ln_part, void *stream);
+/* producer with ln_part != NULL (N % 64 == 0): also stores, per row and 64-column segment of the 16-bit copy, (mean, sum of
+ * squared deviations) into ln_part [N/64][M][2]; la_ln_stats_finalize combines them into stats [M][2] = (mean, rstd) --
+ * the same numbers la_row_stats16 computes, without reading the copy back. */
+int la_ln_stats_finalize(const float *part, int32_t slots, int32_t M, float eps, float *stats, void *stream);
 int la_row_stats16(int32_t dtype, const void *x, int64_t ldx, int32_t M, int32_t d, float eps, float *stats, void *stream);
 
 /* Backward-pass building blocks of the Whisper encoder (float32): la_gemm with a row pitch for W and per-batch strides

@@ -31,6 +31,8 @@ struct GemmParams {
     int64_t ldc2 = 0, strideC2 = 0;
     const float *ln_stats = nullptr;   // consumer: per-row (mean, rstd) of the raw A rows, [M][2]
     const float *ln_csum = nullptr;    // consumer: c[n] = sum_k W'[n][k] of the gamma-folded weights, [N]
+    float *ln_part = nullptr;          // producer (optional): per-row partial statistics of the 16-bit copy, [N/64][M][2] =
+                                       // (mean, sum of squared deviations) of each 64-column segment (la_ln_stats_finalize)
 };
 
 template <typename T, bool OUT_F32, typename CF>
@@ -183,6 +185,28 @@ __global__ __launch_bounds__(CF::THREADS, 2) void gemm_kernel(GemmParams p) {
 }
 
 // 256x256 ping-pong kernel (bf16 operands only): same epilogue contract as gemm_kernel.
+// sum over the 16 lanes of a DPP row (every lane of the row gets it): quad_perm [1,0,3,2], [2,3,0,1], row_ror 4, row_ror 8
+__device__ __forceinline__ float row16_sum(float x) {
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xf, 0xf, true));
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xf, 0xf, true));
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x124, 0xf, 0xf, true));
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xf, 0xf, true));
+    return x;
+}
+__device__ __forceinline__ float half_bits_to_f32(unsigned short b, bf16_t) { return __uint_as_float((unsigned)b << 16); }
+__device__ __forceinline__ float half_bits_to_f32(unsigned short b, la::f16_t) { return (float)__builtin_bit_cast(_Float16, b); }
+
+// Partial LayerNorm statistics of one 64-column row segment held by the 16 lanes of a DPP row (4 columns each), taken from
+// the ROUNDED values the next GEMM will read: exact two-pass inside the segment (mean, then squared deviations).
+template <typename T16>
+__device__ __forceinline__ float2 segment_stats(const ushort4 pk) {
+    const float e0 = half_bits_to_f32(pk.x, T16{}), e1 = half_bits_to_f32(pk.y, T16{}), e2 = half_bits_to_f32(pk.z, T16{}),
+                e3 = half_bits_to_f32(pk.w, T16{});
+    const float mean = row16_sum((e0 + e1) + (e2 + e3)) * (1.0f / 64.0f);
+    const float d0 = e0 - mean, d1 = e1 - mean, d2 = e2 - mean, d3 = e3 - mean;
+    return make_float2(mean, row16_sum(fmaf(d0, d0, d1 * d1) + fmaf(d2, d2, d3 * d3)));
+}
+
 // LNM: 0 = plain; 1 = producer of the LayerNorm fold (second, 16-bit copy of the f32 rows); 2 = consumer (LayerNorm epilogue).
 // Separate instantiations: one body with run-time switches for all three spilled 40-48 VGPRs in every mode.
 template <bool OUT_F32, int DBG, typename T16, int LNM = 0>
@@ -277,7 +301,11 @@ __global__ __launch_bounds__(PP::THREADS, 2) void gemm_pp_kernel(GemmParams p) {
         const float *rw = do_res ? R + (int64_t)wrow0 * p.ldr + wcol0 + r * 4 : nullptr;
         // producer: the 16-bit copy has the row pitch and batch stride of C (checked on the host), so one element offset serves both
         T16 *c2w = nullptr;
-        if constexpr (LNM == 1 && OUT_F32) c2w = reinterpret_cast<T16 *>(p.C2) + (int64_t)z * p.strideC + (int64_t)wrow0 * p.ldc + wcol0 + r * 4;
+        float2 *part = nullptr;            // this wave's 128 rows of segment (wcol0 / 64): [N/64][M] (mean, M2) pairs
+        if constexpr (LNM == 1 && OUT_F32) {
+            c2w = reinterpret_cast<T16 *>(p.C2) + (int64_t)z * p.strideC + (int64_t)wrow0 * p.ldc + wcol0 + r * 4;
+            if (p.ln_part) part = reinterpret_cast<float2 *>(p.ln_part) + (int64_t)(wcol0 >> 6) * p.M + wrow0;
+        }
         auto fast = [&](auto resc) {
             constexpr bool RES = decltype(resc)::value;
 #pragma unroll
@@ -301,7 +329,14 @@ __global__ __launch_bounds__(PP::THREADS, 2) void gemm_pp_kernel(GemmParams p) {
                     TC *c = cw + off;
                     if constexpr (sizeof(TC) == 4) {
                         *reinterpret_cast<float4 *>(c) = make_float4(v[0], v[1], v[2], v[3]);
-                        if constexpr (LNM == 1) *reinterpret_cast<ushort4 *>(c2w + off) = la::Pack4<T16>::run(v[0], v[1], v[2], v[3]);
+                        if constexpr (LNM == 1) {
+                            const ushort4 pk = la::Pack4<T16>::run(v[0], v[1], v[2], v[3]);
+                            *reinterpret_cast<ushort4 *>(c2w + off) = pk;
+                            if (part) {
+                                const float2 st = segment_stats<T16>(pk);
+                                if (r == 0) part[h * 32 + rl] = st;
+                            }
+                        }
                     } else {
                         *reinterpret_cast<ushort4 *>(c) = la::Pack4<TC>::run(v[0], v[1], v[2], v[3]);
                     }
@@ -349,6 +384,10 @@ __global__ __launch_bounds__(PP::THREADS, 2) void gemm_pp_kernel(GemmParams p) {
             }
             if constexpr (LNM == 1) {
                 for (int j = 0; j < nv; ++j) la::Elem<T16>::store(C2 + (int64_t)m * p.ldc + n + j, v[j]);
+                if (p.ln_part) {                             // N % 64 == 0 on this path (host check): the 16 lanes of the row are all here
+                    const float2 st = segment_stats<T16>(la::Pack4<T16>::run(v[0], v[1], v[2], v[3]));
+                    if (r == 0) reinterpret_cast<float2 *>(p.ln_part)[(int64_t)(wcol0 >> 6) * p.M + m] = st;
+                }
             }
         }
     }
@@ -442,7 +481,25 @@ __global__ void splitk_reduce_kernel(const float *P, int S, int M, int N, float 
 struct LnFuse {
     void *C2; int64_t ldc2, strideC2;
     const float *stats, *csum;
+    float *part;
 };
+
+// Row statistics from the producers' per-segment partials (Chan et al. combination of equal-sized groups):
+// mean = avg(mean_k), M2 = sum(M2_k) + 64 sum((mean_k - mean)^2), rstd = 1 / sqrt(M2 / (64 slots) + eps).
+__global__ void ln_stats_finalize_kernel(const float2 *part, int slots, int M, float eps, float2 *stats) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= M) return;
+    float mean = 0.f;
+    for (int k = 0; k < slots; ++k) mean += part[(int64_t)k * M + row].x;
+    mean /= (float)slots;
+    float m2 = 0.f;
+    for (int k = 0; k < slots; ++k) {
+        const float2 pk = part[(int64_t)k * M + row];
+        const float d = pk.x - mean;
+        m2 += pk.y + 64.0f * d * d;
+    }
+    stats[row] = make_float2(mean, 1.0f / sqrtf(m2 / (64.0f * (float)slots) + eps));
+}
 
 static int gemm_run_ldw(int dtype, int M, int N, int K, int batch, const void *A, int64_t lda, int64_t strideA, const void *W,
                         int64_t ldw_arg, int64_t strideW, void *C, int64_t ldc, int64_t strideC, const float *bias, int64_t strideBias,
@@ -481,7 +538,9 @@ static int gemm_run_ldw(int dtype, int M, int N, int K, int batch, const void *A
             LA_CHECK_ARG(!(ln->C2 && ln->stats), "gemm_fused_ln: a GEMM is the producer or the consumer of a folded LayerNorm, not both");
             LA_CHECK_ARG((ln->stats == nullptr) == (ln->csum == nullptr), "gemm_fused_ln: stats and csum go together");
             LA_CHECK_ARG(!ln->stats || batch == 1, "gemm_fused_ln: the LayerNorm epilogue takes batch 1");
-            p.C2 = ln->C2; p.ldc2 = ln->ldc2; p.strideC2 = ln->strideC2; p.ln_stats = ln->stats; p.ln_csum = ln->csum;
+            LA_CHECK_ARG(!ln->part || (ln->C2 && N % 64 == 0 && batch == 1 && (uintptr_t)ln->part % 8 == 0),
+                         "gemm_fused_ln: partial statistics go with the 16-bit copy, N % 64 == 0, batch 1");
+            p.C2 = ln->C2; p.ldc2 = ln->ldc2; p.strideC2 = ln->strideC2; p.ln_stats = ln->stats; p.ln_csum = ln->csum; p.ln_part = ln->part;
         }
         if (pp && !(epilogue & LA_EPI_MISH)) {
             if (half) return out_f32 ? launch_pp<true, la::f16_t>(p, batch, stream) : launch_pp<false, la::f16_t>(p, batch, stream);
@@ -527,15 +586,26 @@ static int gemm_run_ldw(int dtype, int M, int N, int K, int batch, const void *A
 extern "C" int la_gemm_fused_ln(int32_t dtype, int32_t M, int32_t N, int32_t K, int32_t batch, const void *A, int64_t lda,
                                 int64_t strideA, const void *W, void *C, int64_t ldc, int64_t strideC, const float *bias,
                                 const float *residual, int64_t ldr, int64_t strideR, int32_t epilogue, void *C2, int64_t ldc2,
-                                int64_t strideC2, const float *ln_stats, const float *ln_csum, void *stream_) {
+                                int64_t strideC2, const float *ln_stats, const float *ln_csum, float *ln_part, void *stream_) {
     if (dtype != LA_BF16 && dtype != LA_F16) {
         la::set_error("gemm_fused_ln: 16-bit compute dtypes only");
         return LA_EUNSUPPORTED;
     }
     LA_CHECK_ARG(C2 || ln_stats, "gemm_fused_ln: neither a second output nor row statistics given");
-    const LnFuse ln{C2, ldc2, strideC2, ln_stats, ln_csum};
+    const LnFuse ln{C2, ldc2, strideC2, ln_stats, ln_csum, ln_part};
     return gemm_run_ldw(dtype, M, N, K, batch, A, lda, strideA, W, 0, 0, C, ldc, strideC, bias, 0, residual, ldr, strideR, epilogue,
                         (hipStream_t)stream_, &ln);
+}
+
+extern "C" int la_ln_stats_finalize(const float *part, int32_t slots, int32_t M, float eps, float *stats, void *stream_) {
+    if (M == 0) return LA_OK;
+    LA_CHECK_ARG(part && stats && slots > 0 && M > 0, "ln_stats_finalize: bad arguments");
+    hipStream_t stream = (hipStream_t)stream_;
+    la::TimerScope ts("layernorm", stream);
+    hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3(la::cdiv(M, 256)), dim3(256), 0, stream, reinterpret_cast<const float2 *>(part), slots, M,
+                       eps, reinterpret_cast<float2 *>(stats));
+    LA_LAUNCH_CHECK();
+    return LA_OK;
 }
 
 int la::gemm_run(int dtype, int M, int N, int K, int batch, const void *A, int64_t lda, int64_t strideA, const void *W,

@@ -31,6 +31,10 @@ N_FRAMES = 3000   # whisper.audio.N_FRAMES
 N_CTX = 1500      # encoder positions
 C_PAD = 128       # mel channels padded so 3*C is a multiple of the GEMM K tile
 LN_FUSION = os.environ.get("LA_LN_FUSION", "1") != "0"   # developer switch: 0 = always the separate LayerNorm pass
+# Row statistics of the folded LayerNorm: "pass" (default) = row_stats16 reads the bf16 copy back (98 MB, 21 us);
+# "epilogue" = the producer GEMM takes them per 64-column segment while the rows pass through its registers + a finalize
+# kernel.  Measured in the pipeline: the epilogue form costs the residual GEMMs more (+0.7 ms) than the pass it removes.
+LN_STATS_IN_EPILOGUE = os.environ.get("LA_LN_STATS", "pass") == "epilogue"
 HEAD_CLIPS_MAX = 256   # clips per head launch set (GRU: 16 workgroup groups of 16 clips co-resident = 192 CUs, out buffer < 2 GiB)
 
 
@@ -253,14 +257,16 @@ class AlignEngine:
                  stride_a=(N_FRAMES + 2) * d, stride_c=N_CTX * d, ldc=d, ldr=d, stride_r=0, out16=h if fused else None)
         if fused:
             stats = self._get("ln_stats", (M, 2), torch.float32)
+            part = self._get("ln_part", (d // 64, M, 2), torch.float32) if (LN_STATS_IN_EPILOGUE and d % 64 == 0) else None
+            ops.row_stats16(h, out=stats)                                                     # of the stem's output (batched GEMM)
             for blk in e.blocks:
-                ops.row_stats16(h, out=stats)
                 ops.gemm(h, blk.wqkv_ln, qkv, bias=blk.bqkv_ln, ln_stats=stats, ln_csum=blk.cqkv)
                 ops.attention(qkv, B, N_CTX, e.n_head, out=att)
-                ops.gemm(att, blk.wo, x, bias=blk.bo, residual=x, out_f32=True, out16=h)     # x += out-proj; h = bf16(x)
-                ops.row_stats16(h, out=stats)
+                ops.gemm(att, blk.wo, x, bias=blk.bo, residual=x, out_f32=True, out16=h, ln_part=part)   # x += out-proj; h = bf16(x)
+                ops.ln_stats_finalize(part, out=stats) if part is not None else ops.row_stats16(h, out=stats)
                 ops.gemm(h, blk.w1_ln, u, bias=blk.b1_ln, gelu=True, ln_stats=stats, ln_csum=blk.c1)
-                ops.gemm(u, blk.w2, x, bias=blk.b2, residual=x, out_f32=True, out16=h)       # x += mlp; h = bf16(x)
+                ops.gemm(u, blk.w2, x, bias=blk.b2, residual=x, out_f32=True, out16=h, ln_part=part)     # x += mlp; h = bf16(x)
+                ops.ln_stats_finalize(part, out=stats) if part is not None else ops.row_stats16(h, out=stats)
         for blk in (() if fused else e.blocks):
             ops.layernorm(x, blk.ln1_g, blk.ln1_b, dt, out=h)
             ops.gemm(h, blk.wqkv, qkv, bias=blk.bqkv)

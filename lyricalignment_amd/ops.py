@@ -78,11 +78,13 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None, *
          residual: Optional[torch.Tensor] = None, gelu: bool = False, mish: bool = False, out_f32: bool = False,
          M: Optional[int] = None, lda: Optional[int] = None, batch: int = 1, stride_a: int = 0, stride_c: int = 0,
          stride_r: int = 0, ldc: Optional[int] = None, ldr: Optional[int] = None, out16: Optional[torch.Tensor] = None,
-         ln_stats: Optional[torch.Tensor] = None, ln_csum: Optional[torch.Tensor] = None) -> torch.Tensor:
+         ln_stats: Optional[torch.Tensor] = None, ln_csum: Optional[torch.Tensor] = None,
+         ln_part: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[z][m][n] = epi(sum_k a[z][m][k] w[n][k]).  `a` may be a flat buffer addressed through
     (M, lda, stride_a): that is how the conv-as-GEMM views (overlapping rows) are expressed.
     LayerNorm folded into the neighbouring GEMMs (la_gemm_fused_ln): `out16` = a second, 16-bit copy of the f32 result rows
-    (same row pitch / batch stride as out); `ln_stats` [M,2] + `ln_csum` [N] = apply rstd (acc - mean c) before the bias."""
+    (same row pitch / batch stride as out), `ln_part` [N/64, M, 2] = also its per-segment partial row statistics
+    (ln_stats_finalize turns them into [M,2]); `ln_stats` [M,2] + `ln_csum` [N] = apply rstd (acc - mean c) before the bias."""
     _dev(a, "a"); _dev(w, "w")
     dt = dtype_code(w.dtype)
     if a.dtype != w.dtype:
@@ -129,16 +131,34 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None, *
             _dev(out16, "out16", w.dtype)
             if c_dtype != torch.float32 or _capacity(out16) < (batch - 1) * stride_c + (M - 1) * ldc + N:
                 raise ValueError("gemm: out16 accompanies an f32 out of the same layout")
+        if ln_part is not None:
+            _dev(ln_part, "ln_part", torch.float32)
+            if out16 is None or N % 64 or ln_part.numel() < (N // 64) * M * 2 or not ln_part.is_contiguous():
+                raise ValueError("gemm: ln_part [N/64, M, 2] goes with out16, N % 64 == 0")
         if ln_stats is not None:
             _dev(ln_stats, "ln_stats", torch.float32); _dev(ln_csum, "ln_csum", torch.float32)
             if ln_stats.numel() < 2 * M or ln_csum.numel() < N or batch != 1 or not ln_stats.is_contiguous():
                 raise ValueError("gemm: ln_stats [M,2] / ln_csum [N] expected (batch 1)")
         check(lib().la_gemm_fused_ln(dt, M, N, K, batch, ptr(a), lda, stride_a, ptr(w), ptr(out), ldc, stride_c, ptr(bias),
                                      ptr(residual), ldr or 0, stride_r, epi, ptr(out16), ldc, stride_c, ptr(ln_stats), ptr(ln_csum),
-                                     stream_ptr()), "gemm_fused_ln")
+                                     ptr(ln_part), stream_ptr()), "gemm_fused_ln")
         return out
     check(lib().la_gemm(dt, M, N, K, batch, ptr(a), lda, stride_a, ptr(w), ptr(out), ldc, stride_c, ptr(bias),
                         ptr(residual), ldr or 0, stride_r, epi, stream_ptr()), "gemm")
+    return out
+
+
+def ln_stats_finalize(part: torch.Tensor, out: Optional[torch.Tensor] = None, eps: float = 1e-5) -> torch.Tensor:
+    """part [slots, M, 2] (mean, sum of squared deviations) of 64-column row segments -> [M,2] (mean, 1/sqrt(var + eps))."""
+    _dev(part, "part", torch.float32)
+    if part.dim() != 3 or part.shape[2] != 2 or not part.is_contiguous():
+        raise ValueError("ln_stats_finalize: [slots, M, 2] expected")
+    slots, M, _ = part.shape
+    if out is None:
+        out = torch.empty((M, 2), dtype=torch.float32, device=part.device)
+    if out.shape != (M, 2) or out.dtype != torch.float32 or not out.is_contiguous():
+        raise ValueError("ln_stats_finalize: bad out buffer")
+    check(lib().la_ln_stats_finalize(ptr(part), slots, M, float(eps), ptr(out), stream_ptr()), "ln_stats_finalize")
     return out
 
 

@@ -652,7 +652,12 @@ def test_layernorm_folded_into_gemms_matches_separate_pass(monkeypatch):
     with torch.no_grad():
         ref = e32.encode(mel).float().clone()
         monkeypatch.setattr(eng_mod, "LN_FUSION", True)
+        monkeypatch.setattr(eng_mod, "LN_STATS_IN_EPILOGUE", True)
         fused = e16.encode(mel, out_dtype=torch.float32).clone()
+        monkeypatch.setattr(eng_mod, "LN_STATS_IN_EPILOGUE", False)          # statistics by a separate read of the bf16 copy
+        fused_pass = e16.encode(mel, out_dtype=torch.float32).clone()
+        assert float((fused - fused_pass).abs().max()) < 2e-2
+        monkeypatch.setattr(eng_mod, "LN_STATS_IN_EPILOGUE", True)
         monkeypatch.setattr(eng_mod, "LN_FUSION", False)
         plain = e16.encode(mel, out_dtype=torch.float32).clone()
     assert not torch.equal(fused, plain)                    # the folded path did run

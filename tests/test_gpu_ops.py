@@ -278,6 +278,13 @@ def test_gemm_fused_layernorm_pieces():
     ops.gemm(a, wl.cuda(), c, bias=bl, residual=c, out_f32=True, out16=c16)
     c_ref = ops.gemm(a, wl.cuda(), bias=bl, residual=res, out_f32=True)
     assert torch.equal(c, c_ref) and torch.equal(c16, c_ref.bfloat16())
+    # ... and the copy's row statistics taken inside that epilogue (per 64-column segment) + finalize == a read of the copy
+    c = res.clone(); part = torch.full((N // 64, M, 2), float("nan"), device="cuda")
+    ops.gemm(a, wl.cuda(), c, bias=bl, residual=c, out_f32=True, out16=c16, ln_part=part)
+    assert torch.equal(c, c_ref) and torch.equal(c16, c_ref.bfloat16()) and bool(torch.isfinite(part).all())
+    st_e = ops.ln_stats_finalize(part).cpu(); st_p = ops.row_stats16(c16).cpu()
+    np.testing.assert_allclose(st_e[:, 0].numpy(), st_p[:, 0].numpy(), rtol=0, atol=1e-5)
+    np.testing.assert_allclose(st_e[:, 1].numpy(), st_p[:, 1].numpy(), rtol=2e-5)
     # shapes that do not run on the 256x256 kernel are refused loudly
     with pytest.raises(NotImplementedError):
         ops.gemm(xb[:300], wl.cuda(), bias=bl, ln_stats=st[:300].contiguous().cuda(), ln_csum=csum, out_f32=True)
