@@ -117,7 +117,7 @@ def pack_encoder(sd: Dict[str, torch.Tensor], n_head: int, dtype: torch.dtype, d
             _f32(g(b + "mlp_ln.weight"), device), _f32(g(b + "mlp_ln.bias"), device),
             g(b + "mlp.0.weight").detach().to(device=device, dtype=dtype).contiguous(), _f32(g(b + "mlp.0.bias"), device),
             g(b + "mlp.2.weight").detach().to(device=device, dtype=dtype).contiguous(), _f32(g(b + "mlp.2.bias"), device))
-        if dtype == torch.bfloat16:
+        if dtype in (torch.bfloat16, torch.float16):
             blk.wqkv_ln, blk.cqkv, blk.bqkv_ln = _fold_ln(wqkv, bqkv, g(b + "attn_ln.weight"), g(b + "attn_ln.bias"), dtype, device)
             blk.w1_ln, blk.c1, blk.b1_ln = _fold_ln(g(b + "mlp.0.weight"), g(b + "mlp.0.bias"), g(b + "mlp_ln.weight"),
                                                     g(b + "mlp_ln.bias"), dtype, device)
@@ -250,8 +250,9 @@ class AlignEngine:
         # LayerNorm folded into the GEMMs around it: the GEMMs that write the f32 residual stream x also store it rounded to
         # bf16 (h = raw x), a small kernel takes the row statistics of h, and the QKV / MLP-up GEMMs apply
         # rstd (acc - mean c) + b' in their epilogue on gamma-folded weights.  Only where every GEMM of a block runs on the
-        # 256x256 kernel (>= 192 tiles, i.e. >= 9 clips at d = 1024) and in bfloat16; otherwise the separate LayerNorm pass.
-        fused = (LN_FUSION and dt == torch.bfloat16 and e.blocks and e.blocks[0].wqkv_ln is not None and d > 128
+        # 256x256 kernel (>= 192 tiles, i.e. >= 9 clips at d = 1024) and in the 16-bit modes (float16: the raw stream must stay
+        # below 65504, as it must for whisper's own fp16 inference); otherwise the separate LayerNorm pass.
+        fused = (LN_FUSION and dt in (torch.bfloat16, torch.float16) and e.blocks and e.blocks[0].wqkv_ln is not None and d > 128
                  and -(-M // 256) * -(-d // 256) >= 192 and -(-N_CTX // 256) * -(-d // 256) * B >= 192)
         ops.gemm(y1, e.conv2_w, x, bias=e.conv2_b, gelu=True, residual=e.pos, out_f32=True, M=N_CTX, lda=2 * d, batch=B,
                  stride_a=(N_FRAMES + 2) * d, stride_c=N_CTX * d, ldc=d, ldr=d, stride_r=0, out16=h if fused else None)

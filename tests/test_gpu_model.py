@@ -633,7 +633,8 @@ def test_head_chunking_for_huge_batches(monkeypatch):
         assert torch.equal(r, g)
 
 
-def test_layernorm_folded_into_gemms_matches_separate_pass(monkeypatch):
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_layernorm_folded_into_gemms_matches_separate_pass(monkeypatch, dtype):
     """Encoder blocks at a size where every GEMM runs on the 256x256 kernel (d = 1024, 9 clips): the LayerNorm-folded path
     (GEMMs that write the f32 residual stream also emit its bf16 copy, row statistics, rstd (acc - mean c) + b' epilogue on
     gamma-folded weights) against the separate LayerNorm pass and against the float32 engine.  Same function, different
@@ -646,7 +647,7 @@ def test_layernorm_folded_into_gemms_matches_separate_pass(monkeypatch):
         wm.encoder.conv2.bias[::97].mul_(8.0)
     sd = {"encoder." + k: v for k, v in wm.encoder.state_dict().items()}
     dev = torch.device("cuda")
-    e16 = eng_mod.AlignEngine(eng_mod.pack_encoder(sd, 16, torch.bfloat16, dev), None, dev)
+    e16 = eng_mod.AlignEngine(eng_mod.pack_encoder(sd, 16, dtype, dev), None, dev)
     e32 = eng_mod.AlignEngine(eng_mod.pack_encoder(sd, 16, torch.float32, dev), None, dev)
     mel = torch.from_numpy(np.random.RandomState(78).uniform(-1, 1, size=(9, 80, 3000)).astype(np.float32)).cuda()
     with torch.no_grad():
