@@ -480,7 +480,7 @@ struct GruBwdParams {
 // Backward recurrence dh_{t-1} = dh_t * z_t + dgh_t W_hh: the contraction runs over all 3H gate units, so (as in the
 // forward kernel) the H hidden units are split over workgroups, each wave keeps its 16 columns of W_hh (as W_hh^T rows,
 // [16][3H] f32 = 72 KiB) resident in LDS, and dgh of the previous step is exchanged through HBM with the same
-// release / acquire hand-off.  2 waves per workgroup, H/32 workgroups per direction.
+// write-through (sc1) hand-off.  2 waves per workgroup, H/32 workgroups per direction.
 template <int MT>
 __global__ __launch_bounds__(128, 1) void gru_bwd_kernel(GruBwdParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -510,6 +510,9 @@ __global__ __launch_bounds__(128, 1) void gru_bwd_kernel(GruBwdParams p) {
     const unsigned char *wl = lds + 16 + (int64_t)(wave * 16) * row_bytes;
     unsigned *ctr = p.counters + ((int64_t)group * 2 + dir) * T_;
     const int64_t g4 = 4 * (int64_t)H, g3 = 3 * (int64_t)H;
+    // write-through hand-off of dgh (as in the forward kernel): sc1 stores, drained, relaxed counter, sc1 loads -- no fences
+    const __amdgpu_buffer_rsrc_t dgh_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        p.dgh, 0, (int)((int64_t)p.B * T_ * 2 * g3 * 4), 0x00020000);
 
     float carry[MT][4];   // dh_t * z_t of the step processed before (the direct path of the recurrence)
 #pragma unroll
@@ -543,8 +546,6 @@ __global__ __launch_bounds__(128, 1) void gru_bwd_kernel(GruBwdParams p) {
         if (step > 0) {
             if (tid == 0) {
                 const bool ok = wait_counter(ctr + (step - 1), (unsigned)p.nsplit, p.abort_flag);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 *ok_s = ok ? 1 : 0;
             }
             __syncthreads();
@@ -552,17 +553,19 @@ __global__ __launch_bounds__(128, 1) void gru_bwd_kernel(GruBwdParams p) {
             if (!alive) break;
             // dgh of the step before, 12 k-steps (12 x MT fragments) requested at a time: with one fragment per iteration the
             // loop was 3H/16 = 72 dependent L2 round trips per step (the whole 22.7 us of it).  3H/16 = 12 (H/64).
-            const unsigned char *arow_ptr[MT];
+            int arow_off[MT];            // byte offsets into dgh
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-                arow_ptr[mt] = reinterpret_cast<const unsigned char *>(p.dgh + (((int64_t)arow[mt] * T_ + tnext) * 2 + dir) * g3) + q * 16;
+            for (int mt = 0; mt < MT; ++mt) arow_off[mt] = (int)(((((int64_t)arow[mt] * T_ + tnext) * 2 + dir) * g3) * 4) + q * 16;
             for (int kb = 0; kb < nks; kb += 12) {
                 uint4 a[12][MT];
 #pragma unroll
                 for (int u = 0; u < 12; ++u)
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-                        a[u][mt] = *reinterpret_cast<const uint4 *>(arow_ptr[mt] + (kb + u) * 64);
+                    for (int mt = 0; mt < MT; ++mt) {
+                        typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+                        const u32x4 t4 = __builtin_amdgcn_raw_buffer_load_b128(dgh_rsrc, arow_off[mt] + (kb + u) * 64, 0, 16 /* sc1 */);
+                        a[u][mt] = make_uint4(t4[0], t4[1], t4[2], t4[3]);
+                    }
 #pragma unroll
                 for (int u = 0; u < 12; ++u) {
                     const int ks = kb + u;
@@ -586,18 +589,16 @@ __global__ __launch_bounds__(128, 1) void gru_bwd_kernel(GruBwdParams p) {
                 carry[mt][i] = dh * z;
                 if (bl < nb) {
                     float *o1 = p.dgi + (((int64_t)b * T_ + t) * 2 + dir) * g3 + kcol;
-                    float *o2 = p.dgh + (((int64_t)b * T_ + t) * 2 + dir) * g3 + kcol;
+                    const int o2 = (int)(((((int64_t)b * T_ + t) * 2 + dir) * g3 + kcol) * 4);
                     o1[0] = dr_pre; o1[H] = dz_pre; o1[2 * H] = dn_pre;
-                    o2[0] = dr_pre; o2[H] = dz_pre; o2[2 * H] = dn_pre * r;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dr_pre), dgh_rsrc, o2, 0, 16 /* sc1 */);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dz_pre), dgh_rsrc, o2 + H * 4, 0, 16);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dn_pre * r), dgh_rsrc, o2 + 2 * H * 4, 0, 16);
                 }
             }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_fetch_add(ctr + step, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (tid == 0) __hip_atomic_fetch_add(ctr + step, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (!alive && tid == 0 && p.timeout_flag) *p.timeout_flag = 1;
 }
@@ -617,6 +618,7 @@ extern "C" int la_gru_layer_bwd(const float *gates, const float *out, const floa
     const int groups = gru_groups(batch);
     const int nsplit = hidden / 32;
     LA_CHECK_ARG(nsplit * 2 * groups <= 224, "gru_layer_bwd: batch too large for one co-resident launch");
+    LA_CHECK_ARG((int64_t)batch * frames * 2 * 3 * hidden * 4 < (int64_t)2147483647, "gru_layer_bwd: dgh exceeds the 2 GiB buffer-descriptor range");
     LA_HIP(hipMemsetAsync(workspace, 0, need, stream));
     GruBwdParams p{gates, out, dout, w_hh, dgi, dgh, batch, frames, hidden,
                    reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(workspace) + 16),
