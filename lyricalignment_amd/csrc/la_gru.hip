@@ -16,6 +16,8 @@
 // stores -> every wave vmcnt(0) -> barrier -> lane 0 release fence -> counter add; consumers poll
 // the counter relaxed, one lane acquires, barrier, then plain loads.  Every wait is bounded.
 // Clips are independent, so batches larger than 32 become extra workgroup groups (grid.z).
+#include <type_traits>
+
 #include "la_common.h"
 
 using la::bf16_t;
@@ -260,6 +262,68 @@ __global__ __launch_bounds__(GruTraits<T>::NW * 64, 1) void gru_kernel(GruParams
                             for (int mt = 0; mt < MT; ++mt) mma_step(a[mt], wreg[g][ks], acc[g][mt], T{});
                     }
                 }
+            } else if (MT == 1 && nb <= 4) {
+                // <= 4 clips (the fine-tune batch): a 16x16x4 f32 MFMA spends its 32 cycles on 16 batch rows of which <= 4 exist --
+                // 288 of them per wave and step, 4.4 us.  Here each lane multiplies its 4-k slice of the 48 weight rows with the
+                // clips' h directly (v_fma_f32, 4 x fewer issue cycles at 2 clips), and the four k-quarters (q) are added across lanes.
+                auto small = [&](auto nbc) {
+                    constexpr int NBV = decltype(nbc)::value;
+                    float part[3][NBV];
+#pragma unroll
+                    for (int g = 0; g < 3; ++g)
+#pragma unroll
+                        for (int b = 0; b < NBV; ++b) part[g][b] = 0.f;
+#pragma unroll
+                    for (int kb = 0; kb < MAXKS; kb += 12) {
+                        uint4 hb[12][NBV];
+#pragma unroll
+                        for (int u = 0; u < 12; ++u)
+#pragma unroll
+                            for (int b = 0; b < NBV; ++b)
+                                if (kb + u < nks) {
+                                    const int64_t eoff = (int64_t)(b0 + b) * out_bs + (int64_t)tprev * out_ts + dir * H;
+                                    if constexpr (WT) {
+                                        typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+                                        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(
+                                            out_rsrc, (int)(eoff * (int64_t)sizeof(T)) + (kb + u) * 64 + q * 16, 0, 16 /* sc1 */);
+                                        hb[u][b] = make_uint4(v[0], v[1], v[2], v[3]);
+                                    } else {
+                                        hb[u][b] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(out + eoff) + (kb + u) * 64 + q * 16);
+                                    }
+                                }
+#pragma unroll
+                        for (int u = 0; u < 12; ++u)
+                            if (kb + u < nks) {
+                                const int ks = kb + u;
+#pragma unroll
+                                for (int g = 0; g < 3; ++g) {
+                                    const uint4 w = *reinterpret_cast<const uint4 *>(wl + (int64_t)(g * 16 + r16) * row_bytes + (((ks * 4 + q) ^ r16) << 4));
+#pragma unroll
+                                    for (int b = 0; b < NBV; ++b) {
+                                        float a = part[g][b];
+                                        a = fmaf(__uint_as_float(w.x), __uint_as_float(hb[u][b].x), a);
+                                        a = fmaf(__uint_as_float(w.y), __uint_as_float(hb[u][b].y), a);
+                                        a = fmaf(__uint_as_float(w.z), __uint_as_float(hb[u][b].z), a);
+                                        a = fmaf(__uint_as_float(w.w), __uint_as_float(hb[u][b].w), a);
+                                        part[g][b] = a;
+                                    }
+                                }
+                            }
+                    }
+#pragma unroll
+                    for (int g = 0; g < 3; ++g)
+#pragma unroll
+                        for (int b = 0; b < NBV; ++b) {
+                            float v = part[g][b];
+                            v += __shfl_xor(v, 16);
+                            v += __shfl_xor(v, 32);
+                            acc[g][0][b] = v;               // clip b = C row b of the q = 0 lanes (rows >= nb are never stored)
+                        }
+                };
+                if (nb == 1) small(std::integral_constant<int, 1>{});
+                else if (nb == 2) small(std::integral_constant<int, 2>{});
+                else if (nb == 3) small(std::integral_constant<int, 3>{});
+                else small(std::integral_constant<int, 4>{});
             } else {
 #pragma unroll
                 for (int ks = 0; ks < MAXKS; ++ks) {
