@@ -620,6 +620,54 @@ __global__ __launch_bounds__(128, 1) void gru_bwd_kernel(GruBwdParams p) {
             int arow_off[MT];            // byte offsets into dgh
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) arow_off[mt] = (int)(((((int64_t)arow[mt] * T_ + tnext) * 2 + dir) * g3) * 4) + q * 16;
+            if (MT == 1 && nb <= 4) {
+                // <= 4 clips: v_fma on the lane's 4-k slices instead of 16-row f32 MFMAs (see the forward kernel)
+                auto small = [&](auto nbc) {
+                    constexpr int NBV = decltype(nbc)::value;
+                    float part[NBV];
+#pragma unroll
+                    for (int b = 0; b < NBV; ++b) part[b] = 0.f;
+                    int boff[NBV];
+#pragma unroll
+                    for (int b = 0; b < NBV; ++b) boff[b] = (int)(((((int64_t)(b0 + b) * T_ + tnext) * 2 + dir) * g3) * 4) + q * 16;
+                    for (int kb = 0; kb < nks; kb += 12) {
+                        uint4 a[12][NBV];
+#pragma unroll
+                        for (int u = 0; u < 12; ++u)
+#pragma unroll
+                            for (int b = 0; b < NBV; ++b) {
+                                typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+                                const u32x4 t4 = __builtin_amdgcn_raw_buffer_load_b128(dgh_rsrc, boff[b] + (kb + u) * 64, 0, 16 /* sc1 */);
+                                a[u][b] = make_uint4(t4[0], t4[1], t4[2], t4[3]);
+                            }
+#pragma unroll
+                        for (int u = 0; u < 12; ++u) {
+                            const int ks = kb + u;
+                            const uint4 w = *reinterpret_cast<const uint4 *>(wl + (int64_t)r16 * row_bytes + (((ks * 4 + q) ^ r16) << 4));
+#pragma unroll
+                            for (int b = 0; b < NBV; ++b) {
+                                float s = part[b];
+                                s = fmaf(__uint_as_float(w.x), __uint_as_float(a[u][b].x), s);
+                                s = fmaf(__uint_as_float(w.y), __uint_as_float(a[u][b].y), s);
+                                s = fmaf(__uint_as_float(w.z), __uint_as_float(a[u][b].z), s);
+                                s = fmaf(__uint_as_float(w.w), __uint_as_float(a[u][b].w), s);
+                                part[b] = s;
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int b = 0; b < NBV; ++b) {
+                        float v = part[b];
+                        v += __shfl_xor(v, 16);
+                        v += __shfl_xor(v, 32);
+                        acc[0][b] = v;
+                    }
+                };
+                if (nb == 1) small(std::integral_constant<int, 1>{});
+                else if (nb == 2) small(std::integral_constant<int, 2>{});
+                else if (nb == 3) small(std::integral_constant<int, 3>{});
+                else small(std::integral_constant<int, 4>{});
+            } else
             for (int kb = 0; kb < nks; kb += 12) {
                 uint4 a[12][MT];
 #pragma unroll
