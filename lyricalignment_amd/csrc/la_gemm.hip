@@ -31,6 +31,7 @@ struct GemmParams {
     int64_t ldc2 = 0, strideC2 = 0;
     const float *ln_stats = nullptr;   // consumer: per-row (mean, rstd) of the raw A rows, [M][2]
     const float *ln_csum = nullptr;    // consumer: c[n] = sum_k W'[n][k] of the gamma-folded weights, [N]
+    int K_tail = 0;                    // split-K: K of the LAST batch slot when the chunks are uneven (0 = p.K)
     float *ln_part = nullptr;          // producer (optional): per-row partial statistics of the 16-bit copy, [N/64][M][2] =
                                        // (mean, sum of squared deviations) of each 64-column segment (la_ln_stats_finalize)
 };
@@ -48,7 +49,7 @@ __global__ __launch_bounds__(CF::THREADS, 2) void gemm_kernel(GemmParams p) {
     const float *bias = p.bias ? p.bias + (int64_t)z * p.strideBias : nullptr;
 
     f32x4 acc[4][4];
-    mainloop<T, CF>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
+    mainloop<T, CF>(A, p.lda, p.M, W, p.ldw, p.N, (p.K_tail && z == (int)gridDim.y - 1) ? p.K_tail : p.K, m0, n0, lds, acc);
 
     typedef typename std::conditional<OUT_F32, float, T>::type TC;
     TC *C = reinterpret_cast<TC *>(p.C) + (int64_t)z * p.strideC;
@@ -556,15 +557,25 @@ static int gemm_run_ldw(int dtype, int M, int N, int K, int batch, const void *A
     // partial-sum buffer, and a second kernel adds them in a fixed order and applies the epilogue.
     if (batch == 1) {
         const int tiles = la::cdiv(M, Small::TM) * la::cdiv(N, BN);
+        // S: chunks of whole 32-element k-steps, the last one may be shorter.  Few tiles -> fill the chip (<= 256 workgroups);
+        // a partial last round of tiles (192 or 384 tiles on 256 CUs) -> S = 4 / 2 makes the rounds finer (768 quarter / half
+        // tiles = 3 full rounds) when K is long enough to pay for the partial-sum pass.
+        const int ksteps = K / 32;
         int S = 1;
-        while (S < 16 && tiles * S * 2 <= 256 && K % (S * 2 * 32) == 0 && K / (S * 2) >= 128) S *= 2;
+        while (S < 16 && tiles * S * 2 <= 256 && ksteps / (S * 2) >= 4) S *= 2;
+        if (S == 1 && K >= 1024 && (int64_t)M * N <= ((int64_t)4 << 20)) {
+            if (tiles * 4 % 256 == 0 && tiles % 256 != 0 && tiles < 256) S = 4;
+            else if (tiles * 2 % 256 == 0 && tiles % 256 != 0 && tiles < 512) S = 2;
+        }
         static const bool no_split = getenv("LA_GEMM_NO_SPLITK") != nullptr;
         if (S > 1 && !no_split && !(epilogue & 256)) {
             float *part = static_cast<float *>(la::stream_scratch(stream, la::SCRATCH_SPLITK, (size_t)S * M * N * sizeof(float)));
             if (!part) { la::set_error("gemm: split-K scratch allocation failed"); return LA_EHIP; }
-            const int Kc = K / S;
+            const int Kc = la::cdiv(ksteps, S) * 32;                   // S - 1 chunks of Kc, the last one takes the rest
+            if (K - (S - 1) * Kc <= 0) S = la::cdiv(K, Kc);
             GemmParams ps{M, N, Kc, A, lda, (int64_t)Kc, W, p.ldw, (int64_t)Kc, part, (int64_t)N, (int64_t)M * N, nullptr, 0, nullptr, 0, 0,
                           LA_EPI_OUT_F32, 0, la::cdiv(N, BN), pick_group(Kc, es, la::cdiv(N, BN))};
+            ps.K_tail = K - (S - 1) * Kc;
             const int rc = launch<float, true, Small>(ps, S, stream, "gemm_f32");
             if (rc == LA_OK) {
                 const int64_t total = (int64_t)M * N;

@@ -58,11 +58,12 @@ def test_gemm_epilogues(dtype):
         np.testing.assert_allclose(out.float().numpy(), torch.nn.functional.gelu(base).numpy(), rtol=1e-2, atol=1e-2)
 
 
-@pytest.mark.parametrize("M,N,K", [(80, 1024, 4096), (80, 1000, 1024), (129, 260, 3072)])
+@pytest.mark.parametrize("M,N,K", [(80, 1024, 4096), (80, 1000, 1024), (129, 260, 3072), (80, 1024, 1632), (3000, 1024, 1024), (80, 512, 51872)])
 def test_gemm_f32_split_k_small_grids(M, N, K):
     """float32 GEMMs with few output tiles and a long K (the text decoder's 80-row GEMMs in the fine-tune step) run as S
     K-chunks + a fixed-order reduction that applies the epilogue: same results as the one-pass kernel within f32 rounding,
-    run-to-run identical (no atomics)."""
+    run-to-run identical (no atomics).  Also: uneven chunks (K = 51 and 1621 k-steps) and the 192-tile case that is split
+    4 ways to fill its last round of tiles."""
     from lyricalignment_amd import ops
     a = _rand(M, K, seed=13, scale=0.3); w = _rand(N, K, seed=14, scale=0.3)
     bias = _rand(N, seed=15); res = _rand(M, N, seed=16)
