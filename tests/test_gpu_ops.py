@@ -161,7 +161,7 @@ def test_attention_online_rescale_spike():
         np.testing.assert_allclose(out.double().numpy(), ref.numpy(), rtol=0, atol=tol)
 
 
-@pytest.mark.parametrize("B,T,H", [(1, 1, 64), (3, 7, 64), (32, 50, 128), (40, 23, 384), (2, 300, 384)])
+@pytest.mark.parametrize("B,T,H", [(1, 1, 64), (3, 7, 64), (32, 50, 128), (40, 23, 384), (2, 300, 384), (20, 11, 128)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_gru_layer(B, T, H, dtype):
     """Persistent bidirectional GRU recurrence vs torch.nn.GRU (CPU fp32) fed the same input projections."""
