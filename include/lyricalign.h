@@ -159,7 +159,12 @@ enum {
     LA_EPI_GELU = 2,      /* exact erf GELU after the bias                            */
     LA_EPI_RESIDUAL = 4,  /* + residual[m][n] (f32, own strides; batch stride may be 0) */
     LA_EPI_OUT_F32 = 8,   /* C is f32 regardless of the operand dtype                 */
-    LA_EPI_MISH = 16      /* x * tanh(softplus(x)) after the bias                     */
+    LA_EPI_MISH = 16,     /* x * tanh(softplus(x)) after the bias                     */
+    /* operand layout flags of la_gemm_ex (float32 only), OR-ed into the same word: the operand is stored TRANSPOSED,
+     * [K][rows] with pitch lda / ldw >= rows (rows % 4 == 0).  Both set: K may be any length (the weight-gradient shape
+     * dW[n][k] = sum_m dY[m][n] X[m][k] reads dY and X as they are).  Replaces a transpose pass per operand. */
+    LA_GEMM_TRANS_A = 512,
+    LA_GEMM_TRANS_W = 1024
 };
 
 /*

@@ -36,7 +36,7 @@ struct GemmParams {
                                        // (mean, sum of squared deviations) of each 64-column segment (la_ln_stats_finalize)
 };
 
-template <typename T, bool OUT_F32, typename CF>
+template <typename T, bool OUT_F32, typename CF, bool TA = false, bool TW = false>
 __global__ __launch_bounds__(CF::THREADS, 2) void gemm_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int nwg = p.tiles_m * p.tiles_n;
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(CF::THREADS, 2) void gemm_kernel(GemmParams p) {
     const float *bias = p.bias ? p.bias + (int64_t)z * p.strideBias : nullptr;
 
     f32x4 acc[4][4];
-    mainloop<T, CF>(A, p.lda, p.M, W, p.ldw, p.N, (p.K_tail && z == (int)gridDim.y - 1) ? p.K_tail : p.K, m0, n0, lds, acc);
+    mainloop<T, CF, TA, TW>(A, p.lda, p.M, W, p.ldw, p.N, (p.K_tail && z == (int)gridDim.y - 1) ? p.K_tail : p.K, m0, n0, lds, acc);
 
     typedef typename std::conditional<OUT_F32, float, T>::type TC;
     TC *C = reinterpret_cast<TC *>(p.C) + (int64_t)z * p.strideC;
@@ -437,9 +437,9 @@ int launch_pp_dbg(GemmParams p, int batch, hipStream_t stream) {
     return LA_OK;
 }
 
-template <typename T, bool OUT_F32, typename CF>
+template <typename T, bool OUT_F32, typename CF, bool TA = false, bool TW = false>
 int launch(GemmParams p, int batch, hipStream_t stream, const char *family) {
-    auto kern = gemm_kernel<T, OUT_F32, CF>;
+    auto kern = gemm_kernel<T, OUT_F32, CF, TA, TW>;
     static bool attr_done = false;
     if (!attr_done) {
         LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS));
@@ -479,6 +479,15 @@ __global__ void splitk_reduce_kernel(const float *P, int S, int M, int N, float 
     C[(int64_t)m * ldc + n] = v;
 }
 
+// float32 kernel by operand layout: NT (both K-contiguous), TT (both [K][rows]: weight gradients), NT/TW (input gradients)
+static int launch_f32(const GemmParams &p, int batch, bool tA, bool tW, hipStream_t stream) {
+    typedef Cfg<2, 2> Small;
+    if (tA && tW) return launch<float, true, Small, true, true>(p, batch, stream, "gemm_f32");
+    if (tW) return launch<float, true, Small, false, true>(p, batch, stream, "gemm_f32");
+    if (tA) return launch<float, true, Small, true, false>(p, batch, stream, "gemm_f32");
+    return launch<float, true, Small>(p, batch, stream, "gemm_f32");
+}
+
 struct LnFuse {
     void *C2; int64_t ldc2, strideC2;
     const float *stats, *csum;
@@ -511,13 +520,21 @@ static int gemm_run_ldw(int dtype, int M, int N, int K, int batch, const void *A
     LA_CHECK_ARG(dtype == LA_F32 || dtype == LA_BF16 || dtype == LA_F16, "gemm: bad dtype");
     const int ke = dtype == LA_F32 ? 32 : 64;
     const int es = dtype == LA_F32 ? 4 : 2;
-    LA_CHECK_ARG(K % ke == 0, "gemm: K=%d must be a multiple of %d", K, ke);
+    const bool tA = epilogue & LA_GEMM_TRANS_A, tW = epilogue & LA_GEMM_TRANS_W;
+    epilogue &= ~(LA_GEMM_TRANS_A | LA_GEMM_TRANS_W);
+    if (tA || tW) {
+        LA_CHECK_ARG(dtype == LA_F32, "gemm: transposed operands are float32 only");
+        LA_CHECK_ARG((!tA || (M % 4 == 0 && lda >= M)) && (!tW || (N % 4 == 0 && (ldw_arg == 0 || ldw_arg >= N))),
+                     "gemm: a transposed operand [K][rows] needs rows %% 4 == 0 and a pitch >= rows");
+        LA_CHECK_ARG(!ln, "gemm: no LayerNorm fold with transposed operands");
+    }
+    LA_CHECK_ARG(K % ke == 0 || (tA && tW), "gemm: K=%d must be a multiple of %d", K, ke);
     LA_CHECK_ARG((lda * es) % 16 == 0 && (strideA * es) % 16 == 0 && ((uintptr_t)A % 16 == 0) && ((uintptr_t)W % 16 == 0),
                  "gemm: A/W rows must be 16-byte aligned");
     LA_CHECK_ARG(!(epilogue & LA_EPI_RESIDUAL) || residual, "gemm: residual epilogue without pointer");
     LA_CHECK_ARG(!(epilogue & LA_EPI_BIAS) || bias, "gemm: bias epilogue without pointer");
     LA_CHECK_ARG((strideW * es) % 16 == 0 && (ldw_arg * es) % 16 == 0, "gemm: W batch stride / row pitch must be 16-byte aligned");
-    GemmParams p{M, N, K, A, lda, strideA, W, ldw_arg > 0 ? ldw_arg : (int64_t)K, strideW, C, ldc, strideC, bias, strideBias, residual, ldr, strideR, epilogue,
+    GemmParams p{M, N, K, A, lda, strideA, W, ldw_arg > 0 ? ldw_arg : (int64_t)(tW ? N : K), strideW, C, ldc, strideC, bias, strideBias, residual, ldr, strideR, epilogue,
                  0, la::cdiv(N, BN), pick_group(K, es, la::cdiv(N, BN))};
     const bool out_f32 = epilogue & LA_EPI_OUT_F32;
     typedef Cfg<2, 2> Small;
@@ -560,7 +577,7 @@ static int gemm_run_ldw(int dtype, int M, int N, int K, int batch, const void *A
         // S: chunks of whole 32-element k-steps, the last one may be shorter.  Few tiles -> fill the chip (<= 256 workgroups);
         // a partial last round of tiles (192 or 384 tiles on 256 CUs) -> S = 4 / 2 makes the rounds finer (768 quarter / half
         // tiles = 3 full rounds) when K is long enough to pay for the partial-sum pass.
-        const int ksteps = K / 32;
+        const int ksteps = la::cdiv(K, 32);
         int S = 1;
         while (S < 16 && tiles * S * 2 <= 256 && ksteps / (S * 2) >= 4) S *= 2;
         if (S == 1 && K >= 1024 && (int64_t)M * N <= ((int64_t)4 << 20)) {
@@ -573,10 +590,10 @@ static int gemm_run_ldw(int dtype, int M, int N, int K, int batch, const void *A
             if (!part) { la::set_error("gemm: split-K scratch allocation failed"); return LA_EHIP; }
             const int Kc = la::cdiv(ksteps, S) * 32;                   // S - 1 chunks of Kc, the last one takes the rest
             if (K - (S - 1) * Kc <= 0) S = la::cdiv(K, Kc);
-            GemmParams ps{M, N, Kc, A, lda, (int64_t)Kc, W, p.ldw, (int64_t)Kc, part, (int64_t)N, (int64_t)M * N, nullptr, 0, nullptr, 0, 0,
+            GemmParams ps{M, N, Kc, A, lda, tA ? (int64_t)Kc * lda : (int64_t)Kc, W, p.ldw, tW ? (int64_t)Kc * p.ldw : (int64_t)Kc, part, (int64_t)N, (int64_t)M * N, nullptr, 0, nullptr, 0, 0,
                           LA_EPI_OUT_F32, 0, la::cdiv(N, BN), pick_group(Kc, es, la::cdiv(N, BN))};
             ps.K_tail = K - (S - 1) * Kc;
-            const int rc = launch<float, true, Small>(ps, S, stream, "gemm_f32");
+            const int rc = launch_f32(ps, S, tA, tW, stream);
             if (rc == LA_OK) {
                 const int64_t total = (int64_t)M * N;
                 hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)la::cdiv(total, (int64_t)256)), dim3(256), 0, stream, part, S, M, N,
@@ -587,7 +604,7 @@ static int gemm_run_ldw(int dtype, int M, int N, int K, int batch, const void *A
             return LA_OK;
         }
     }
-    return launch<float, true, Small>(p, batch, stream, "gemm_f32");
+    return launch_f32(p, batch, tA, tW, stream);
 }
 
 // LayerNorm folded into the GEMMs on either side of it (encoder blocks, 16-bit modes, shapes that run on the 256x256 kernel):
@@ -637,7 +654,7 @@ extern "C" int la_gemm(int32_t dtype, int32_t M, int32_t N, int32_t K, int32_t b
 extern "C" int la_gemm_ex(int32_t dtype, int32_t M, int32_t N, int32_t K, int32_t batch, const void *A, int64_t lda,
                           int64_t strideA, const void *W, int64_t ldw, int64_t strideW, void *C, int64_t ldc, int64_t strideC,
                           const float *bias, int32_t epilogue, void *stream_) {
-    LA_CHECK_ARG(ldw >= K, "gemm_ex: ldw < K");
+    LA_CHECK_ARG(ldw >= ((epilogue & LA_GEMM_TRANS_W) ? N : K), "gemm_ex: ldw smaller than a row of W");
     return gemm_run_ldw(dtype, M, N, K, batch, A, lda, strideA, W, ldw, strideW, C, ldc, strideC, bias, 0, nullptr, 0, 0, epilogue,
                         (hipStream_t)stream_);
 }

@@ -62,6 +62,43 @@ __device__ __forceinline__ uint4 read_frag(const unsigned char *lds_tile, int ro
     return *reinterpret_cast<const uint4 *>(lds_tile + row * BKB + ((slot ^ swz(row)) << 4));
 }
 
+// ---- transposed operand (float32 only): the matrix is stored [K][rows] (rows contiguous), e.g. the activations X[m][k_in] as
+// the "W operand" of dW[n][k_in] = sum_m dY[m][n] X[m][k_in], where the contraction index m is the slow one.  One stage =
+// 32 k-rows x 128 rows x 4 B = the same 16 KiB; a wave instruction moves two k-rows of 512 B.  LDS image: k-row kk at
+// kk*512, its 16-byte chunk c (4 consecutive rows) in slot c ^ g(kk), g(kk) = ((kk >> 2) & 3) << 2: a lane (r, q) then reads
+// its four k = 16 ks + 4q + j as four ds_read_b32 at rows 16 i + r, and the four q groups land on disjoint bank quarters.
+__device__ __forceinline__ int swz_t(int kk) { return ((kk >> 2) & 3) << 2; }
+
+template <int NWAVES>
+__device__ __forceinline__ void stage_tile_t(const unsigned char *src, int64_t ld_bytes, int k0, int last_k, int row0, int rows_total,
+                                             unsigned char *lds_tile, int wave, int lane) {
+    constexpr int PER_WAVE = 16 / NWAVES;          // 16 instructions of two k-rows each
+    static_assert(PER_WAVE >= 1 && PER_WAVE * NWAVES == 16, "16 two-row pieces must split evenly over the waves");
+    const int h = lane >> 5, s = lane & 31;
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i) {
+        const int piece = wave * PER_WAVE + i;
+        const int kk = piece * 2 + h;
+        int krow = k0 + kk;
+        krow = krow > last_k ? last_k : krow;      // rows past K are re-reads of the last one; their products are masked
+        int m = row0 + ((s ^ swz_t(kk)) << 2);
+        m = m > rows_total - 4 ? rows_total - 4 : m;   // rows_total % 4 == 0 (host check): stays inside the k-row
+        const unsigned char *g = src + (int64_t)krow * ld_bytes + (int64_t)m * 4;
+        la::glds16(g, lds_tile + piece * 1024);
+    }
+}
+
+// the four k = 16 ks + 4 q + j (j = 0..3) of tile row `row` -> same element order as read_frag's 16-byte K-slot 4 ks + q
+__device__ __forceinline__ uint4 read_frag_t(const unsigned char *lds_tile, int row, int ks, int q) {
+    const unsigned char *b = lds_tile + (ks * 16 + 4 * q) * 512 + ((((row >> 2) ^ (q << 2)) << 4) | ((row & 3) << 2));
+    uint4 v;
+    v.x = *reinterpret_cast<const unsigned *>(b);
+    v.y = *reinterpret_cast<const unsigned *>(b + 512);
+    v.z = *reinterpret_cast<const unsigned *>(b + 1024);
+    v.w = *reinterpret_cast<const unsigned *>(b + 1536);
+    return v;
+}
+
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
     __device__ static __forceinline__ void run(const uint4 &w, const uint4 &a, f32x4 &acc) {
@@ -106,14 +143,17 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 }
 
 // acc[mi][ni]: rows m = m0 + wm*64 + mi*16 + (lane & 15); cols n = n0 + wn*64 + ni*16 + (lane >> 4)*4 + reg
-template <typename T, typename C>
+// TA / TW (float32 only): that operand is stored transposed, [K][rows] with pitch lda / ldw (see stage_tile_t).  With both
+// transposed K need not be a multiple of the 32-element stage: the last stage's k >= K are masked out of the A fragments.
+template <typename T, typename C, bool TA = false, bool TW = false>
 __device__ __forceinline__ void mainloop(const T *A, int64_t lda, int M, const T *W, int64_t ldw, int N, int K,
                                          int m0, int n0, unsigned char *lds, f32x4 (&acc)[4][4]) {
+    static_assert((!TA && !TW) || sizeof(T) == 4, "transposed operands are built for float32");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int r = lane & 15, q = lane >> 4;
     constexpr int KE = KElems<T>::v;
-    const int nk = K / KE;
+    const int nk = (K + KE - 1) / KE;
     const unsigned char *Ab = reinterpret_cast<const unsigned char *>(A);
     const unsigned char *Wb = reinterpret_cast<const unsigned char *>(W);
     const int64_t lda_b = lda * (int64_t)sizeof(T), ldw_b = ldw * (int64_t)sizeof(T);
@@ -126,20 +166,40 @@ __device__ __forceinline__ void mainloop(const T *A, int64_t lda, int M, const T
     auto stage = [&](int kt, int buf) {
         unsigned char *st = lds + buf * C::STAGE;
         const int64_t koff = (int64_t)kt * BKB;
-        stage_tile<C::TM, C::NW>(Ab + koff, lda_b, m0, M - 1, st, wave, lane);
-        stage_tile<C::TN, C::NW>(Wb + koff, ldw_b, n0, N - 1, st + C::TM * BKB, wave, lane);
+        if constexpr (TA) {
+            static_assert(!TA || C::TM == 128, "transposed A: 128-row tiles");
+            stage_tile_t<C::NW>(Ab, lda_b, kt * KE, K - 1, m0, M, st, wave, lane);
+        } else {
+            stage_tile<C::TM, C::NW>(Ab + koff, lda_b, m0, M - 1, st, wave, lane);
+        }
+        if constexpr (TW) stage_tile_t<C::NW>(Wb, ldw_b, kt * KE, K - 1, n0, N, st + C::TM * BKB, wave, lane);
+        else stage_tile<C::TN, C::NW>(Wb + koff, ldw_b, n0, N - 1, st + C::TM * BKB, wave, lane);
     };
-    auto compute = [&](int buf) {
+    auto compute = [&](int buf, int kvalid) {
         const unsigned char *st = lds + buf * C::STAGE;
-        const unsigned char *at = st + (wm * 64) * BKB;
-        const unsigned char *wt = st + C::TM * BKB + (wn * 64) * BKB;
+        const unsigned char *at = st + (TA ? 0 : (wm * 64) * BKB);
+        const unsigned char *wt = st + C::TM * BKB + (TW ? 0 : (wn * 64) * BKB);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             uint4 af[4], wf[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                af[i] = read_frag(at, i * 16 + r, ks * 4 + q);
-                wf[i] = read_frag(wt, i * 16 + r, ks * 4 + q);
+                if constexpr (TA) af[i] = read_frag_t(at, wm * 64 + i * 16 + r, ks, q);
+                else af[i] = read_frag(at, i * 16 + r, ks * 4 + q);
+                if constexpr (TW) wf[i] = read_frag_t(wt, wn * 64 + i * 16 + r, ks, q);
+                else wf[i] = read_frag(wt, i * 16 + r, ks * 4 + q);
+            }
+            if constexpr (TA && TW) {
+                if (kvalid < KE) {                 // last, partial stage: k = 16 ks + 4 q + j >= kvalid contributes nothing
+                    const int kb = ks * 16 + 4 * q;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (kb + 0 >= kvalid) af[i].x = 0u;
+                        if (kb + 1 >= kvalid) af[i].y = 0u;
+                        if (kb + 2 >= kvalid) af[i].z = 0u;
+                        if (kb + 3 >= kvalid) af[i].w = 0u;
+                    }
+                }
             }
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
@@ -156,7 +216,7 @@ __device__ __forceinline__ void mainloop(const T *A, int64_t lda, int M, const T
         int cur = 0;
         for (int kt = 0; kt < nk; ++kt) {
             if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
-            compute(cur);
+            compute(cur, K - kt * KE);
             wait_vmcnt<0>();
             __syncthreads();
             cur ^= 1;
@@ -173,7 +233,7 @@ __device__ __forceinline__ void mainloop(const T *A, int64_t lda, int M, const T
             if (kt + 1 < nk) wait_vmcnt<C::LOADS>(); else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
             if (kt + 2 < nk) stage(kt + 2, nxt2);
-            compute(cur);
+            compute(cur, K - kt * KE);
             cur = cur == 2 ? 0 : cur + 1;
             nxt2 = nxt2 == 2 ? 0 : nxt2 + 1;
         }

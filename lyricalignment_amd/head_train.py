@@ -60,13 +60,38 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = Non
     return ops.gemm(_padK(a), _padK(w), bias=bias, out_f32=True)
 
 
+def _rows_ok(t: torch.Tensor) -> bool:
+    """usable as a transposed ([K][rows]) operand of la_gemm_ex: f32 row view, rows % 4 == 0, 16-byte aligned rows"""
+    return (t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1 and t.shape[1] % 4 == 0 and t.stride(0) % 4 == 0
+            and t.data_ptr() % 16 == 0)
+
+
+def _gemm_ex_flags(Mg: int, Ng: int, Kg: int, a: torch.Tensor, w: torch.Tensor, flags: int) -> torch.Tensor:
+    from ._lib import LA_F32
+    out = torch.empty((Mg, Ng), dtype=torch.float32, device=a.device)
+    check(lib().la_gemm_ex(LA_F32, Mg, Ng, Kg, 1, ptr(a), a.stride(0), 0, ptr(w), w.stride(0), 0, ptr(out), Ng, 0, None, flags,
+                           stream_ptr()), "gemm_ex")
+    return out
+
+
 def gemm_tn(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-    """a [M,N]^T . b [M,K] -> [N,K]: the weight-gradient shape (contraction over the rows of both)."""
+    """a [M,N]^T . b [M,K] -> [N,K]: the weight-gradient shape (contraction over the rows of both).  Both operands are read
+    as they lie (la_gemm_ex, LA_GEMM_TRANS_A | LA_GEMM_TRANS_W); shapes the transposed staging does not take go through
+    explicit transposes."""
+    if a.shape[0] != b.shape[0]:
+        raise ValueError("gemm_tn: row mismatch")
+    if _rows_ok(a) and _rows_ok(b):
+        return _gemm_ex_flags(a.shape[1], b.shape[1], a.shape[0], a, b, _lib.GEMM_TRANS_A | _lib.GEMM_TRANS_W)
     return ops.gemm(transpose_pad(a), transpose_pad(b), out_f32=True)
 
 
 def gemm_nn(a: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
-    """a [M,N] . w [N,K] -> [M,K]: the input-gradient shape."""
+    """a [M,N] . w [N,K] -> [M,K]: the input-gradient shape (w read as it lies: LA_GEMM_TRANS_W)."""
+    if a.shape[1] != w.shape[0]:
+        raise ValueError("gemm_nn: inner size mismatch")
+    if (_rows_ok(w) and a.dtype == torch.float32 and a.dim() == 2 and a.stride(1) == 1 and a.shape[1] % 32 == 0
+            and a.stride(0) % 4 == 0 and a.data_ptr() % 16 == 0):
+        return _gemm_ex_flags(a.shape[0], w.shape[1], a.shape[1], a, w, _lib.GEMM_TRANS_W)
     return ops.gemm(_padK(a), transpose_pad(w), out_f32=True)
 
 

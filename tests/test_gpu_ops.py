@@ -289,3 +289,21 @@ def test_gemm_fused_layernorm_pieces():
     # shapes that do not run on the 256x256 kernel are refused loudly
     with pytest.raises(NotImplementedError):
         ops.gemm(xb[:300], wl.cuda(), bias=bl, ln_stats=st[:300].contiguous().cuda(), ln_csum=csum, out_f32=True)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (1024, 1024, 3000), (260, 136, 77), (64, 4096, 1500), (1152, 384, 33)])
+def test_gemm_f32_transposed_operands(M, N, K):
+    """la_gemm_ex with LA_GEMM_TRANS_A | LA_GEMM_TRANS_W: C[m][n] = sum_k At[k][m] Wt[k][n] reads both operands as [K][rows]
+    (the weight-gradient shape; any K), and LA_GEMM_TRANS_W alone: C = A Wt (the input-gradient shape) -- against float64."""
+    from lyricalignment_amd import head_train as ht
+    at = _rand(K, M, seed=31, scale=0.3).cuda(); wt = _rand(K, N, seed=32, scale=0.3).cuda()
+    ref = at.double().cpu().T @ wt.double().cpu()
+    tol = 2e-4 * (K / 64) ** 0.5
+    out = ht.gemm_tn(at, wt).cpu()                            # [M, N] = at^T wt
+    np.testing.assert_allclose(out.double().numpy(), ref.numpy(), rtol=0, atol=tol)
+    views = ht.gemm_tn(at[:, : M - 4] if M > 8 else at, wt).cpu()          # row views with a pitch larger than the row
+    np.testing.assert_allclose(views.double().numpy(), (ref[: M - 4] if M > 8 else ref).numpy(), rtol=0, atol=tol)
+    if K % 32 == 0:
+        a = _rand(M, K, seed=33, scale=0.3).cuda()
+        out = ht.gemm_nn(a, wt).cpu()                         # [M, N] = a wt
+        np.testing.assert_allclose(out.double().numpy(), (a.double().cpu() @ wt.double().cpu()).numpy(), rtol=0, atol=tol)
