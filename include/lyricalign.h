@@ -161,8 +161,9 @@ enum {
     LA_EPI_OUT_F32 = 8,   /* C is f32 regardless of the operand dtype                 */
     LA_EPI_MISH = 16,     /* x * tanh(softplus(x)) after the bias                     */
     /* operand layout flags of la_gemm_ex (float32 only), OR-ed into the same word: the operand is stored TRANSPOSED,
-     * [K][rows] with pitch lda / ldw >= rows (rows % 4 == 0).  Both set: K may be any length (the weight-gradient shape
-     * dW[n][k] = sum_m dY[m][n] X[m][k] reads dY and X as they are).  Replaces a transpose pass per operand. */
+     * [K][rows] with pitch lda / ldw >= rows (rows % 4 == 0).  With a flag set K may be any length (a K-contiguous operand
+     * must then have a pitch >= K rounded up to 32); both set = the weight-gradient shape
+     * dW[n][k] = sum_m dY[m][n] X[m][k], which reads dY and X as they are.  Replaces a transpose pass per operand. */
     LA_GEMM_TRANS_A = 512,
     LA_GEMM_TRANS_W = 1024
 };

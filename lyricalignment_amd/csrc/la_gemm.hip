@@ -528,7 +528,8 @@ static int gemm_run_ldw(int dtype, int M, int N, int K, int batch, const void *A
                      "gemm: a transposed operand [K][rows] needs rows %% 4 == 0 and a pitch >= rows");
         LA_CHECK_ARG(!ln, "gemm: no LayerNorm fold with transposed operands");
     }
-    LA_CHECK_ARG(K % ke == 0 || (tA && tW), "gemm: K=%d must be a multiple of %d", K, ke);
+    LA_CHECK_ARG(K % ke == 0 || ((tA || tW) && (tA || lda >= la::round_up(K, ke)) && (tW || (ldw_arg >= la::round_up(K, ke)))),
+                 "gemm: K=%d must be a multiple of %d (or: a transposed operand, and K-contiguous rows pitched to the rounded-up K)", K, ke);
     LA_CHECK_ARG((lda * es) % 16 == 0 && (strideA * es) % 16 == 0 && ((uintptr_t)A % 16 == 0) && ((uintptr_t)W % 16 == 0),
                  "gemm: A/W rows must be 16-byte aligned");
     LA_CHECK_ARG(!(epilogue & LA_EPI_RESIDUAL) || residual, "gemm: residual epilogue without pointer");

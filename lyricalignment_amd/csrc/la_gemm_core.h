@@ -143,8 +143,9 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 }
 
 // acc[mi][ni]: rows m = m0 + wm*64 + mi*16 + (lane & 15); cols n = n0 + wn*64 + ni*16 + (lane >> 4)*4 + reg
-// TA / TW (float32 only): that operand is stored transposed, [K][rows] with pitch lda / ldw (see stage_tile_t).  With both
-// transposed K need not be a multiple of the 32-element stage: the last stage's k >= K are masked out of the A fragments.
+// TA / TW (float32 only): that operand is stored transposed, [K][rows] with pitch lda / ldw (see stage_tile_t).  With a
+// transposed operand K need not be a multiple of the 32-element stage: the last stage's k >= K are masked out of the A
+// fragments (a K-contiguous operand must then have a row pitch that covers the rounded-up K: its tail reads stay in the row).
 template <typename T, typename C, bool TA = false, bool TW = false>
 __device__ __forceinline__ void mainloop(const T *A, int64_t lda, int M, const T *W, int64_t ldw, int N, int K,
                                          int m0, int n0, unsigned char *lds, f32x4 (&acc)[4][4]) {
@@ -189,7 +190,7 @@ __device__ __forceinline__ void mainloop(const T *A, int64_t lda, int M, const T
                 if constexpr (TW) wf[i] = read_frag_t(wt, wn * 64 + i * 16 + r, ks, q);
                 else wf[i] = read_frag(wt, i * 16 + r, ks * 4 + q);
             }
-            if constexpr (TA && TW) {
+            if constexpr (TA || TW) {
                 if (kvalid < KE) {                 // last, partial stage: k = 16 ks + 4 q + j >= kvalid contributes nothing
                     const int kb = ks * 16 + 4 * q;
 #pragma unroll

@@ -75,8 +75,8 @@ def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor):
     return dx, colsum(t), colsum(dy)
 
 
-def gemm_ex(M, N, K, batch, a, lda, stride_a, w, ldw, stride_w, c, ldc, stride_c):
-    check(lib().la_gemm_ex(LA_F32, M, N, K, batch, ptr(a), lda, stride_a, ptr(w), ldw, stride_w, ptr(c), ldc, stride_c, None, 0,
+def gemm_ex(M, N, K, batch, a, lda, stride_a, w, ldw, stride_w, c, ldc, stride_c, flags: int = 0):
+    check(lib().la_gemm_ex(LA_F32, M, N, K, batch, ptr(a), lda, stride_a, ptr(w), ldw, stride_w, ptr(c), ldc, stride_c, None, flags,
                            stream_ptr()), "gemm_ex")
 
 
@@ -93,12 +93,15 @@ def attention_bwd_ex(q, k, v, do, dq, dk, dv, B: int, Tq: int, Tk: int, H: int, 
     f = dict(dtype=torch.float32, device=q.device)
     P = torch.empty((H, Tq, Tkp), **f)
     dS = torch.empty((H, Tq, Tkp), **f)
-    Pt = torch.empty((H, Tk, Tqp), **f)
-    dSt = torch.empty((H, Tk, Tqp), **f)
-    Kt = torch.empty((H, 64, Tkp), **f)
-    Qt = torch.empty((H, 64, Tqp), **f)
-    dOt = torch.empty((H, 64, Tqp), **f)
     lq, lk, lv, ldo = q.stride(0), k.stride(0), v.stride(0), do.stride(0)
+    in_place = Tk % 4 == 0                # transposed-operand GEMMs (la_gemm_ex flags) read P, dS, q, k, dO as they lie
+    if not in_place:
+        Pt = torch.empty((H, Tk, Tqp), **f)
+        dSt = torch.empty((H, Tk, Tqp), **f)
+        Kt = torch.empty((H, 64, Tkp), **f)
+        Qt = torch.empty((H, 64, Tqp), **f)
+        dOt = torch.empty((H, 64, Tqp), **f)
+    TA, TW = _lib.GEMM_TRANS_A, _lib.GEMM_TRANS_W
     for b in range(B):
         qb, dob, dqb = q[b * Tq:(b + 1) * Tq], do[b * Tq:(b + 1) * Tq], dq[b * Tq:(b + 1) * Tq]
         kb, vb = k[b * Tk:(b + 1) * Tk], v[b * Tk:(b + 1) * Tk]
@@ -107,6 +110,11 @@ def attention_bwd_ex(q, k, v, do, dq, dk, dv, B: int, Tq: int, Tk: int, H: int, 
         check(lib().la_softmax_rows_f32(ptr(P), Tkp, H * Tq, Tk, Tq if causal else 0, stream_ptr()), "softmax_rows")
         gemm_ex(Tq, Tk, 64, H, dob, ldo, 64, vb, lv, 64, dS, Tkp, Tq * Tkp)
         check(lib().la_softmax_bwd_rows_f32(ptr(P), ptr(dS), Tkp, H * Tq, Tk, stream_ptr()), "softmax_bwd_rows")
+        if in_place:
+            gemm_ex(Tq, 64, Tk, H, dS, Tkp, Tq * Tkp, kb, lk, 64, dqb, dq.stride(0), 64, TW)           # dQ = dS k      (k: [Tk][64] = [K][rows])
+            gemm_ex(Tk, 64, Tq, H, dS, Tkp, Tq * Tkp, qb, lq, 64, dkb, dk.stride(0), 64, TA | TW)      # dK = dS^T q
+            gemm_ex(Tk, 64, Tq, H, P, Tkp, Tq * Tkp, dob, ldo, 64, dvb, dv.stride(0), 64, TA | TW)     # dV = P^T dO
+            continue
         transpose_batched(kb, lk, 64, Tk, 64, Kt, Tkp, 64 * Tkp, 64, Tkp, H)
         transpose_batched(qb, lq, 64, Tq, 64, Qt, Tqp, 64 * Tqp, 64, Tqp, H)
         transpose_batched(dob, ldo, 64, Tq, 64, dOt, Tqp, 64 * Tqp, 64, Tqp, H)
