@@ -259,23 +259,31 @@ class AlignEngine:
         if fused:
             stats = self._get("ln_stats", (M, 2), torch.float32)
             part = self._get("ln_part", (d // 64, M, 2), torch.float32) if (LN_STATS_IN_EPILOGUE and d % 64 == 0) else None
+
+            def row_stats():
+                if part is not None:
+                    ops.ln_stats_finalize(part, out=stats)
+                else:
+                    ops.row_stats16(h, out=stats)
+
             ops.row_stats16(h, out=stats)                                                     # of the stem's output (batched GEMM)
             for blk in e.blocks:
                 ops.gemm(h, blk.wqkv_ln, qkv, bias=blk.bqkv_ln, ln_stats=stats, ln_csum=blk.cqkv)
                 ops.attention(qkv, B, N_CTX, e.n_head, out=att)
                 ops.gemm(att, blk.wo, x, bias=blk.bo, residual=x, out_f32=True, out16=h, ln_part=part)   # x += out-proj; h = bf16(x)
-                ops.ln_stats_finalize(part, out=stats) if part is not None else ops.row_stats16(h, out=stats)
+                row_stats()
                 ops.gemm(h, blk.w1_ln, u, bias=blk.b1_ln, gelu=True, ln_stats=stats, ln_csum=blk.c1)
                 ops.gemm(u, blk.w2, x, bias=blk.b2, residual=x, out_f32=True, out16=h, ln_part=part)     # x += mlp; h = bf16(x)
-                ops.ln_stats_finalize(part, out=stats) if part is not None else ops.row_stats16(h, out=stats)
-        for blk in (() if fused else e.blocks):
-            ops.layernorm(x, blk.ln1_g, blk.ln1_b, dt, out=h)
-            ops.gemm(h, blk.wqkv, qkv, bias=blk.bqkv)
-            ops.attention(qkv, B, N_CTX, e.n_head, out=att)
-            ops.gemm(att, blk.wo, x, bias=blk.bo, residual=x, out_f32=True)          # x += out-proj (in place)
-            ops.layernorm(x, blk.ln2_g, blk.ln2_b, dt, out=h)
-            ops.gemm(h, blk.w1, u, bias=blk.b1, gelu=True)
-            ops.gemm(u, blk.w2, x, bias=blk.b2, residual=x, out_f32=True)            # x += mlp (in place)
+                row_stats()
+        else:
+            for blk in e.blocks:
+                ops.layernorm(x, blk.ln1_g, blk.ln1_b, dt, out=h)
+                ops.gemm(h, blk.wqkv, qkv, bias=blk.bqkv)
+                ops.attention(qkv, B, N_CTX, e.n_head, out=att)
+                ops.gemm(att, blk.wo, x, bias=blk.bo, residual=x, out_f32=True)          # x += out-proj (in place)
+                ops.layernorm(x, blk.ln2_g, blk.ln2_b, dt, out=h)
+                ops.gemm(h, blk.w1, u, bias=blk.b1, gelu=True)
+                ops.gemm(u, blk.w2, x, bias=blk.b2, residual=x, out_f32=True)            # x += mlp (in place)
         out_dtype = out_dtype or dt
         y = out if out is not None else self._get(f"enc_out{slot}", (M, d), out_dtype)
         ops.layernorm(x, e.lnp_g, e.lnp_b, out_dtype, out=y)
