@@ -183,3 +183,37 @@ def test_emissions_from_logits(variant):
         np.testing.assert_allclose(em[b, :, 0].numpy(), ls_o[b, :, 0].numpy(), rtol=0, atol=1e-4)
         idx = (lab[b, :L].long() - 1)
         np.testing.assert_allclose(em[b, :, 1:1 + L].numpy(), lp_o[b][:, idx].numpy(), rtol=0, atol=1e-4)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_random_ragged_batches_bit_exact(seed):
+    """Randomised sweep: 48 utterances per launch with ragged T (1..1700) and L (1..70), emission scales from 'all ties'
+    (0) to well separated, quantised emissions (many exact ties), repeated labels, infeasible ones (T < L) -- frames, float64
+    scores and status codes equal to the C oracle for every utterance."""
+    from oracle import alignment_oracle as ao
+    rs = np.random.RandomState(1000 + seed)
+    ems, labs = [], []
+    for _ in range(48):
+        L = int(rs.randint(1, 71))
+        T = int(rs.randint(1, 1701)) if rs.rand() > 0.15 else int(rs.randint(1, 2 * L + 2))
+        scale = [0.0, 1e-3, 0.05, 1.0, 3.0][int(rs.randint(0, 5))]
+        em = (-rs.rand(T, L + 1) * scale).astype(np.float32)
+        if rs.rand() < 0.3:
+            em = np.round(em * 4) / 4                       # quarter-step values: exact ties everywhere
+        lab = rs.randint(1, 400, size=L)
+        for _ in range(int(rs.randint(0, 4))):
+            if L > 1:
+                j = int(rs.randint(1, L)); lab[j] = lab[j - 1]
+        _fix_repeats(em, lab)
+        ems.append(em); labs.append(lab.tolist())
+    on, off, score, status = _run(ems, labs)
+    n_bad = 0
+    for b, (em, lab) in enumerate(zip(ems, labs)):
+        rc, on_o, off_o, score_o = ao.align_frames_compact(em, np.array(lab))
+        assert status[b] == rc, (b, status[b], rc)
+        if rc == 0:
+            assert on[b, : len(lab)].tolist() == on_o.tolist() and off[b, : len(lab)].tolist() == off_o.tolist(), b
+            assert score[b] == score_o
+        else:
+            n_bad += 1
+    assert n_bad < 48
