@@ -307,3 +307,25 @@ def test_cer_matches_reference_golden():
         cer, nb = CER(hypothesis=c["hyp"], reference=c["ref"])
         assert float(cer) == c["cer"], c
         assert {k: int(v) for k, v in nb.items()} == c["nb_map"], c
+
+
+def test_song_major_chunks_layout():
+    """Long form (module/align_model.py:94-105): the host bookkeeping that lets the head read a song's frames in place.
+    Chunk c of song s sits at batch row s*C + c, zero padded to 3000 mel frames; every chunk but the last keeps 1500 encoder
+    frames, so song s owns encoder rows s*C*1500 .. + sum(kept)."""
+    import torch
+    from lyricalignment_amd.module.align_model import frame_plan, song_major_chunks
+    from lyricalignment_amd.whisper_compat import pad_or_trim
+    n_mel = 7302
+    plan = frame_plan(n_mel, True)
+    assert [(s, e) for s, e, _ in plan] == [(0, 3000), (3000, 6000), (6000, 7302)] and [k for _, _, k in plan] == [1500, 1500, 651]
+    mel = torch.arange(2 * 80 * n_mel, dtype=torch.float32).view(2, 80, n_mel)
+    chunks = song_major_chunks(mel, plan)
+    assert tuple(chunks.shape) == (6, 80, 3000)
+    for s in range(2):
+        for c, (a, b, _) in enumerate(plan):
+            want = pad_or_trim(mel[s:s + 1, :, a:b], 3000)[0]
+            assert torch.equal(chunks[s * 3 + c], want)
+    # Python's round() (banker's) on the last chunk, as the reference computes it
+    assert frame_plan(6301, True)[-1][2] == 150 and frame_plan(6303, True)[-1][2] == 152
+    assert frame_plan(2001, True) == [(0, 2001, 1000)] and frame_plan(9000, False) == [(0, 3000, 1500)]
