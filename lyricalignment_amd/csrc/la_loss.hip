@@ -93,7 +93,7 @@ __global__ __launch_bounds__(NT) void ctc_lattice_kernel(const float *logits, in
                                                          const float *lse_all, const int32_t *labels, int labels_stride,
                                                          const int32_t *n_labels, double *alpha_ws, int S_pad,
                                                          float *dlogits, int64_t ldd_b, int64_t ldd, float scale,
-                                                         int batch, LossAcc *acc, float *nll_out) {
+                                                         int batch, LossAcc *acc, float *nll_out, int reuse_alpha) {
     __shared__ double rowbuf[2][NT + 2];
     __shared__ double fin[2];
     const int b = blockIdx.x, s = threadIdx.x;
@@ -114,35 +114,43 @@ __global__ __launch_bounds__(NT) void ctc_lattice_kernel(const float *logits, in
         return;
     }
     if (s < 2) { rowbuf[0][s] = -INFINITY; rowbuf[1][s] = -INFINITY; }
-    // ---- alpha ----
-    double a = -INFINITY;
-    {
-        const double lp = valid && cls_ok ? (double)xb[cls] - (double)lseb[0] : -INFINITY;
-        if (s <= 1 && valid) a = lp;
-        if (valid) aw[s] = a;
-    }
     int par = 0;
-    for (int t = 1; t < T; ++t) {
-        rowbuf[par][s + 2] = a;
+    double nll;
+    if (reuse_alpha) {
+        // gradient launch after the loss launch: the alpha rows (and with them log p(labels)) are in the workspace already
+        const double ll = S > 1 ? log_add(aw[(int64_t)(T - 1) * S_pad + S - 1], aw[(int64_t)(T - 1) * S_pad + S - 2])
+                                : aw[(int64_t)(T - 1) * S_pad + S - 1];
+        nll = -ll;
+    } else {
+        // ---- alpha ----
+        double a = -INFINITY;
+        {
+            const double lp = valid && cls_ok ? (double)xb[cls] - (double)lseb[0] : -INFINITY;
+            if (s <= 1 && valid) a = lp;
+            if (valid) aw[s] = a;
+        }
+        for (int t = 1; t < T; ++t) {
+            rowbuf[par][s + 2] = a;
+            __syncthreads();
+            const double a1 = rowbuf[par][s + 1], a2 = rowbuf[par][s];
+            par ^= 1;
+            double acc3 = log_add(a, a1);
+            if (can_skip) acc3 = log_add(acc3, a2);
+            const double lp = valid && cls_ok ? (double)xb[(int64_t)t * ldl + cls] - (double)lseb[t] : -INFINITY;
+            a = valid ? acc3 + lp : -INFINITY;
+            if (valid) aw[(int64_t)t * S_pad + s] = a;
+        }
         __syncthreads();
-        const double a1 = rowbuf[par][s + 1], a2 = rowbuf[par][s];
-        par ^= 1;
-        double acc3 = log_add(a, a1);
-        if (can_skip) acc3 = log_add(acc3, a2);
-        const double lp = valid && cls_ok ? (double)xb[(int64_t)t * ldl + cls] - (double)lseb[t] : -INFINITY;
-        a = valid ? acc3 + lp : -INFINITY;
-        if (valid) aw[(int64_t)t * S_pad + s] = a;
-    }
-    __syncthreads();
-    if (s == S - 1) fin[0] = a;
-    if (s == S - 2) fin[1] = a;
-    __syncthreads();
-    const double ll = S > 1 ? log_add(fin[0], fin[1]) : fin[0];
-    const double nll = -ll;
-    if (s == 0) {
-        nll_out[b] = (float)nll;
-        if (isinf(nll)) atomicAdd(&acc->v[4], 1.0);
-        atomicAdd(&acc->v[3], nll / (double)L);
+        if (s == S - 1) fin[0] = a;
+        if (s == S - 2) fin[1] = a;
+        __syncthreads();
+        const double ll = S > 1 ? log_add(fin[0], fin[1]) : fin[0];
+        nll = -ll;
+        if (s == 0) {
+            nll_out[b] = (float)nll;
+            if (isinf(nll)) atomicAdd(&acc->v[4], 1.0);
+            atomicAdd(&acc->v[3], nll / (double)L);
+        }
     }
     if (!dlogits) return;
     // ---- beta + occupancy scatter ----
@@ -276,7 +284,7 @@ extern "C" int la_multitask_loss(const float *logits, int64_t batch_stride, int6
 #define LA_CTC_CASE(NTV)                                                                                                   \
     hipLaunchKernelGGL((ctc_lattice_kernel<NTV>), dim3(batch), dim3(NTV), 0, stream, logits, batch_stride, row_stride, frames,  \
                        vocab, lse_all, ctc_labels, labels_stride, n_labels, alpha_ws, S_pad, dl, d_batch_stride, d_row_stride,   \
-                       scale, batch, dl ? acc + 1 : acc, nll)
+                       scale, batch, dl ? acc + 1 : acc, nll, dl ? 1 : 0)
         if (S <= 64) LA_CTC_CASE(64);
         else if (S <= 128) LA_CTC_CASE(128);
         else if (S <= 256) LA_CTC_CASE(256);
@@ -295,8 +303,8 @@ extern "C" int la_multitask_loss(const float *logits, int64_t batch_stride, int6
                            lse_ce, frame_labels, n_labels, nll, acc, use_ce, use_ctc, scale, batch, dlogits, d_row_stride);
         LA_LAUNCH_CHECK();
         if (use_ctc) {
-            launch_lattice(dlogits);   // alpha + beta sweeps again, occupancies subtracted from the dense softmax part
-            LA_LAUNCH_CHECK();          // (its accumulator writes go to a scratch slot)
+            launch_lattice(dlogits);   // beta sweep on the stored alpha rows, occupancies subtracted from the dense softmax part
+            LA_LAUNCH_CHECK();
         }
     }
     hipLaunchKernelGGL(finish_losses_kernel, dim3(1), dim3(1), 0, stream, acc, rows, batch, losses);
