@@ -307,3 +307,17 @@ def test_gemm_f32_transposed_operands(M, N, K):
         a = _rand(M, K, seed=33, scale=0.3).cuda()
         out = ht.gemm_nn(a, wt).cpu()                         # [M, N] = a wt
         np.testing.assert_allclose(out.double().numpy(), (a.double().cpu() @ wt.double().cpu()).numpy(), rtol=0, atol=tol)
+
+
+def test_colsum_deterministic():
+    """la_colsum_f32 (bias gradients): double partials per row chunk added in a fixed order; back-to-back calls of different
+    shapes share the per-stream scratch."""
+    from lyricalignment_amd import head_train as ht
+    for rows, cols in [(3000, 1024), (7, 5), (3000, 4096), (80, 51865), (1, 64), (3000, 1024), (40000, 130)]:
+        x = _rand(rows, cols, seed=rows + cols, scale=1.0).cuda()
+        got = ht.colsum(x)
+        again = ht.colsum(x)
+        assert torch.equal(got, again)
+        np.testing.assert_allclose(got.cpu().double().numpy(), x.double().sum(0).cpu().numpy(), rtol=0, atol=1e-6 * max(1.0, rows ** 0.5) * 4)
+    v = _rand(3000, 2048, seed=9).cuda()[:, 100:1124]        # row view with a pitch
+    np.testing.assert_allclose(ht.colsum(v).cpu().double().numpy(), v.double().sum(0).cpu().numpy(), rtol=0, atol=3e-4)
