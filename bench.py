@@ -148,6 +148,101 @@ def cpu_baseline(model, mel_cpu: np.ndarray, labels_row: np.ndarray, n_head: int
                       f"median of {len(times)} after 1 warm-up, {sec:.2f} s per clip"}, res
 
 
+def finetune_mode(args, rank, world, local_rank, device, dist):
+    """BASELINE configs[2]: multitask fine-tune (CE + silence BCE + CTC on the align logits, decoder CE), float32 like the
+    reference, data parallel: every rank runs `accum` micro-steps of 2 x 30 s clips (reference defaults, train_multitask.py:
+    240,325), then ONE all-reduce (sum) per flat gradient bucket over RCCL / xGMI, the fused clip + AdamW (:337-340).
+    A step = one optimizer step; value = audio-seconds the whole job trained on per wall-second."""
+    from lyricalignment_amd import _lib, finetune as ft, whisper_compat as wc
+    from lyricalignment_amd.module.align_model import AlignModel
+    _lib.require_gpu()
+    log(f"rank {rank}/{world}: building random-init whisper-{args.model} weights (fine-tune mode)")
+    dims = wc.dims_for(args.model)
+    wm = wc.build_model(args.model, seed=0, with_decoder=True)
+    torch.manual_seed(0)                       # the head's torch-default initialisation: identical on every rank
+    model = AlignModel(wm, embed_dim=dims.n_audio_state, hidden_dim=HIDDEN, output_dim=VOCAB, dropout=0.15, train_transcript=True,
+                       device=f"cuda:{local_rank}").to(device)
+    tuner = ft.FineTuner(model, warmup_steps=1, train_steps=10000)
+    B, n_tok = 2, 32
+    rs = np.random.RandomState(114514 + rank)   # reference seed (train_multitask.py:136-139) + rank: every rank its own clips
+    audios = [(rs.randn(480000) * 0.1).astype(np.float32) for _ in range(B)]
+    labels = torch.from_numpy(rs.randint(1, 402, size=(B, 26)))
+    fl = torch.full((B, T_FRAMES), -100, dtype=torch.long)
+    for b in range(B):
+        for i in range(26):                     # frame labels from uniformly spaced on / offsets (SURVEY 8d cfg 3)
+            fl[b, 40 + 50 * i: 40 + 50 * i + 30] = labels[b, i]
+    dec_in = torch.from_numpy(rs.randint(0, 50000, size=(B, n_tok)))
+    dec_out = torch.from_numpy(rs.randint(0, 50000, size=(B, n_tok)))
+    ar_events = []
+
+    def step(timed):
+        for _ in range(args.accum):
+            tuner.micro_step(audios, labels, fl, dec_in, dec_out, accum_grad_steps=args.accum)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        ft.allreduce_mean_(tuner.grad, tuner.world)          # the one exchange step of the data-parallel path
+        e1.record()
+        if timed:
+            ar_events.append((e0, e1))
+        tuner.step(allreduced=True)
+
+    for _ in range(args.warmup):
+        step(False)
+    torch.cuda.synchronize()
+    L = _lib.lib()
+    L.la_timer_reset()
+    L.la_timer_enable(os.environ.get("LA_BENCH_TIMER", "gemm_f32").encode())
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    L.la_timer_disable()
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    import ctypes
+    total_ms, launches = ctypes.c_double(0.0), ctypes.c_int64(0)
+    _lib.check(L.la_timer_read(ctypes.byref(total_ms), ctypes.byref(launches)), "timer_read")
+    d, nl = dims.n_audio_state, dims.n_audio_layer
+    T = T_FRAMES
+    # algorithmic GEMM flops of one micro-step (forward + the two backward products of every Linear = 3 x forward):
+    # encoder Linears / convs, GRU input projections + FC, decoder (cross-attention K/V projections over 1500 frames dominate)
+    fwd = (2 * 3000 * 80 * 3 * d + 2 * T * d * 3 * d + nl * 24 * T * d * d) + (2 * (2 * T * d * 3 * HIDDEN) + 2 * (2 * T * 2 * HIDDEN * 3 * HIDDEN)
+           + 2 * T * 2 * HIDDEN * VOCAB) + dims.n_text_layer * (2 * T * d * 2 * d + n_tok * 22 * d * d) + 2 * n_tok * d * 51865
+    gemm_flops_step = 3.0 * fwd * B * args.accum
+    achieved = gemm_flops_step * args.steps / (total_ms.value * 1e-3) / 1e12 if total_ms.value > 0 else 0.0
+    ar_ms = float(np.mean([a.elapsed_time(b) for a, b in ar_events])) if ar_events else 0.0
+    grad_bytes = int(sum(g.numel() for g in tuner.grad) * 4)
+    if rank == 0:
+        audio_sec = world * B * CLIP_SECONDS * args.accum * args.steps
+        print(json.dumps({
+            "metric": f"fine-tuned audio-sec/sec, Whisper-{args.model} multitask (CTC + CE + decoder CE), DP={world}",
+            "value": audio_sec / elapsed, "unit": "audio-sec/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (Gaussian waveforms, random class-id / frame / token labels, random-init weights)",
+            "config": {"workload": f"whisper-{args.model} multitask fine-tune step, per-GPU micro-batch {B} x 30 s x accum {args.accum} "
+                                   "(BASELINE.json configs[2])", "mode": "finetune", "micro_batch": B, "accum": args.accum,
+                       "decoder_tokens": n_tok, "grad_bytes_per_step": grad_bytes,
+                       "sharding": "clips over ranks; one all-reduce (sum) per flat gradient bucket per optimizer step"},
+            "micro_step_ms": (elapsed / args.steps * 1e3 - ar_ms) / args.accum,
+            "allreduce_ms_per_step": ar_ms,
+            "roofline": {"bound": "mfma", "kernel": "gemm_kernel<float> (v_mfma_f32_16x16x4_f32; every Linear forward + both backward products)",
+                         "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s", "frac": achieved / 157.3, "traffic": None,
+                         "launches_per_step": launches.value / max(args.steps, 1), "avg_launch_ms": total_ms.value / max(launches.value, 1)},
+            "cpu_baseline": None,
+            "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -160,6 +255,11 @@ def main():
     ap.add_argument("--encoder-streams", type=int, default=1, help="HIP streams the encoders of consecutive batches alternate between")
     ap.add_argument("--head-group", type=int, default=2,
                     help="batches whose head (GRU / FC / DP) runs as one launch set in the two-stream pipeline")
+    ap.add_argument("--mode", choices=["align", "finetune"], default="align",
+                    help="align = BASELINE configs[1] (the headline metric); finetune = configs[2], the data-parallel multitask "
+                         "fine-tune step (float32, per-GPU micro-batch 2 x 30 s, --accum micro-steps, ONE gradient all-reduce per step)")
+    ap.add_argument("--model", default=MODEL, help="finetune mode only: whisper architecture (medium = configs[2])")
+    ap.add_argument("--accum", type=int, default=8, help="finetune mode: micro-steps per optimizer step (reference default 8)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -185,6 +285,9 @@ def main():
             dist.init_process_group(backend="nccl", device_id=device)
         else:
             dist.init_process_group(backend=backend)
+
+    if args.mode == "finetune":
+        return finetune_mode(args, rank, world, local_rank, device, dist)
 
     log(f"rank {rank}/{world}: building random-init whisper-{MODEL} weights")
     from lyricalignment_amd import _lib, whisper_compat as wc

@@ -12,10 +12,13 @@
 // a wave computes [batch x H] * [H x 48] with MFMA 16x16 tiles (batch on the rows), applies the
 // gates lane-locally (the r/z/n accumulators share one layout), writes its h slice into `out`
 // (which IS the exchange buffer: the next layer / the FC read it anyway) and signals a per-step
-// arrival counter.  Hand-off = agent-scope release / acquire (cdna guide, Guideline 16): plain
-// stores -> every wave vmcnt(0) -> barrier -> lane 0 release fence -> counter add; consumers poll
-// the counter relaxed, one lane acquires, barrier, then plain loads.  Every wait is bounded.
-// Clips are independent, so batches larger than 32 become extra workgroup groups (grid.z).
+// arrival counter.  Hand-off (cdna guide, Guideline 16), default = the write-through form: every
+// handed-off byte is stored sc1 -> every wave vmcnt(0) -> barrier -> lane 0 relaxed agent-scope
+// counter add; consumers poll the counter with sc1 loads, pass a barrier, then read with sc1 loads
+// only.  LA_GRU_FENCE=1 selects the release / acquire form instead (plain stores -> vmcnt(0) ->
+// barrier -> lane 0 release fence -> counter add; one lane acquires, barrier, plain loads), 1.7x
+// slower per step.  Every wait is bounded.
+// Clips are independent, so batches larger than 16 become extra workgroup groups (grid.z).
 #include <type_traits>
 
 #include "la_common.h"

@@ -192,7 +192,141 @@ __global__ __launch_bounds__(NW * 64) void viterbi_kernel(VitParams p) {
     }
 }
 
+
+// Lattices beyond 1024 states (whole songs with more than 511 characters; the reference's run_viterbi_core has no limit):
+// 1024 threads, each owning R CONSECUTIVE states k = tid*R + r, so 1024*R states per workgroup (R = 2, 4, 8 -> up to 4095
+// labels).  Same recurrence, same comparison order, float64; the previous row goes through a double-buffered f64 row in
+// LDS (one barrier per frame).  Backpointer masks: [frame][r][wave][2] 64-bit ballots in the caller's workspace.
+// Onset / offset go straight to the outputs (no LDS copies: the row buffers take the LDS at R = 8).
+template <int R>
+__global__ __launch_bounds__(1024) void viterbi_strip_kernel(VitParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NT = 1024, NS = NT * R, SPF = 4;
+    double *rowbuf = reinterpret_cast<double *>(smem);      // [2][NS + 2]
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int L = p.n_labels[b];
+    const int T = p.n_frames[b];
+    const int S = 2 * L + 1;
+    int32_t *on_g = p.onset + (int64_t)b * p.out_stride, *off_g = p.offset + (int64_t)b * p.out_stride;
+    for (int n = tid; n < p.max_labels; n += NT) { on_g[n] = -1; off_g[n] = -1; }
+    if (L <= 0) {
+        if (tid == 0) { p.status[b] = LA_EEMPTY; p.final_score[b] = 0.0; }
+        return;
+    }
+    if (T <= 0 || T > p.max_frames || L > p.max_labels || S > NS) {
+        if (tid == 0) { p.status[b] = LA_EINVAL; p.final_score[b] = 0.0; }
+        return;
+    }
+    unsigned long long *bt = p.bt_global + (int64_t)b * p.max_frames * R * 32;
+    const int32_t *lab = p.labels + (int64_t)b * p.labels_stride;
+    const int k0 = tid * R;
+    int col[R];
+    bool can_skip[R], valid[R];
+    double cur[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int k = k0 + r, n = k >> 1;
+        valid[r] = k < S;
+        const bool odd = (k & 1) != 0;
+        col[r] = (odd && valid[r]) ? 1 + n : 0;
+        can_skip[r] = odd && valid[r] && k >= 3 && lab[n] != lab[n - 1];
+    }
+    const float *emb = p.em + (int64_t)b * p.em_bs;
+#pragma unroll
+    for (int r = 0; r < R; ++r) cur[r] = (k0 + r <= 1) ? (double)emb[col[r]] : kNeg;
+    if (tid == 0) { rowbuf[0] = kNeg; rowbuf[1] = kNeg; rowbuf[NS + 2] = kNeg; rowbuf[NS + 3] = kNeg; }
+
+    float e_buf[SPF][R];
+#pragma unroll
+    for (int i = 0; i < SPF; ++i)
+#pragma unroll
+        for (int r = 0; r < R; ++r) e_buf[i][r] = (1 + i) < T ? emb[(int64_t)(1 + i) * p.em_rs + col[r]] : 0.0f;
+    int parity = 0;
+    for (int j0 = 1; j0 < T; j0 += SPF) {
+        float e_cur[SPF][R];
+#pragma unroll
+        for (int i = 0; i < SPF; ++i)
+#pragma unroll
+            for (int r = 0; r < R; ++r) e_cur[i][r] = e_buf[i][r];
+#pragma unroll
+        for (int i = 0; i < SPF; ++i)
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int jj = j0 + SPF + i;
+                e_buf[i][r] = jj < T ? emb[(int64_t)jj * p.em_rs + col[r]] : 0.0f;
+            }
+#pragma unroll
+        for (int i = 0; i < SPF; ++i) {
+            const int j = j0 + i;
+            if (j >= T) break;
+            double *rb = rowbuf + parity * (NS + 2);
+            // the two rightmost states of this thread are the k-1 / k-2 neighbours of the next thread's first states
+            rb[k0 + 2 + R - 1] = cur[R - 1];
+            rb[k0 + 2 + R - 2] = cur[R - 2];
+            __syncthreads();
+            double prev[R + 2];
+            prev[0] = rb[k0];
+            prev[1] = rb[k0 + 1];
+#pragma unroll
+            for (int r = 0; r < R; ++r) prev[r + 2] = cur[r];
+            parity ^= 1;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const double p0 = prev[r + 2], p1 = prev[r + 1], p2 = prev[r];
+                const bool stay = p0 > p1;
+                const bool skip = can_skip[r] && (p2 >= p1) && (p2 >= p0);
+                int code = skip ? 2 : (stay ? 0 : 1);
+                double best = skip ? p2 : (stay ? p0 : p1);
+                if (k0 + r == 0) { code = 0; best = p0; }
+                cur[r] = best + (double)e_cur[i][r];
+                const unsigned long long lo = __ballot(code & 1);
+                const unsigned long long hi = __ballot(code >> 1);
+                if (lane == 0) {
+                    unsigned long long *row = bt + (((int64_t)j * R + r) * 16 + wave) * 2;
+                    row[0] = lo;
+                    row[1] = hi;
+                }
+            }
+        }
+    }
+    // termination + backtrace by one thread; the masks were written by other waves of this workgroup: drain + barrier first
+    __syncthreads();
+    double *fin = rowbuf;
+#pragma unroll
+    for (int r = 0; r < R; ++r) fin[k0 + r] = cur[r];
+    __threadfence_block();
+    __syncthreads();
+    if (tid == 0) {
+        int kk = (fin[S - 1] > fin[S - 2]) ? (S - 1) : (S - 2);
+        p.final_score[b] = fin[kk];
+        int knext = -1, entered = 0;
+        for (int j = T - 1; j >= 0; --j) {
+            if (kk & 1) {
+                const int nn = kk >> 1;
+                if (kk != knext) { off_g[nn] = j + 1; ++entered; }
+                if (j == 0) on_g[nn] = 0;
+            }
+            int knew = kk;
+            if (j > 0) {
+                const int t2 = kk / R, r = kk - t2 * R;
+                const unsigned long long *row = bt + (((int64_t)j * R + r) * 16 + (t2 >> 6)) * 2;
+                const int sh = t2 & 63;
+                const int code = (int)((row[0] >> sh) & 1ull) | ((int)((row[1] >> sh) & 1ull) << 1);
+                knew = kk - code;
+                if ((kk & 1) && knew != kk) on_g[kk >> 1] = j;   // frame j is the first one in this state
+            }
+            knext = kk;
+            kk = knew;
+        }
+        // the path is monotone in k, so every odd state is entered at most once: all L labels visited <=> L entries
+        p.status[b] = entered == L ? LA_OK : LA_EINFEASIBLE;   // reference: ValueError from list.index (:183)
+    }
+}
+
 struct VitPlan {
+    int strip;   // 0: one lane per state (<= 1024 states); else R = states per thread of the 1024-thread strip kernel
     int nw;
     bool bt_in_lds;
     size_t lds_bytes;
@@ -205,7 +339,18 @@ bool plan_viterbi(int batch, int max_frames, int max_labels, VitPlan *pl) {
     const int S = 2 * max_labels + 1;
     int nw = 1;
     while (nw * 64 < S) nw *= 2;
-    if (nw > 16) return false;
+    pl->strip = 0;
+    if (nw > 16) {
+        int R = 2;
+        while (1024 * R < S) R *= 2;
+        if (R > 8) return false;
+        pl->strip = R;
+        pl->nw = 16;
+        pl->bt_in_lds = false;
+        pl->lds_bytes = 2 * (size_t)(1024 * R + 2) * sizeof(double);
+        pl->ws_bytes = (size_t)batch * max_frames * R * 32 * sizeof(unsigned long long);
+        return true;
+    }
     const size_t fixed = 2 * (size_t)(nw * 64 + 2) * sizeof(double) + 2 * (size_t)((max_labels + 3) & ~3) * sizeof(int32_t);
     const size_t fixed_al = (fixed + 15) & ~(size_t)15;
     const size_t bt_bytes = (size_t)max_frames * nw * 16;
@@ -234,7 +379,7 @@ extern "C" int la_viterbi_workspace_bytes(int32_t batch, int32_t max_frames, int
     LA_CHECK_ARG(bytes && batch >= 0 && max_frames > 0 && max_labels > 0, "viterbi_workspace_bytes: bad arguments");
     VitPlan pl;
     if (!plan_viterbi(batch, max_frames, max_labels, &pl)) {
-        la::set_error("viterbi: max_labels %d exceeds 511 (1024 lattice states per workgroup)", max_labels);
+        la::set_error("viterbi: max_labels %d exceeds 4095 (8192 lattice states per workgroup)", max_labels);
         return LA_EUNSUPPORTED;
     }
     *bytes = pl.ws_bytes;
@@ -255,15 +400,32 @@ extern "C" int la_viterbi_batch(const float *em, int64_t em_batch_stride, int64_
                  "viterbi_batch: strides smaller than max_labels");
     VitPlan pl;
     if (!plan_viterbi(batch, max_frames, max_labels, &pl)) {
-        la::set_error("viterbi: max_labels %d exceeds 511", max_labels);
+        la::set_error("viterbi: max_labels %d exceeds 4095", max_labels);
         return LA_EUNSUPPORTED;
     }
     LA_CHECK_ARG(pl.ws_bytes == 0 || (workspace && workspace_bytes >= pl.ws_bytes),
                  "viterbi_batch: workspace too small (%zu < %zu)", workspace_bytes, pl.ws_bytes);
+    LA_CHECK_ARG(pl.ws_bytes == 0 || (uintptr_t)workspace % 8 == 0, "viterbi_batch: workspace must be 8-byte aligned");
     VitParams p{em, em_batch_stride, em_row_stride, labels, labels_stride, n_labels, n_frames, max_frames,
                 max_labels, onset, offset, out_stride, final_score, status,
                 reinterpret_cast<unsigned long long *>(workspace), pl.bt_in_lds ? 1 : 0, nullptr, nullptr};
     static const bool no_dpp = getenv("LA_VITERBI_NO_DPP") != nullptr;
+    if (pl.strip) {
+        la::TimerScope ts("viterbi", stream);
+#define LA_STRIP_CASE(RV)                                                                                                  \
+    case RV:                                                                                                               \
+        LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(viterbi_strip_kernel<RV>),                               \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes));                        \
+        hipLaunchKernelGGL(viterbi_strip_kernel<RV>, dim3(batch), dim3(1024), pl.lds_bytes, stream, p);                    \
+        break;
+        switch (pl.strip) {
+            LA_STRIP_CASE(2) LA_STRIP_CASE(4) LA_STRIP_CASE(8)
+            default: return LA_EUNSUPPORTED;
+        }
+#undef LA_STRIP_CASE
+        LA_LAUNCH_CHECK();
+        return LA_OK;
+    }
     switch (pl.nw) {
         case 1: return no_dpp ? launch_viterbi<1, false>(p, pl, batch, stream) : launch_viterbi<1, true>(p, pl, batch, stream);
         case 2: return launch_viterbi<2, false>(p, pl, batch, stream);
@@ -284,8 +446,8 @@ extern "C" int la_viterbi_core(const float *em, int64_t em_row_stride, const int
     LA_CHECK_ARG(em && labels && n_labels && n_frames && dp && bt && scratch_i32 && scratch_f64, "viterbi_core: null pointer");
     LA_CHECK_ARG(n_labels_host > 0 && n_frames_host > 0 && em_row_stride >= n_labels_host + 1, "viterbi_core: bad sizes");
     VitPlan pl;
-    if (!plan_viterbi(1, n_frames_host, n_labels_host, &pl)) {
-        la::set_error("viterbi_core: more than 511 labels");
+    if (!plan_viterbi(1, n_frames_host, n_labels_host, &pl) || pl.strip) {
+        la::set_error("viterbi_core: more than 511 labels (the dp / bt dump face is one lane per state)");
         return LA_EUNSUPPORTED;
     }
     LA_CHECK_ARG(pl.ws_bytes == 0 || (workspace && workspace_bytes >= pl.ws_bytes), "viterbi_core: workspace too small");

@@ -212,6 +212,7 @@ class AlignEngine:
         _lib.require_gpu()
         self.enc, self.head, self.dec, self.device = enc, head, dec, torch.device(device)
         self._buf: Dict[Tuple, torch.Tensor] = {}
+        self._gru_flag: Optional[torch.Tensor] = None   # timeout word shared by this engine's GRU launches (check_gru reads it)
 
     # ---- scratch -----------------------------------------------------------------
     def _get(self, name: str, shape, dtype, zero: bool = False) -> torch.Tensor:
@@ -471,27 +472,47 @@ class AlignEngine:
         return out_tokens, out_lp
 
     # ---- head: align_rnn up to Mish ------------------------------------------------------
+    def head_clip_cap(self, T: int) -> int:
+        """Clips one launch set of the persistent GRU recurrence can take: every workgroup of the launch must be resident
+        (la_gru.hip: 2 directions x hidden/(16 * waves) workgroups per 16 clips, at most 224 per launch -> 288 clips in the
+        16-bit modes, 144 in float32 at hidden 384) and the out buffer is addressed through a 2 GiB buffer descriptor."""
+        hw = self.head
+        es = 4 if hw.dtype == torch.float32 else 2
+        nsplit = hw.hidden // (16 * (2 if hw.dtype == torch.float32 else 4))
+        by_cus = (224 // (2 * nsplit)) * 16
+        by_desc = (2 ** 31 - 1) // (max(1, T) * 2 * hw.hidden * es)
+        return max(1, min(HEAD_CLIPS_MAX, by_cus, by_desc))
+
     def head_hidden(self, feats: torch.Tensor, B: int, T: int, feat_clip_stride: int) -> torch.Tensor:
-        """feats: rows [.., d] in compute dtype, clip b at rows b*feat_clip_stride .. +T.  -> Mish(GRU) [B*T, 2H]."""
+        """feats: rows [.., d] in compute dtype, clip b at rows b*feat_clip_stride .. +T.  -> Mish(GRU) [B*T, 2H].
+        More clips than one launch set of the recurrence takes (head_clip_cap) run as consecutive slices of clips."""
+        hw = self.head
+        H, dt = hw.hidden, hw.dtype
+        cap = self.head_clip_cap(T)
+        act = self._get("head_act", (B * T, 2 * H), dt)
+        for b0 in range(0, B, cap):
+            b1 = min(B, b0 + cap)
+            self._head_slice(feats[b0 * feat_clip_stride:], b1 - b0, T, feat_clip_stride, min(B, cap), act[b0 * T: b1 * T])
+        return act
+
+    def _head_slice(self, feats: torch.Tensor, B: int, T: int, feat_clip_stride: int, Bbuf: int, act_out: torch.Tensor) -> None:
         hw = self.head
         H, dt = hw.hidden, hw.dtype
         x = feats
         lda, stride_a = feats.stride(0), feat_clip_stride * feats.stride(0)
-        act = None
         n_layers = len(hw.w_ih)
         for layer in range(n_layers):
-            gi = self._get("gi", (B, T, 2, 3 * H), torch.float32)
+            gi = self._get("gi", (Bbuf, T, 2, 3 * H), torch.float32)[:B]
             ops.gemm(x, hw.w_ih[layer], gi.view(B * T, 6 * H), bias=hw.b_ih[layer], out_f32=True, M=T, lda=lda, batch=B,
                      stride_a=stride_a, stride_c=T * 6 * H, ldc=6 * H)
-            out = self._get(f"gru{layer}", (B, T, 2 * H), dt)
+            out = self._get(f"gru{layer}", (Bbuf, T, 2 * H), dt)[:B]
             last = layer == n_layers - 1
-            res = ops.gru_layer(gi, hw.w_hh[layer], hw.b_hh[layer], out=out, want_mish=last)
-            self._last_gru_flag = res[-1]
-            if last:
-                act = res[1]
+            if self._gru_flag is None:
+                self._gru_flag = torch.zeros((1,), dtype=torch.int32, device=self.device)
+            ops.gru_layer(gi, hw.w_hh[layer], hw.b_hh[layer], out=out, out_mish=act_out.view(B, T, 2 * H) if last else None,
+                          flag=self._gru_flag)
             x = out.view(B * T, 2 * H)
             lda, stride_a = 2 * H, T * 2 * H
-        return act.view(B * T, 2 * H)
 
     def logits(self, feats: torch.Tensor, B: int, T: int, feat_clip_stride: int) -> torch.Tensor:
         """Materialised align logits [B, T, V] f32 (the reference's frame_manual_forward output)."""
@@ -506,9 +527,9 @@ class AlignEngine:
         return ops.fc_emissions(act, self.head.w_fc, self.head.b_fc, B, T, labels, n_labels, variant)
 
     def check_gru(self) -> None:
-        """Host check of the persistent GRU kernel's bounded waits (synchronises)."""
-        flag = getattr(self, "_last_gru_flag", None)
-        if flag is not None and int(flag.item()) != 0:
+        """Host check of the persistent GRU kernel's bounded waits (synchronises): every launch since the last check."""
+        if self._gru_flag is not None and int(self._gru_flag.item()) != 0:
+            self._gru_flag.zero_()
             raise TimeoutError("persistent GRU kernel: a bounded inter-workgroup wait timed out")
 
     # ---- whole path on a ready mel batch ---------------------------------------------------
@@ -518,20 +539,9 @@ class AlignEngine:
         B = mel.shape[0]
         feats = self.encode(mel)
         variant = LA_VARIANT_CTC if use_ctc else LA_VARIANT_PLAIN
-        if B <= HEAD_CLIPS_MAX:
-            em = self.emissions(feats, B, n_frames, N_CTX, labels, n_labels, variant)
-            nf = torch.full((B,), n_frames, dtype=torch.int32, device=self.device)
-            return ops.viterbi_batch(em, labels, n_labels, nf)
-        # Very large batches (BASELINE configs[3]: "batch sized to fill 288 GB"): the encoder takes them whole, the head runs
-        # over slices of clips -- the persistent GRU recurrence needs all its workgroups resident (one group of 12 per 32
-        # clips) and addresses its exchange buffer through a 2 GiB buffer descriptor.
-        outs = []
-        for b0 in range(0, B, HEAD_CLIPS_MAX):
-            b1 = min(B, b0 + HEAD_CLIPS_MAX)
-            em = self.emissions(feats[b0 * N_CTX: b1 * N_CTX], b1 - b0, n_frames, N_CTX, labels[b0:b1], n_labels[b0:b1].contiguous(), variant)
-            nf = torch.full((b1 - b0,), n_frames, dtype=torch.int32, device=self.device)
-            outs.append(ops.viterbi_batch(em, labels[b0:b1], n_labels[b0:b1].contiguous(), nf))
-        return tuple(torch.cat([o[i] for o in outs], dim=0) for i in range(4))
+        em = self.emissions(feats, B, n_frames, N_CTX, labels, n_labels, variant)
+        nf = torch.full((B,), n_frames, dtype=torch.int32, device=self.device)
+        return ops.viterbi_batch(em, labels, n_labels, nf)
 
 
 class PipelinedAligner:
@@ -629,6 +639,10 @@ class PipelinedAligner:
                torch.empty((B,), dtype=torch.float64, device=eng.device), torch.empty((B,), dtype=torch.int32, device=eng.device))
         for t_ in out:
             t_.record_stream(self.stream_h)          # written on stream H: the allocator must not recycle them under it
+        # read on stream H when the group is flushed, possibly long after the caller dropped its references: the caching
+        # allocator must not hand these blocks back to the caller's stream before the head has consumed them
+        labels.record_stream(self.stream_h)
+        n_labels.record_stream(self.stream_h)
         self._pending.append(dict(labels=labels, n_labels=n_labels, out=out, host_out=host_out))
         if len(self._pending) == self.G:
             self._flush()

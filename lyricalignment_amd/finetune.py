@@ -204,9 +204,11 @@ class FineTuner:
             self._accumulate()
         return out
 
-    def step(self) -> torch.Tensor:
-        """All-reduce + clip + AdamW + schedule; returns the device scalar sum(grad^2) over the summed buckets."""
-        allreduce_mean_(self.grad, self.world)
+    def step(self, allreduced: bool = False) -> torch.Tensor:
+        """All-reduce + clip + AdamW + schedule; returns the device scalar sum(grad^2) over the summed buckets.
+        allreduced=True: the caller has already run allreduce_mean_(self.grad, self.world) (bench.py times it separately)."""
+        if not allreduced:
+            allreduce_mean_(self.grad, self.world)
         sumsq = self.opt.step(self.grad, max_norm=self.max_grad_norm, grad_prescale=1.0 / self.world,
                               lr_scale=linear_warmup_scale(self.steps_done, self.warmup_steps, self.train_steps))
         self.steps_done += 1

@@ -230,8 +230,10 @@ def attention(qkv: torch.Tensor, batch: int, frames: int, n_head: int, out: Opti
 
 
 def gru_layer(gi: torch.Tensor, w_hh: torch.Tensor, b_hh: torch.Tensor, out: Optional[torch.Tensor] = None,
-              want_mish: bool = False):
-    """gi [B,T,2,3H] f32; w_hh [2,3H,H] (f32 | bf16); b_hh [2,3H] f32 -> out [B,T,2H] (w_hh dtype) [, Mish(out)]."""
+              want_mish: bool = False, out_mish: Optional[torch.Tensor] = None, flag: Optional[torch.Tensor] = None):
+    """gi [B,T,2,3H] f32; w_hh [2,3H,H] (f32 | bf16); b_hh [2,3H] f32 -> out [B,T,2H] (w_hh dtype) [, Mish(out)].
+    `out_mish`: caller-owned [B,T,2H] buffer for Mish(out) (implies want_mish); `flag`: caller-owned int32 [1] word the
+    kernel sets when one of its bounded waits times out (default: a fresh zeroed one per call)."""
     _dev(gi, "gi", torch.float32); _dev(w_hh, "w_hh"); _dev(b_hh, "b_hh", torch.float32)
     dt = dtype_code(w_hh.dtype)
     if gi.dim() != 4 or gi.shape[2] != 2 or not gi.is_contiguous() or not w_hh.is_contiguous() or not b_hh.is_contiguous():
@@ -244,11 +246,18 @@ def gru_layer(gi: torch.Tensor, w_hh: torch.Tensor, b_hh: torch.Tensor, out: Opt
         out = torch.empty((B, T, 2 * H), dtype=w_hh.dtype, device=gi.device)
     if out.shape != (B, T, 2 * H) or out.dtype != w_hh.dtype or not out.is_contiguous():
         raise ValueError("gru_layer: bad out buffer")
-    out_mish = torch.empty_like(out) if want_mish else None
+    if out_mish is not None:
+        want_mish = True
+        if out_mish.shape != out.shape or out_mish.dtype != out.dtype or not out_mish.is_contiguous():
+            raise ValueError("gru_layer: bad out_mish buffer")
+    elif want_mish:
+        out_mish = torch.empty_like(out)
     need = ctypes.c_size_t(0)
     check(lib().la_gru_workspace_bytes(B, T, H, ctypes.byref(need)), "gru_workspace_bytes")
     ws = torch.empty((need.value,), dtype=torch.uint8, device=gi.device)
-    flag = torch.zeros((1,), dtype=torch.int32, device=gi.device)
+    if flag is None:
+        flag = torch.zeros((1,), dtype=torch.int32, device=gi.device)
+    _dev(flag, "flag", torch.int32)
     check(lib().la_gru_layer(dt, ptr(gi), ptr(w_hh), ptr(b_hh), ptr(out), ptr(out_mish), B, T, H, ptr(ws), need.value,
                              ptr(flag), stream_ptr()), "gru_layer")
     return (out, out_mish, flag) if want_mish else (out, flag)

@@ -217,16 +217,20 @@ def test_fc_emissions_fused(variant, dtype, B, T, K, V):
         assert torch.equal(em[b, :, 5], em[b, :, 6]) if b == 0 else True  # repeated label -> identical columns
 
 
-@pytest.mark.parametrize("wt", [False, True])
-def test_gru_handoff_under_uneven_load(wt):
+@pytest.mark.parametrize("fence", [False, True])
+def test_gru_handoff_under_uneven_load(fence):
     """The in-launch inter-workgroup hand-off of the persistent GRU must not depend on timing or placement: 12 runs of the
-    config-2 shape while another stream keeps the chip busy with GEMMs of varying size give bit-identical outputs."""
-    if wt:   # the write-through variant is selected per process: run this test body in a child with LA_GRU_WT=1
+    config-2 shape while another stream keeps the chip busy with GEMMs of varying size give bit-identical outputs.
+    fence=False: the default write-through form (sc1 stores, drained; sc1 loads); fence=True: the release / acquire fence
+    form, which the library selects per process (LA_GRU_FENCE=1) -- that case runs this test body in a child process."""
+    if fence:
         import os, subprocess, sys
-        env = dict(os.environ, LA_GRU_WT="1")
-        r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-m", "gpu", "-k", "test_gru_handoff_under_uneven_load and False"],
-                           env=env, capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        if os.environ.get("LA_GRU_FENCE"):
+            pytest.skip("already inside the LA_GRU_FENCE child")
+        env = dict(os.environ, LA_GRU_FENCE="1")
+        r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-m", "gpu", "-k",
+                            "test_gru_handoff_under_uneven_load and False"], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
         return
     from lyricalignment_amd import ops
     B, T, H = 32, 400, 384

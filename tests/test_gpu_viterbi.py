@@ -111,6 +111,54 @@ def test_multiwave_lattices_match_oracle(T, L):
     assert score[0] == score_o
 
 
+@pytest.mark.parametrize("T,L,scale", [(2500, 600, 0.05), (3000, 1100, 1.0), (4500, 2100, 0.0), (9000, 1024, 0.001)])
+def test_strip_lattices_beyond_1024_states_match_oracle(T, L, scale):
+    """S > 1024 states (whole songs with > 511 characters; the reference's run_viterbi_core has no limit): the strip kernel
+    (1024 threads x R consecutive states each, R = 2 / 4 / 8) against the C oracle, bit for bit -- incl. scale 0 (every
+    emission equal: pure tie-breaking) and a repeated label."""
+    from oracle import alignment_oracle as ao
+    rs = np.random.RandomState(T + L)
+    em = (-rs.rand(T, L + 1) * scale).astype(np.float32)
+    lab = rs.randint(1, 400, size=L)
+    lab[L // 2] = lab[L // 2 - 1]
+    lab[7] = lab[6]
+    _fix_repeats(em, lab)
+    rc, on_o, off_o, score_o = ao.align_frames_compact(em, lab)
+    on, off, score, status = _run([em], [lab.tolist()])
+    assert status[0] == rc == 0
+    assert on[0, :L].tolist() == on_o.tolist() and off[0, :L].tolist() == off_o.tolist()
+    assert score[0] == score_o
+
+
+def test_strip_lattice_ragged_batch_and_infeasible():
+    """One launch of the strip kernel over utterances of different T and L (one of them too short for its labels:
+    LA_EINFEASIBLE like the reference's ValueError, one empty: LA_EEMPTY), checked against the oracle per utterance."""
+    from oracle import alignment_oracle as ao
+    rs = np.random.RandomState(99)
+    specs = [(1800, 700), (900, 30), (650, 640), (1300, 0), (1290, 640), (2000, 513)]
+    ems, labs = [], []
+    for T, L in specs:
+        ems.append((-rs.rand(T, L + 1) * 0.3).astype(np.float32))
+        lab = rs.randint(1, 400, size=L)
+        for i in range(1, L):                  # (650, 640) with 12 forced repeats needs 652 frames: infeasible
+            if i % 53 == 0:
+                lab[i] = lab[i - 1]
+        _fix_repeats(ems[-1], lab)
+        labs.append(lab.tolist())
+    on, off, score, status = _run(ems, labs)
+    for b, (T, L) in enumerate(specs):
+        if L == 0:
+            assert status[b] == 3
+            continue
+        rc, on_o, off_o, score_o = ao.align_frames_compact(ems[b], np.array(labs[b]))
+        assert status[b] == rc, (T, L)
+        if rc == 0:
+            assert on[b, :L].tolist() == on_o.tolist() and off[b, :L].tolist() == off_o.tolist()
+            assert score[b] == score_o
+            assert (on[b, L:] == -1).all() and (off[b, L:] == -1).all()
+    assert status[2] == 2 and status[4] == 0
+
+
 def test_full_size_properties():
     """BASELINE config-2 size (B=32, T=1500, L<=26): monotone, in-range, contiguous coverage,
     and identical to the oracle on a sample of the batch."""

@@ -43,7 +43,10 @@ def test_argument_validation_without_gpu():
     need = ctypes.c_size_t(0)
     assert L.la_viterbi_workspace_bytes(32, 1500, 26, ctypes.byref(need)) == _lib.LA_OK and need.value == 0      # backpointers fit LDS
     assert L.la_viterbi_workspace_bytes(1, 9000, 238, ctypes.byref(need)) == _lib.LA_OK and need.value == 9000 * 8 * 16
-    assert L.la_viterbi_workspace_bytes(1, 100, 600, ctypes.byref(need)) == _lib.LA_EUNSUPPORTED
+    # > 1024 lattice states: the strip kernel (1024 threads x R states each), masks [T][R][16 waves][2] x 8 B in the workspace
+    assert L.la_viterbi_workspace_bytes(1, 100, 600, ctypes.byref(need)) == _lib.LA_OK and need.value == 100 * 2 * 32 * 8
+    assert L.la_viterbi_workspace_bytes(2, 100, 4095, ctypes.byref(need)) == _lib.LA_OK and need.value == 2 * 100 * 8 * 32 * 8
+    assert L.la_viterbi_workspace_bytes(1, 100, 4096, ctypes.byref(need)) == _lib.LA_EUNSUPPORTED and "4095" in _lib.last_error()
     # header + arrival counters [groups of 16 clips][2 directions][frames] u32, padded to 256 B
     assert L.la_gru_workspace_bytes(32, 1500, 384, ctypes.byref(need)) == _lib.LA_OK and need.value == (16 + 2 * 2 * 1500 * 4 + 255) // 256 * 256
     # entry points added for the training / decoding rows: the same host-side rejection before any HIP call

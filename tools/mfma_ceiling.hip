@@ -1,0 +1,150 @@
+// mfma_ceiling.hip -- what a bare bf16 MFMA loop sustains on THIS MI355X on random data (developer tool; DESIGN.md quotes it so
+// that the gap between the GEMM kernels and the 2.5 PF datasheet peak is attributable: clock under load vs schedule).
+//   hipcc --offload-arch=gfx950 -O3 tools/mfma_ceiling.hip -o /tmp/mfma_ceiling && /tmp/mfma_ceiling
+// Variants (512-thread workgroups = 2 waves per SIMD, one workgroup per CU x 256 CUs, every wave a 128x64 output tile =
+// 8x4 accumulators of v_mfma_f32_16x16x32_bf16 or 4x2 of v_mfma_f32_32x32x16_bf16, operands random bf16):
+//   reg16 / reg32 : operands stay in registers (matrix pipe + register file only)
+//   lds16 / lds32 : every K-step re-reads its A / B fragments from LDS with ds_read_b128 (conflict-free image), no barriers, no DMA
+// Output per variant: TFLOP/s (wall, HIP events), cycles per MFMA per SIMD, in-kernel clock (s_memtime / s_memrealtime).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+struct Stamp { unsigned long long cyc, rt; };
+
+template <int SHAPE, bool LDS>
+__global__ __launch_bounds__(512, 2) void loop_kernel(const uint4 *seed, float *sink, Stamp *stamps, int iters) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[64 * 1024];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // fill LDS with random bf16 bits (finite: exponent field masked into a sane range)
+    for (int i = tid; i < 64 * 1024 / 16; i += 512) {
+        uint4 v = seed[(blockIdx.x * 131 + i) & 4095];
+        reinterpret_cast<uint4 *>(lds)[i] = v;
+    }
+    __syncthreads();
+    uint4 a[8], b[4];
+    for (int i = 0; i < 8; ++i) a[i] = reinterpret_cast<const uint4 *>(lds)[(wave * 64 + lane + i * 512) & 4095];
+    for (int i = 0; i < 4; ++i) b[i] = reinterpret_cast<const uint4 *>(lds)[(wave * 64 + lane + i * 512 + 77) & 4095];
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    float acc_out = 0.f;
+    if constexpr (SHAPE == 16) {
+        f32x4 acc[8][4];
+        for (int m = 0; m < 8; ++m) for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0, 0, 0, 0};
+        for (int it = 0; it < iters; ++it) {
+            // one K = 64 tile: 2 k-steps x 8 x 4 MFMAs = 64 MFMAs (1024 cycles per wave at 16 cycles each)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                uint4 af[8], bf[4];
+                if constexpr (LDS) {
+                    const unsigned char *base = lds + ((it & 1) * 32768);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const uint4 *>(base + ((i * 16 + (lane & 15)) * 128 + ((((ks * 4 + (lane >> 4)) ^ ((lane >> 1) & 7))) << 4)));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) bf[i] = *reinterpret_cast<const uint4 *>(base + 16384 + ((i * 16 + (lane & 15)) * 128 + ((((ks * 4 + (lane >> 4)) ^ ((lane >> 1) & 7))) << 4)));
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) af[i] = a[i];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) bf[i] = b[i];
+                }
+#pragma unroll
+                for (int m = 0; m < 8; ++m)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bf[n]), __builtin_bit_cast(bf16x8, af[m]), acc[m][n], 0, 0, 0);
+            }
+        }
+        for (int m = 0; m < 8; ++m) for (int n = 0; n < 4; ++n) acc_out += acc[m][n][0] + acc[m][n][3];
+    } else {
+        f32x16 acc[4][2];
+        for (int m = 0; m < 4; ++m) for (int n = 0; n < 2; ++n) for (int j = 0; j < 16; ++j) acc[m][n][j] = 0.f;
+        for (int it = 0; it < iters; ++it) {
+            // one K = 64 tile: 4 k-steps x 4 x 2 MFMAs = 32 MFMAs (1024 cycles per wave at 32 cycles each)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                uint4 af[4], bf[2];
+                if constexpr (LDS) {
+                    const unsigned char *base = lds + ((it & 1) * 32768);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const uint4 *>(base + ((i * 32 + (lane & 31)) * 128 + ((((ks * 2 + (lane >> 5)) ^ ((lane >> 1) & 7))) << 4)));
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) bf[i] = *reinterpret_cast<const uint4 *>(base + 16384 + ((i * 32 + (lane & 31)) * 128 + ((((ks * 2 + (lane >> 5)) ^ ((lane >> 1) & 7))) << 4)));
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) af[i] = a[(i + ks) & 7];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) bf[i] = b[(i + ks) & 3];
+                }
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bf[n]), __builtin_bit_cast(bf16x8, af[m]), acc[m][n], 0, 0, 0);
+            }
+        }
+        for (int m = 0; m < 4; ++m) for (int n = 0; n < 2; ++n) acc_out += acc[m][n][0] + acc[m][n][15];
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (lane == 0 && wave == 0) stamps[blockIdx.x] = Stamp{c1 - c0, r1 - r0};
+    if (acc_out == 12345.678f) sink[blockIdx.x] = acc_out;   // keeps the accumulators live
+}
+
+template <int SHAPE, bool LDS>
+void run(const char *name, const uint4 *seed, float *sink, Stamp *stamps, int blocks) {
+    const int iters = 4000;
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    for (int w = 0; w < 40; ++w) hipLaunchKernelGGL((loop_kernel<SHAPE, LDS>), dim3(blocks), dim3(512), 0, 0, seed, sink, stamps, iters);   // ~2 s of load first (DVFS settles)
+    CHECK(hipDeviceSynchronize());
+    std::vector<float> ms;
+    for (int r = 0; r < 7; ++r) {
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL((loop_kernel<SHAPE, LDS>), dim3(blocks), dim3(512), 0, 0, seed, sink, stamps, iters);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        float t; CHECK(hipEventElapsedTime(&t, e0, e1)); ms.push_back(t);
+    }
+    std::sort(ms.begin(), ms.end());
+    std::vector<Stamp> h(blocks);
+    CHECK(hipMemcpy(h.data(), stamps, blocks * sizeof(Stamp), hipMemcpyDeviceToHost));
+    std::vector<double> clk, cyc;
+    for (auto &s : h) { clk.push_back((double)s.cyc / (double)s.rt * 100.0); cyc.push_back((double)s.cyc); }
+    std::sort(clk.begin(), clk.end()); std::sort(cyc.begin(), cyc.end());
+    const double flops = (double)blocks * 8 * iters * (128.0 * 64 * 64 * 2);
+    const double mfma_per_wave = (double)iters * (SHAPE == 16 ? 64 : 32);
+    printf("%-6s  %8.1f TFLOP/s (median of 7; min-time %8.1f)   cycles/MFMA/SIMD %.2f (2 waves share a SIMD)   in-kernel clock %.0f MHz (median over %d workgroups)\n",
+           name, flops / (ms[3] * 1e-3) / 1e12, flops / (ms[0] * 1e-3) / 1e12, cyc[blocks / 2] / (2.0 * mfma_per_wave), clk[blocks / 2], blocks);
+    fflush(stdout);
+}
+
+int main() {
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, 0));
+    const int blocks = prop.multiProcessorCount;
+    std::vector<unsigned> host(4096 * 4);
+    unsigned s = 12345u;
+    for (auto &v : host) {
+        s = s * 1664525u + 1013904223u; unsigned lo = s >> 16;
+        s = s * 1664525u + 1013904223u; unsigned hi = s >> 16;
+        // two bf16 with random sign / mantissa and exponents in [2^-3, 2^1): uniform-ish magnitudes like activations x weights
+        auto fix = [](unsigned h) { return (h & 0x807Fu) | ((124u + (h >> 7) % 4u) << 7); };
+        v = fix(lo & 0xFFFF) | (fix(hi & 0xFFFF) << 16);
+    }
+    uint4 *seed; float *sink; Stamp *stamps;
+    CHECK(hipMalloc(&seed, host.size() * 4)); CHECK(hipMalloc(&sink, blocks * 4)); CHECK(hipMalloc(&stamps, blocks * sizeof(Stamp)));
+    CHECK(hipMemcpy(seed, host.data(), host.size() * 4, hipMemcpyHostToDevice));
+    printf("device: %s, %d CUs; peak quoted in DESIGN.md: 2500 TFLOP/s dense bf16 (2.4 GHz x 256 CUs x 4 SIMDs x 1024 flop/clk)\n", prop.gcnArchName, blocks);
+    run<16, false>("reg16", seed, sink, stamps, blocks);
+    run<32, false>("reg32", seed, sink, stamps, blocks);
+    run<16, true>("lds16", seed, sink, stamps, blocks);
+    run<32, true>("lds32", seed, sink, stamps, blocks);
+    return 0;
+}
