@@ -21,12 +21,23 @@
  *   - the caller owns every buffer; scratch comes from a caller-provided
  *     workspace sized by the matching *_workspace_bytes() query;
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream);
- *     calls only enqueue work, they never synchronise, allocate or free;
+ *     calls only enqueue work: on the inference path (everything the two
+ *     model-level entry points la_encoder_forward / la_align_head_forward
+ *     and the alignment DP call) they never synchronise, allocate or free;
  *   - return value: la_status.  Nothing throws across the boundary.
  *     Per-utterance outcomes of the DP are reported in a device `status`
  *     array with the same codes.
- *   - re-entrant: no global mutable state except the optional kernel timer
- *     (la_timer_*), which is for bench.py only.
+ *   - re-entrant.  Library-owned state, all of it mutex-guarded:
+ *       (1) the optional kernel timer (la_timer_*), for bench.py only;
+ *       (2) one scratch buffer per (device, stream, purpose) for two
+ *           TRAINING-path calls whose scratch size depends on a run-time split
+ *           decision -- float32 la_gemm / la_gemm_ex when they split K over
+ *           extra workgroups (few tiles, long K: the text decoder's 80-row
+ *           GEMMs) and la_colsum_f32.  Its first use on a stream calls
+ *           hipMalloc (>= 1 MiB); growing it calls hipStreamSynchronize on that
+ *           stream, hipFree and hipMalloc once; it lives until the process ends.
+ *           LA_GEMM_NO_SPLITK=1 keeps la_gemm off it.  No 16-bit (inference)
+ *           call touches it.
  */
 #ifndef LYRICALIGN_H
 #define LYRICALIGN_H
@@ -390,6 +401,71 @@ int la_resample_poly_f32(const float *x, int64_t n_in, const float *h, int64_t h
 /* elementwise helpers used by the host-side plumbing */
 int la_cast_f32_to_bf16(const float *x, void *y, int64_t n, void *stream);
 int la_cast_bf16_to_f32(const void *x, float *y, int64_t n, void *stream);
+
+/* ------------------------------------------------------------------------- */
+/* model-level entry points: one call per stage of the hot path                */
+/* ------------------------------------------------------------------------- */
+/*
+ * Packed weights (device pointers; layouts = lyricalignment_amd/engine.py pack_encoder / pack_head, which build these
+ * structs from an openai-whisper AudioEncoder state_dict and the reference's RNN state_dict):
+ *   matrices keep nn.Linear's [out][in] layout in the compute dtype; vectors are f32;
+ *   wqkv [3d][d] = rows of query (pre-scaled by head_dim^-0.5), key, value; bqkv its bias (key part zero);
+ *   conv1_w [d][3][128] (tap-major, mel channels zero-padded 80 -> 128), conv2_w [d][3][d];
+ *   *_ln (16-bit modes, optional): the LayerNorm-folded forms la_gemm_fused_ln consumes -- W' = gamma o W rounded to the
+ *   compute dtype, c[n] = sum_k W'[n][k], b' = b + W beta; NULL = always the separate LayerNorm pass.
+ */
+typedef struct la_encoder_block {
+    const float *ln1_g, *ln1_b;
+    const void *wqkv; const float *bqkv;
+    const void *wo; const float *bo;
+    const float *ln2_g, *ln2_b;
+    const void *w1; const float *b1;
+    const void *w2; const float *b2;
+    const void *wqkv_ln; const float *cqkv, *bqkv_ln;
+    const void *w1_ln; const float *c1, *b1_ln;
+} la_encoder_block;
+
+typedef struct la_encoder_weights {
+    int32_t dtype, d, n_head, n_layer, n_mels;
+    const void *conv1_w; const float *conv1_b;
+    const void *conv2_w; const float *conv2_b;
+    const float *pos;                     /* [1500][d] sinusoids                                   */
+    const float *lnp_g, *lnp_b;           /* ln_post                                               */
+    const la_encoder_block *blocks;       /* HOST array of n_layer entries                         */
+} la_encoder_weights;
+
+/*
+ * whisper_model.embed_audio(mel) (module/align_model.py:91,101,112,137 = whisper AudioEncoder.forward): mel [batch][n_mels][3000]
+ * f32 -> out [batch*1500][d] rows (`out_dtype`, row pitch ld_out) = ln_post(blocks(conv stem(mel) + positional embedding)).
+ * Enqueues the whole kernel sequence on `stream` out of `workspace` (256-byte aligned, la_encoder_workspace_bytes; about
+ * 58 MB per clip for Whisper-medium in bf16).  No allocation, no synchronisation.
+ */
+int la_encoder_workspace_bytes(const la_encoder_weights *w, int32_t batch, size_t *bytes);
+int la_encoder_forward(const la_encoder_weights *w, const float *mel, int64_t mel_batch_stride, int64_t mel_row_stride,
+                       int32_t batch, void *out, int64_t ld_out, int32_t out_dtype, void *workspace, size_t workspace_bytes,
+                       void *stream);
+
+typedef struct la_head_weights {
+    int32_t dtype, hidden, in_dim, vocab, n_layers;   /* n_layers = 2, bidirectional (module/align_model.py:23-28) */
+    const void *w_ih[2]; const float *b_ih[2];        /* per layer [6H][in] (forward rows, then reverse), [6H]     */
+    const void *w_hh[2]; const float *b_hh[2];        /* per layer [2][3H][H], [2][3H]                              */
+    const void *w_fc; const float *b_fc;              /* [V][2H], [V]                                               */
+} la_head_weights;
+
+/*
+ * align_rnn(embed) + perform_viterbi(_ctc) (module/align_model.py:35-38; utils/alignment.py:13-71,121-188) without the
+ * logits: feats rows [.][ld_feats] (compute dtype), clip b at rows b*clip_stride_rows .. +frames -> 2 x {input-projection
+ * GEMM, persistent BiGRU recurrence} -> Mish -> fused Linear + emission prep -> batched DP -> onset / offset frames
+ * (same outputs as la_viterbi_batch).  emissions_out (optional) [batch][frames][max_labels+1] f32 receives the compact
+ * emissions.  More clips than one launch set of the recurrence takes (288 in the 16-bit modes at hidden 384) run as
+ * consecutive slices inside this call.  `timeout_flag`: see la_gru_layer.
+ */
+int la_align_head_workspace_bytes(const la_head_weights *w, int32_t batch, int32_t frames, int32_t max_labels, size_t *bytes);
+int la_align_head_forward(const la_head_weights *w, const void *feats, int64_t ld_feats, int64_t clip_stride_rows,
+                          int32_t batch, int32_t frames, int32_t variant, const int32_t *labels, int32_t labels_stride,
+                          const int32_t *n_labels, int32_t max_labels, int32_t *onset, int32_t *offset, int32_t out_stride,
+                          double *final_score, int32_t *status, float *emissions_out, void *workspace, size_t workspace_bytes,
+                          int32_t *timeout_flag, void *stream);
 
 #ifdef __cplusplus
 }

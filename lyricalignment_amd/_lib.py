@@ -78,8 +78,34 @@ SYMBOLS = {
     "la_col2im3_f32": (c_int32, [_P, _I32, _I32, _I32, _I32, _P, _I32, _P]),
     "la_resample_poly_f32": (c_int32, [_P, _I64, _P, _I64, _I32, _I32, _I64, _P, _I64, _P]),
     "la_cast_f32_to_bf16": (c_int32, [_P, _P, _I64, _P]),
+    "la_encoder_workspace_bytes": (c_int32, [_P, _I32, POINTER(_SZ)]),
+    "la_encoder_forward": (c_int32, [_P, _P, _I64, _I64, _I32, _P, _I64, _I32, _P, _SZ, _P]),
+    "la_align_head_workspace_bytes": (c_int32, [_P, _I32, _I32, _I32, POINTER(_SZ)]),
+    "la_align_head_forward": (c_int32, [_P, _P, _I64, _I64, _I32, _I32, _I32, _P, _I32, _P, _I32, _P, _P, _I32, _P, _P, _P, _P, _SZ, _P, _P]),
     "la_cast_bf16_to_f32": (c_int32, [_P, _P, _I64, _P]),
 }
+
+
+
+class EncoderBlockC(ctypes.Structure):
+    """la_encoder_block (include/lyricalign.h): device pointers of one residual attention block."""
+    _fields_ = [(n, c_void_p) for n in ("ln1_g", "ln1_b", "wqkv", "bqkv", "wo", "bo", "ln2_g", "ln2_b", "w1", "b1", "w2", "b2",
+                                        "wqkv_ln", "cqkv", "bqkv_ln", "w1_ln", "c1", "b1_ln")]
+
+
+class EncoderWeightsC(ctypes.Structure):
+    """la_encoder_weights."""
+    _fields_ = [("dtype", c_int32), ("d", c_int32), ("n_head", c_int32), ("n_layer", c_int32), ("n_mels", c_int32),
+                ("conv1_w", c_void_p), ("conv1_b", c_void_p), ("conv2_w", c_void_p), ("conv2_b", c_void_p), ("pos", c_void_p),
+                ("lnp_g", c_void_p), ("lnp_b", c_void_p), ("blocks", POINTER(EncoderBlockC))]
+
+
+class HeadWeightsC(ctypes.Structure):
+    """la_head_weights."""
+    _fields_ = [("dtype", c_int32), ("hidden", c_int32), ("in_dim", c_int32), ("vocab", c_int32), ("n_layers", c_int32),
+                ("w_ih", c_void_p * 2), ("b_ih", c_void_p * 2), ("w_hh", c_void_p * 2), ("b_hh", c_void_p * 2),
+                ("w_fc", c_void_p), ("b_fc", c_void_p)]
+
 
 _lib = None
 

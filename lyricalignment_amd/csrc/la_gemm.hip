@@ -210,13 +210,20 @@ __device__ __forceinline__ float2 segment_stats(const ushort4 pk) {
 
 // LNM: 0 = plain; 1 = producer of the LayerNorm fold (second, 16-bit copy of the f32 rows); 2 = consumer (LayerNorm epilogue).
 // Separate instantiations: one body with run-time switches for all three spilled 40-48 VGPRs in every mode.
+// DBG selects the main loop (developer A/B, LA_PP_DBG): 0 ping-pong quadrants (default) | 1, 2, 4 its probes | 8 flat256 |
+// 16-18 k2 ring of 4 | 20, 21 k2 ring of 5 | 24, 25 k2f ring of 4 / 5 | 64 half tile (128 x 256, 4 waves, two workgroups per CU)
+template <int DBG> struct PPGeom {
+    static constexpr bool HALF = DBG == 64;
+    static constexpr int TM = HALF ? KH::TM : PP::TM, THREADS = HALF ? KH::THREADS : PP::THREADS;
+    static constexpr int LDS = HALF ? KH::LDS : ((DBG >= 20 && DBG != 24 && DBG < 64) ? K2<5>::LDS : PP::LDS);
+};
 template <bool OUT_F32, int DBG, typename T16, int LNM = 0>
-__global__ __launch_bounds__(PP::THREADS, 2) void gemm_pp_kernel(GemmParams p) {
+__global__ __launch_bounds__(PPGeom<DBG>::THREADS, 2) void gemm_pp_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int nwg = p.tiles_m * p.tiles_n;
     const int tile = xcd_remap(blockIdx.x, nwg);
     const TileCoord tc = tile_coord(tile, p.tiles_m, p.tiles_n, p.group);
-    const int m0 = tc.tm * PP::TM, n0 = tc.tn * PP::TN;
+    const int m0 = tc.tm * PPGeom<DBG>::TM, n0 = tc.tn * PP::TN;
     const int z = blockIdx.y;
     const T16 *A = reinterpret_cast<const T16 *>(p.A) + (int64_t)z * p.strideA;
     const T16 *W = reinterpret_cast<const T16 *>(p.W) + (int64_t)z * p.strideW;
@@ -236,6 +243,11 @@ __global__ __launch_bounds__(PP::THREADS, 2) void gemm_pp_kernel(GemmParams p) {
 
     f32x4 acc[8][4];
     if constexpr (DBG == 8 && std::is_same<T16, bf16_t>::value) mainloop_flat256(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
+    else if constexpr (DBG == 64) mainloop_half<T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
+    else if constexpr (DBG == 24) mainloop_k2f<4, T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
+    else if constexpr (DBG == 25) mainloop_k2f<5, T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
+    else if constexpr (DBG >= 20) mainloop_k2<DBG & 3, 5, T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
+    else if constexpr (DBG >= 16) mainloop_k2<DBG & 3, 4, T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
     else mainloop_pp<DBG, T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
 
     typedef typename std::conditional<OUT_F32, float, T16>::type TC;
@@ -399,9 +411,14 @@ int launch_pp_dbg(GemmParams p, int batch, hipStream_t stream);
 
 template <bool OUT_F32, typename T16>
 int launch_pp(GemmParams p, int batch, hipStream_t stream) {
-    static const int dbg = getenv("LA_PP_DBG") ? atoi(getenv("LA_PP_DBG")) : 0;
+    const char *dbg_env = getenv("LA_PP_DBG");               // read per launch: tools/kbench.py flips it between rounds of one process
+    const int dbg = dbg_env ? atoi(dbg_env) : 0;
     if constexpr (std::is_same<T16, bf16_t>::value) {       // the developer probes exist for the bf16 instantiation
         switch (dbg) {
+            case 16: return launch_pp_dbg<OUT_F32, 16, T16>(p, batch, stream);
+            case 20: return launch_pp_dbg<OUT_F32, 20, T16>(p, batch, stream);
+            case 24: return launch_pp_dbg<OUT_F32, 24, T16>(p, batch, stream);
+            case 64: return launch_pp_dbg<OUT_F32, 64, T16>(p, batch, stream);
             case 1: return launch_pp_dbg<OUT_F32, 1, T16>(p, batch, stream);
             case 2: return launch_pp_dbg<OUT_F32, 2, T16>(p, batch, stream);
             case 3: return launch_pp_dbg<OUT_F32, 3, T16>(p, batch, stream);
@@ -420,19 +437,20 @@ int launch_pp(GemmParams p, int batch, hipStream_t stream) {
 template <bool OUT_F32, int DBG, typename T16, int LNM>
 int launch_pp_dbg(GemmParams p, int batch, hipStream_t stream) {
     auto kern = gemm_pp_kernel<OUT_F32, DBG, T16, LNM>;
+    typedef PPGeom<DBG> G;
     static bool attr_done = false;
     if (!attr_done) {
-        LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, PP::LDS));
+        LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
         attr_done = true;
     }
-    p.tiles_m = la::cdiv(p.M, PP::TM);
+    p.tiles_m = la::cdiv(p.M, G::TM);
     p.tiles_n = la::cdiv(p.N, PP::TN);
     // column tiles that walk the M dimension together (their W panels share the XCD's L2 with the streaming A panel).
     // At least 4: with fewer, the K=4096 GEMM (N = 4 tiles) re-reads its 2 MB-per-row-block A panel once per column tile
     // (in-pipeline sweep: 1 -> 46.1 ms/step, 4 -> 45.7, 8 -> 45.9, 16 -> 46.4).
     p.group = getenv("LA_GEMM_GROUP") ? std::min(p.group, p.tiles_n) : std::min(p.tiles_n, std::max(4, p.group / 2));
     la::TimerScope ts("gemm_bf16", stream);
-    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, batch), dim3(PP::THREADS), PP::LDS, stream, p);
+    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, batch), dim3(G::THREADS), G::LDS, stream, p);
     LA_LAUNCH_CHECK();
     return LA_OK;
 }

@@ -100,7 +100,9 @@ __device__ __forceinline__ void mainloop_pp(const T16 *A, int64_t lda, int M, co
     // ---- prologue: K-tiles 0 and 1 completely (the steady-state schedule starts with tile 2) ----
     issue_w(0, 0); issue_w(0, 1); issue_a(0, 0); issue_a(0, 1);
     if (nk > 1) { issue_w(1, 0); issue_w(1, 1); issue_a(1, 0); issue_a(1, 1); }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // only K-tile 0 has to be here for the first MFMA; tile 1's eight pieces stay in flight and are retired by the counted
+    // waits that close iteration 0 (they are older than everything those waits leave outstanding)
+    if ((DBG & 32) || nk == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     LA_PP_BARRIER();
     if (wr == 1) LA_PP_BARRIER();   // stagger: group 1 runs one barrier behind group 0
 
@@ -190,6 +192,287 @@ __device__ __forceinline__ void mainloop_pp(const T16 *A, int64_t lda, int M, co
         LA_PP_BARRIER();
     }
     if (wr == 0) LA_PP_BARRIER();   // re-align the groups
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// "k2" main loop: the same 256x256 tile / 2 (M) x 4 (N) wave layout / ping-pong of the two wave groups, cut differently:
+//   * a PHASE is one k-step (K = 32) of the wave's whole 128x64 tile: LOAD = 8 A + 4 W fragment reads (ds_read_b128) +
+//     this wave's 4 DMA pieces, COMPUTE = 32 MFMAs (512 matrix cycles).  Every phase has the same 12 reads (the quadrant
+//     schedule above has 12 / 4 / 8 / 0 per 16 MFMAs: its first LOAD segment alone is 48 KiB of LDS reads per wave
+//     group = 192 LDS cycles + latency against a 256-cycle partner segment) and there are 4 barriers per K = 64, not 8.
+//   * a STAGE is one k-step of both operands: 256 rows x 64 B each (32 KiB), ring of 4 stages (128 KiB).  A DMA piece is
+//     16 rows x 64 B (lane l -> row l >> 2, 16-byte chunk l & 3); chunk c of row r sits in slot c ^ ((-(r >> 2)) & 3),
+//     which makes the 16-row fragment reads conflict-free for ds_read_b128's lane groups (checked exhaustively against
+//     the bank rule of MI355X_MICROARCH.md: 4 LDS cycles per read).
+//   * prefetch distance 2: in LOAD(s) a wave issues its pieces of stage s + 2 into the slot stage s - 2 occupied.
+//     Time in segments (one per barrier), group 0: LOAD(s) = 2s, COMPUTE(s) = 2s + 1; group 1 one segment later.
+//     WAR: the last reads of stage s - 2 (group 1, LOAD(s - 2) = segment 2s - 3) were retired by its lgkmcnt(0) at the start
+//       of segment 2s - 2; the refill is issued in segment 2s (group 0) / 2s + 1 (group 1): >= 2 barriers later.
+//     RAW: stage s + 1 is first read in segment 2s + 2 (group 0).  Every wave retires its stage-(s + 1) pieces with one
+//       counted vmcnt before the barrier that ends segment 2s + 1 -- group 0 at the end of COMPUTE(s), group 1 at the end
+//       of LOAD(s) -- leaving only the 4 pieces of stage s + 2 in flight; the read follows one barrier after that wait.
+template <int NST_> struct K2 {
+    static constexpr int SB = 64;             // bytes of K per stage and row (32 x 16-bit)
+    static constexpr int OPS = 256 * SB;      // one operand of one stage: 16 KiB
+    static constexpr int STAGE = 2 * OPS;     // 32 KiB
+    static constexpr int NST = NST_;          // ring slots: 4 (128 KiB, prefetch distance 2) or 5 (all 160 KiB of the CU, distance 3)
+    static constexpr int LDS = NST * STAGE;
+};
+__device__ __forceinline__ int swz2(int row) { return (-(row >> 2)) & 3; }
+__device__ __forceinline__ uint4 read_frag2(const unsigned char *op, int row, int q) {
+    return *reinterpret_cast<const uint4 *>(op + row * 64 + ((q ^ swz2(row)) << 4));
+}
+template <int N> __device__ __forceinline__ void wait_vm() {
+    static_assert(N == 0 || N == 4 || N == 8 || N == 12, "add the literal");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+}
+
+// Prefetch distance DIST = NST - 2 stages: in LOAD(s) a wave issues its pieces of stage s + DIST into the slot stage
+// s + DIST - NST = s - 2 occupied (WAR above).  More stages in flight = more bytes in flight per CU: with a DMA latency of
+// ~1 us under load, 64 KiB in flight cap the CU's L2 -> LDS rate near 50 GB/s, which is what the 2-buffer loop measures
+// with the MFMAs removed; the wait that retires stage s + 1 then leaves 4 (DIST - 1) younger pieces in flight.
+// VAR (developer A/B): bit0 = DMA issue before the fragment reads of a LOAD segment; bit1 = s_setprio 1 on waves 4-7
+template <int VAR, int NST, typename T16 = bf16_t>
+__device__ __forceinline__ void mainloop_k2(const T16 *A, int64_t lda, int M, const T16 *W, int64_t ldw, int N, int K,
+                                            int m0, int n0, unsigned char *lds, f32x4 (&acc)[8][4]) {
+    typedef K2<NST> C;
+    constexpr int DIST = NST - 2;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int r = lane & 15, q = lane >> 4;
+    const int ns = K / 32;
+    const int64_t lda_b = lda * 2, ldw_b = ldw * 2;
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // this wave's pieces of every stage: rows 32 wave .. 32 wave + 31 of A and of W (two 16-row pieces each)
+    unsigned voff_a[2], voff_w[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int rt = (2 * wave + i) * 16 + (lane >> 2);
+        const int sw = ((lane & 3) ^ swz2(rt)) << 4;
+        int ra = m0 + rt; ra = ra > M - 1 ? M - 1 : ra;
+        int rw = n0 + rt; rw = rw > N - 1 ? N - 1 : rw;
+        voff_a[i] = (unsigned)((int64_t)(ra - m0) * lda_b) + sw;      // relative to row m0: stays < 2^32
+        voff_w[i] = (unsigned)((int64_t)(rw - n0) * ldw_b) + sw;
+    }
+    const unsigned char *a_row0 = reinterpret_cast<const unsigned char *>(A) + (int64_t)m0 * lda_b;
+    const unsigned char *w_row0 = reinterpret_cast<const unsigned char *>(W) + (int64_t)n0 * ldw_b;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_u32(lds));
+    auto issue = [&](int st, int slot) {     // this wave's 4 pieces of stage st into ring slot `slot`
+        const unsigned dst = lds0 + slot * C::STAGE + (2 * wave) * 1024;
+        const unsigned char *sa = a_row0 + (int64_t)st * C::SB, *sw = w_row0 + (int64_t)st * C::SB;
+        glds16_so(voff_w[0], sw, dst + C::OPS);
+        glds16_so(voff_a[0], sa, dst);
+        glds16_so(voff_w[1], sw, dst + C::OPS + 1024);
+        glds16_so(voff_a[1], sa, dst + 1024);
+    };
+
+#pragma unroll
+    for (int st = 0; st < DIST; ++st)
+        if (st < ns) issue(st, st);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    LA_PP_BARRIER();
+    if (wr == 1) LA_PP_BARRIER();   // stagger: group 1 runs one barrier behind group 0
+    if ((VAR & 2) && wr == 1) __builtin_amdgcn_s_setprio(1);
+
+    int slot_r = 0, slot_w = DIST;               // ring slots of stage s (read) and of stage s + DIST (refill)
+    for (int s = 0; s < ns; ++s) {
+        const unsigned char *abuf = lds + slot_r * C::STAGE + (wr * 128) * C::SB;
+        const unsigned char *wbuf = lds + slot_r * C::STAGE + C::OPS + (wc * 64) * C::SB;
+        const bool pf = s + DIST < ns;
+        // pieces this wave may leave in flight when it retires stage s + 1: those of stages s + 2 .. min(s + DIST, ns - 1)
+        const int ahead = (ns - 1 < s + DIST ? ns - 1 : s + DIST) - (s + 1);
+        auto retire = [&]() {
+            if (ahead >= 2 && DIST >= 3) wait_vm<8>();
+            else if (ahead == 1) wait_vm<4>();
+            else wait_vm<0>();
+        };
+        uint4 af[8], bf[4];
+        // ---------------- LOAD(s) ----------------
+        if ((VAR & 1) && pf) issue(s + DIST, slot_w);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) bf[ni] = read_frag2(wbuf, ni * 16 + r, q);
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) af[mi] = read_frag2(abuf, mi * 16 + r, q);
+        if (!(VAR & 1) && pf) issue(s + DIST, slot_w);
+        if (wr == 1) retire();   // group 1: its LOAD segment ends with the barrier that precedes group 0's first read of stage s + 1
+        LA_PP_BARRIER();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        // ---------------- COMPUTE(s) ----------------
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) Mma<T16>::run(bf[ni], af[mi], acc[mi][ni]);
+        if (wr == 0) retire();   // group 0: its COMPUTE segment ends with that same barrier
+        LA_PP_BARRIER();
+        slot_r = slot_r + 1 == NST ? 0 : slot_r + 1;
+        slot_w = slot_w + 1 == NST ? 0 : slot_w + 1;
+    }
+    if ((VAR & 2) && wr == 1) __builtin_amdgcn_s_setprio(0);
+    if (wr == 0) LA_PP_BARRIER();   // re-align the groups
+}
+
+// "k2f": the k2 stages WITHOUT the ping-pong -- all eight waves run the same program, ONE barrier per k-step, fragment reads
+// and MFMAs interleaved by the compiler inside a wave and by the hardware between the two waves of a SIMD.  Per stage s:
+//   counted vmcnt (own pieces of stage s landed; those of stages s + 1 .. s + DIST - 1 stay in flight)  ->  barrier (every
+//   wave's pieces of stage s are in LDS; every wave's reads of stage s - 1 were consumed by MFMAs issued before it)  ->
+//   refill the slot of stage s - 1 with stage s + DIST (so NST = DIST + 1 slots)  ->  12 fragment reads, 32 MFMAs.
+template <int NST, typename T16 = bf16_t>
+__device__ __forceinline__ void mainloop_k2f(const T16 *A, int64_t lda, int M, const T16 *W, int64_t ldw, int N, int K,
+                                             int m0, int n0, unsigned char *lds, f32x4 (&acc)[8][4]) {
+    typedef K2<NST> C;
+    constexpr int DIST = NST - 1;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int r = lane & 15, q = lane >> 4;
+    const int ns = K / 32;
+    const int64_t lda_b = lda * 2, ldw_b = ldw * 2;
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    unsigned voff_a[2], voff_w[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int rt = (2 * wave + i) * 16 + (lane >> 2);
+        const int sw = ((lane & 3) ^ swz2(rt)) << 4;
+        int ra = m0 + rt; ra = ra > M - 1 ? M - 1 : ra;
+        int rw = n0 + rt; rw = rw > N - 1 ? N - 1 : rw;
+        voff_a[i] = (unsigned)((int64_t)(ra - m0) * lda_b) + sw;
+        voff_w[i] = (unsigned)((int64_t)(rw - n0) * ldw_b) + sw;
+    }
+    const unsigned char *a_row0 = reinterpret_cast<const unsigned char *>(A) + (int64_t)m0 * lda_b;
+    const unsigned char *w_row0 = reinterpret_cast<const unsigned char *>(W) + (int64_t)n0 * ldw_b;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_u32(lds));
+    auto issue = [&](int st, int slot) {
+        const unsigned dst = lds0 + slot * C::STAGE + (2 * wave) * 1024;
+        const unsigned char *sa = a_row0 + (int64_t)st * C::SB, *sw = w_row0 + (int64_t)st * C::SB;
+        glds16_so(voff_w[0], sw, dst + C::OPS);
+        glds16_so(voff_a[0], sa, dst);
+        glds16_so(voff_w[1], sw, dst + C::OPS + 1024);
+        glds16_so(voff_a[1], sa, dst + 1024);
+    };
+#pragma unroll
+    for (int st = 0; st < DIST; ++st)
+        if (st < ns) issue(st, st);
+    int slot_r = 0, slot_w = DIST;
+    for (int s = 0; s < ns; ++s) {
+        // pieces younger than stage s that this wave has issued so far: stages s + 1 .. min(s + DIST - 1, ns - 1)
+        const int ahead = (ns - 1 < s + DIST - 1 ? ns - 1 : s + DIST - 1) - s;
+        if (ahead >= 3 && DIST >= 4) wait_vm<12>();
+        else if (ahead >= 2 && DIST >= 3) wait_vm<8>();
+        else if (ahead == 1) wait_vm<4>();
+        else wait_vm<0>();
+        LA_PP_BARRIER();
+        if (s + DIST < ns) issue(s + DIST, slot_w);
+        const unsigned char *abuf = lds + slot_r * C::STAGE + (wr * 128) * C::SB;
+        const unsigned char *wbuf = lds + slot_r * C::STAGE + C::OPS + (wc * 64) * C::SB;
+        uint4 af[8], bf[4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) bf[ni] = read_frag2(wbuf, ni * 16 + r, q);
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) af[mi] = read_frag2(abuf, mi * 16 + r, q);
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) Mma<T16>::run(bf[ni], af[mi], acc[mi][ni]);
+        slot_r = slot_r + 1 == NST ? 0 : slot_r + 1;
+        slot_w = slot_w + 1 == NST ? 0 : slot_w + 1;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    LA_PP_BARRIER();      // every wave is done with the ring before the epilogue reuses the LDS
+}
+
+// "half" main loop: a 128 x 256 tile for a 4-wave workgroup (waves 1 (M) x 4 (N), the same 128 x 64 wave tile), TWO such
+// workgroups per CU (72 KiB of LDS and <= 256 VGPRs each).  The two workgroups of a CU are not synchronised with each
+// other, so one's prologue, barrier waits and -- above all -- epilogue (7-30 k cycles per tile, un-overlapped when the CU
+// holds a single 8-wave workgroup) run beside the other's MFMAs.  Price: the W stage is staged once per workgroup, so the
+// L2 -> LDS traffic per flop is 1.5 x the 256 x 256 tile's (96 KiB per 2 x 64 K-steps per CU; tools/loadpath_bench.hip measures
+// 116 GB/s per CU for this staging form against the ~45 GB/s the 256 x 256 loop draws).
+// Stages: one k-step (K = 32): A 128 rows x 64 B (8 KiB) | W 256 rows x 64 B (16 KiB); ring of 3 (72 KiB), prefetch distance 2,
+// one barrier per stage (the k2f scheme); per wave and stage 2 A pieces + 4 W pieces.
+struct KH {
+    static constexpr int TM = 128, TN = 256, THREADS = 256;
+    static constexpr int SB = 64, OPA = 128 * SB, OPW = 256 * SB, STAGE = OPA + OPW, NST = 3, LDS = NST * STAGE;
+};
+template <int N> __device__ __forceinline__ void wait_vm6() {
+    static_assert(N == 0 || N == 6, "add the literal");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+}
+template <typename T16 = bf16_t>
+__device__ __forceinline__ void mainloop_half(const T16 *A, int64_t lda, int M, const T16 *W, int64_t ldw, int N, int K,
+                                              int m0, int n0, unsigned char *lds, f32x4 (&acc)[8][4]) {
+    typedef KH C;
+    constexpr int DIST = C::NST - 1;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // 0..3 = wc
+    const int r = lane & 15, q = lane >> 4;
+    const int ns = K / 32;
+    const int64_t lda_b = lda * 2, ldw_b = ldw * 2;
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    unsigned voff_a[2], voff_w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rt = (4 * wave + i) * 16 + (lane >> 2);            // W rows 64 wave .. + 63
+        int rw = n0 + rt; rw = rw > N - 1 ? N - 1 : rw;
+        voff_w[i] = (unsigned)((int64_t)(rw - n0) * ldw_b) + (((lane & 3) ^ swz2(rt)) << 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int rt = (2 * wave + i) * 16 + (lane >> 2);            // A rows 32 wave .. + 31
+        int ra = m0 + rt; ra = ra > M - 1 ? M - 1 : ra;
+        voff_a[i] = (unsigned)((int64_t)(ra - m0) * lda_b) + (((lane & 3) ^ swz2(rt)) << 4);
+    }
+    const unsigned char *a_row0 = reinterpret_cast<const unsigned char *>(A) + (int64_t)m0 * lda_b;
+    const unsigned char *w_row0 = reinterpret_cast<const unsigned char *>(W) + (int64_t)n0 * ldw_b;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_u32(lds));
+    auto issue = [&](int st, int slot) {
+        const unsigned da = lds0 + slot * C::STAGE + (2 * wave) * 1024, dw = lds0 + slot * C::STAGE + C::OPA + (4 * wave) * 1024;
+        const unsigned char *sa = a_row0 + (int64_t)st * C::SB, *sw = w_row0 + (int64_t)st * C::SB;
+        glds16_so(voff_w[0], sw, dw);
+        glds16_so(voff_a[0], sa, da);
+        glds16_so(voff_w[1], sw, dw + 1024);
+        glds16_so(voff_w[2], sw, dw + 2048);
+        glds16_so(voff_a[1], sa, da + 1024);
+        glds16_so(voff_w[3], sw, dw + 3072);
+    };
+#pragma unroll
+    for (int st = 0; st < DIST; ++st)
+        if (st < ns) issue(st, st);
+    int slot_r = 0, slot_w = DIST;
+    for (int s = 0; s < ns; ++s) {
+        if (s + 1 < ns) wait_vm6<6>(); else wait_vm6<0>();      // own pieces of stage s landed; stage s + 1's six stay in flight
+        LA_PP_BARRIER();
+        if (s + DIST < ns) issue(s + DIST, slot_w);
+        const unsigned char *abuf = lds + slot_r * C::STAGE;
+        const unsigned char *wbuf = lds + slot_r * C::STAGE + C::OPA + (wave * 64) * C::SB;
+        uint4 af[8], bf[4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) bf[ni] = read_frag2(wbuf, ni * 16 + r, q);
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) af[mi] = read_frag2(abuf, mi * 16 + r, q);
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) Mma<T16>::run(bf[ni], af[mi], acc[mi][ni]);
+        slot_r = slot_r + 1 == C::NST ? 0 : slot_r + 1;
+        slot_w = slot_w + 1 == C::NST ? 0 : slot_w + 1;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    LA_PP_BARRIER();
 }
 
 // Same 256x256 tile / wave layout with the plain structure: ONE barrier per K-tile, the next tile's 8 DMA pieces per

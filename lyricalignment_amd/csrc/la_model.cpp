@@ -1,0 +1,221 @@
+// la_model.cpp -- model-level entry points: the kernel SEQUENCES of the hot path behind one C call each, so that a consumer
+// that is not Python does not have to re-implement lyricalignment_amd/engine.py:
+//   la_encoder_forward     whisper_model.embed_audio(mel)          module/align_model.py:91,101,112,137
+//   la_align_head_forward  align_rnn(embed) -> emission prep -> perform_viterbi(_ctc) -> onset / offset frames
+//                          module/align_model.py:35-38,107,115; utils/alignment.py:13-71,121-188
+// Host code only: it enqueues the op-level kernels of this library (la_gemm, la_attention, la_gru_layer, ...) on the
+// caller's stream in the order engine.AlignEngine.encode / head_hidden / emissions do, out of a caller-provided workspace.
+#include "la_common.h"
+
+namespace {
+
+constexpr int N_FRAMES = 3000, N_CTX = 1500, C_PAD = 128;
+
+struct Carve {
+    unsigned char *base;
+    size_t off = 0;
+    explicit Carve(void *p) : base(static_cast<unsigned char *>(p)) {}
+    void *take(size_t bytes) {
+        void *p = base ? base + off : nullptr;
+        off += (size_t)la::round_up((int64_t)bytes, 256);
+        return p;
+    }
+};
+
+size_t esize(int dtype) { return dtype == LA_F32 ? 4 : 2; }
+
+struct EncBufs {
+    void *rows0, *y1, *h, *qkv, *att, *u;
+    float *x, *stats;
+    size_t total;
+};
+
+EncBufs carve_encoder(void *ws, int dtype, int batch, int d) {
+    Carve c(ws);
+    const size_t es = esize(dtype), M = (size_t)batch * N_CTX;
+    EncBufs b;
+    b.rows0 = c.take((size_t)batch * (N_FRAMES + 2) * C_PAD * es);
+    b.y1 = c.take((size_t)batch * (N_FRAMES + 2) * d * es);
+    b.x = static_cast<float *>(c.take(M * d * 4));
+    b.h = c.take(M * d * es);
+    b.qkv = c.take(M * 3 * d * es);
+    b.att = c.take(M * d * es);
+    b.u = c.take(M * 4 * d * es);
+    b.stats = static_cast<float *>(c.take(M * 2 * 4));
+    b.total = c.off;
+    return b;
+}
+
+bool encoder_fused_ln(const la_encoder_weights *w, int batch) {
+    if (w->dtype == LA_F32 || w->n_layer < 1 || !w->blocks[0].wqkv_ln || w->d <= 128) return false;
+    static const char *off = getenv("LA_LN_FUSION");
+    if (off && off[0] == '0') return false;
+    const int64_t M = (int64_t)batch * N_CTX;
+    // every GEMM of a block (and the batched conv2) must run on the 256x256 kernel the fold is built into: >= 192 tiles
+    return la::cdiv(M, 256) * la::cdiv(w->d, 256) >= 192 && (int64_t)la::cdiv(N_CTX, 256) * la::cdiv(w->d, 256) * batch >= 192;
+}
+
+#define LA_TRY(expr)                   \
+    do {                               \
+        const int rc_ = (expr);        \
+        if (rc_ != LA_OK) return rc_;  \
+    } while (0)
+
+}  // namespace
+
+extern "C" int la_encoder_workspace_bytes(const la_encoder_weights *w, int32_t batch, size_t *bytes) {
+    LA_CHECK_ARG(w && bytes && batch > 0 && w->d > 0, "encoder_workspace_bytes: bad arguments");
+    *bytes = carve_encoder(nullptr, w->dtype, batch, w->d).total;
+    return LA_OK;
+}
+
+extern "C" int la_encoder_forward(const la_encoder_weights *w, const float *mel, int64_t mel_batch_stride, int64_t mel_row_stride,
+                                  int32_t batch, void *out, int64_t ld_out, int32_t out_dtype, void *workspace,
+                                  size_t workspace_bytes, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (batch == 0) return LA_OK;
+    LA_CHECK_ARG(w && mel && out && workspace && batch > 0, "encoder_forward: null pointer / bad batch");
+    LA_CHECK_ARG(w->dtype == LA_F32 || w->dtype == LA_BF16 || w->dtype == LA_F16, "encoder_forward: bad compute dtype");
+    LA_CHECK_ARG(w->d > 0 && w->d % 64 == 0 && w->n_head * 64 == w->d, "encoder_forward: kernels are built for head_dim 64 (d = %d, heads = %d)", w->d, w->n_head);
+    LA_CHECK_ARG(w->n_mels > 0 && w->n_mels <= C_PAD && w->n_layer >= 0 && (w->n_layer == 0 || w->blocks), "encoder_forward: bad dimensions");
+    LA_CHECK_ARG((uintptr_t)workspace % 256 == 0, "encoder_forward: workspace must be 256-byte aligned");
+    const int dt = w->dtype, d = w->d, M = batch * N_CTX;
+    const EncBufs b = carve_encoder(workspace, dt, batch, d);
+    LA_CHECK_ARG(workspace_bytes >= b.total, "encoder_forward: workspace too small (%zu < %zu)", workspace_bytes, b.total);
+    const size_t es = esize(dt);
+    const int out_f32 = dt == LA_F32 ? 0 : LA_EPI_OUT_F32;       // the residual stream is f32 in every mode
+
+    // conv stem as GEMMs over overlapping row views of channels-last, zero-bordered activations (engine.encode)
+    LA_TRY(la_mel_to_rows(mel, mel_batch_stride, mel_row_stride, batch, w->n_mels, N_FRAMES, b.rows0, C_PAD, dt, stream));
+    const size_t clip1 = (size_t)(N_FRAMES + 2) * d * es;
+    LA_HIP(hipMemset2DAsync(b.y1, clip1, 0, (size_t)d * es, batch, stream));                                        // row 0 of every clip
+    LA_HIP(hipMemset2DAsync(static_cast<unsigned char *>(b.y1) + (size_t)(N_FRAMES + 1) * d * es, clip1, 0, (size_t)d * es, batch, stream));
+    LA_TRY(la_gemm(dt, N_FRAMES, d, 3 * C_PAD, batch, b.rows0, C_PAD, (int64_t)(N_FRAMES + 2) * C_PAD, w->conv1_w,
+                   static_cast<unsigned char *>(b.y1) + (size_t)d * es, d, (int64_t)(N_FRAMES + 2) * d, w->conv1_b, nullptr, 0, 0,
+                   LA_EPI_BIAS | LA_EPI_GELU, stream));
+    const bool fused = encoder_fused_ln(w, batch);
+    const int epi2 = LA_EPI_BIAS | LA_EPI_GELU | LA_EPI_RESIDUAL | out_f32;
+    if (fused) {
+        LA_TRY(la_gemm_fused_ln(dt, N_CTX, d, 3 * d, batch, b.y1, 2 * d, (int64_t)(N_FRAMES + 2) * d, w->conv2_w, b.x, d, (int64_t)N_CTX * d,
+                                w->conv2_b, w->pos, d, 0, epi2, b.h, d, (int64_t)N_CTX * d, nullptr, nullptr, nullptr, stream));
+        LA_TRY(la_row_stats16(dt, b.h, d, M, d, 1e-5f, b.stats, stream));
+    } else {
+        LA_TRY(la_gemm(dt, N_CTX, d, 3 * d, batch, b.y1, 2 * d, (int64_t)(N_FRAMES + 2) * d, w->conv2_w, b.x, d, (int64_t)N_CTX * d,
+                       w->conv2_b, w->pos, d, 0, epi2, stream));
+    }
+    const int epi_res = LA_EPI_BIAS | LA_EPI_RESIDUAL | out_f32;
+    for (int l = 0; l < w->n_layer; ++l) {
+        const la_encoder_block &k = w->blocks[l];
+        if (fused) {
+            LA_CHECK_ARG(k.wqkv_ln && k.cqkv && k.bqkv_ln && k.w1_ln && k.c1 && k.b1_ln, "encoder_forward: block %d lacks the LayerNorm-folded weights", l);
+            LA_TRY(la_gemm_fused_ln(dt, M, 3 * d, d, 1, b.h, d, 0, k.wqkv_ln, b.qkv, 3 * d, 0, k.bqkv_ln, nullptr, 0, 0, LA_EPI_BIAS, nullptr, 0, 0,
+                                    b.stats, k.cqkv, nullptr, stream));
+            LA_TRY(la_attention(dt, b.qkv, 3 * d, b.att, d, batch, N_CTX, w->n_head, stream));
+            LA_TRY(la_gemm_fused_ln(dt, M, d, d, 1, b.att, d, 0, k.wo, b.x, d, 0, k.bo, b.x, d, 0, epi_res, b.h, d, 0, nullptr, nullptr, nullptr, stream));
+            LA_TRY(la_row_stats16(dt, b.h, d, M, d, 1e-5f, b.stats, stream));
+            LA_TRY(la_gemm_fused_ln(dt, M, 4 * d, d, 1, b.h, d, 0, k.w1_ln, b.u, 4 * d, 0, k.b1_ln, nullptr, 0, 0, LA_EPI_BIAS | LA_EPI_GELU, nullptr, 0, 0,
+                                    b.stats, k.c1, nullptr, stream));
+            LA_TRY(la_gemm_fused_ln(dt, M, d, 4 * d, 1, b.u, 4 * d, 0, k.w2, b.x, d, 0, k.b2, b.x, d, 0, epi_res, b.h, d, 0, nullptr, nullptr, nullptr, stream));
+            LA_TRY(la_row_stats16(dt, b.h, d, M, d, 1e-5f, b.stats, stream));
+        } else {
+            LA_TRY(la_layernorm(b.x, d, M, d, k.ln1_g, k.ln1_b, b.h, d, dt, stream));
+            LA_TRY(la_gemm(dt, M, 3 * d, d, 1, b.h, d, 0, k.wqkv, b.qkv, 3 * d, 0, k.bqkv, nullptr, 0, 0, LA_EPI_BIAS, stream));
+            LA_TRY(la_attention(dt, b.qkv, 3 * d, b.att, d, batch, N_CTX, w->n_head, stream));
+            LA_TRY(la_gemm(dt, M, d, d, 1, b.att, d, 0, k.wo, b.x, d, 0, k.bo, b.x, d, 0, epi_res, stream));
+            LA_TRY(la_layernorm(b.x, d, M, d, k.ln2_g, k.ln2_b, b.h, d, dt, stream));
+            LA_TRY(la_gemm(dt, M, 4 * d, d, 1, b.h, d, 0, k.w1, b.u, 4 * d, 0, k.b1, nullptr, 0, 0, LA_EPI_BIAS | LA_EPI_GELU, stream));
+            LA_TRY(la_gemm(dt, M, d, 4 * d, 1, b.u, 4 * d, 0, k.w2, b.x, d, 0, k.b2, b.x, d, 0, epi_res, stream));
+        }
+    }
+    return la_layernorm(b.x, d, M, d, w->lnp_g, w->lnp_b, out, ld_out, out_dtype, stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+int head_clip_cap(const la_head_weights *w, int frames) {
+    const int nsplit = w->hidden / (16 * (w->dtype == LA_F32 ? 2 : 4));
+    const int64_t by_cus = (224 / (2 * nsplit)) * 16;
+    const int64_t by_desc = (int64_t)2147483647 / ((int64_t)frames * 2 * w->hidden * (int64_t)esize(w->dtype));
+    int64_t cap = by_cus < by_desc ? by_cus : by_desc;
+    if (cap > 256) cap = 256;
+    const char *force = getenv("LA_HEAD_CLIP_CAP");          // test switch: exercise the slicing with a handful of clips
+    if (force && atoi(force) > 0 && atoi(force) < cap) cap = atoi(force);
+    return cap < 1 ? 1 : (int)cap;
+}
+
+struct HeadBufs {
+    float *gi, *em;
+    void *gru[2], *act, *gru_ws, *fc_ws, *vit_ws;
+    int32_t *n_frames;
+    size_t gru_ws_bytes, fc_ws_bytes, vit_ws_bytes, total;
+};
+
+int carve_head(void *ws, const la_head_weights *w, int batch, int frames, int max_labels, HeadBufs *b) {
+    Carve c(ws);
+    const size_t es = esize(w->dtype);
+    const int H = w->hidden, cap = head_clip_cap(w, frames), bb = batch < cap ? batch : cap;
+    b->gi = static_cast<float *>(c.take((size_t)bb * frames * 6 * H * 4));
+    b->gru[0] = c.take((size_t)bb * frames * 2 * H * es);
+    b->gru[1] = c.take((size_t)bb * frames * 2 * H * es);
+    b->act = c.take((size_t)batch * frames * 2 * H * es);
+    b->em = static_cast<float *>(c.take((size_t)batch * frames * (max_labels + 1) * 4));
+    b->n_frames = static_cast<int32_t *>(c.take((size_t)batch * 4));
+    LA_TRY(la_gru_workspace_bytes(bb, frames, H, &b->gru_ws_bytes));
+    b->gru_ws = c.take(b->gru_ws_bytes);
+    LA_TRY(la_fc_emissions_workspace_bytes(w->dtype, batch, frames, 2 * H, w->vocab, max_labels, &b->fc_ws_bytes));
+    b->fc_ws = c.take(b->fc_ws_bytes);
+    LA_TRY(la_viterbi_workspace_bytes(batch, frames, max_labels, &b->vit_ws_bytes));
+    b->vit_ws = c.take(b->vit_ws_bytes > 16 ? b->vit_ws_bytes : 16);
+    b->total = c.off;
+    return LA_OK;
+}
+
+}  // namespace
+
+extern "C" int la_align_head_workspace_bytes(const la_head_weights *w, int32_t batch, int32_t frames, int32_t max_labels, size_t *bytes) {
+    LA_CHECK_ARG(w && bytes && batch > 0 && frames > 0 && max_labels > 0 && w->hidden > 0 && w->hidden % 64 == 0, "align_head_workspace_bytes: bad arguments");
+    HeadBufs b;
+    LA_TRY(carve_head(nullptr, w, batch, frames, max_labels, &b));
+    *bytes = b.total;
+    return LA_OK;
+}
+
+extern "C" int la_align_head_forward(const la_head_weights *w, const void *feats, int64_t ld_feats, int64_t clip_stride_rows,
+                                     int32_t batch, int32_t frames, int32_t variant, const int32_t *labels, int32_t labels_stride,
+                                     const int32_t *n_labels, int32_t max_labels, int32_t *onset, int32_t *offset, int32_t out_stride,
+                                     double *final_score, int32_t *status, float *emissions_out, void *workspace,
+                                     size_t workspace_bytes, int32_t *timeout_flag, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (batch == 0) return LA_OK;
+    LA_CHECK_ARG(w && feats && labels && n_labels && onset && offset && final_score && status && workspace, "align_head_forward: null pointer");
+    LA_CHECK_ARG(batch > 0 && frames > 0 && max_labels > 0 && w->n_layers == 2 && w->hidden % 64 == 0, "align_head_forward: bad sizes (2 GRU layers expected)");
+    LA_CHECK_ARG((uintptr_t)workspace % 256 == 0, "align_head_forward: workspace must be 256-byte aligned");
+    HeadBufs b;
+    LA_TRY(carve_head(workspace, w, batch, frames, max_labels, &b));
+    LA_CHECK_ARG(workspace_bytes >= b.total, "align_head_forward: workspace too small (%zu < %zu)", workspace_bytes, b.total);
+    const int dt = w->dtype, H = w->hidden;
+    const size_t es = esize(dt);
+    const int out_f32 = dt == LA_F32 ? 0 : LA_EPI_OUT_F32;
+    const int cap = head_clip_cap(w, frames);
+    for (int b0 = 0; b0 < batch; b0 += cap) {        // the persistent recurrence takes one launch set of clips at a time
+        const int nb = batch - b0 < cap ? batch - b0 : cap;
+        const unsigned char *x = static_cast<const unsigned char *>(feats) + (size_t)b0 * clip_stride_rows * ld_feats * es;
+        int64_t lda = ld_feats, stride_a = clip_stride_rows * ld_feats;
+        int in_dim = w->in_dim;
+        for (int layer = 0; layer < 2; ++layer) {
+            LA_TRY(la_gemm(dt, frames, 6 * H, in_dim, nb, x, lda, stride_a, w->w_ih[layer], b.gi, 6 * H, (int64_t)frames * 6 * H, w->b_ih[layer],
+                           nullptr, 0, 0, LA_EPI_BIAS | out_f32, stream));
+            void *mish = layer == 1 ? static_cast<unsigned char *>(b.act) + (size_t)b0 * frames * 2 * H * es : nullptr;
+            LA_TRY(la_gru_layer(dt, b.gi, w->w_hh[layer], w->b_hh[layer], b.gru[layer], mish, nb, frames, H, b.gru_ws, b.gru_ws_bytes, timeout_flag, stream));
+            x = static_cast<const unsigned char *>(b.gru[layer]);
+            lda = 2 * H; stride_a = (int64_t)frames * 2 * H; in_dim = 2 * H;
+        }
+    }
+    float *em = emissions_out ? emissions_out : b.em;
+    LA_TRY(la_fc_emissions(dt, b.act, 2 * H, w->w_fc, w->b_fc, batch, frames, 2 * H, w->vocab, variant, labels, labels_stride, n_labels, max_labels,
+                           em, (int64_t)frames * (max_labels + 1), max_labels + 1, b.fc_ws, b.fc_ws_bytes, stream));
+    LA_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(b.n_frames), frames, batch, stream));
+    return la_viterbi_batch(em, (int64_t)frames * (max_labels + 1), max_labels + 1, labels, labels_stride, n_labels, b.n_frames, batch, frames,
+                            max_labels, onset, offset, out_stride, final_score, status, b.vit_ws, b.vit_ws_bytes, stream);
+}

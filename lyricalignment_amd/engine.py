@@ -20,6 +20,7 @@ from __future__ import annotations
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 
+import ctypes
 import os
 
 import torch
@@ -35,6 +36,10 @@ LN_FUSION = os.environ.get("LA_LN_FUSION", "1") != "0"   # developer switch: 0 =
 # "epilogue" = the producer GEMM takes them per 64-column segment while the rows pass through its registers + a finalize
 # kernel.  Measured in the pipeline: the epilogue form costs the residual GEMMs more (+0.7 ms) than the pass it removes.
 LN_STATS_IN_EPILOGUE = os.environ.get("LA_LN_STATS", "pass") == "epilogue"
+# The kernel sequences of encode() and of the head + DP exist twice: as ONE C call each (csrc/la_model.cpp: la_encoder_forward,
+# la_align_head_forward -- the default) and spelled out below in Python over the op-level calls (LA_ENGINE_PY=1; also what the
+# training path and the developer switches above use).  Same kernels, same order, same results.
+ENGINE_PY = os.environ.get("LA_ENGINE_PY", "0") == "1"
 HEAD_CLIPS_MAX = 256   # clips per head launch set (GRU: 16 workgroup groups of 16 clips co-resident = 192 CUs, out buffer < 2 GiB)
 
 
@@ -212,7 +217,30 @@ class AlignEngine:
         _lib.require_gpu()
         self.enc, self.head, self.dec, self.device = enc, head, dec, torch.device(device)
         self._buf: Dict[Tuple, torch.Tensor] = {}
+        self._ws: Dict[str, torch.Tensor] = {}          # workspaces of the model-level C entry points
+        self._enc_c = self._encoder_struct(enc)
+        self._head_c = self._head_struct(head) if head is not None and len(head.w_ih) == 2 else None
         self._gru_flag: Optional[torch.Tensor] = None   # timeout word shared by this engine's GRU launches (check_gru reads it)
+
+    # ---- C structs of the packed weights (la_encoder_weights / la_head_weights) -------------
+    @staticmethod
+    def _encoder_struct(e: EncoderWeights):
+        P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+        blocks = (_lib.EncoderBlockC * max(1, len(e.blocks)))()
+        for i, b in enumerate(e.blocks):
+            blocks[i] = _lib.EncoderBlockC(P(b.ln1_g), P(b.ln1_b), P(b.wqkv), P(b.bqkv), P(b.wo), P(b.bo), P(b.ln2_g), P(b.ln2_b),
+                                           P(b.w1), P(b.b1), P(b.w2), P(b.b2), P(b.wqkv_ln), P(b.cqkv), P(b.bqkv_ln), P(b.w1_ln), P(b.c1), P(b.b1_ln))
+        c = _lib.EncoderWeightsC(_lib.dtype_code(e.dtype), e.d, e.n_head, len(e.blocks), e.n_mels, P(e.conv1_w), P(e.conv1_b), P(e.conv2_w),
+                                 P(e.conv2_b), P(e.pos), P(e.lnp_g), P(e.lnp_b), blocks)
+        c._keep = blocks            # the struct points into this host array
+        return c
+
+    @staticmethod
+    def _head_struct(h: HeadWeights):
+        V2 = ctypes.c_void_p * 2
+        P = lambda t: t.data_ptr()
+        return _lib.HeadWeightsC(_lib.dtype_code(h.dtype), h.hidden, h.in_dim, h.vocab, 2, V2(P(h.w_ih[0]), P(h.w_ih[1])), V2(P(h.b_ih[0]), P(h.b_ih[1])),
+                                 V2(P(h.w_hh[0]), P(h.w_hh[1])), V2(P(h.b_hh[0]), P(h.b_hh[1])), P(h.w_fc), P(h.b_fc))
 
     # ---- scratch -----------------------------------------------------------------
     def _get(self, name: str, shape, dtype, zero: bool = False) -> torch.Tensor:
@@ -239,6 +267,10 @@ class AlignEngine:
             mel = mel.contiguous()
         B, d, dt = mel.shape[0], e.d, e.dtype
         M = B * N_CTX
+        if not ENGINE_PY and (LN_FUSION or dt == torch.float32) and not LN_STATS_IN_EPILOGUE:
+            out_dtype = out_dtype or dt
+            y = out if out is not None else self._get(f"enc_out{slot}", (M, d), out_dtype)
+            return ops.encoder_forward(self._enc_c, mel, y, self._ws)          # the sequence below, enqueued by one C call
         rows0 = ops.mel_to_rows(mel, C_PAD, dt)                                     # [B, 3002, 128]
         y1 = self._get("y1", (B, N_FRAMES + 2, d), dt, zero=True)                    # border rows stay zero
         ops.gemm(rows0, e.conv1_w, y1.view(-1)[d:], bias=e.conv1_b, gelu=True, M=N_FRAMES, lda=C_PAD, batch=B,
@@ -526,6 +558,17 @@ class AlignEngine:
         act = self.head_hidden(feats, B, T, feat_clip_stride)
         return ops.fc_emissions(act, self.head.w_fc, self.head.b_fc, B, T, labels, n_labels, variant)
 
+    def align_feats(self, feats: torch.Tensor, B: int, T: int, feat_clip_stride: int, labels: torch.Tensor, n_labels: torch.Tensor,
+                    variant: int):
+        """Encoder rows -> (onset, offset, final_score, status): head + emission prep + DP (one C call unless LA_ENGINE_PY=1)."""
+        if ENGINE_PY or self._head_c is None or HEAD_CLIPS_MAX != 256:
+            em = self.emissions(feats, B, T, feat_clip_stride, labels, n_labels, variant)
+            nf = torch.full((B,), T, dtype=torch.int32, device=self.device)
+            return ops.viterbi_batch(em, labels, n_labels, nf)
+        if self._gru_flag is None:
+            self._gru_flag = torch.zeros((1,), dtype=torch.int32, device=self.device)
+        return ops.align_head_forward(self._head_c, feats, feat_clip_stride, B, T, labels, n_labels, variant, self._gru_flag, ws_cache=self._ws)
+
     def check_gru(self) -> None:
         """Host check of the persistent GRU kernel's bounded waits (synchronises): every launch since the last check."""
         if self._gru_flag is not None and int(self._gru_flag.item()) != 0:
@@ -539,9 +582,7 @@ class AlignEngine:
         B = mel.shape[0]
         feats = self.encode(mel)
         variant = LA_VARIANT_CTC if use_ctc else LA_VARIANT_PLAIN
-        em = self.emissions(feats, B, n_frames, N_CTX, labels, n_labels, variant)
-        nf = torch.full((B,), n_frames, dtype=torch.int32, device=self.device)
-        return ops.viterbi_batch(em, labels, n_labels, nf)
+        return self.align_feats(feats, B, n_frames, N_CTX, labels, n_labels, variant)
 
 
 class PipelinedAligner:
@@ -662,9 +703,7 @@ class PipelinedAligner:
             n_labels = self._pending[0]["n_labels"] if n == 1 else torch.cat([q["n_labels"] for q in self._pending], dim=0)
             variant = LA_VARIANT_CTC if use_ctc else LA_VARIANT_PLAIN
             feats = self._feats[slot][: n * B * clip_rows]
-            em = eng.emissions(feats, n * B, n_frames, clip_rows, labels, n_labels, variant)
-            nf = torch.full((n * B,), n_frames, dtype=torch.int32, device=eng.device)
-            res = ops.viterbi_batch(em, labels, n_labels, nf)
+            res = eng.align_feats(feats, n * B, n_frames, clip_rows, labels, n_labels, variant)
             for j, q in enumerate(self._pending):
                 for dst, src in zip(q["out"], res):
                     dst.copy_(src[j * B:(j + 1) * B], non_blocking=True)

@@ -50,7 +50,8 @@ def multitask_loss(logits: torch.Tensor, frame_labels: Optional[torch.Tensor], c
         lab = torch.where(cl == -100, torch.zeros_like(cl), cl).to(torch.int32).contiguous()
         Lmax = max(1, lab.shape[1])
     losses = torch.empty((3,), dtype=torch.float32, device=dev)
-    dlogits = torch.empty_like(logits) if want_grad else None
+    # the gradient kernel writes columns 0 .. vocab_size of every row; wider logits get exact zeros in the columns past them
+    dlogits = (torch.zeros_like(logits) if W > vocab_size + 1 else torch.empty_like(logits)) if want_grad else None
     need = ctypes.c_size_t(0)
     check(lib().la_multitask_loss_workspace_bytes(B, T, Lmax, ctypes.byref(need)), "multitask_loss_workspace_bytes")
     ws = torch.empty((need.value,), dtype=torch.uint8, device=dev)
@@ -118,12 +119,18 @@ def linear_warmup_scale(step: int, warmup_steps: int, train_steps: int) -> float
 class FineTuner:
     """The reference's train_step (train_multitask.py:215-342) on the HIP kernels, one process per GPU.
 
-    micro_step(): frame_manual_forward under autograd (encoder / head / decoder forward + backward kernels), the fused
-    CE + silence-BCE + CTC loss kernel on the alignment logits and the cross-entropy kernel on the decoder logits, each
-    already divided by accum_grad_steps, gradients accumulated into two flat float32 buckets (head, backbone).
+    micro_step(): both sub-batches of the reference's micro-step -- the multitask one (clips with frame labels: frame CE
+    [+ silence BCE + CTC when use_ctc_loss] on the align logits, decoder CE; :250-291) and the transcript-only one (clips
+    without frame labels: decoder CE [+ CTC on the align logits]; :299-321) -- each through frame_manual_forward under
+    autograd (encoder / head / decoder forward + backward kernels) and the loss kernels, divided by accum_grad_steps.
+    Gradients land DIRECTLY in two flat float32 buckets (head, backbone): every parameter's .grad is a view of its bucket,
+    so autograd's accumulation is the bucket accumulation (no concatenation pass, no second copy of the gradients).
     step(): ONE all-reduce (sum) per bucket over RCCL -- the only exchange of the data-parallel path -- then the fused
     global-norm clip + AdamW over the buckets (mean over ranks folded into the update), linear warm-up schedule.
-    The module's parameters are views into the flat buckets, so the update is in place and nothing is scattered back."""
+    The module's parameters are views into the flat parameter buckets, so the update is in place and nothing is scattered
+    back.  Parameters that cannot receive a gradient under the model's flags (the decoder without train_transcript, the
+    head without train_alignment, anything with requires_grad False) stay out of the buckets: torch.optim.AdamW skips
+    parameters whose .grad is None (no weight decay either), and so does this."""
 
     def __init__(self, model, lr: float = 5e-3, backbone_lr: float = 5e-6, weight_decay: float = 1e-5, warmup_steps: int = 0,
                  train_steps: int = 2000, max_grad_norm: float = 1.0, use_ctc_loss: bool = True, vocab_size: int = 21128,
@@ -137,9 +144,12 @@ class FineTuner:
             world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.world = world
         dev = model._device()
-        self.groups: List[List[torch.nn.Parameter]] = [
-            [p for p in model.align_rnn.parameters() if p.requires_grad],          # lr        (:683)
-            [p for p in model.whisper_model.parameters() if p.requires_grad]]      # backbone_lr (:684)
+        decoder = getattr(model.whisper_model, "decoder", None)
+        dec_ids = {id(p) for p in decoder.parameters()} if decoder is not None else set()
+        head = [p for p in model.align_rnn.parameters() if p.requires_grad] if model.train_alignment else []
+        backbone = [p for p in model.whisper_model.parameters()
+                    if p.requires_grad and (model.train_transcript or id(p) not in dec_ids)]
+        self.groups: List[List[torch.nn.Parameter]] = [head, backbone]     # lr (:683), backbone_lr (:684)
         lrs = [lr, backbone_lr]
         self.flat, self.grad = [], []
         opt_groups = []
@@ -148,13 +158,15 @@ class FineTuner:
                 continue
             n = sum(p.numel() for p in params)
             flat = torch.empty((n,), dtype=torch.float32, device=dev)
+            gflat = torch.zeros_like(flat)
             off = 0
-            for p in params:                                   # parameters become views of the bucket (data movement only)
+            for p in params:                                   # parameters and their .grad become views of the buckets
                 flat[off: off + p.numel()].copy_(p.detach().reshape(-1))
                 p.data = flat[off: off + p.numel()].view_as(p)
+                p.grad = gflat[off: off + p.numel()].view_as(p)
                 off += p.numel()
             self.flat.append(flat)
-            self.grad.append(torch.zeros_like(flat))
+            self.grad.append(gflat)
             opt_groups.append({"params": flat, "lr": group_lr})
         self.groups = [g for g in self.groups if g]
         if self.world > 1:                                     # replicas start from rank 0's parameters (the head's initialisation
@@ -162,46 +174,73 @@ class FineTuner:
             for flat in self.flat:
                 dist.broadcast(flat, src=0)
         self.opt = FlatAdamW(opt_groups, weight_decay=weight_decay)
-        self._dirty = False
 
-    def _accumulate(self) -> None:
-        """p.grad of this micro-batch -> += into the flat buckets (la_add_f32), then dropped."""
+    def _check_grad_views(self) -> None:
+        """autograd must have accumulated IN PLACE into the bucket views (it does while .grad is defined and grad mode is
+        off in backward); a replaced .grad tensor would silently drop gradients from the all-reduce / update."""
         for params, acc in zip(self.groups, self.grad):
-            g = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params]).contiguous()
-            check(lib().la_add_f32(ptr(acc), ptr(g), ptr(acc), acc.numel(), stream_ptr()), "add")
+            lo, hi = acc.data_ptr(), acc.data_ptr() + acc.numel() * 4
             for p in params:
-                p.grad = None
-        self._dirty = True
+                if p.grad is None or not (lo <= p.grad.data_ptr() < hi):
+                    raise RuntimeError("FineTuner: a parameter's .grad was replaced; gradients must accumulate into the flat bucket")
+
+    def _align_losses(self, align_logit, frame_labels, ctc_labels, s: float, out: torch.Tensor, roots, grads) -> None:
+        """compute_ce_loss (+ compute_ctc_loss) on the align logits (train_multitask.py:271-281, 587-633), forward + d/dlogits."""
+        logits = align_logit.detach().contiguous()
+        if self.use_ctc_loss:
+            l3, dlog = multitask_loss(logits, frame_labels, ctc_labels, vocab_size=self.vocab_size, scale=s)
+            out[:3] += l3
+        else:
+            # compute_sil == False (:603-605): plain cross-entropy over ALL output columns, labels unshifted, -100 ignored
+            if frame_labels is None:
+                return
+            from .decoder_train import cross_entropy
+            fl = pad_frame_labels(frame_labels.to(logits.device), logits.shape[1])
+            l, dlog = cross_entropy(logits, fl, scale_grad=s)
+            out[0] += l
+        roots.append(align_logit); grads.append(dlog)
 
     def micro_step(self, audios, ctc_labels=None, frame_labels=None, decoder_input=None, decoder_output=None,
-                   accum_grad_steps: int = 1, get_orig_len: bool = False):
-        """One micro-batch: forward, losses, backward.  Labels are pinyin-class ids with -100 padding (the caller maps
-        tokens -> classes as train_step :259-268 does; harness.PinyinClassLUT).  Returns the device loss vector
-        [word CE, silence BCE, CTC, decoder CE] (un-scaled, like the reference's logging)."""
+                   accum_grad_steps: int = 1, get_orig_len: bool = False, transcript_batch=None):
+        """One micro-batch of train_step: forward, losses, backward.  Labels are pinyin-class ids with -100 padding (the
+        caller maps tokens -> classes as train_step :259-268 does; harness.PinyinClassLUT).
+        audios / ctc_labels / frame_labels / decoder_input / decoder_output: the MULTITASK sub-batch (clips with frame
+        labels; None or empty audios = absent).  transcript_batch = (audios, ctc_labels, decoder_input, decoder_output): the
+        TRANSCRIPT-ONLY sub-batch (clips without frame labels, :299-321): decoder CE, plus CTC on its align logits when
+        use_ctc_loss and train_alignment.  Returns the device loss vector [align CE (word CE with use_ctc_loss), silence BCE,
+        CTC (both sub-batches), decoder CE (both sub-batches)], un-scaled like the reference's logging."""
         m = self.model
         m.train()
-        if m.train_alignment and not self.use_ctc_loss:
-            raise NotImplementedError("FineTuner: the alignment losses are built for the CTC configuration (output_dim = "
-                                      "vocab_size + 1 with the silence column), the one the reference's scripts train")
-        y_in = decoder_input if (m.train_transcript and decoder_input is not None) else None
-        align_logit, trans_logit = m.frame_manual_forward(audios, y_in, get_orig_len=get_orig_len)
         out = torch.zeros((4,), dtype=torch.float32, device=self.flat[0].device)
-        roots, grads = [], []
         s = 1.0 / float(accum_grad_steps)
-        if align_logit is not None and m.train_alignment:
-            logits = align_logit.detach().contiguous()
-            l3, dlog = multitask_loss(logits, frame_labels, ctc_labels if self.use_ctc_loss else None,
-                                      vocab_size=self.vocab_size, scale=s)
-            out[:3] = l3
-            roots.append(align_logit); grads.append(dlog)
-        if trans_logit is not None and decoder_output is not None:
-            from .decoder_train import cross_entropy
-            l, dl = cross_entropy(trans_logit.detach().contiguous(), decoder_output, scale_grad=s)
-            out[3] = l
-            roots.append(trans_logit); grads.append(dl)
-        if roots:
-            torch.autograd.backward(roots, grads)
-            self._accumulate()
+        from .decoder_train import cross_entropy
+        if audios is not None and len(audios) > 0:
+            roots, grads = [], []
+            y_in = decoder_input if (m.train_transcript and decoder_input is not None) else None
+            align_logit, trans_logit = m.frame_manual_forward(audios, y_in, get_orig_len=get_orig_len)
+            if align_logit is not None and m.train_alignment:
+                self._align_losses(align_logit, frame_labels, ctc_labels, s, out, roots, grads)
+            if trans_logit is not None and decoder_output is not None:
+                l, dl = cross_entropy(trans_logit.detach().contiguous(), decoder_output, scale_grad=s)
+                out[3] += l
+                roots.append(trans_logit); grads.append(dl)
+            if roots:
+                torch.autograd.backward(roots, grads)
+        if transcript_batch is not None and len(transcript_batch[0]) > 0:
+            t_audios, t_ctc, t_in, t_out = transcript_batch
+            roots, grads = [], []
+            align_logit, trans_logit = m.frame_manual_forward(t_audios, t_in if m.train_transcript else None, get_orig_len=get_orig_len)
+            if trans_logit is not None and t_out is not None:
+                l, dl = cross_entropy(trans_logit.detach().contiguous(), t_out, scale_grad=s)
+                out[3] += l
+                roots.append(trans_logit); grads.append(dl)
+            if self.use_ctc_loss and m.train_alignment and align_logit is not None and t_ctc is not None:
+                l3, dlog = multitask_loss(align_logit.detach().contiguous(), None, t_ctc, vocab_size=self.vocab_size, scale=s)
+                out[2] += l3[2]
+                roots.append(align_logit); grads.append(dlog)
+            if roots:
+                torch.autograd.backward(roots, grads)
+        self._check_grad_views()
         return out
 
     def step(self, allreduced: bool = False) -> torch.Tensor:
@@ -214,6 +253,5 @@ class FineTuner:
         self.steps_done += 1
         for g in self.grad:
             g.zero_()
-        self._dirty = False
         self.model._engine_key = None        # parameters changed under the packed inference weights: re-pack on next use
         return sumsq

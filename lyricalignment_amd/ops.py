@@ -366,3 +366,62 @@ def topk_rows(x: torch.Tensor, k: int):
     lse = torch.empty((R,), dtype=torch.float32, device=x.device)
     check(lib().la_topk_rows_f32(ptr(x), x.stride(0), R, x.shape[1], k, ptr(vals), ptr(idx), ptr(lse), stream_ptr()), "topk_rows")
     return vals, idx, lse
+
+
+# --------------------------------------------------------------------------- #
+# model-level entry points (csrc/la_model.cpp)                                  #
+# --------------------------------------------------------------------------- #
+def _workspace(nbytes: int, device, cache: Optional[dict], key: str) -> torch.Tensor:
+    """A 256-byte aligned device byte buffer of at least `nbytes` (torch's caching allocator aligns to 512 B); kept in `cache`
+    (one buffer per stage and engine: uses on one stream are ordered) and regrown when a larger one is asked for."""
+    if cache is not None:
+        t = cache.get(key)
+        if t is not None and t.numel() >= nbytes and t.device == device:
+            return t
+    t = torch.empty((max(int(nbytes), 256),), dtype=torch.uint8, device=device)
+    if cache is not None:
+        cache[key] = t
+    return t
+
+
+def encoder_forward(weights_c, mel: torch.Tensor, out: torch.Tensor, ws_cache: Optional[dict] = None) -> torch.Tensor:
+    """la_encoder_forward: mel [B, n_mels, 3000] f32 -> out [B*1500, d] rows; the whole stem + blocks + ln_post sequence is
+    enqueued by ONE C call (whisper_model.embed_audio, module/align_model.py:91)."""
+    _dev(mel, "mel", torch.float32); _dev(out, "out")
+    if mel.dim() != 3 or mel.shape[2] != 3000 or mel.stride(2) != 1 or mel.shape[1] != weights_c.n_mels:
+        raise ValueError("encoder_forward: mel [B, n_mels, 3000] with unit inner stride expected")
+    B = mel.shape[0]
+    if out.dim() != 2 or out.shape != (B * 1500, weights_c.d) or out.stride(1) != 1:
+        raise ValueError("encoder_forward: out must be [B*1500, d] rows")
+    need = ctypes.c_size_t(0)
+    check(lib().la_encoder_workspace_bytes(ctypes.byref(weights_c), B, ctypes.byref(need)), "encoder_workspace_bytes")
+    ws = _workspace(need.value, mel.device, ws_cache, "encoder")
+    check(lib().la_encoder_forward(ctypes.byref(weights_c), ptr(mel), mel.stride(0), mel.stride(1), B, ptr(out), out.stride(0),
+                                   dtype_code(out.dtype), ptr(ws), ws.numel(), stream_ptr()), "encoder_forward")
+    return out
+
+
+def align_head_forward(weights_c, feats: torch.Tensor, clip_stride_rows: int, batch: int, frames: int, labels: torch.Tensor,
+                       n_labels: torch.Tensor, variant: int, flag: torch.Tensor, want_emissions: bool = False,
+                       ws_cache: Optional[dict] = None):
+    """la_align_head_forward: encoder rows -> BiGRU x 2 -> Mish -> fused FC + emission prep -> DP, ONE C call.
+    -> (onset, offset, score, status[, emissions])."""
+    _dev(feats, "feats"); _dev(labels, "labels", torch.int32); _dev(n_labels, "n_labels", torch.int32); _dev(flag, "flag", torch.int32)
+    if feats.dim() != 2 or feats.stride(1) != 1 or feats.shape[1] != weights_c.in_dim:
+        raise ValueError("align_head_forward: feats must be [rows, in_dim] with unit inner stride")
+    if feats.shape[0] < (batch - 1) * clip_stride_rows + frames or labels.shape[0] != batch or n_labels.shape != (batch,) or labels.stride(1) != 1:
+        raise ValueError("align_head_forward: inconsistent shapes")
+    Lmax = labels.shape[1]
+    dev = feats.device
+    onset = torch.empty((batch, Lmax), dtype=torch.int32, device=dev)
+    offset = torch.empty((batch, Lmax), dtype=torch.int32, device=dev)
+    score = torch.empty((batch,), dtype=torch.float64, device=dev)
+    status = torch.empty((batch,), dtype=torch.int32, device=dev)
+    em = torch.empty((batch, frames, Lmax + 1), dtype=torch.float32, device=dev) if want_emissions else None
+    need = ctypes.c_size_t(0)
+    check(lib().la_align_head_workspace_bytes(ctypes.byref(weights_c), batch, frames, Lmax, ctypes.byref(need)), "align_head_workspace_bytes")
+    ws = _workspace(need.value, dev, ws_cache, "head")
+    check(lib().la_align_head_forward(ctypes.byref(weights_c), ptr(feats), feats.stride(0), clip_stride_rows, batch, frames, variant,
+                                      ptr(labels), labels.stride(0), ptr(n_labels.contiguous()), Lmax, ptr(onset), ptr(offset), Lmax,
+                                      ptr(score), ptr(status), ptr(em), ptr(ws), ws.numel(), ptr(flag), stream_ptr()), "align_head_forward")
+    return (onset, offset, score, status, em) if want_emissions else (onset, offset, score, status)

@@ -326,6 +326,108 @@ def test_full_finetune_micro_step_gradients_match_torch_autograd():
         assert not bad, bad
 
 
+@pytest.mark.parametrize("use_ctc", [True, False])
+def test_whole_micro_step_with_both_sub_batches_matches_float64_torch(use_ctc):
+    """train_step's micro-step as the reference composes it (train_multitask.py:241-326): the MULTITASK sub-batch (clips with
+    frame labels: compute_ce_loss -- with compute_sil = use_ctc_loss, i.e. the plain all-column cross-entropy of :603-605 in
+    the non-CTC configuration -- [+ compute_ctc_loss] + decoder CE) AND the TRANSCRIPT-ONLY sub-batch (second
+    frame_manual_forward: decoder CE [+ CTC on its align logits]), summed, divided by accum_grad_steps, one backward each.
+    Every loss term and every parameter gradient in the flat buckets against float64 torch autograd through the oracle."""
+    from oracle import model_oracle as mo
+    from lyricalignment_amd import finetune as ft
+    from lyricalignment_amd import whisper_compat as wc
+    from lyricalignment_amd.module.align_model import AlignModel
+    F = torch.nn.functional
+    V = 40
+    dims = wc.ModelDimensions(n_audio_state=128, n_audio_head=2, n_audio_layer=1, n_text_state=128, n_text_head=2, n_text_layer=1,
+                              n_vocab=311, n_text_ctx=64)
+    wm = wc.build_model(dims=dims, seed=190, std=0.05, with_decoder=True)
+    model = AlignModel(wm, embed_dim=128, hidden_dim=64, output_dim=V + int(use_ctc), dropout=0.0, train_transcript=True, device="cuda").to("cuda")
+    sd = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+    audios, labels, frame_labels, dec_in, dec_out = _tiny_batch()
+    rs = np.random.RandomState(191)
+    t_audios = [(rs.randn(14000) * 0.1).astype(np.float32)]
+    t_labels = torch.tensor([[4, 4, 30]])
+    t_in, t_out = torch.tensor([[1, 7, 8, 9]]), torch.tensor([[7, 8, 9, 2]])
+    tuner = ft.FineTuner(model, vocab_size=V, use_ctc_loss=use_ctc, world=1)
+    losses = tuner.micro_step(audios, labels, frame_labels, dec_in, dec_out, accum_grad_steps=2, get_orig_len=False,
+                              transcript_batch=(t_audios, t_labels, t_in, t_out)).cpu()
+    # ---- reference: the same two forward passes as float64 torch on the CPU ----
+    p = {}
+    for k, v in sd.items():
+        key = k[len("whisper_model."):] if k.startswith("whisper_model.") else k
+        p[key] = v.double().requires_grad_("encoder.positional_embedding" not in k)
+
+    def forward(auds, y_in):
+        n = max(map(len, auds))
+        batch = np.zeros((len(auds), n), dtype=np.float32)
+        for i, a in enumerate(auds):
+            batch[i, : len(a)] = a
+        xa = mo.encoder_forward(p, mo.pad_or_trim(mo.log_mel_spectrogram(batch), 3000).double(), n_head=2)
+        return mo.gru_head_forward(p, xa), mo.decoder_forward(p, y_in, xa, n_head=2)
+
+    def ctc(logits, lab):
+        lsm = F.log_softmax(logits[:, :, :V], dim=2).transpose(0, 1)
+        return F.ctc_loss(lsm, lab, torch.full((lab.shape[0],), logits.shape[1], dtype=torch.long), (lab != -100).sum(1))
+
+    al, tr = forward(audios, dec_in)
+    fl = ft.pad_frame_labels(frame_labels, al.shape[1])
+    if use_ctc:
+        ce = mo.ce_loss(al, frame_labels.clone(), vocab_size=V)
+        align_ctc = ctc(al, labels)
+    else:
+        ce = F.cross_entropy(al.permute(0, 2, 1), fl)            # compute_sil == False (:603-605)
+        align_ctc = torch.zeros((), dtype=torch.float64)
+    tr_ce = F.cross_entropy(tr.permute(0, 2, 1), dec_out)
+    al2, tr2 = forward(t_audios, t_in)
+    t_ce = F.cross_entropy(tr2.permute(0, 2, 1), t_out)
+    t_ctc = ctc(al2, t_labels) if use_ctc else torch.zeros((), dtype=torch.float64)
+    ((ce + align_ctc + tr_ce + t_ce + t_ctc) / 2).backward()
+    np.testing.assert_allclose(float(losses[0] + losses[1]), float(ce.detach()), rtol=2e-4)
+    np.testing.assert_allclose(float(losses[2]), float((align_ctc + t_ctc).detach()), rtol=2e-4, atol=1e-12)
+    np.testing.assert_allclose(float(losses[3]), float((tr_ce + t_ce).detach()), rtol=2e-4)
+    for bucket, params, prefix in ((tuner.grad[0], model.align_rnn.named_parameters(), "align_rnn."),
+                                   (tuner.grad[1], model.whisper_model.named_parameters(), "")):
+        got = bucket.cpu()
+        off = 0
+        bad = {}
+        for name, prm in params:
+            if not prm.requires_grad:
+                continue
+            g = got[off: off + prm.numel()].view(prm.shape); off += prm.numel()
+            ref = p[prefix + name].grad
+            err = float((g - ref).abs().max() / ref.abs().max().clamp_min(1e-12))
+            if err > 2e-3:
+                bad[name] = err
+        assert off == got.numel() and not bad, bad
+
+
+def test_finetuner_leaves_parameters_without_gradient_alone():
+    """torch.optim.AdamW skips parameters whose .grad is None -- no update and no weight decay.  A model built with a decoder
+    but train_transcript=False never produces decoder gradients: its parameters stay out of the flat buckets and are
+    bit-identical after optimizer steps, while head and encoder move."""
+    from lyricalignment_amd import finetune as ft
+    from lyricalignment_amd import whisper_compat as wc
+    from lyricalignment_amd.module.align_model import AlignModel
+    dims = wc.ModelDimensions(n_audio_state=128, n_audio_head=2, n_audio_layer=1, n_text_state=128, n_text_head=2, n_text_layer=1,
+                              n_vocab=311, n_text_ctx=64)
+    wm = wc.build_model(dims=dims, seed=195, std=0.05, with_decoder=True)
+    model = AlignModel(wm, embed_dim=128, hidden_dim=64, output_dim=41, dropout=0.0, train_transcript=False, device="cuda").to("cuda")
+    dec_before = {k: v.detach().clone() for k, v in model.whisper_model.decoder.state_dict().items()}
+    enc_before = model.whisper_model.encoder.conv1.weight.detach().clone()
+    audios, labels, frame_labels, dec_in, dec_out = _tiny_batch()
+    tuner = ft.FineTuner(model, lr=5e-3, backbone_lr=1e-3, weight_decay=0.1, vocab_size=40, world=1)
+    n_dec = sum(p.numel() for p in model.whisper_model.decoder.parameters())
+    n_enc = sum(p.numel() for p in model.whisper_model.encoder.parameters() if p.requires_grad)
+    assert tuner.flat[1].numel() == n_enc and n_dec > 0
+    for _ in range(2):
+        tuner.micro_step(audios, labels, frame_labels, dec_in, dec_out, accum_grad_steps=1)
+        tuner.step()
+    for k, v in model.whisper_model.decoder.state_dict().items():
+        assert torch.equal(v, dec_before[k]), k
+    assert not torch.equal(model.whisper_model.encoder.conv1.weight, enc_before)
+
+
 def test_full_finetune_steps_reduce_the_loss():
     """FineTuner: a few optimizer steps (2 micro-batches each) of whole-model fine-tuning on a fixed tiny batch; the
     parameters are views of the flat buckets, so the fused AdamW updates the module in place and eval re-packs."""

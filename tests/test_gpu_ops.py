@@ -325,3 +325,23 @@ def test_colsum_deterministic():
         np.testing.assert_allclose(got.cpu().double().numpy(), x.double().sum(0).cpu().numpy(), rtol=0, atol=1e-6 * max(1.0, rows ** 0.5) * 4)
     v = _rand(3000, 2048, seed=9).cuda()[:, 100:1124]        # row view with a pitch
     np.testing.assert_allclose(ht.colsum(v).cpu().double().numpy(), v.double().sum(0).cpu().numpy(), rtol=0, atol=3e-4)
+
+
+@pytest.mark.parametrize("variant", [16, 20, 24, 64])
+def test_gemm_main_loop_ab_variants_are_bit_identical(variant, monkeypatch):
+    """The developer A/B main loops of the 256x256 kernel (LA_PP_DBG: 16 / 20 = one-k-step phases on a ring of 4 / 5 stages,
+    24 = the same stages without the ping-pong, 64 = 128x256 half tiles, two 4-wave workgroups per CU) walk k in the same order
+    per accumulator as the default quadrant ping-pong: identical bits, including the ragged last row / column of tiles."""
+    from lyricalignment_amd import ops
+    M, N, K = 256 * 49 + 40, 1024 + 64, 1024
+    a = _rand(M, K, seed=91).bfloat16().cuda()
+    w = _rand(N, K, seed=92, scale=K ** -0.5).bfloat16().cuda()
+    bias = _rand(N, seed=93).cuda()
+    res = _rand(M, N, seed=94).cuda()
+    monkeypatch.delenv("LA_PP_DBG", raising=False)
+    ref16 = ops.gemm(a, w, bias=bias, gelu=True).clone()
+    ref32 = ops.gemm(a, w, bias=bias, residual=res, out_f32=True).clone()
+    monkeypatch.setenv("LA_PP_DBG", str(variant))
+    for _ in range(3):
+        assert torch.equal(ops.gemm(a, w, bias=bias, gelu=True), ref16)
+        assert torch.equal(ops.gemm(a, w, bias=bias, residual=res, out_f32=True), ref32)

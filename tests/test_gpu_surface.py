@@ -330,3 +330,65 @@ def test_pipelined_aligner_with_fresh_label_tensors_per_submit():
     for r, o in zip(ref, outs):
         for a, b in zip(r, o):
             assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------------------------------------ model-level C entry points
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_model_level_c_entry_points_equal_the_python_sequencing(dtype, monkeypatch):
+    """la_encoder_forward / la_align_head_forward (csrc/la_model.cpp: one C call per stage, caller workspace) enqueue the same
+    kernels in the same order as the op-by-op sequencing in engine.py (LA_ENGINE_PY=1): bit-identical encoder rows, frames,
+    scores; also with the head sliced over clips inside the C call (LA_HEAD_CLIP_CAP) and on the long-form clip stride."""
+    from lyricalignment_amd import engine as eng_mod
+    model = _model(dtype, seed=80)
+    eng = model.engine()
+    rs = np.random.RandomState(81)
+    B = 5
+    mel = torch.from_numpy(rs.uniform(-1, 1, size=(B, 80, 3000)).astype(np.float32)).cuda()
+    labels = torch.from_numpy(rs.randint(1, 299, size=(B, 9)).astype(np.int32)).cuda()
+    n_labels = torch.tensor([9, 5, 2, 7, 1], dtype=torch.int32).cuda()
+    with torch.no_grad():
+        monkeypatch.setattr(eng_mod, "ENGINE_PY", True)
+        enc_py = eng.encode(mel, out_dtype=torch.float32).clone()
+        res_py = [t.clone() for t in eng.align_mel(mel, labels, n_labels, n_frames=700)]
+        monkeypatch.setattr(eng_mod, "ENGINE_PY", False)
+        enc_c = eng.encode(mel, out_dtype=torch.float32).clone()
+        res_c = [t.clone() for t in eng.align_mel(mel, labels, n_labels, n_frames=700)]
+        monkeypatch.setenv("LA_HEAD_CLIP_CAP", "2")
+        res_sliced = [t.clone() for t in eng.align_mel(mel, labels, n_labels, n_frames=700)]
+        monkeypatch.delenv("LA_HEAD_CLIP_CAP")
+        feats = eng.encode(mel)
+        two = eng.align_feats(feats, 2, 2900, 3000, labels[:2], n_labels[:2].contiguous(), 1)       # 2 "songs" of 2 chunks each
+        monkeypatch.setattr(eng_mod, "ENGINE_PY", True)
+        two_py = eng.align_feats(feats, 2, 2900, 3000, labels[:2], n_labels[:2].contiguous(), 1)
+    eng.check_gru()
+    assert torch.equal(enc_py, enc_c)
+    for i, (a, b, c) in enumerate(zip(res_py, res_c, res_sliced)):
+        assert torch.equal(a, b)
+        if dtype == torch.bfloat16:
+            assert torch.equal(a, c)
+        elif i == 2:      # float32: launches of <= 4 clips run the recurrence on v_fma_f32, larger ones on f32 MFMA tiles -- same
+            np.testing.assert_allclose(c.cpu().numpy(), a.cpu().numpy(), rtol=1e-6)     # sums in another order: scores agree to rounding
+    for a, b in zip(two, two_py):
+        assert torch.equal(a, b)
+    assert int(res_c[3].abs().sum()) == 0
+
+
+def test_encoder_c_entry_point_takes_the_layernorm_folded_path_at_scale(monkeypatch):
+    """From 9 clips at d = 1024 the blocks' LayerNorms are folded into the GEMMs: la_encoder_forward makes that choice itself
+    and must equal the Python sequencing of the same folded path bit for bit."""
+    from lyricalignment_amd import engine as eng_mod, whisper_compat as wc
+    dims = wc.ModelDimensions(n_audio_state=1024, n_audio_head=16, n_audio_layer=2, n_text_state=1024, n_text_head=16, n_text_layer=0)
+    wm = wc.build_model(dims=dims, seed=83, std=0.02)
+    sd = {"encoder." + k: v for k, v in wm.encoder.state_dict().items()}
+    dev = torch.device("cuda")
+    e16 = eng_mod.AlignEngine(eng_mod.pack_encoder(sd, 16, torch.bfloat16, dev), None, dev)
+    mel = torch.from_numpy(np.random.RandomState(84).uniform(-1, 1, size=(9, 80, 3000)).astype(np.float32)).cuda()
+    with torch.no_grad():
+        monkeypatch.setattr(eng_mod, "ENGINE_PY", True)
+        ref = e16.encode(mel, out_dtype=torch.float32).clone()
+        monkeypatch.setattr(eng_mod, "LN_FUSION", False)
+        plain = e16.encode(mel, out_dtype=torch.float32).clone()
+        monkeypatch.setattr(eng_mod, "LN_FUSION", True)
+        monkeypatch.setattr(eng_mod, "ENGINE_PY", False)
+        got = e16.encode(mel, out_dtype=torch.float32).clone()
+    assert torch.equal(got, ref) and not torch.equal(got, plain)

@@ -59,6 +59,20 @@ def test_argument_validation_without_gpu():
     assert L.la_softmax_rows_f32(P, 8, 4, 16, 0, 0) == _lib.LA_EINVAL                                                  # ld < cols
     assert L.la_col2im3_f32(P, 1, 10, 2, 8, P, 5, 0) == _lib.LA_EINVAL                                                 # output rows too few
     assert L.la_cross_entropy_f32(P, 4, 2, 8, P, 1.0, P, P, 0, 0, 0) == _lib.LA_EINVAL                                 # ld < vocab
+    # model-level entry points: workspace queries are pure host arithmetic; bad geometry is rejected before any HIP call
+    blk = (_lib.EncoderBlockC * 1)()
+    ew = _lib.EncoderWeightsC(_lib.LA_BF16, 1024, 16, 1, 80, P, P, P, P, P, P, P, blk)
+    assert L.la_encoder_workspace_bytes(ctypes.byref(ew), 32, ctypes.byref(need)) == _lib.LA_OK
+    es, M, d = 2, 32 * 1500, 1024
+    want = sum((b + 255) // 256 * 256 for b in (32 * 3002 * 128 * es, 32 * 3002 * d * es, M * d * 4, M * d * es, M * 3 * d * es, M * d * es, M * 4 * d * es, M * 8))
+    assert need.value == want
+    ew.n_head = 12
+    assert L.la_encoder_forward(ctypes.byref(ew), P, 0, 0, 1, P, 1024, 1, 256, 1 << 40, 0) == _lib.LA_EINVAL and "head_dim 64" in _lib.last_error()
+    V2 = ctypes.c_void_p * 2
+    hw = _lib.HeadWeightsC(_lib.LA_BF16, 384, 1024, 21129, 2, V2(P, P), V2(P, P), V2(P, P), V2(P, P), P, P)
+    assert L.la_align_head_workspace_bytes(ctypes.byref(hw), 32, 1500, 26, ctypes.byref(need)) == _lib.LA_OK and need.value > 32 * 1500 * 768 * 2
+    assert L.la_align_head_forward(ctypes.byref(hw), P, 1024, 1500, 32, 1500, 1, P, 26, P, 26, P, P, 26, P, P, 0, 256, 16, 0, 0) == _lib.LA_EINVAL
+    assert "workspace too small" in _lib.last_error()
     with pytest.raises(ValueError):
         _lib.check(_lib.LA_EINVAL, "x")
     with pytest.raises(NotImplementedError):

@@ -25,6 +25,38 @@ def rnd(*shape, dtype=torch.bfloat16, scale=1.0):
     return (torch.randn(*shape, device="cuda") * scale).to(dtype)
 
 
+def bench_gemm_variants(iters, variants, rounds=5):
+    """A/B of main-loop variants (LA_PP_DBG, read per launch) in ONE process: interleaved rounds, random operands, and a race
+    screen -- every variant's output must equal variant 0's bit for bit (same k order per accumulator) in every round."""
+    M = 48000
+    shapes = [("qkv", 3072, 1024, False, False), ("mlp_up+gelu", 4096, 1024, False, False), ("out_proj+res", 1024, 1024, True, True),
+              ("mlp_down+res", 1024, 4096, True, True)]
+    for name, N, K, f32out, res_ in shapes:
+        a, w = rnd(M, K), rnd(N, K, scale=K ** -0.5)
+        bias = torch.randn(N, device="cuda")
+        res = torch.randn(M, N, device="cuda") if res_ else None
+        outs = {v: torch.empty(M, N, device="cuda", dtype=torch.float32 if f32out else torch.bfloat16) for v in variants}
+
+        def run(v):
+            os.environ["LA_PP_DBG"] = str(v)
+            ops.gemm(a, w, outs[v], bias=bias, residual=res, gelu="gelu" in name, out_f32=f32out)
+
+        times = {v: [] for v in variants}
+        bad = {v: 0 for v in variants}
+        for rd in range(rounds):
+            for v in variants:
+                med, mn = timeit(lambda: run(v), iters)
+                times[v].append(med)
+                if v != variants[0] and not torch.equal(outs[v], outs[variants[0]]):
+                    bad[v] += 1
+        fl = 2.0 * M * N * K
+        for v in variants:
+            t = sorted(times[v])
+            print(f"gemm {name:14s} N={N} K={K} variant {v:3d}: median {t[len(t)//2]*1e3:8.1f} us  min {t[0]*1e3:8.1f} us  "
+                  f"{fl/t[len(t)//2]/1e9:7.1f} TF/s  mismatching rounds vs variant {variants[0]}: {bad[v]}/{rounds}", flush=True)
+    os.environ.pop("LA_PP_DBG", None)
+
+
 def bench_gemm(iters):
     M = 48000
     shapes = [("qkv", 3072, 1024, False), ("mlp_up+gelu", 4096, 1024, False), ("mlp_up_plain", 4096, 1024, False), ("out_proj+res", 1024, 1024, True),
@@ -83,8 +115,12 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("what", nargs="?", default="all")
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--variants", default="", help="gemm: comma-separated LA_PP_DBG values to A/B in one process (first = reference)")
     a = ap.parse_args()
     torch.manual_seed(0)
+    if a.what == "gemm" and a.variants:
+        bench_gemm_variants(a.iters, [int(v) for v in a.variants.split(",")])
+        sys.exit(0)
     if a.what in ("gemm", "all"): bench_gemm(a.iters)
     if a.what in ("attn", "all"): bench_attn(a.iters)
     if a.what in ("gru", "all"): bench_gru(a.iters)

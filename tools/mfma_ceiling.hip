@@ -5,6 +5,8 @@
 // 8x4 accumulators of v_mfma_f32_16x16x32_bf16 or 4x2 of v_mfma_f32_32x32x16_bf16, operands random bf16):
 //   reg16 / reg32 : operands stay in registers (matrix pipe + register file only)
 //   lds16 / lds32 : every K-step re-reads its A / B fragments from LDS with ds_read_b128 (conflict-free image), no barriers, no DMA
+//   lds16+dma / reg16+dma : the same plus the GEMM's LDS-DMA staging volume (64 KiB per workgroup and K = 64 tile) into a region
+//                   nobody reads -- the matrix pipe, the LDS reads and the DMA writes sharing the CU, still without barriers
 // Output per variant: TFLOP/s (wall, HIP events), cycles per MFMA per SIMD, in-kernel clock (s_memtime / s_memrealtime).
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -20,10 +22,16 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 
 struct Stamp { unsigned long long cyc, rt; };
 
-template <int SHAPE, bool LDS>
-__global__ __launch_bounds__(512, 2) void loop_kernel(const uint4 *seed, float *sink, Stamp *stamps, int iters) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[64 * 1024];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__device__ __forceinline__ void glds16_so(unsigned voff, const void *sbase, unsigned m0_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(m0_dst) : "memory");
+}
+
+// DMA: every K = 64 tile each wave also issues its 8 LDS-DMA pieces (64 KiB per workgroup and tile, the GEMM's staging volume)
+// from an L2-resident panel into the upper half of the LDS (never read: no hazards, no barriers) behind a counted vmcnt(8)
+template <int SHAPE, bool LDS, bool DMA = false>
+__global__ __launch_bounds__(512, 2) void loop_kernel(const uint4 *seed, float *sink, Stamp *stamps, int iters, const unsigned char *panel = nullptr) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // fill LDS with random bf16 bits (finite: exponent field masked into a sane range)
     for (int i = tid; i < 64 * 1024 / 16; i += 512) {
         uint4 v = seed[(blockIdx.x * 131 + i) & 4095];
@@ -38,10 +46,20 @@ __global__ __launch_bounds__(512, 2) void loop_kernel(const uint4 *seed, float *
     if constexpr (SHAPE == 16) {
         f32x4 acc[8][4];
         for (int m = 0; m < 8; ++m) for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0, 0, 0, 0};
+        unsigned voff[4];
+        for (int i = 0; i < 4; ++i) voff[i] = (unsigned)(((4 * wave + i) * 8 + (lane >> 3)) * 2048 + ((lane & 7) << 4));
+        const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(const __attribute__((address_space(3))) void *)lds);
+        const unsigned char *pa = panel + (size_t)(blockIdx.x % 64) * 256 * 2048, *pw = panel + (size_t)(64 + (blockIdx.x / 8) % 4) * 256 * 2048;
         for (int it = 0; it < iters; ++it) {
             // one K = 64 tile: 2 k-steps x 8 x 4 MFMAs = 64 MFMAs (1024 cycles per wave at 16 cycles each)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
+                if constexpr (DMA) {      // 4 pieces per k-step: A pieces in the first, W pieces in the second
+                    const unsigned dst = lds0 + 65536 + (it & 1) * 32768 + wave * 4096;
+                    const unsigned char *src = (ks ? pw : pa) + (it & 15) * 128;
+                    for (int i = 0; i < 4; ++i) glds16_so(voff[i], src, dst + i * 1024);
+                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                }
                 uint4 af[8], bf[4];
                 if constexpr (LDS) {
                     const unsigned char *base = lds + ((it & 1) * 32768);
@@ -97,17 +115,18 @@ __global__ __launch_bounds__(512, 2) void loop_kernel(const uint4 *seed, float *
     if (acc_out == 12345.678f) sink[blockIdx.x] = acc_out;   // keeps the accumulators live
 }
 
-template <int SHAPE, bool LDS>
-void run(const char *name, const uint4 *seed, float *sink, Stamp *stamps, int blocks) {
+template <int SHAPE, bool LDS, bool DMA = false>
+void run(const char *name, const uint4 *seed, float *sink, Stamp *stamps, int blocks, const unsigned char *panel = nullptr) {
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(loop_kernel<SHAPE, LDS, DMA>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
     const int iters = 4000;
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    for (int w = 0; w < 40; ++w) hipLaunchKernelGGL((loop_kernel<SHAPE, LDS>), dim3(blocks), dim3(512), 0, 0, seed, sink, stamps, iters);   // ~2 s of load first (DVFS settles)
+    for (int w = 0; w < 40; ++w) hipLaunchKernelGGL((loop_kernel<SHAPE, LDS, DMA>), dim3(blocks), dim3(512), 131072, 0, seed, sink, stamps, iters, panel);   // ~2 s of load first (DVFS settles)
     CHECK(hipDeviceSynchronize());
     std::vector<float> ms;
     for (int r = 0; r < 7; ++r) {
         CHECK(hipEventRecord(e0));
-        hipLaunchKernelGGL((loop_kernel<SHAPE, LDS>), dim3(blocks), dim3(512), 0, 0, seed, sink, stamps, iters);
+        hipLaunchKernelGGL((loop_kernel<SHAPE, LDS, DMA>), dim3(blocks), dim3(512), 131072, 0, seed, sink, stamps, iters, panel);
         CHECK(hipEventRecord(e1));
         CHECK(hipEventSynchronize(e1));
         float t; CHECK(hipEventElapsedTime(&t, e0, e1)); ms.push_back(t);
@@ -146,5 +165,10 @@ int main() {
     run<32, false>("reg32", seed, sink, stamps, blocks);
     run<16, true>("lds16", seed, sink, stamps, blocks);
     run<32, true>("lds32", seed, sink, stamps, blocks);
+    unsigned char *panel;
+    CHECK(hipMalloc(&panel, (size_t)68 * 256 * 2048));
+    CHECK(hipMemset(panel, 0x3c, (size_t)68 * 256 * 2048));
+    run<16, true, true>("lds16+dma", seed, sink, stamps, blocks, panel);
+    run<16, false, true>("reg16+dma", seed, sink, stamps, blocks, panel);
     return 0;
 }
