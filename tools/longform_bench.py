@@ -3,13 +3,16 @@ encoder batch -> BiGRU over T = 9000 frames per song -> emissions -> Viterbi wit
 Prints ms per pass, audio-seconds per second and the split encoder / head+DP (events on the launch stream).
 With batches > 1 the same songs also go through PipelinedAligner.submit_songs (head of batch i under the encoder of i+1).
 usage: longform_bench.py [songs=5] [labels=238] [size=medium] [batches=4] [head_group=1]"""
-import sys, os, time
+import json, sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from lyricalignment_amd import whisper_compat as wc, _lib, ops
 from lyricalignment_amd.module.align_model import AlignModel
 
+json_out = None
+if "--json" in sys.argv:
+    i = sys.argv.index("--json"); json_out = sys.argv[i + 1]; del sys.argv[i:i + 2]
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 238
 size = sys.argv[3] if len(sys.argv) > 3 else "medium"
@@ -53,6 +56,10 @@ with torch.no_grad():
     torch.cuda.synchronize()
     print(f"{size}: {S} songs x 180 s, {L} labels, T={T}: {ms:.1f} ms per pass = {S * 180 / ms * 1e3:.0f} audio-s/s; "
           f"encoder {ev[0].elapsed_time(ev[1]):.1f} ms, head + DP {ev[1].elapsed_time(ev[2]):.1f} ms")
+    rec = {"workload": f"BASELINE configs[4]: {S} songs x 180 s (6 chunks of 30 s each, T = {T} frames per song), {L} labels per song, "
+                       f"whisper-{size} bf16, one MI355X", "songs_per_batch": S, "labels": L, "frames": T,
+           "single_stream": {"ms_per_batch": ms, "audio_s_per_s": S * 180 / ms * 1e3, "encoder_ms": ev[0].elapsed_time(ev[1]),
+                             "head_dp_ms": ev[1].elapsed_time(ev[2])}}
     if NB > 1:
         from lyricalignment_amd.engine import PipelinedAligner
         pipe = PipelinedAligner(eng, head_group=G)
@@ -69,3 +76,7 @@ with torch.no_grad():
             pipe.drain()
         ms = (time.perf_counter() - t0) / (reps * NB) * 1e3
         print(f"pipelined (head_group {G}, {NB} batches): {ms:.1f} ms per batch of {S} songs = {S * 180 / ms * 1e3:.0f} audio-s/s")
+        rec["pipelined"] = {"head_group": G, "batches": NB, "ms_per_batch": ms, "audio_s_per_s": S * 180 / ms * 1e3}
+    rec["peak_hbm_bytes"] = int(torch.cuda.max_memory_allocated())
+    if json_out:
+        json.dump(rec, open(json_out, "w"), indent=1)
