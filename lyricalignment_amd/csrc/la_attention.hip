@@ -93,30 +93,35 @@ __device__ __forceinline__ int vswz(int r) { return ((r >> 1) & 1) << 2; }
 // pitch + source-side swizzled slot) is loop invariant; the tile advance is a scalar base bump.  Rows past the end of
 // the clip (last tile only) are clamped to the last key -- they are masked to -inf in the scores.
 struct KvOff { unsigned k[2], v[2]; };
+template <int PER>     // pieces of K (and of V) per wave and tile: 8 / waves per workgroup
 __device__ __forceinline__ KvOff kv_offsets_bf16(int64_t ld, int key0, int T, int wave, int lane) {
     KvOff o;
     const int r8 = lane >> 3, ps = lane & 7;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int r = (wave * 2 + i) * 8 + r8;
+    for (int i = 0; i < PER; ++i) {
+        const int r = (wave * PER + i) * 8 + r8;
         int rr = key0 + r < T ? r : T - 1 - key0;
         o.k[i] = (unsigned)(rr * ld * 2) + ((ps ^ kswz(r)) << 4);
         o.v[i] = (unsigned)(rr * ld * 2) + ((ps ^ vswz(r)) << 4);
     }
     return o;
 }
+template <int PER>
 __device__ __forceinline__ void stage_kv_bf16(const bf16_t *kbase, const bf16_t *vbase, int64_t ld, int key0, const KvOff &o,
                                               unsigned kl, unsigned vl, int wave) {
     const bf16_t *ks = kbase + (int64_t)key0 * ld, *vs = vbase + (int64_t)key0 * ld;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        la::glds16_so(o.k[i], ks, kl + (wave * 2 + i) * 1024);
-        la::glds16_so(o.v[i], vs, vl + (wave * 2 + i) * 1024);
+    for (int i = 0; i < PER; ++i) {
+        la::glds16_so(o.k[i], ks, kl + (wave * PER + i) * 1024);
+        la::glds16_so(o.v[i], vs, vl + (wave * PER + i) * 1024);
     }
 }
 
-template <typename T16>
-__global__ __launch_bounds__(256, 2) void attention_bf16_kernel(AttnParams p) {
+// NW = waves per workgroup (32 queries each): 4 (128 queries, 5 workgroups = 20 waves per CU by LDS) or 8 (256 queries: every
+// K / V tile is staged once for twice the queries, 4 workgroups = 32 waves per CU)
+template <typename T16, int NW = 4>
+__global__ __launch_bounds__(64 * NW, 2) void attention_bf16_kernel(AttnParams p) {
+    constexpr int QT = 32 * NW, PER = 8 / NW;
     typedef Half16<T16> HT;
     typedef typename HT::vec8 vec8;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * KT * 128];  // [buf][K|V][64][128 B] = 32 KiB
@@ -150,9 +155,9 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(AttnParams p) {
     const int nkv_all = nkv;
     if (p.causal) nkv = min(nkv, (min(p.q_len, (qt + 1) * QT) - 1) / KT + 1);   // tiles above the block's diagonal are all masked
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(la::lds_addr_u32(lds));
-    const KvOff off_full = kv_offsets_bf16(p.ld_kv, 0, KT, wave, lane);                      // every row valid
-    const KvOff off_last = kv_offsets_bf16(p.ld_kv, (nkv_all - 1) * KT, T, wave, lane);      // rows clamped to key T-1
-    stage_kv_bf16(kbase, vbase, p.ld_kv, 0, nkv_all == 1 ? off_last : off_full, lds0, lds0 + KT * 128, wave);
+    const KvOff off_full = kv_offsets_bf16<PER>(p.ld_kv, 0, KT, wave, lane);                      // every row valid
+    const KvOff off_last = kv_offsets_bf16<PER>(p.ld_kv, (nkv_all - 1) * KT, T, wave, lane);      // rows clamped to key T-1
+    stage_kv_bf16<PER>(kbase, vbase, p.ld_kv, 0, nkv_all == 1 ? off_last : off_full, lds0, lds0 + KT * 128, wave);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -166,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(AttnParams p) {
         const unsigned char *vl = kl + KT * 128;
         if (t + 1 < nkv) {
             const unsigned nk = lds0 + (cur ^ 1) * (2 * KT * 128);
-            stage_kv_bf16(kbase, vbase, p.ld_kv, (t + 1) * KT, t + 2 == nkv_all ? off_last : off_full, nk, nk + KT * 128, wave);
+            stage_kv_bf16<PER>(kbase, vbase, p.ld_kv, (t + 1) * KT, t + 2 == nkv_all ? off_last : off_full, nk, nk + KT * 128, wave);
         }
         // ---- S^T = K Q^T : two 32-key sub-tiles ----
         // all eight K fragments are requested before the first MFMA (32 VGPRs; the kernel has room): the reads return under
@@ -415,8 +420,13 @@ static int attention_launch(int dtype, AttnParams p, int batch, hipStream_t stre
     const dim3 grid(la::cdiv(p.q_len, QT) * p.n_head * batch), block(256);
     if (dtype == LA_BF16 || dtype == LA_F16) {
         la::TimerScope ts("attention_bf16", stream);
-        if (dtype == LA_F16) hipLaunchKernelGGL(attention_bf16_kernel<la::f16_t>, grid, block, 0, stream, p);
-        else hipLaunchKernelGGL(attention_bf16_kernel<bf16_t>, grid, block, 0, stream, p);
+        const char *nw_env = getenv("LA_ATTN_NW");        // developer A/B (read per launch): 8 = 256-query workgroups
+        if (nw_env && atoi(nw_env) == 8 && p.q_len >= 256) {
+            const dim3 grid8(la::cdiv(p.q_len, 256) * p.n_head * batch), block8(512);
+            if (dtype == LA_F16) hipLaunchKernelGGL((attention_bf16_kernel<la::f16_t, 8>), grid8, block8, 0, stream, p);
+            else hipLaunchKernelGGL((attention_bf16_kernel<bf16_t, 8>), grid8, block8, 0, stream, p);
+        } else if (dtype == LA_F16) hipLaunchKernelGGL((attention_bf16_kernel<la::f16_t, 4>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((attention_bf16_kernel<bf16_t, 4>), grid, block, 0, stream, p);
     } else {
         static bool attr_done = false;
         if (!attr_done) {

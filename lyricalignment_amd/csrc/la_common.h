@@ -155,6 +155,21 @@ __device__ __forceinline__ f32x2 gelu_pk(f32x2 x) {
     return (x + u) * f32x2{0.5f, 0.5f};
 }
 
+// GELU as x * sigmoid(z(x)), z an odd quintic in x clamped to |x| <= 8: one multiply-chain, v_exp_f32, v_rcp_f32 -- 11 issue
+// slots per value against 15.5 for gelu_pk (the MLP-up epilogue is VALU-bound at one workgroup per CU).  Minimax fit of
+// x sigmoid(x (a + b x^2 + c x^4)) to x Phi(x) on [-9, 9] (tools fit in DESIGN.md): max ABSOLUTE error 2.5e-5 (at x = -0.56);
+// for results rounded to bf16 / f16 only.  The clamp keeps z monotone where the quintic's negative x^5 term would turn it
+// (|x| > 11) and saturates the sigmoid to exactly 1 / ~1e-12 beyond |x| = 8, where Phi is 1 - 6e-16 / 6e-16.
+// log2(e) is folded into the coefficients (and the sign, so that the exponential is exp2(-z log2 e)).
+__device__ __forceinline__ float gelu_sig(float x) {
+    const float xc = __builtin_amdgcn_fmed3f(x, -8.0f, 8.0f);
+    const float s = xc * xc;
+    float p = fmaf(1.0148166172e-03f, s, -1.0677913190e-01f);     // -log2e * (c, b)
+    p = fmaf(p, s, -2.3011175945e+00f);                            // -log2e * a
+    const float e = __builtin_amdgcn_exp2f(p * xc);
+    return x * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
 // nn.Mish: x * tanh(softplus(x)); softplus with torch's threshold 20
 __device__ __forceinline__ float mish(float x) {
     float sp = x > 20.0f ? x : log1pf(expf(x));

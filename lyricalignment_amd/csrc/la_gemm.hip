@@ -290,10 +290,15 @@ __global__ __launch_bounds__(PPGeom<DBG>::THREADS, 2) void gemm_pp_kernel(GemmPa
         for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
-                if constexpr (!OUT_F32) {                        // result is rounded to bf16: packed-FP32 form
-                    const la::f32x2 lo = la::gelu_pk(la::f32x2{acc[mi][ni][0], acc[mi][ni][1]});
-                    const la::f32x2 hi = la::gelu_pk(la::f32x2{acc[mi][ni][2], acc[mi][ni][3]});
-                    acc[mi][ni] = f32x4{lo.x, lo.y, hi.x, hi.y};
+                if constexpr (!OUT_F32) {                        // result is rounded to 16 bits: the 11-slot sigmoid form
+                    if (p.epilogue & 4096) {                     // developer A/B (LA_GELU_PK=1): the erfc form on the packed pipe
+                        const la::f32x2 lo = la::gelu_pk(la::f32x2{acc[mi][ni][0], acc[mi][ni][1]});
+                        const la::f32x2 hi = la::gelu_pk(la::f32x2{acc[mi][ni][2], acc[mi][ni][3]});
+                        acc[mi][ni] = f32x4{lo.x, lo.y, hi.x, hi.y};
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[mi][ni][j] = la::gelu_sig(acc[mi][ni][j]);
+                    }
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[mi][ni][j] = la::gelu_erf(acc[mi][ni][j]);
@@ -449,6 +454,7 @@ int launch_pp_dbg(GemmParams p, int batch, hipStream_t stream) {
     // At least 4: with fewer, the K=4096 GEMM (N = 4 tiles) re-reads its 2 MB-per-row-block A panel once per column tile
     // (in-pipeline sweep: 1 -> 46.1 ms/step, 4 -> 45.7, 8 -> 45.9, 16 -> 46.4).
     p.group = getenv("LA_GEMM_GROUP") ? std::min(p.group, p.tiles_n) : std::min(p.tiles_n, std::max(4, p.group / 2));
+    if (getenv("LA_GELU_PK")) p.epilogue |= 4096;
     la::TimerScope ts("gemm_bf16", stream);
     hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, batch), dim3(G::THREADS), G::LDS, stream, p);
     LA_LAUNCH_CHECK();

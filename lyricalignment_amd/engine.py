@@ -192,20 +192,33 @@ def pack_decoder(sd: Dict[str, torch.Tensor], n_head: int, dtype: torch.dtype, d
 
 
 def pack_head(sd: Dict[str, torch.Tensor], dtype: torch.dtype, device, prefix: str = "align_rnn.") -> HeadWeights:
-    """RNN state_dict (nn.GRU 2 layers bidirectional + nn.Linear, module/align_model.py:23-33) -> kernel layout."""
+    """RNN state_dict (nn.GRU 2 layers + nn.Linear, module/align_model.py:23-33) -> kernel layout.
+    bidirectional=False (module/align_model.py:20,48; the reference's scripts always build the bidirectional head) runs on the
+    same kernels with an all-zero reverse direction: zero W_ih / W_hh / biases keep that direction's state at exactly 0
+    (n = tanh(0) = 0, h' = (1 - z) * 0 + z * 0), and the next layer's / the Linear's columns that would read it are zero
+    columns appended to their weights -- so the forward direction's arithmetic is unchanged and the results are those of the
+    unidirectional nn.GRU, at the price of the idle half of the recurrence."""
     g = lambda k: sd[prefix + k].detach()
     H = g("rnn.weight_hh_l0").shape[1]
-    if f"{prefix}rnn.weight_ih_l0_reverse" not in sd:
-        raise NotImplementedError("unidirectional head: the kernels implement the bidirectional GRU the reference trains")
+    bidir = f"{prefix}rnn.weight_ih_l0_reverse" in sd
     w_ih, b_ih, w_hh, b_hh = [], [], [], []
     layer = 0
     while f"{prefix}rnn.weight_ih_l{layer}" in sd:
-        w_ih.append(torch.cat([g(f"rnn.weight_ih_l{layer}"), g(f"rnn.weight_ih_l{layer}_reverse")], 0).to(device=device, dtype=dtype).contiguous())
-        b_ih.append(_f32(torch.cat([g(f"rnn.bias_ih_l{layer}"), g(f"rnn.bias_ih_l{layer}_reverse")], 0), device))
-        w_hh.append(torch.stack([g(f"rnn.weight_hh_l{layer}"), g(f"rnn.weight_hh_l{layer}_reverse")], 0).to(device=device, dtype=dtype).contiguous())
-        b_hh.append(_f32(torch.stack([g(f"rnn.bias_hh_l{layer}"), g(f"rnn.bias_hh_l{layer}_reverse")], 0), device))
+        wf, bf_, hf, cf = g(f"rnn.weight_ih_l{layer}").float(), g(f"rnn.bias_ih_l{layer}").float(), g(f"rnn.weight_hh_l{layer}").float(), g(f"rnn.bias_hh_l{layer}").float()
+        if bidir:
+            wr, br, hr, cr = (g(f"rnn.{n}_l{layer}_reverse").float() for n in ("weight_ih", "bias_ih", "weight_hh", "bias_hh"))
+        else:
+            if layer > 0:                                   # layer input = [forward | (absent) reverse]: zero columns for the latter
+                wf = torch.cat([wf, torch.zeros_like(wf)], dim=1)
+            wr, br, hr, cr = torch.zeros_like(wf), torch.zeros_like(bf_), torch.zeros_like(hf), torch.zeros_like(cf)
+        w_ih.append(torch.cat([wf, wr], 0).to(device=device, dtype=dtype).contiguous())
+        b_ih.append(_f32(torch.cat([bf_, br], 0), device))
+        w_hh.append(torch.stack([hf, hr], 0).to(device=device, dtype=dtype).contiguous())
+        b_hh.append(_f32(torch.stack([cf, cr], 0), device))
         layer += 1
-    w_fc = g("fc.weight")
+    w_fc = g("fc.weight").float()
+    if not bidir:
+        w_fc = torch.cat([w_fc, torch.zeros_like(w_fc)], dim=1)
     return HeadWeights(H, w_ih[0].shape[1], w_fc.shape[0], dtype, w_ih, b_ih, w_hh, b_hh,
                        w_fc.to(device=device, dtype=dtype).contiguous(), _f32(g("fc.bias"), device))
 

@@ -392,3 +392,30 @@ def test_encoder_c_entry_point_takes_the_layernorm_folded_path_at_scale(monkeypa
         monkeypatch.setattr(eng_mod, "ENGINE_PY", False)
         got = e16.encode(mel, out_dtype=torch.float32).clone()
     assert torch.equal(got, ref) and not torch.equal(got, plain)
+
+
+def test_unidirectional_head_matches_oracle():
+    """AlignModel(bidirectional=False) (module/align_model.py:20,48): the head's kernels are bidirectional; the unidirectional GRU
+    runs on them with an all-zero reverse direction (engine.pack_head).  Logits against the oracle's unidirectional head,
+    float32 within 1e-3; fused align() seconds == the oracle's end-to-end result."""
+    from lyricalignment_amd import whisper_compat as wc
+    from lyricalignment_amd.module.align_model import AlignModel
+    from oracle import alignment_oracle as ao, model_oracle as mo
+    dims = wc.ModelDimensions(n_audio_state=128, n_audio_head=2, n_audio_layer=2, n_text_state=128, n_text_head=2, n_text_layer=0)
+    wm = wc.build_model(dims=dims, seed=95, std=0.05)
+    model = AlignModel(wm, embed_dim=128, hidden_dim=64, output_dim=300, bidirectional=False, device="cuda").eval()
+    g = torch.Generator().manual_seed(96)
+    with torch.no_grad():
+        for n, p_ in model.align_rnn.named_parameters():
+            p_.copy_((torch.rand(p_.shape, generator=g) * 2 - 1) * ((6.0 if n.startswith("fc.weight") else 1.5) / 64 ** 0.5))
+    assert "rnn.weight_ih_l0_reverse" not in model.align_rnn.state_dict() and model.align_rnn.fc.weight.shape == (300, 64)
+    audio = _wave(60096, 97)
+    labels = torch.tensor([[5, 17, 17, 250, 9, 33]])
+    with torch.no_grad():
+        lg, _ = model.frame_manual_forward([audio])
+        got = model.align([audio], labels, use_ctc=True)
+    p = _oracle_params(model)
+    mel = mo.pad_or_trim(mo.log_mel_spectrogram(audio[None]), 3000)
+    ref = mo.gru_head_forward(p, mo.encoder_forward(p, mel, n_head=2)[:, :188], bidirectional=False)
+    np.testing.assert_allclose(lg.cpu().numpy(), ref.numpy(), rtol=0, atol=1e-3)
+    assert got == ao.perform_viterbi_ctc(ref, labels)

@@ -38,7 +38,11 @@ def bench_gemm_variants(iters, variants, rounds=5):
         outs = {v: torch.empty(M, N, device="cuda", dtype=torch.float32 if f32out else torch.bfloat16) for v in variants}
 
         def run(v):
-            os.environ["LA_PP_DBG"] = str(v)
+            if v == 1000:                      # pseudo-variant: default main loop, erfc-form GELU on the packed pipe (LA_GELU_PK)
+                os.environ["LA_GELU_PK"] = "1"
+            else:
+                os.environ.pop("LA_GELU_PK", None)
+            os.environ["LA_PP_DBG"] = str(0 if v == 1000 else v)
             ops.gemm(a, w, outs[v], bias=bias, residual=res, gelu="gelu" in name, out_f32=f32out)
 
         times = {v: [] for v in variants}
@@ -49,12 +53,16 @@ def bench_gemm_variants(iters, variants, rounds=5):
                 times[v].append(med)
                 if v != variants[0] and not torch.equal(outs[v], outs[variants[0]]):
                     bad[v] += 1
+                    if rd == 0:
+                        d = (outs[v].float() - outs[variants[0]].float()).abs()
+                        print(f"   variant {v} vs {variants[0]} on {name}: max abs diff {float(d.max()):.3e}, differing elements {float((d > 0).float().mean()):.4f}", flush=True)
         fl = 2.0 * M * N * K
         for v in variants:
             t = sorted(times[v])
             print(f"gemm {name:14s} N={N} K={K} variant {v:3d}: median {t[len(t)//2]*1e3:8.1f} us  min {t[0]*1e3:8.1f} us  "
                   f"{fl/t[len(t)//2]/1e9:7.1f} TF/s  mismatching rounds vs variant {variants[0]}: {bad[v]}/{rounds}", flush=True)
     os.environ.pop("LA_PP_DBG", None)
+    os.environ.pop("LA_GELU_PK", None)
 
 
 def bench_gemm(iters):
@@ -85,9 +93,17 @@ def bench_attn(iters):
     qkv = rnd(B * T, 3 * H * 64)
     qkv[:, : H * 64] *= float(os.environ.get("KB_QSCALE", "0.125"))   # q pre-scaled by 1/8: scores ~ N(0, 1) like a real layer
     out = torch.empty(B * T, H * 64, device="cuda", dtype=torch.bfloat16)
-    med, mn = timeit(lambda: ops.attention(qkv, B, T, H, out=out), iters)
     fl = 4.0 * T * T * H * 64 * B
-    print(f"attention B={B} T={T} H={H}: median {med*1e3:.1f} us  {fl/med/1e9:.1f} TF/s", flush=True)
+    ref = None
+    for rd in range(3):
+        for nw in ("4", "8"):
+            os.environ["LA_ATTN_NW"] = nw
+            med, mn = timeit(lambda: ops.attention(qkv, B, T, H, out=out), iters)
+            if ref is None:
+                ref = out.clone()
+            same = bool(torch.equal(out, ref))
+            print(f"attention B={B} T={T} H={H} waves/workgroup {nw}: median {med*1e3:.1f} us  min {mn*1e3:.1f} us  {fl/med/1e9:.1f} TF/s  identical to the first run: {same}", flush=True)
+    os.environ.pop("LA_ATTN_NW", None)
 
 
 def bench_gru(iters):
