@@ -31,11 +31,13 @@ template <typename T16> struct Half16;
 template <> struct Half16<bf16_t> {
     typedef bf16x8 vec8;
     typedef __bf16 elem;
+    static constexpr unsigned kOnes = 0x3F803F80u;   // two 1.0
     __device__ static __forceinline__ f32x16 mfma32(vec8 a, vec8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 };
 template <> struct Half16<la::f16_t> {
     typedef f16x8 vec8;
     typedef _Float16 elem;
+    static constexpr unsigned kOnes = 0x3C003C00u;
     __device__ static __forceinline__ f32x16 mfma32(vec8 a, vec8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 };
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -119,7 +121,10 @@ __device__ __forceinline__ void stage_kv_bf16(const bf16_t *kbase, const bf16_t 
 
 // NW = waves per workgroup (32 queries each): 4 (128 queries, 5 workgroups = 20 waves per CU by LDS) or 8 (256 queries: every
 // K / V tile is staged once for twice the queries, 4 workgroups = 32 waves per CU)
-template <typename T16, int NW = 4>
+// MSUM: the softmax denominator on the matrix pipe -- one extra MFMA per 16 keys with an all-ones A operand accumulates
+// sum_k P[k][q] (of the ROUNDED P, like the numerator) in a third accumulator, instead of 32 v_add_f32 per key tile on the
+// vector pipe, which is the busier one in this kernel (VALU 71 % / MFMA 45 % of the SIMD cycles).
+template <typename T16, int NW = 4, bool MSUM = false>
 __global__ __launch_bounds__(64 * NW, 2) void attention_bf16_kernel(AttnParams p) {
     constexpr int QT = 32 * NW, PER = 8 / NW;
     typedef Half16<T16> HT;
@@ -150,6 +155,10 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_bf16_kernel(AttnParams p
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[b][r] = 0.f;
     float m_run = -INFINITY, l_part = 0.f;
+    f32x16 osum;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) osum[r] = 0.f;
+    const uint4 ones4 = uint4{HT::kOnes, HT::kOnes, HT::kOnes, HT::kOnes};
 
     int nkv = (T + KT - 1) / KT;
     const int nkv_all = nkv;
@@ -220,14 +229,18 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_bf16_kernel(AttnParams p
             for (int r = 0; r < 16; ++r) {
                 const float pv = __builtin_amdgcn_exp2f(fmaf(s[sub][r], kLog2e, -m_new));
                 s[sub][r] = pv;
-                psum += pv;
+                if constexpr (!MSUM) psum += pv;
             }
-        l_part = l_part * alpha + psum;
+        if constexpr (!MSUM) l_part = l_part * alpha + psum;
         if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {   // wave-uniform; exact: alpha == 1 changes nothing
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[b][r] *= alpha;
+            if constexpr (MSUM) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) osum[r] *= alpha;
+            }
         }
         // ---- O^T += V^T P^T ----
 #pragma unroll
@@ -237,6 +250,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_bf16_kernel(AttnParams p
                 vec8 pf;  // element j <-> accumulator register 8*ks + j <-> key sub*32 + 16ks + 8(j>>2) + 4h + (j&3)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) pf[j] = (typename HT::elem)s[sub][8 * ks + j];
+                if constexpr (MSUM) osum = HT::mfma32(__builtin_bit_cast(vec8, ones4), pf, osum);
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
                     // lane (dv = 32b + 16(g&1) + (lane&15), half h = g>>1): 4 keys key0 .. key0+3 per read
@@ -261,7 +275,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_bf16_kernel(AttnParams p
     }
 
     // ---- epilogue: O[q][dv] = O^T / l ----
-    const float l = l_part + __shfl_xor(l_part, 32);
+    const float l = MSUM ? osum[0] : l_part + __shfl_xor(l_part, 32);      // every row of osum holds the query's whole sum
     const float inv = 1.0f / l;
     if (q_valid) {
         bf16_t *orow = reinterpret_cast<bf16_t *>(p.out) + ((int64_t)clip * p.out_bs + qrow) * p.ld_out + head * 64;
@@ -425,6 +439,9 @@ static int attention_launch(int dtype, AttnParams p, int batch, hipStream_t stre
             const dim3 grid8(la::cdiv(p.q_len, 256) * p.n_head * batch), block8(512);
             if (dtype == LA_F16) hipLaunchKernelGGL((attention_bf16_kernel<la::f16_t, 8>), grid8, block8, 0, stream, p);
             else hipLaunchKernelGGL((attention_bf16_kernel<bf16_t, 8>), grid8, block8, 0, stream, p);
+        } else if (getenv("LA_ATTN_MSUM")) {                 // developer A/B: softmax denominator on the matrix pipe
+            if (dtype == LA_F16) hipLaunchKernelGGL((attention_bf16_kernel<la::f16_t, 4, true>), grid, block, 0, stream, p);
+            else hipLaunchKernelGGL((attention_bf16_kernel<bf16_t, 4, true>), grid, block, 0, stream, p);
         } else if (dtype == LA_F16) hipLaunchKernelGGL((attention_bf16_kernel<la::f16_t, 4>), grid, block, 0, stream, p);
         else hipLaunchKernelGGL((attention_bf16_kernel<bf16_t, 4>), grid, block, 0, stream, p);
     } else {

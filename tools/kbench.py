@@ -96,14 +96,19 @@ def bench_attn(iters):
     fl = 4.0 * T * T * H * 64 * B
     ref = None
     for rd in range(3):
-        for nw in ("4", "8"):
+        for nw, msum in (("4", False), ("8", False), ("4", True)):
             os.environ["LA_ATTN_NW"] = nw
+            if msum:
+                os.environ["LA_ATTN_MSUM"] = "1"
+            else:
+                os.environ.pop("LA_ATTN_MSUM", None)
             med, mn = timeit(lambda: ops.attention(qkv, B, T, H, out=out), iters)
             if ref is None:
                 ref = out.clone()
-            same = bool(torch.equal(out, ref))
-            print(f"attention B={B} T={T} H={H} waves/workgroup {nw}: median {med*1e3:.1f} us  min {mn*1e3:.1f} us  {fl/med/1e9:.1f} TF/s  identical to the first run: {same}", flush=True)
-    os.environ.pop("LA_ATTN_NW", None)
+            dmax = float((out.float() - ref.float()).abs().max())
+            print(f"attention B={B} T={T} H={H} waves/workgroup {nw} msum {int(msum)}: median {med*1e3:.1f} us  min {mn*1e3:.1f} us  {fl/med/1e9:.1f} TF/s  "
+                  f"max abs diff to the first run: {dmax:.3e}", flush=True)
+    os.environ.pop("LA_ATTN_NW", None); os.environ.pop("LA_ATTN_MSUM", None)
 
 
 def bench_gru(iters):
