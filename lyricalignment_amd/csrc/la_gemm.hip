@@ -215,7 +215,7 @@ __device__ __forceinline__ float2 segment_stats(const ushort4 pk) {
 template <int DBG> struct PPGeom {
     static constexpr bool HALF = DBG == 64;
     static constexpr int TM = HALF ? KH::TM : PP::TM, THREADS = HALF ? KH::THREADS : PP::THREADS;
-    static constexpr int LDS = HALF ? KH::LDS : ((DBG >= 20 && DBG != 24 && DBG < 64) ? K2<5>::LDS : PP::LDS);
+    static constexpr int LDS = HALF ? KH::LDS : ((DBG >= 20 && DBG != 24 && DBG < 32) ? K2<5>::LDS : PP::LDS);
 };
 template <bool OUT_F32, int DBG, typename T16, int LNM = 0>
 __global__ __launch_bounds__(PPGeom<DBG>::THREADS, 2) void gemm_pp_kernel(GemmParams p) {
@@ -246,6 +246,7 @@ __global__ __launch_bounds__(PPGeom<DBG>::THREADS, 2) void gemm_pp_kernel(GemmPa
     else if constexpr (DBG == 64) mainloop_half<T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
     else if constexpr (DBG == 24) mainloop_k2f<4, T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
     else if constexpr (DBG == 25) mainloop_k2f<5, T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
+    else if constexpr (DBG >= 32) mainloop_pp<DBG, T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
     else if constexpr (DBG >= 20) mainloop_k2<DBG & 3, 5, T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
     else if constexpr (DBG >= 16) mainloop_k2<DBG & 3, 4, T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
     else mainloop_pp<DBG, T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
@@ -423,6 +424,9 @@ int launch_pp(GemmParams p, int batch, hipStream_t stream) {
             case 16: return launch_pp_dbg<OUT_F32, 16, T16>(p, batch, stream);
             case 20: return launch_pp_dbg<OUT_F32, 20, T16>(p, batch, stream);
             case 24: return launch_pp_dbg<OUT_F32, 24, T16>(p, batch, stream);
+            case 32: return launch_pp_dbg<OUT_F32, 32, T16>(p, batch, stream);
+            case 40: return launch_pp_dbg<OUT_F32, 40, T16>(p, batch, stream);
+            case 48: return launch_pp_dbg<OUT_F32, 48, T16>(p, batch, stream);
             case 64: return launch_pp_dbg<OUT_F32, 64, T16>(p, batch, stream);
             case 1: return launch_pp_dbg<OUT_F32, 1, T16>(p, batch, stream);
             case 2: return launch_pp_dbg<OUT_F32, 2, T16>(p, batch, stream);

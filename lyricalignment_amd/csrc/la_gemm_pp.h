@@ -82,27 +82,31 @@ __device__ __forceinline__ void mainloop_pp(const T16 *A, int64_t lda, int M, co
     const unsigned char *a_row0 = Ab + (int64_t)m0 * lda_b;
     const unsigned char *w_row0 = Wb + (int64_t)n0 * ldw_b;
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_u32(lds));
-    auto issue_w = [&](int kt, int half) {   // half 0/1 -> pieces 4*wave + 2*half + {0,1} of the W tile of K-tile kt
+    // one DMA piece: j = 0 / 1 of the pair (half) of this wave's four pieces of the W (A) tile of K-tile kt
+    auto issue_w1 = [&](int kt, int half, int j) {
         if ((DBG & 1) && kt >= 2) return;
-        const unsigned dst = lds0 + (kt & 1) * PP::BUF + PP::OPB + (4 * wave + 2 * half) * 1024;
-        const unsigned char *src = w_row0 + (int64_t)kt * BKB;
-        glds16_so(voff_w[2 * half], src, dst);
-        glds16_so(voff_w[2 * half + 1], src, dst + 1024);
+        const unsigned dst = lds0 + (kt & 1) * PP::BUF + PP::OPB + (4 * wave + 2 * half + j) * 1024;
+        glds16_so(voff_w[2 * half + j], w_row0 + (int64_t)kt * BKB, dst);
     };
-    auto issue_a = [&](int kt, int half) {
+    auto issue_a1 = [&](int kt, int half, int j) {
         if ((DBG & 1) && kt >= 2) return;
-        const unsigned dst = lds0 + (kt & 1) * PP::BUF + (4 * wave + 2 * half) * 1024;
-        const unsigned char *src = a_row0 + (int64_t)kt * BKB;
-        glds16_so(voff_a[2 * half], src, dst);
-        glds16_so(voff_a[2 * half + 1], src, dst + 1024);
+        const unsigned dst = lds0 + (kt & 1) * PP::BUF + (4 * wave + 2 * half + j) * 1024;
+        glds16_so(voff_a[2 * half + j], a_row0 + (int64_t)kt * BKB, dst);
     };
+    auto issue_w = [&](int kt, int half) { issue_w1(kt, half, 0); issue_w1(kt, half, 1); };
+    auto issue_a = [&](int kt, int half) { issue_a1(kt, half, 0); issue_a1(kt, half, 1); };
+    // HEADN (developer A/B, LA_PP_DBG = 40 / 48): how many of a phase's two pieces are issued at the HEAD of the COMPUTE
+    // segment -- after the barrier, under the s_waitcnt lgkmcnt(0) that waits for the fragment reads anyway -- instead of at
+    // the end of the LOAD segment.  Later issue only relaxes the WAR conditions; the RAW waits keep their places and count
+    // what is still to come (group 1's wait precedes its phase-3 COMPUTE head).
+    constexpr int HEADN = (DBG == 40) ? 1 : (DBG == 48 ? 2 : 0);
 
     // ---- prologue: K-tiles 0 and 1 completely (the steady-state schedule starts with tile 2) ----
     issue_w(0, 0); issue_w(0, 1); issue_a(0, 0); issue_a(0, 1);
     if (nk > 1) { issue_w(1, 0); issue_w(1, 1); issue_a(1, 0); issue_a(1, 1); }
     // only K-tile 0 has to be here for the first MFMA; tile 1's eight pieces stay in flight and are retired by the counted
     // waits that close iteration 0 (they are older than everything those waits leave outstanding)
-    if ((DBG & 32) || nk == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (nk == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     LA_PP_BARRIER();
     if (wr == 1) LA_PP_BARRIER();   // stagger: group 1 runs one barrier behind group 0
 
@@ -142,47 +146,77 @@ __device__ __forceinline__ void mainloop_pp(const T16 *A, int64_t lda, int M, co
         const unsigned char *abuf = lds + (kt & 1) * PP::BUF;
         const unsigned char *wbuf = abuf + PP::OPB;
         const bool pf2 = kt + 2 < nk;
+        const bool pf1 = kt >= 1 && kt + 1 < nk;
         // Issue slots while tile kt is computed (2 instructions per phase and wave; a buffer half is refilled only
         // after the barrier that follows the completion of its last fragment read by BOTH groups):
         //   group 0:  ph0 W half 1 of kt+1 | ph1 A half 0 of kt+1 | ph2 A half 1 of kt+1 | ph3 W half 0 of kt+2
         //   group 1:  ph0 A half 0 of kt+1 | ph1 A half 1 of kt+1 | ph2 W half 0 of kt+2 | ph3 W half 1 of kt+2
+        auto piece = [&](int ph, int j) {          // piece j (0 / 1) of this wave's phase-ph slot
+            if (wr == 0) {
+                if (ph == 0) { if (pf1) issue_w1(kt + 1, 1, j); }
+                else if (ph == 1) { if (pf1) issue_a1(kt + 1, 0, j); }
+                else if (ph == 2) { if (pf1) issue_a1(kt + 1, 1, j); }
+                else { if (pf2) issue_w1(kt + 2, 0, j); }
+            } else {
+                if (ph == 0) { if (pf1) issue_a1(kt + 1, 0, j); }
+                else if (ph == 1) { if (pf1) issue_a1(kt + 1, 1, j); }
+                else if (ph == 2) { if (pf2) issue_w1(kt + 2, 0, j); }
+                else { if (pf2) issue_w1(kt + 2, 1, j); }
+            }
+        };
+        auto dma_load = [&](int ph) {              // the pieces of the slot that go at the end of the LOAD segment
+#pragma unroll
+            for (int j = 0; j < 2 - HEADN; ++j) piece(ph, j);
+        };
+        auto dma_head = [&](int ph) {              // ... and those at the head of the COMPUTE segment
+#pragma unroll
+            for (int j = 2 - HEADN; j < 2; ++j) piece(ph, j);
+        };
+        const bool dma_first = (DBG == 32) && (wc & 1);      // developer A/B: odd wave columns issue their DMA before their reads
         // ---------------- phase 0: quadrant (a0, b0) ----------------
+        if (dma_first) dma_load(0);
         read_a(abuf, 0);
         read_b(wbuf, 0, b0f);
-        if (wr == 0) { if (kt >= 1 && kt + 1 < nk) issue_w(kt + 1, 1); }   // g0: 2nd W half of tile kt+1 (buffer of kt-1)
-        else         { if (kt >= 1 && kt + 1 < nk) issue_a(kt + 1, 0); }   // g1: 1st A half of tile kt+1
+        if (!dma_first) dma_load(0);
         LA_PP_BARRIER();
+        dma_head(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         mma_quadrant(0, 0, b0f);
         LA_PP_BARRIER();
         // ---------------- phase 1: quadrant (a0, b1) ----------------
+        if (dma_first) dma_load(1);
         read_b(wbuf, 1, b1f);
-        if (wr == 0) { if (kt >= 1 && kt + 1 < nk) issue_a(kt + 1, 0); }   // g0: 1st A half of tile kt+1
-        else         { if (kt >= 1 && kt + 1 < nk) issue_a(kt + 1, 1); }   // g1: 2nd A half of tile kt+1
+        if (!dma_first) dma_load(1);
         LA_PP_BARRIER();
+        dma_head(1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         mma_quadrant(0, 1, b1f);
         LA_PP_BARRIER();
         // ---------------- phase 2: quadrant (a1, b1) ----------------
+        if (dma_first) dma_load(2);
         read_a(abuf, 1);
-        if (wr == 0) { if (kt >= 1 && kt + 1 < nk) issue_a(kt + 1, 1); }   // g0: 2nd A half of tile kt+1
-        else         { if (pf2) issue_w(kt + 2, 0); }                       // g1: 1st W half of tile kt+2 (W of kt dead after phase 1)
+        if (!dma_first) dma_load(2);
         LA_PP_BARRIER();
+        dma_head(2);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         mma_quadrant(1, 1, b1f);
         LA_PP_BARRIER();
         // ---------------- phase 3: quadrant (a1, b0) ----------------
-        if (wr == 0) { if (pf2) issue_w(kt + 2, 0); }                       // g0: 1st W half of tile kt+2
-        else {
-            if (pf2) issue_w(kt + 2, 1);                                    // g1: 2nd W half of tile kt+2
+        dma_load(3);
+        if (wr == 1) {
             // g1's LOAD segment closes with the barrier that precedes g0's first read of tile kt+1: retire everything
-            // of tile kt+1 (issued >= 2 segments ago); only tile kt+2's 4 W instructions may stay in flight
-            if (pf2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // of tile kt+1 (issued >= 2 segments ago); only tile kt+2's W pieces issued so far may stay in flight
+            // (the 2 of phase 2 + the 2 - HEADN of this segment)
+            if (!pf2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if constexpr (HEADN == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if constexpr (HEADN == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         }
         LA_PP_BARRIER();
+        dma_head(3);
         __builtin_amdgcn_sched_barrier(0);
         mma_quadrant(1, 0, b0f);
         if (wr == 0) {
