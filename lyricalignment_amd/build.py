@@ -21,7 +21,7 @@ LIB = os.path.join(HERE, "liblyricalign_hip.so")
 ARCH = "gfx950"
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
-            "-fno-fast-math", "-ffp-contract=on"]
+            "-fno-fast-math", "-ffp-contract=on"] + os.environ.get("LA_EXTRA_CXXFLAGS", "").split()
 
 
 def _sources():

@@ -32,6 +32,7 @@ struct GemmParams {
     const float *ln_stats = nullptr;   // consumer: per-row (mean, rstd) of the raw A rows, [M][2]
     const float *ln_csum = nullptr;    // consumer: c[n] = sum_k W'[n][k] of the gamma-folded weights, [N]
     int K_tail = 0;                    // split-K: K of the LAST batch slot when the chunks are uneven (0 = p.K)
+    unsigned *stamps = nullptr;        // diagnostic build (-DLA_PP_STAMPS): per-segment s_memtime of one K-tile, [64 workgroups][8 waves][32]
     float *ln_part = nullptr;          // producer (optional): per-row partial statistics of the 16-bit copy, [N/64][M][2] =
                                        // (mean, sum of squared deviations) of each 64-column segment (la_ln_stats_finalize)
 };
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(PPGeom<DBG>::THREADS, 2) void gemm_pp_kernel(GemmPa
     else if constexpr (DBG >= 32) mainloop_pp<DBG, T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
     else if constexpr (DBG >= 20) mainloop_k2<DBG & 3, 5, T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
     else if constexpr (DBG >= 16) mainloop_k2<DBG & 3, 4, T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
-    else mainloop_pp<DBG, T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
+    else mainloop_pp<DBG, T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc, p.stamps);
 
     typedef typename std::conditional<OUT_F32, float, T16>::type TC;
     TC *C = reinterpret_cast<TC *>(p.C) + (int64_t)z * p.strideC;
@@ -412,6 +413,80 @@ __global__ __launch_bounds__(PPGeom<DBG>::THREADS, 2) void gemm_pp_kernel(GemmPa
     }
 }
 
+// Developer experiment (LA_PP_DBG=72): the "mono" main loop (one wave per SIMD, 128x128 wave tiles) with a plain epilogue --
+// bias, GELU, f32 residual, f32 or 16-bit result -- enough to time the loop on the encoder's shapes.
+template <bool OUT_F32, typename T16>
+__global__ __launch_bounds__(MONO::THREADS, 1) void gemm_mono_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int tile = xcd_remap(blockIdx.x, nwg);
+    const TileCoord tc = tile_coord(tile, p.tiles_m, p.tiles_n, p.group);
+    const int m0 = tc.tm * 256, n0 = tc.tn * 256;
+    const T16 *A = reinterpret_cast<const T16 *>(p.A), *W = reinterpret_cast<const T16 *>(p.W);
+    f32x4 acc[8][8];
+    mainloop_mono<T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
+    typedef typename std::conditional<OUT_F32, float, T16>::type TC;
+    TC *C = reinterpret_cast<TC *>(p.C);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 1, wc = wave & 1, r = lane & 15, q = lane >> 4;
+    const bool has_bias = (p.epilogue & LA_EPI_BIAS) && p.bias, do_gelu = p.epilogue & LA_EPI_GELU, do_res = (p.epilogue & LA_EPI_RESIDUAL) && p.residual;
+    constexpr int PITCH = 528;                                   // 128 f32 + 16 B
+    unsigned char *reg = lds + wave * (32 * PITCH);
+    const int wrow0 = m0 + wr * 128, wcol0 = n0 + wc * 128;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+            for (int ni = 0; ni < 8; ++ni) {
+                f32x4 v = acc[2 * h + mm][ni];
+                if (has_bias) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] += p.bias[min(wcol0 + ni * 16 + q * 4 + j, p.N - 1)];
+                }
+                if (do_gelu) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = OUT_F32 ? la::gelu_erf(v[j]) : la::gelu_sig(v[j]);
+                }
+                *reinterpret_cast<f32x4 *>(reg + (mm * 16 + r) * PITCH + (ni * 16 + q * 4) * 4) = v;
+            }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int rl = it * 4 + q, m = wrow0 + h * 32 + rl;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int n = wcol0 + half * 64 + r * 4;
+                f32x4 v = *reinterpret_cast<const f32x4 *>(reg + rl * PITCH + half * 256 + r * 16);
+                if (m >= p.M || n + 3 >= p.N) continue;         // experiment: whole float4s only (N % 4 == 0 shapes)
+                if (do_res) {
+                    const float4 t = *reinterpret_cast<const float4 *>(p.residual + (int64_t)m * p.ldr + n);
+                    v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+                }
+                TC *c = C + (int64_t)m * p.ldc + n;
+                if constexpr (sizeof(TC) == 4) *reinterpret_cast<float4 *>(c) = make_float4(v[0], v[1], v[2], v[3]);
+                else *reinterpret_cast<ushort4 *>(c) = la::Pack4<T16>::run(v[0], v[1], v[2], v[3]);
+            }
+        }
+    }
+}
+
+template <bool OUT_F32, typename T16>
+int launch_mono(GemmParams p, int batch, hipStream_t stream) {
+    auto kern = gemm_mono_kernel<OUT_F32, T16>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, MONO::LDS));
+        attr_done = true;
+    }
+    p.tiles_m = la::cdiv(p.M, 256);
+    p.tiles_n = la::cdiv(p.N, 256);
+    p.group = std::min(p.tiles_n, std::max(4, p.group / 2));
+    la::TimerScope ts("gemm_bf16", stream);
+    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, 1), dim3(MONO::THREADS), MONO::LDS, stream, p);
+    LA_LAUNCH_CHECK();
+    return LA_OK;
+}
+
 template <bool OUT_F32, int DBG, typename T16, int LNM = 0>
 int launch_pp_dbg(GemmParams p, int batch, hipStream_t stream);
 
@@ -420,6 +495,7 @@ int launch_pp(GemmParams p, int batch, hipStream_t stream) {
     const char *dbg_env = getenv("LA_PP_DBG");               // read per launch: tools/kbench.py flips it between rounds of one process
     const int dbg = dbg_env ? atoi(dbg_env) : 0;
     if constexpr (std::is_same<T16, bf16_t>::value) {       // the developer probes exist for the bf16 instantiation
+        if (dbg == 72 && batch == 1 && p.N % 4 == 0 && !p.C2 && !p.ln_stats) return launch_mono<OUT_F32, T16>(p, batch, stream);
         switch (dbg) {
             case 16: return launch_pp_dbg<OUT_F32, 16, T16>(p, batch, stream);
             case 20: return launch_pp_dbg<OUT_F32, 20, T16>(p, batch, stream);
@@ -459,6 +535,9 @@ int launch_pp_dbg(GemmParams p, int batch, hipStream_t stream) {
     // (in-pipeline sweep: 1 -> 46.1 ms/step, 4 -> 45.7, 8 -> 45.9, 16 -> 46.4).
     p.group = getenv("LA_GEMM_GROUP") ? std::min(p.group, p.tiles_n) : std::min(p.tiles_n, std::max(4, p.group / 2));
     if (getenv("LA_GELU_PK")) p.epilogue |= 4096;
+#ifdef LA_PP_STAMPS
+    if (const char *sp = getenv("LA_STAMP_PTR")) p.stamps = reinterpret_cast<unsigned *>(strtoull(sp, nullptr, 0));
+#endif
     la::TimerScope ts("gemm_bf16", stream);
     hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, batch), dim3(G::THREADS), G::LDS, stream, p);
     LA_LAUNCH_CHECK();

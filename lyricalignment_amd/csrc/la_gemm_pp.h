@@ -52,7 +52,7 @@ __device__ __forceinline__ void pp_stage_piece(const unsigned char *src, int64_t
 // DBG (developer probes, LA_PP_DBG): bit0 = no in-loop DMA, bit1 = no MFMA, bit2 = s_setprio around the MFMA clusters
 template <int DBG, typename T16 = bf16_t>
 __device__ __forceinline__ void mainloop_pp(const T16 *A, int64_t lda, int M, const T16 *W, int64_t ldw, int N, int K,
-                                            int m0, int n0, unsigned char *lds, f32x4 (&acc)[8][4]) {
+                                            int m0, int n0, unsigned char *lds, f32x4 (&acc)[8][4], unsigned *stamp_out = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: scalar branches, no exec masking
     const int wr = wave >> 2, wc = wave & 3;       // group = wr: waves 0-3 / 4-7 pair up on the SIMDs
@@ -142,6 +142,16 @@ __device__ __forceinline__ void mainloop_pp(const T16 *A, int64_t lda, int M, co
         if (DBG & 4) __builtin_amdgcn_s_setprio(0);
     };
 
+#ifdef LA_PP_STAMPS
+    // diagnostic build only (python -m lyricalignment_amd.build with LA_EXTRA_CXXFLAGS=-DLA_PP_STAMPS): s_memtime at the six
+    // points of every phase of ONE K-tile (kt == 6), written to the buffer whose address LA_STAMP_PTR names
+    unsigned st[25];
+#pragma unroll
+    for (int i = 0; i < 25; ++i) st[i] = 0;
+#define LA_STAMP(i) do { if (kt == 6) st[i] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define LA_STAMP(i) do { } while (0)
+#endif
     for (int kt = 0; kt < nk; ++kt) {
         const unsigned char *abuf = lds + (kt & 1) * PP::BUF;
         const unsigned char *wbuf = abuf + PP::OPB;
@@ -174,37 +184,57 @@ __device__ __forceinline__ void mainloop_pp(const T16 *A, int64_t lda, int M, co
         };
         const bool dma_first = (DBG == 32) && (wc & 1);      // developer A/B: odd wave columns issue their DMA before their reads
         // ---------------- phase 0: quadrant (a0, b0) ----------------
+        LA_STAMP(0);
         if (dma_first) dma_load(0);
         read_a(abuf, 0);
         read_b(wbuf, 0, b0f);
+        LA_STAMP(1);
         if (!dma_first) dma_load(0);
+        LA_STAMP(2);
         LA_PP_BARRIER();
+        LA_STAMP(3);
         dma_head(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+        LA_STAMP(4);
         mma_quadrant(0, 0, b0f);
+        LA_STAMP(5);
         LA_PP_BARRIER();
         // ---------------- phase 1: quadrant (a0, b1) ----------------
+        LA_STAMP(6);
         if (dma_first) dma_load(1);
         read_b(wbuf, 1, b1f);
+        LA_STAMP(7);
         if (!dma_first) dma_load(1);
+        LA_STAMP(8);
         LA_PP_BARRIER();
+        LA_STAMP(9);
         dma_head(1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+        LA_STAMP(10);
         mma_quadrant(0, 1, b1f);
+        LA_STAMP(11);
         LA_PP_BARRIER();
         // ---------------- phase 2: quadrant (a1, b1) ----------------
+        LA_STAMP(12);
         if (dma_first) dma_load(2);
         read_a(abuf, 1);
+        LA_STAMP(13);
         if (!dma_first) dma_load(2);
+        LA_STAMP(14);
         LA_PP_BARRIER();
+        LA_STAMP(15);
         dma_head(2);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+        LA_STAMP(16);
         mma_quadrant(1, 1, b1f);
+        LA_STAMP(17);
         LA_PP_BARRIER();
         // ---------------- phase 3: quadrant (a1, b0) ----------------
+        LA_STAMP(18);
+        LA_STAMP(19);
         dma_load(3);
         if (wr == 1) {
             // g1's LOAD segment closes with the barrier that precedes g0's first read of tile kt+1: retire everything
@@ -215,16 +245,28 @@ __device__ __forceinline__ void mainloop_pp(const T16 *A, int64_t lda, int M, co
             else if constexpr (HEADN == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         }
+        LA_STAMP(20);
         LA_PP_BARRIER();
+        LA_STAMP(21);
         dma_head(3);
         __builtin_amdgcn_sched_barrier(0);
+        LA_STAMP(22);
         mma_quadrant(1, 0, b0f);
+        LA_STAMP(23);
         if (wr == 0) {
             // g0's COMPUTE segment closes with the same barrier: only tile kt+2's 2 W instructions may stay in flight
             if (pf2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         LA_PP_BARRIER();
+        LA_STAMP(24);
     }
+#ifdef LA_PP_STAMPS
+    if (stamp_out && lane == 0 && blockIdx.x < 64) {
+        unsigned *o = stamp_out + ((size_t)blockIdx.x * 8 + wave) * 32;
+#pragma unroll
+        for (int i = 0; i < 25; ++i) o[i] = st[i];
+    }
+#endif
     if (wr == 0) LA_PP_BARRIER();   // re-align the groups
 }
 
@@ -565,6 +607,99 @@ __device__ __forceinline__ void mainloop_flat256(const bf16_t *A, int64_t lda, i
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+}  // namespace gemm
+}  // namespace la
+
+// ---------------------------------------------------------------------------------------------------------------------
+// "mono" main loop (developer experiment, LA_PP_DBG=72): ONE wave per SIMD.  256x256 tile, 4 waves = 2 (M) x 2 (N), every
+// wave a 128x128 output tile (256 accumulator VGPRs of the 512 a lone wave may use) -- a third fewer LDS fragment bytes per
+// flop than the 128x64 wave tiles (16 + 16 reads per 128 MFMAs instead of 2 x (16 + 8) per 128), no partner wave: the
+// wave's own stream interleaves, per k-step (K = 32, 64 MFMAs), the 16 fragment reads of the NEXT k-step (second fragment
+// register set) and its 8 DMA pieces among the MFMAs.  Stages as in k2 (64-byte rows, ring of NST, one barrier per k-step).
+namespace la {
+namespace gemm {
+
+struct MONO { static constexpr int THREADS = 256, NST = 4, LDS = NST * 32768; };
+
+template <typename T16 = bf16_t>
+__device__ __forceinline__ void mainloop_mono(const T16 *A, int64_t lda, int M, const T16 *W, int64_t ldw, int N, int K,
+                                              int m0, int n0, unsigned char *lds, f32x4 (&acc)[8][8]) {
+    constexpr int NST = MONO::NST, DIST = NST - 1, STAGE = 32768, OPS = 16384, SB = 64;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int r = lane & 15, q = lane >> 4;
+    const int ns = K / 32;
+    const int64_t lda_b = lda * 2, ldw_b = ldw * 2;
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 8; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // this wave's pieces of every stage: 4 of A (rows 64 wave .. + 63) and 4 of W
+    unsigned voff_a[4], voff_w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rt = (4 * wave + i) * 16 + (lane >> 2);
+        const int sw = ((lane & 3) ^ swz2(rt)) << 4;
+        int ra = m0 + rt; ra = ra > M - 1 ? M - 1 : ra;
+        int rw = n0 + rt; rw = rw > N - 1 ? N - 1 : rw;
+        voff_a[i] = (unsigned)((int64_t)(ra - m0) * lda_b) + sw;
+        voff_w[i] = (unsigned)((int64_t)(rw - n0) * ldw_b) + sw;
+    }
+    const unsigned char *a_row0 = reinterpret_cast<const unsigned char *>(A) + (int64_t)m0 * lda_b;
+    const unsigned char *w_row0 = reinterpret_cast<const unsigned char *>(W) + (int64_t)n0 * ldw_b;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_u32(lds));
+    auto issue1 = [&](int st, int slot, int i) {      // piece i (0..7: 4 of W, then 4 of A) of this wave's share of stage st
+        const unsigned dst = lds0 + slot * STAGE + (i < 4 ? OPS : 0) + (4 * wave + (i & 3)) * 1024;
+        if (i < 4) glds16_so(voff_w[i], w_row0 + (int64_t)st * SB, dst);
+        else glds16_so(voff_a[i - 4], a_row0 + (int64_t)st * SB, dst);
+    };
+    auto frag_a = [&](int slot, int mi) { return read_frag2(lds + slot * STAGE + (wr * 128) * SB, mi * 16 + r, q); };
+    auto frag_w = [&](int slot, int ni) { return read_frag2(lds + slot * STAGE + OPS + (wc * 128) * SB, ni * 16 + r, q); };
+
+#pragma unroll
+    for (int st = 0; st < DIST; ++st)
+        if (st < ns) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) issue1(st, st, i);
+        }
+    // stage 0 landed (own pieces: all but the 8 (DIST - 1) younger ones), everyone's after the barrier; its fragments
+    if (ns > 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else if (ns > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    LA_PP_BARRIER();
+    uint4 fa[2][8], fw[2][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { fa[0][i] = frag_a(0, i); fw[0][i] = frag_w(0, i); }
+
+    int slot_n = 1, slot_w = DIST % NST;      // ring slots of stage s + 1 (next fragments) and of stage s + DIST (refill)
+    auto kstep = [&](int s, auto curc) {
+        constexpr int cur = decltype(curc)::value;
+        // stage s + 1 must be in LDS before its fragments are read below: own pieces landed, then the barrier; the barrier
+        // also says that every wave has its stage-s fragments in registers, so the slot of stage s - 1 ... wait: refill target
+        // is the slot stage s - 1 occupied (read during iteration s - 2, consumed in s - 1)
+        const int ahead = (ns - 1 < s + DIST - 1 ? ns - 1 : s + DIST - 1) - (s + 1);   // stages younger than s + 1 already issued
+        if (s + 1 < ns) {
+            if (ahead >= 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        LA_PP_BARRIER();
+        const bool pf = s + DIST < ns, nx = s + 1 < ns;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {       // 8 groups of 8 MFMAs: row tile g x all 8 column tiles
+            if (nx) { fa[cur ^ 1][g] = frag_a(slot_n, g); fw[cur ^ 1][g] = frag_w(slot_n, g); }
+            if (pf) issue1(s + DIST, slot_w, g);
+#pragma unroll
+            for (int ni = 0; ni < 8; ++ni) Mma<T16>::run(fw[cur][ni], fa[cur][g], acc[g][ni]);
+        }
+        slot_n = slot_n + 1 == NST ? 0 : slot_n + 1;
+        slot_w = slot_w + 1 == NST ? 0 : slot_w + 1;
+    };
+    for (int s = 0; s < ns; s += 2) {
+        kstep(s, std::integral_constant<int, 0>{});
+        if (s + 1 < ns) kstep(s + 1, std::integral_constant<int, 1>{});
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    LA_PP_BARRIER();
 }
 
 }  // namespace gemm
