@@ -83,10 +83,15 @@ __global__ __launch_bounds__(CF::THREADS, 2) void gemm_kernel(GemmParams p) {
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
-                if constexpr (!OUT_F32 && sizeof(T) == 2) {      // result is rounded to bf16: packed-FP32 form
-                    const la::f32x2 lo = la::gelu_pk(la::f32x2{acc[mi][ni][0], acc[mi][ni][1]});
-                    const la::f32x2 hi = la::gelu_pk(la::f32x2{acc[mi][ni][2], acc[mi][ni][3]});
-                    acc[mi][ni] = f32x4{lo.x, lo.y, hi.x, hi.y};
+                if constexpr (!OUT_F32 && sizeof(T) == 2) {      // result is rounded to 16 bits: the same form as the 256x256 kernel's
+                    if (p.epilogue & 4096) {                     // (LA_GELU_PK=1: the erfc form on the packed pipe)
+                        const la::f32x2 lo = la::gelu_pk(la::f32x2{acc[mi][ni][0], acc[mi][ni][1]});
+                        const la::f32x2 hi = la::gelu_pk(la::f32x2{acc[mi][ni][2], acc[mi][ni][3]});
+                        acc[mi][ni] = f32x4{lo.x, lo.y, hi.x, hi.y};
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[mi][ni][j] = la::gelu_sig(acc[mi][ni][j]);
+                    }
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[mi][ni][j] = la::gelu_erf(acc[mi][ni][j]);
@@ -553,6 +558,7 @@ int launch(GemmParams p, int batch, hipStream_t stream, const char *family) {
         attr_done = true;
     }
     p.tiles_m = la::cdiv(p.M, CF::TM);
+    if (getenv("LA_GELU_PK")) p.epilogue |= 4096;
     la::TimerScope ts(family, stream);
     hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, batch), dim3(CF::THREADS), CF::LDS, stream, p);
     LA_LAUNCH_CHECK();
