@@ -243,6 +243,103 @@ def finetune_mode(args, rank, world, local_rank, device, dist):
         dist.destroy_process_group()
 
 
+
+def other_config_mode(args, rank, world, local_rank, device, dist):
+    """BASELINE configs[3] / configs[4] through the same harness (their records under profiles/ come from tools/large_v2_fill.py and
+    tools/longform_bench.py; this prints them in the bench line's format, clips / songs sharded over ranks with no collective).
+    largev2: Whisper-large-v2, float16, --clips x 30 s per GPU and step, single stream (the batch is the parallelism).
+    longform: --songs x 180 s per GPU and step (6 x 30 s chunks per song through the encoder as one song-major batch, GRU + DP over
+    T = 9000 frames per song), consecutive steps pipelined over two streams with head_group 2."""
+    from lyricalignment_amd import _lib, whisper_compat as wc
+    from lyricalignment_amd.module.align_model import AlignModel
+    _lib.require_gpu()
+    large = args.mode == "largev2"
+    name = "large-v2" if large else MODEL
+    log(f"rank {rank}/{world}: building random-init whisper-{name} weights ({args.mode} mode)")
+    dims = wc.dims_for(name)
+    dt = torch.float16 if large else torch.bfloat16
+    model = AlignModel(wc.build_model(name, seed=0), embed_dim=dims.n_audio_state, hidden_dim=HIDDEN, output_dim=VOCAB,
+                       device=f"cuda:{local_rank}", compute_dtype=dt).eval()
+    with torch.no_grad():
+        eng = model.engine()
+    rs = np.random.RandomState(2)
+    if large:
+        units, unit_s, L = args.clips, CLIP_SECONDS, 26
+        mel = torch.from_numpy(rs.uniform(-1, 1, size=(units, 80, 3000)).astype(np.float32)).to(device)
+    else:
+        units, unit_s, L = args.songs, 180.0, 238
+        mel = torch.from_numpy(rs.uniform(-1, 1, size=(units, 80, 18000)).astype(np.float32)).to(device)
+    labels = torch.from_numpy(rs.randint(2, 402, size=(units, L)).astype(np.int32)).to(device)
+    n_labels = torch.full((units,), L, dtype=torch.int32, device=device)
+    pipe = None
+    if not large:
+        from lyricalignment_amd.engine import PipelinedAligner
+        pipe = PipelinedAligner(eng, head_group=2)
+    last = {}
+
+    def step():
+        with torch.no_grad():
+            if pipe is not None:
+                last["out"] = pipe.submit_songs(mel, labels, n_labels)
+            else:
+                last["out"] = eng.align_mel(mel, labels, n_labels, n_frames=T_FRAMES, use_ctc=True)
+
+    def finish():
+        if pipe is not None:
+            pipe.drain()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    finish()
+    eng.check_gru()
+    L_ = _lib.lib()
+    L_.la_timer_reset()
+    L_.la_timer_enable(os.environ.get("LA_BENCH_TIMER", "gemm_bf16").encode())
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    finish()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    L_.la_timer_disable()
+    eng.check_gru()
+    if int((last["out"][3] != 0).sum()) != 0:
+        raise SystemExit("alignment reported non-OK status on the synthetic batch")
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    import ctypes
+    total_ms, launches = ctypes.c_double(0.0), ctypes.c_int64(0)
+    _lib.check(L_.la_timer_read(ctypes.byref(total_ms), ctypes.byref(launches)), "timer_read")
+    clips30 = units if large else units * 6
+    gemm_flops_step = algorithmic_gemm_flops_per_clip(dims.n_audio_state, dims.n_audio_layer) * clips30
+    achieved = gemm_flops_step * args.steps / (total_ms.value * 1e-3) / 1e12 if total_ms.value > 0 else 0.0
+    if rank == 0:
+        print(json.dumps({
+            "metric": f"aligned audio-sec/sec (RTF^-1), Whisper-{name} " + ("30 s clips" if large else "3-minute songs"),
+            "value": world * units * unit_s * args.steps / elapsed, "unit": "audio-sec/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16" if large else "bf16",
+            "data": "synthetic (uniform[-1,1] mel, random class-id labels, random-init weights of the architecture)",
+            "config": {"workload": (f"whisper-large-v2 align, {units} x 30 s clips per GPU and step, float16, single stream (BASELINE.json configs[3])" if large else
+                                    f"whisper-medium long-form align, {units} songs x 180 s per GPU and step (6 chunks each, T = 9000, {L} labels), "
+                                    "two-stream pipeline (BASELINE.json configs[4])"),
+                       "mode": args.mode, "units_per_gpu": units, "sharding": "clips / songs over ranks, no collective"},
+            "roofline": {"bound": "mfma", "kernel": "gemm_pp_kernel / gemm_kernel <16-bit>", "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s",
+                         "frac": achieved / 2500.0, "traffic": None, "launches_per_step": launches.value / max(args.steps, 1),
+                         "avg_launch_ms": total_ms.value / max(launches.value, 1)},
+            "cpu_baseline": None, "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -255,9 +352,13 @@ def main():
     ap.add_argument("--encoder-streams", type=int, default=1, help="HIP streams the encoders of consecutive batches alternate between")
     ap.add_argument("--head-group", type=int, default=2,
                     help="batches whose head (GRU / FC / DP) runs as one launch set in the two-stream pipeline")
-    ap.add_argument("--mode", choices=["align", "finetune"], default="align",
+    ap.add_argument("--mode", choices=["align", "finetune", "largev2", "longform"], default="align",
                     help="align = BASELINE configs[1] (the headline metric); finetune = configs[2], the data-parallel multitask "
-                         "fine-tune step (float32, per-GPU micro-batch 2 x 30 s, --accum micro-steps, ONE gradient all-reduce per step)")
+                         "fine-tune step (float32, per-GPU micro-batch 2 x 30 s, --accum micro-steps, ONE gradient all-reduce per step); "
+                         "largev2 = configs[3] (Whisper-large-v2, float16, --clips 30 s clips per GPU and step); longform = configs[4] "
+                         "(--songs 3-minute songs per GPU and step, 6 chunks each, pipelined)")
+    ap.add_argument("--clips", type=int, default=512, help="largev2 mode: clips per GPU and step (3072 fills 207 GB)")
+    ap.add_argument("--songs", type=int, default=16, help="longform mode: 180 s songs per GPU and step")
     ap.add_argument("--model", default=MODEL, help="finetune mode only: whisper architecture (medium = configs[2])")
     ap.add_argument("--accum", type=int, default=8, help="finetune mode: micro-steps per optimizer step (reference default 8)")
     args = ap.parse_args()
@@ -288,6 +389,8 @@ def main():
 
     if args.mode == "finetune":
         return finetune_mode(args, rank, world, local_rank, device, dist)
+    if args.mode in ("largev2", "longform"):
+        return other_config_mode(args, rank, world, local_rank, device, dist)
 
     log(f"rank {rank}/{world}: building random-init whisper-{MODEL} weights")
     from lyricalignment_amd import _lib, whisper_compat as wc
