@@ -25,11 +25,11 @@ __device__ __forceinline__ uint4 gload16(unsigned voff, const void *sbase) {
 }
 
 // MODE 0 dma 8x128, 1 dma 16x64, 2 vgpr_row, 3 vgpr_frag, 4 mix (dma 8x128 for A, vgpr_frag for W)
-template <int MODE>
-__global__ __launch_bounds__(512, 2) void pull_kernel(const unsigned char *A, const unsigned char *W, int K_bytes, int iters, unsigned *sink) {
+template <int MODE, int NT = 512>
+__global__ __launch_bounds__(NT) void pull_kernel(const unsigned char *A, const unsigned char *W, int K_bytes, int iters, unsigned *sink) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) & 7;      // (16-wave run: two waves share a destination; nobody reads it)
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(const __attribute__((address_space(3))) void *)lds);
     const unsigned char *a0 = A + (size_t)(blockIdx.x % 64) * 256 * K_bytes;     // 64 different A panels
     const unsigned char *w0 = W + (size_t)((blockIdx.x / 8) % 4) * 256 * K_bytes; // 4 W panels
@@ -74,24 +74,24 @@ __global__ __launch_bounds__(512, 2) void pull_kernel(const unsigned char *A, co
     if (acc == 0x12345678u) sink[blockIdx.x] = acc;
 }
 
-template <int MODE>
+template <int MODE, int NT = 512>
 void run(const char *name, const unsigned char *A, const unsigned char *W, unsigned *sink, int blocks) {
     const int K_bytes = 2048, iters = 40;
-    CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pull_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pull_kernel<MODE, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(pull_kernel<MODE>, dim3(blocks), dim3(512), 131072, 0, A, W, K_bytes, iters, sink);
+    for (int w = 0; w < 3; ++w) hipLaunchKernelGGL((pull_kernel<MODE, NT>), dim3(blocks), dim3(NT), 131072, 0, A, W, K_bytes, iters, sink);
     CHECK(hipDeviceSynchronize());
     std::vector<float> ms;
     for (int r = 0; r < 7; ++r) {
         CHECK(hipEventRecord(e0));
-        hipLaunchKernelGGL(pull_kernel<MODE>, dim3(blocks), dim3(512), 131072, 0, A, W, K_bytes, iters, sink);
+        hipLaunchKernelGGL((pull_kernel<MODE, NT>), dim3(blocks), dim3(NT), 131072, 0, A, W, K_bytes, iters, sink);
         CHECK(hipEventRecord(e1));
         CHECK(hipEventSynchronize(e1));
         float t; CHECK(hipEventElapsedTime(&t, e0, e1)); ms.push_back(t);
     }
     std::sort(ms.begin(), ms.end());
-    const double bytes_per_cu = (double)iters * (K_bytes / 128) * 65536.0;
+    const double bytes_per_cu = (double)iters * (K_bytes / 128) * 65536.0 * NT / 512.0;     // every wave moves 8 KiB per K-tile step
     printf("%-10s %7.1f GB/s per CU   %6.2f TB/s chip   (%.3f ms per launch; one 64 KiB K-tile per %.2f us)\n", name,
            bytes_per_cu / (ms[3] * 1e-3) / 1e9, bytes_per_cu * blocks / (ms[3] * 1e-3) / 1e12, ms[3], ms[3] * 1e3 / (iters * (K_bytes / 128)));
     fflush(stdout);
@@ -111,5 +111,11 @@ int main() {
     run<2>("vgpr_row", A, W, sink, blocks);
     run<3>("vgpr_frag", A, W, sink, blocks);
     run<4>("mix", A, W, sink, blocks);
+    printf("waves per CU (same 8 pieces per wave and step; is the rate per wave or per CU?)\n");
+    run<0, 256>("dma 4 waves", A, W, sink, blocks);
+    run<0, 512>("dma 8 waves", A, W, sink, blocks);
+    run<0, 1024>("dma 16 waves", A, W, sink, blocks);
+    run<2, 256>("vgpr 4 waves", A, W, sink, blocks);
+    run<2, 1024>("vgpr 16 wav", A, W, sink, blocks);
     return 0;
 }
