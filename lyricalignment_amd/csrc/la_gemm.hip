@@ -249,6 +249,7 @@ __global__ __launch_bounds__(PPGeom<DBG>::THREADS, 2) void gemm_pp_kernel(GemmPa
 
     f32x4 acc[8][4];
     if constexpr (DBG == 8 && std::is_same<T16, bf16_t>::value) mainloop_flat256(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
+    else if constexpr (DBG == 80) mainloop_k2p<T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
     else if constexpr (DBG == 64) mainloop_half<T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
     else if constexpr (DBG == 24) mainloop_k2f<4, T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
     else if constexpr (DBG == 25) mainloop_k2f<5, T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
@@ -509,6 +510,7 @@ int launch_pp(GemmParams p, int batch, hipStream_t stream) {
             case 40: return launch_pp_dbg<OUT_F32, 40, T16>(p, batch, stream);
             case 48: return launch_pp_dbg<OUT_F32, 48, T16>(p, batch, stream);
             case 64: return launch_pp_dbg<OUT_F32, 64, T16>(p, batch, stream);
+            case 80: return launch_pp_dbg<OUT_F32, 80, T16>(p, batch, stream);
             case 1: return launch_pp_dbg<OUT_F32, 1, T16>(p, batch, stream);
             case 2: return launch_pp_dbg<OUT_F32, 2, T16>(p, batch, stream);
             case 3: return launch_pp_dbg<OUT_F32, 3, T16>(p, batch, stream);

@@ -16,6 +16,8 @@
 // then the A part (dead after phase 2), 2 instructions per phase; they are retired by ONE counted s_waitcnt vmcnt per
 // K-tile, placed before the barrier that precedes the first read of that buffer (hazard analysis in DESIGN.md).
 #pragma once
+#include <type_traits>
+
 #include "la_gemm_core.h"
 
 namespace la {
@@ -466,6 +468,94 @@ __device__ __forceinline__ void mainloop_k2f(const T16 *A, int64_t lda, int M, c
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     LA_PP_BARRIER();      // every wave is done with the ring before the epilogue reuses the LDS
+}
+
+// "k2p" (LA_PP_DBG=80): the k2f stages with the fragment reads SOFTWARE-PIPELINED inside each wave -- a second fragment
+// register set (48 VGPRs) takes the 12 reads of k-step s + 1 while the 32 MFMAs of k-step s issue, and the wave's 4 DMA pieces
+// are spread over the same MFMAs (source order per group of 4 MFMAs: 1-2 reads, every other group one piece).  No LOAD
+// segment: a wave's stream is MFMA-paced, the other wave of the SIMD covers its stalls, one barrier per k-step.
+//   iteration s: vmcnt (own pieces of stage s + 1 landed; stage s + 2's four may fly) -> barrier (stage s + 1 visible to all;
+//   every wave has finished iteration s - 1, so the slot of stage s -- its fragments were read during iteration s - 1 -- and
+//   of every older stage is free) -> refill slot (s + 3) % 4 = slot of stage s - 1 with stage s + 3, read stage s + 1's fragments,
+//   MFMAs of stage s.
+template <typename T16 = bf16_t>
+__device__ __forceinline__ void mainloop_k2p(const T16 *A, int64_t lda, int M, const T16 *W, int64_t ldw, int N, int K,
+                                             int m0, int n0, unsigned char *lds, f32x4 (&acc)[8][4]) {
+    typedef K2<4> C;
+    constexpr int NST = 4, DIST = 3;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int r = lane & 15, q = lane >> 4;
+    const int ns = K / 32;
+    const int64_t lda_b = lda * 2, ldw_b = ldw * 2;
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    unsigned voff_a[2], voff_w[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int rt = (2 * wave + i) * 16 + (lane >> 2);
+        const int sw = ((lane & 3) ^ swz2(rt)) << 4;
+        int ra = m0 + rt; ra = ra > M - 1 ? M - 1 : ra;
+        int rw = n0 + rt; rw = rw > N - 1 ? N - 1 : rw;
+        voff_a[i] = (unsigned)((int64_t)(ra - m0) * lda_b) + sw;
+        voff_w[i] = (unsigned)((int64_t)(rw - n0) * ldw_b) + sw;
+    }
+    const unsigned char *a_row0 = reinterpret_cast<const unsigned char *>(A) + (int64_t)m0 * lda_b;
+    const unsigned char *w_row0 = reinterpret_cast<const unsigned char *>(W) + (int64_t)n0 * ldw_b;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_u32(lds));
+    auto issue1 = [&](int st, int slot, int i) {      // piece i (0, 1: W; 2, 3: A) of this wave's share of stage st
+        const unsigned dst = lds0 + slot * C::STAGE + (i < 2 ? C::OPS : 0) + (2 * wave + (i & 1)) * 1024;
+        if (i < 2) glds16_so(voff_w[i], w_row0 + (int64_t)st * C::SB, dst);
+        else glds16_so(voff_a[i - 2], a_row0 + (int64_t)st * C::SB, dst);
+    };
+    auto frag_a = [&](int slot, int mi) { return read_frag2(lds + slot * C::STAGE + (wr * 128) * C::SB, mi * 16 + r, q); };
+    auto frag_w = [&](int slot, int ni) { return read_frag2(lds + slot * C::STAGE + C::OPS + (wc * 64) * C::SB, ni * 16 + r, q); };
+#pragma unroll
+    for (int st = 0; st < DIST; ++st)
+        if (st < ns) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) issue1(st, st, i);
+        }
+    if (ns > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else if (ns > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    LA_PP_BARRIER();
+    uint4 fa[2][8], fw[2][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) fa[0][i] = frag_a(0, i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fw[0][i] = frag_w(0, i);
+    int slot_n = 1, slot_w = DIST % NST;
+    // (a branch-free steady state -- the flags as template parameters -- lets hipcc software-pipeline harder: 256 VGPRs and
+    // 422 spilled registers, half the speed; with the run-time flags it stays at 237 VGPRs, no spills)
+    auto kstep = [&](int s, auto curc) {
+        constexpr int cur = decltype(curc)::value;
+        const int ahead = (ns - 1 < s + DIST - 1 ? ns - 1 : s + DIST - 1) - (s + 1);   // stages younger than s + 1 already issued
+        if (s + 1 < ns) {
+            if (ahead >= 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        LA_PP_BARRIER();
+        const bool pf = s + DIST < ns, nx = s + 1 < ns;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {       // 8 groups of 4 MFMAs: row tile g x the 4 column tiles
+            if (nx) {
+                fa[cur ^ 1][g] = frag_a(slot_n, g);
+                if (g < 4) fw[cur ^ 1][g] = frag_w(slot_n, g);
+            }
+            if (pf && (g & 1) == 0) issue1(s + DIST, slot_w, g >> 1);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) Mma<T16>::run(fw[cur][ni], fa[cur][g], acc[g][ni]);
+        }
+        slot_n = slot_n + 1 == NST ? 0 : slot_n + 1;
+        slot_w = slot_w + 1 == NST ? 0 : slot_w + 1;
+    };
+    for (int s = 0; s < ns; s += 2) {
+        kstep(s, std::integral_constant<int, 0>{});
+        if (s + 1 < ns) kstep(s + 1, std::integral_constant<int, 1>{});
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    LA_PP_BARRIER();
 }
 
 // "half" main loop: a 128 x 256 tile for a 4-wave workgroup (waves 1 (M) x 4 (N), the same 128 x 64 wave tile), TWO such
