@@ -57,7 +57,28 @@ def build(force: bool = False, jobs: int | None = None) -> str:
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    build_example(force)
     return LIB
+
+
+EXAMPLE_SRC = os.path.join(HERE, "..", "examples", "align_capi.cpp")
+EXAMPLE_BIN = os.path.join(HERE, "..", "examples", "_bin", "align_capi")
+
+
+def build_example(force: bool = False) -> str:
+    """examples/align_capi.cpp: the C ABI's model-level entry points driven from a C++ program (no Python, no torch)."""
+    src, out = os.path.abspath(EXAMPLE_SRC), os.path.abspath(EXAMPLE_BIN)
+    if not os.path.exists(src):
+        return ""
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    if not force and os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(src), os.path.getmtime(LIB)):
+        return out
+    cmd = [HIPCC, f"--offload-arch={ARCH}", "-O2", "-std=c++17", src, "-I", os.path.join(HERE, "..", "include"), "-L", HERE,
+           "-llyricalign_hip", "-Wl,-rpath,$ORIGIN/../../lyricalignment_amd", "-Wl,-rpath," + HERE, "-o", out]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"example build failed:\n{r.stdout}\n{r.stderr}")
+    return out
 
 
 if __name__ == "__main__":

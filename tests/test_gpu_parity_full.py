@@ -108,6 +108,34 @@ def test_medium_24_blocks_float32_within_1e3_of_oracle(medium):
     assert got == secs and two == secs
 
 
+def test_medium_24_blocks_plain_variant_and_batch_of_two_equal_oracle(medium):
+    """The non-CTC variant (perform_viterbi, utils/alignment.py:13-71: log_softmax over all V, silence = column 0) at full
+    depth, float32, on a batch of two clips of different lengths (ragged T via get_orig_len): seconds of the fused path and of the
+    two-step drop-in path == the oracle's perform_viterbi on the oracle's logits."""
+    from lyricalignment_amd.utils import alignment as ua
+    from oracle import alignment_oracle as ao, model_oracle as mo
+    model, dims = _build("medium", torch.float32, medium["wm"])
+    audios = [medium["audio"][: 16000 * 7 + 333], _wave(16000 * 7 + 333 - 4000, 9)]
+    labels = torch.full((2, 9), -100, dtype=torch.long)
+    labels[0] = torch.from_numpy(np.random.RandomState(11).randint(1, 403, size=9))
+    labels[1, :5] = torch.from_numpy(np.random.RandomState(12).randint(1, 403, size=5))
+    labels[0, 5] = labels[0, 4]
+    p = {"encoder." + k: v.detach().float().cpu() for k, v in model.whisper_model.encoder.state_dict().items()}
+    p.update({"align_rnn." + k: v.detach().float().cpu() for k, v in model.align_rnn.state_dict().items()})
+    n = len(audios[0])
+    batch = np.zeros((2, n), dtype=np.float32)
+    batch[0] = audios[0]; batch[1, : len(audios[1])] = audios[1]
+    T = mo.frame_count(n // 160)
+    with torch.no_grad():
+        ref_logits = mo.gru_head_forward(p, mo.encoder_forward(p, mo.pad_or_trim(mo.log_mel_spectrogram(batch), 3000), n_head=dims.n_audio_head)[:, :T])
+        want = ao.perform_viterbi(ref_logits, labels)
+        lg, _ = model.frame_manual_forward(audios)
+        got = model.align(audios, labels, use_ctc=False)
+        two = ua.perform_viterbi(lg, labels)
+    np.testing.assert_allclose(lg.cpu().numpy(), ref_logits.numpy(), rtol=0, atol=1e-3)
+    assert got == want and two == want
+
+
 # Bounds calibrated on MI355X with tools/depth_parity.py (profiles/r2_depth_parity.json holds the measured table):
 # emission error of the 16-bit throughput modes after 24 blocks against the fp32 oracle, and the share of the 52 onset /
 # offset boundaries that equal the oracle's own end-to-end result.

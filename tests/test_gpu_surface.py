@@ -419,3 +419,39 @@ def test_unidirectional_head_matches_oracle():
     ref = mo.gru_head_forward(p, mo.encoder_forward(p, mel, n_head=2)[:, :188], bidirectional=False)
     np.testing.assert_allclose(lg.cpu().numpy(), ref.numpy(), rtol=0, atol=1e-3)
     assert got == ao.perform_viterbi_ctc(ref, labels)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_cpp_consumer_of_the_model_level_c_abi_matches_the_python_path(dtype, tmp_path):
+    """examples/align_capi.cpp -- a C++ program with no Python and no torch in it -- drives the hot path through
+    la_encoder_forward + la_align_head_forward from flat weight / input files (lyricalignment_amd/capi_export.py) and must
+    produce exactly the frames, scores and status AlignEngine.align_mel does."""
+    import struct
+    from lyricalignment_amd import build as la_build, capi_export
+    exe = la_build.build_example()
+    assert exe and os.path.exists(exe)
+    model = _model(dtype, seed=100)
+    eng = model.engine()
+    rs = np.random.RandomState(101)
+    B, Lmax, frames = 3, 8, 900
+    mel = torch.from_numpy(rs.uniform(-1, 1, size=(B, 80, 3000)).astype(np.float32))
+    labels = torch.from_numpy(rs.randint(1, 299, size=(B, Lmax)).astype(np.int32))
+    n_labels = torch.tensor([8, 3, 5], dtype=torch.int32)
+    with torch.no_grad():
+        on, off, score, status = [t.cpu() for t in eng.align_mel(mel.cuda(), labels.cuda(), n_labels.cuda(), n_frames=frames, use_ctc=True)]
+    wpath, ipath, opath = (str(tmp_path / n) for n in ("weights.bin", "input.bin", "output.bin"))
+    capi_export.write_weights(eng, wpath)
+    capi_export.write_input(ipath, mel, labels, n_labels, frames, 1)
+    r = subprocess.run([exe, wpath, ipath, opath], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
+    raw = open(opath, "rb").read()
+    b2, l2 = struct.unpack_from("<2i", raw, 0)
+    assert (b2, l2) == (B, Lmax)
+    o = 8
+    got_on = np.frombuffer(raw, np.int32, B * Lmax, o).reshape(B, Lmax); o += B * Lmax * 4
+    got_off = np.frombuffer(raw, np.int32, B * Lmax, o).reshape(B, Lmax); o += B * Lmax * 4
+    got_st = np.frombuffer(raw, np.int32, B, o); o += B * 4
+    got_sc = np.frombuffer(raw, np.float64, B, o)
+    assert got_st.tolist() == status.tolist() == [0, 0, 0]
+    assert got_on.tolist() == on.tolist() and got_off.tolist() == off.tolist()
+    assert got_sc.tolist() == score.tolist()

@@ -177,6 +177,15 @@ def test_label_lut_and_mae_averaging_match_reference_glue():
     assert avg == fx["avg_mae"]
 
 
+def test_cpp_example_of_the_c_abi_builds_and_links():
+    """examples/align_capi.cpp compiles against include/lyricalign.h and links liblyricalign_hip.so (no GPU needed for that)."""
+    from lyricalignment_amd import build as la_build
+    exe = la_build.build_example()
+    assert exe and os.path.exists(exe) and os.access(exe, os.X_OK)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "usage:" in r.stderr
+
+
 def test_shard_indices():
     from lyricalignment_amd.sharding import shard_indices
     for n in (0, 1, 7, 32):
