@@ -34,13 +34,17 @@ EncBufs carve_encoder(void *ws, int dtype, int batch, int d) {
     Carve c(ws);
     const size_t es = esize(dtype), M = (size_t)batch * N_CTX;
     EncBufs b;
-    b.rows0 = c.take((size_t)batch * (N_FRAMES + 2) * C_PAD * es);
-    b.y1 = c.take((size_t)batch * (N_FRAMES + 2) * d * es);
+    // the conv stem's buffers (channels-last mel rows, conv1 output) are dead once conv2 has run, long before the first MLP-up
+    // GEMM writes `u`: they live inside u's region (u = 4 d per row of M = 1500 B rows >= 3002 B rows x (128 + d) for d >= 128)
+    const size_t stem = (size_t)la::round_up((int64_t)((size_t)batch * (N_FRAMES + 2) * C_PAD * es), 256) + (size_t)batch * (N_FRAMES + 2) * d * es;
+    const size_t u_bytes = M * 4 * d * es;
+    b.u = c.take(u_bytes > stem ? u_bytes : stem);
+    b.rows0 = b.u;
+    b.y1 = b.u ? static_cast<unsigned char *>(b.u) + (size_t)la::round_up((int64_t)((size_t)batch * (N_FRAMES + 2) * C_PAD * es), 256) : nullptr;
     b.x = static_cast<float *>(c.take(M * d * 4));
     b.h = c.take(M * d * es);
     b.qkv = c.take(M * 3 * d * es);
     b.att = c.take(M * d * es);
-    b.u = c.take(M * 4 * d * es);
     b.stats = static_cast<float *>(c.take(M * 2 * 4));
     b.total = c.off;
     return b;

@@ -35,9 +35,10 @@ for B in [int(b) for b in (args or ["32", "128", "512", "1024"])]:
         rows.append({"clips": B, "ms_per_batch": dt * 1e3, "audio_s_per_s": B * 30 / dt, "peak_hbm_bytes": int(torch.cuda.max_memory_allocated()),
                      "all_status_ok": ok})
         del mel, labels, n_labels, out
-        eng._buf.clear(); torch.cuda.empty_cache()
+        eng._buf.clear(); eng._ws.clear(); torch.cuda.empty_cache()
     except Exception as e:
         print(f"B={B}: {type(e).__name__}: {str(e)[:200]}", flush=True)
+        eng._buf.clear(); eng._ws.clear(); torch.cuda.empty_cache()
         rows.append({"clips": B, "error": f"{type(e).__name__}: {str(e)[:200]}"})
         break
 if json_out:
