@@ -573,7 +573,9 @@ class AlignEngine:
 
     def align_feats(self, feats: torch.Tensor, B: int, T: int, feat_clip_stride: int, labels: torch.Tensor, n_labels: torch.Tensor,
                     variant: int):
-        """Encoder rows -> (onset, offset, final_score, status): head + emission prep + DP (one C call unless LA_ENGINE_PY=1)."""
+        """Encoder rows -> (onset, offset, final_score, status): head + emission prep + DP (one C call unless LA_ENGINE_PY=1).
+        The op-by-op Python sequence below is also taken when HEAD_CLIPS_MAX was lowered (a test knob of that sequence; the C
+        call slices by its own cap, LA_HEAD_CLIP_CAP) and for heads the C struct does not describe (not 2 GRU layers)."""
         if ENGINE_PY or self._head_c is None or HEAD_CLIPS_MAX != 256:
             em = self.emissions(feats, B, T, feat_clip_stride, labels, n_labels, variant)
             nf = torch.full((B,), T, dtype=torch.int32, device=self.device)
