@@ -106,6 +106,9 @@ int la_timer_reset(void);
  * such frame + 1 (the Python layer multiplies by hop_size_second exactly as
  * utils/alignment.py:185 does).  status[b] is LA_OK / LA_EINFEASIBLE / LA_EEMPTY
  * / LA_EINVAL.  Rows n >= L_b of onset/offset are set to -1.
+ * Limits: max_labels <= 4095 (one lane per lattice state up to 1024 states; beyond that 1024 threads sweep 2 / 4 / 8
+ * consecutive states each, backpointers in `workspace`); LA_EUNSUPPORTED above -- the reference's numba loop has no limit.
+ * `workspace` (8-byte aligned) is needed when la_viterbi_workspace_bytes() > 0: long utterances or > 511 labels.
  */
 int la_viterbi_workspace_bytes(int32_t batch, int32_t max_frames, int32_t max_labels, size_t *bytes);
 
