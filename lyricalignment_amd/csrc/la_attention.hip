@@ -54,6 +54,7 @@ struct AttnParams {
     int q_len, kv_len, n_head, causal;
     int64_t q_bs, kv_bs, out_bs;   // rows from one clip to the next (== q_len / kv_len / q_len unless the caller says otherwise)
     int batch;
+    float defer_thr;               // 16-bit kernels: deferred-maximum threshold (exp2 domain); 0 = the textbook online softmax
 };
 
 // Block -> (query tile, head, clip).  Workgroups are dealt round-robin over the 8 XCDs in launch order and every XCD has its
@@ -124,7 +125,10 @@ __device__ __forceinline__ void stage_kv_bf16(const bf16_t *kbase, const bf16_t 
 // MSUM: the softmax denominator on the matrix pipe -- one extra MFMA per 16 keys with an all-ones A operand accumulates
 // sum_k P[k][q] (of the ROUNDED P, like the numerator) in a third accumulator, instead of 32 v_add_f32 per key tile on the
 // vector pipe, which is the busier one in this kernel (VALU 71 % / MFMA 45 % of the SIMD cycles).
-template <typename T16, int NW = 4, bool MSUM = false>
+// KO (diagnostic builds only, -DLA_ATTN_KNOCKOUT, results are garbage): a bit mask of the parts left out, to see which of the three
+// pipes the tile time follows -- 1 no exponentials, 2 no V^T fragment reads, 4 no K fragment reads, 8 no staging after tile 0,
+// 16 no MFMAs.
+template <typename T16, int NW = 4, bool MSUM = false, int KO = 0>
 __global__ __launch_bounds__(64 * NW, 2) void attention_bf16_kernel(AttnParams p) {
     constexpr int QT = 32 * NW, PER = 8 / NW;
     typedef Half16<T16> HT;
@@ -168,6 +172,17 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_bf16_kernel(AttnParams p
     const KvOff off_last = kv_offsets_bf16<PER>(p.ld_kv, (nkv_all - 1) * KT, T, wave, lane);      // rows clamped to key T-1
     stage_kv_bf16<PER>(kbase, vbase, p.ld_kv, 0, nkv_all == 1 ? off_last : off_full, lds0, lds0 + KT * 128, wave);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // The Q fragments are "used" here so that hipcc places its own wait for their loads before the loop.  Left to itself it
+    // waits at their first use inside the loop (vmcnt(3) .. vmcnt(0) ahead of the S MFMAs), and in steady state those counts
+    // no longer refer to the Q loads but to the four staging loads of the NEXT tile just issued: every tile then stalls on
+    // its successor's K / V arriving instead of letting them land under the softmax and PV phases.
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 t = __builtin_bit_cast(u32x4, qf[c]);
+        asm volatile("" : "+v"(t));
+        qf[c] = __builtin_bit_cast(uint4, t);
+    }
     __syncthreads();
 
     // per-lane constant parts of the V^T transposed-read address
@@ -178,7 +193,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_bf16_kernel(AttnParams p
         constexpr int cur = decltype(curc)::value;
         const unsigned char *kl = lds + cur * (2 * KT * 128);
         const unsigned char *vl = kl + KT * 128;
-        if (t + 1 < nkv) {
+        if (t + 1 < nkv && !(KO & 8)) {
             const unsigned nk = lds0 + (cur ^ 1) * (2 * KT * 128);
             stage_kv_bf16<PER>(kbase, vbase, p.ld_kv, (t + 1) * KT, t + 2 == nkv_all ? off_last : off_full, nk, nk + KT * 128, wave);
         }
@@ -192,7 +207,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_bf16_kernel(AttnParams p
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
                 const int row = sub * 32 + i32;
-                kf[sub][c] = *reinterpret_cast<const uint4 *>(kl + row * 128 + (((2 * c + h) ^ kswz(row)) << 4));
+                if constexpr (KO & 4) kf[sub][c] = qf[(c + sub) & 3];
+                else kf[sub][c] = *reinterpret_cast<const uint4 *>(kl + row * 128 + (((2 * c + h) ^ kswz(row)) << 4));
             }
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
@@ -202,7 +218,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_bf16_kernel(AttnParams p
         for (int c = 0; c < 4; ++c)
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub)
-                s[sub] = HT::mfma32(__builtin_bit_cast(vec8, kf[sub][c]), __builtin_bit_cast(vec8, qf[c]), s[sub]);
+                if constexpr (KO & 16) s[sub][c] += __builtin_bit_cast(float, kf[sub][c].x) + __builtin_bit_cast(float, kf[sub][c].w);
+                else s[sub] = HT::mfma32(__builtin_bit_cast(vec8, kf[sub][c]), __builtin_bit_cast(vec8, qf[c]), s[sub]);
         // ---- mask keys >= kv_len (last tile) and, for the causal decoder self-attention, keys after the query ----
         if ((t + 1) * KT > T || p.causal) {
             const int kmax = p.causal ? min(T - 1, qrow) : T - 1;
@@ -219,19 +236,34 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_bf16_kernel(AttnParams p
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[sub][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m_run, mx * kLog2e);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // exp2(-inf) = 0 on the first tile
+        // Deferred maximum (cdna guide T13): the running maximum m_run only moves when some query's tile maximum exceeds it by
+        // more than THR (in the exp2 domain); until then p = exp2(s - m_run) may reach 2^THR instead of 1 -- harmless in the f32
+        // accumulators and scale-free for the 16-bit rounding of P -- and the whole rescale of O (and of the running sum) is
+        // skipped.  With scores of a few units the maximum of 1500 keys settles inside the first tile or two, so the rescale
+        // block (32 multiplies per lane) runs on the first tiles only instead of on nearly every one.  thr <= 0: always move.
+        const float mx2 = mx * kLog2e;
+        float m_new = m_run, alpha = 1.0f;
+        if (__builtin_amdgcn_ballot_w64(mx2 > m_run + p.defer_thr) != 0) {     // wave-uniform
+            m_new = fmaxf(m_run, mx2);
+            alpha = __builtin_amdgcn_exp2f(m_run - m_new);          // exp2(-inf) = 0 on the first tile
+        }
         m_run = m_new;
-        float psum = 0.f;
+        // exponent arguments and the row sum two at a time (v_pk_fma_f32 / v_pk_add_f32: 16 + 16 instructions instead of 32 + 32)
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2 psum2 = {0.f, 0.f};
+        const f32x2 l2e2 = {kLog2e, kLog2e}, mneg2 = {-m_new, -m_new};
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float pv = __builtin_amdgcn_exp2f(fmaf(s[sub][r], kLog2e, -m_new));
-                s[sub][r] = pv;
-                if constexpr (!MSUM) psum += pv;
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 sv = {s[sub][r], s[sub][r + 1]};
+                const f32x2 a2 = __builtin_elementwise_fma(sv, l2e2, mneg2);
+                const f32x2 pv = (KO & 1) ? a2 : f32x2{__builtin_amdgcn_exp2f(a2.x), __builtin_amdgcn_exp2f(a2.y)};
+                s[sub][r] = pv.x;
+                s[sub][r + 1] = pv.y;
+                if constexpr (!MSUM) psum2 += pv;
             }
-        if constexpr (!MSUM) l_part = l_part * alpha + psum;
+        if constexpr (!MSUM) l_part = l_part * alpha + (psum2.x + psum2.y);
         if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {   // wave-uniform; exact: alpha == 1 changes nothing
 #pragma unroll
             for (int b = 0; b < 2; ++b)
@@ -257,13 +289,18 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_bf16_kernel(AttnParams p
                     const int key0 = sub * 32 + 16 * ks + 4 * (g >> 1);
                     const int slot = b * 4 + 2 * (g & 1) + (pp >> 1);
                     const int r0 = key0 + q4, r1 = key0 + 8 + q4;
-                    const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4 *)(vl + r0 * 128 + ((slot ^ vswz(r0)) << 4) + (pp & 1) * 8));
-                    const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4 *)(vl + r1 * 128 + ((slot ^ vswz(r1)) << 4) + (pp & 1) * 8));
                     typedef __attribute__((ext_vector_type(8))) short s16x8;
-                    const s16x8 vf = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
-                    o[b] = HT::mfma32(__builtin_bit_cast(vec8, vf), pf, o[b]);
+                    s16x8 vf;
+                    if constexpr (KO & 2) vf = __builtin_bit_cast(s16x8, qf[(2 * sub + ks + b) & 3]);
+                    else {
+                        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) s16x4 *)(vl + r0 * 128 + ((slot ^ vswz(r0)) << 4) + (pp & 1) * 8));
+                        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) s16x4 *)(vl + r1 * 128 + ((slot ^ vswz(r1)) << 4) + (pp & 1) * 8));
+                        vf = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    }
+                    if constexpr (KO & 16) o[b][2 * sub + ks] += (float)vf[0] + (float)vf[7] + (float)pf[0] + (float)pf[7];
+                    else o[b] = HT::mfma32(__builtin_bit_cast(vec8, vf), pf, o[b]);
                 }
             }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -431,6 +468,8 @@ __global__ __launch_bounds__(256, 2) void attention_f32_kernel(AttnParams p) {
 
 static int attention_launch(int dtype, AttnParams p, int batch, hipStream_t stream) {
     p.batch = batch;
+    const char *thr_env = getenv("LA_ATTN_THR");              // developer A/B (read per launch)
+    p.defer_thr = thr_env ? (float)atof(thr_env) : 8.0f;
     const dim3 grid(la::cdiv(p.q_len, QT) * p.n_head * batch), block(256);
     if (dtype == LA_BF16 || dtype == LA_F16) {
         la::TimerScope ts("attention_bf16", stream);
@@ -439,6 +478,16 @@ static int attention_launch(int dtype, AttnParams p, int batch, hipStream_t stre
             const dim3 grid8(la::cdiv(p.q_len, 256) * p.n_head * batch), block8(512);
             if (dtype == LA_F16) hipLaunchKernelGGL((attention_bf16_kernel<la::f16_t, 8>), grid8, block8, 0, stream, p);
             else hipLaunchKernelGGL((attention_bf16_kernel<bf16_t, 8>), grid8, block8, 0, stream, p);
+#ifdef LA_ATTN_KNOCKOUT
+        } else if (const char *ko = getenv("LA_ATTN_KO")) {  // diagnostic build: parts of the tile loop left out (bf16 only)
+            switch (atoi(ko)) {
+#define LA_KO_CASE(n) case n: hipLaunchKernelGGL((attention_bf16_kernel<bf16_t, 4, false, n>), grid, block, 0, stream, p); break;
+                LA_KO_CASE(1) LA_KO_CASE(2) LA_KO_CASE(4) LA_KO_CASE(6) LA_KO_CASE(8) LA_KO_CASE(14) LA_KO_CASE(16) LA_KO_CASE(17)
+                LA_KO_CASE(7) LA_KO_CASE(15) LA_KO_CASE(30)
+#undef LA_KO_CASE
+                default: hipLaunchKernelGGL((attention_bf16_kernel<bf16_t, 4>), grid, block, 0, stream, p);
+            }
+#endif
         } else if (getenv("LA_ATTN_MSUM")) {                 // developer A/B: softmax denominator on the matrix pipe
             if (dtype == LA_F16) hipLaunchKernelGGL((attention_bf16_kernel<la::f16_t, 4, true>), grid, block, 0, stream, p);
             else hipLaunchKernelGGL((attention_bf16_kernel<bf16_t, 4, true>), grid, block, 0, stream, p);

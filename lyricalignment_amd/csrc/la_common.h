@@ -170,6 +170,21 @@ __device__ __forceinline__ float gelu_sig(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
+// gelu_sig on two values: the same operations in the same order (bit-identical results), with the squares, the two polynomial
+// steps, p * x, 1 + e and the final product as packed f32 instructions -- 2 clamps + 5 packed + 4 transcendental issue slots
+// per PAIR instead of 14 + 4.
+__device__ __forceinline__ f32x2 gelu_sig2(f32x2 x) {
+    const f32x2 xc = {__builtin_amdgcn_fmed3f(x.x, -8.0f, 8.0f), __builtin_amdgcn_fmed3f(x.y, -8.0f, 8.0f)};
+    const f32x2 s = xc * xc;
+    f32x2 p = __builtin_elementwise_fma(f32x2{1.0148166172e-03f, 1.0148166172e-03f}, s, f32x2{-1.0677913190e-01f, -1.0677913190e-01f});
+    p = __builtin_elementwise_fma(p, s, f32x2{-2.3011175945e+00f, -2.3011175945e+00f});
+    const f32x2 z = p * xc;
+    const f32x2 e = {__builtin_amdgcn_exp2f(z.x), __builtin_amdgcn_exp2f(z.y)};
+    const f32x2 d = e + f32x2{1.0f, 1.0f};
+    const f32x2 r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    return x * r;
+}
+
 // nn.Mish: x * tanh(softplus(x)); softplus with torch's threshold 20
 __device__ __forceinline__ float mish(float x) {
     float sp = x > 20.0f ? x : log1pf(expf(x));

@@ -89,8 +89,14 @@ __global__ __launch_bounds__(CF::THREADS, 2) void gemm_kernel(GemmParams p) {
                         const la::f32x2 hi = la::gelu_pk(la::f32x2{acc[mi][ni][2], acc[mi][ni][3]});
                         acc[mi][ni] = f32x4{lo.x, lo.y, hi.x, hi.y};
                     } else {
+                        if (p.epilogue & 8192) {                 // developer A/B (LA_GELU_PK=2): one value at a time
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[mi][ni][j] = la::gelu_sig(acc[mi][ni][j]);
+                            for (int j = 0; j < 4; ++j) acc[mi][ni][j] = la::gelu_sig(acc[mi][ni][j]);
+                        } else {
+                            const la::f32x2 lo = la::gelu_sig2(la::f32x2{acc[mi][ni][0], acc[mi][ni][1]});
+                            const la::f32x2 hi = la::gelu_sig2(la::f32x2{acc[mi][ni][2], acc[mi][ni][3]});
+                            acc[mi][ni] = f32x4{lo.x, lo.y, hi.x, hi.y};
+                        }
                     }
                 } else {
 #pragma unroll
@@ -304,8 +310,14 @@ __global__ __launch_bounds__(PPGeom<DBG>::THREADS, 2) void gemm_pp_kernel(GemmPa
                         const la::f32x2 hi = la::gelu_pk(la::f32x2{acc[mi][ni][2], acc[mi][ni][3]});
                         acc[mi][ni] = f32x4{lo.x, lo.y, hi.x, hi.y};
                     } else {
+                        if (p.epilogue & 8192) {                 // developer A/B (LA_GELU_PK=2): one value at a time
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[mi][ni][j] = la::gelu_sig(acc[mi][ni][j]);
+                            for (int j = 0; j < 4; ++j) acc[mi][ni][j] = la::gelu_sig(acc[mi][ni][j]);
+                        } else {
+                            const la::f32x2 lo = la::gelu_sig2(la::f32x2{acc[mi][ni][0], acc[mi][ni][1]});
+                            const la::f32x2 hi = la::gelu_sig2(la::f32x2{acc[mi][ni][2], acc[mi][ni][3]});
+                            acc[mi][ni] = f32x4{lo.x, lo.y, hi.x, hi.y};
+                        }
                     }
                 } else {
 #pragma unroll
@@ -541,7 +553,7 @@ int launch_pp_dbg(GemmParams p, int batch, hipStream_t stream) {
     // At least 4: with fewer, the K=4096 GEMM (N = 4 tiles) re-reads its 2 MB-per-row-block A panel once per column tile
     // (in-pipeline sweep: 1 -> 46.1 ms/step, 4 -> 45.7, 8 -> 45.9, 16 -> 46.4).
     p.group = getenv("LA_GEMM_GROUP") ? std::min(p.group, p.tiles_n) : std::min(p.tiles_n, std::max(4, p.group / 2));
-    if (getenv("LA_GELU_PK")) p.epilogue |= 4096;
+    if (const char *g = getenv("LA_GELU_PK")) p.epilogue |= atoi(g) == 2 ? 8192 : 4096;
 #ifdef LA_PP_STAMPS
     if (const char *sp = getenv("LA_STAMP_PTR")) p.stamps = reinterpret_cast<unsigned *>(strtoull(sp, nullptr, 0));
 #endif
@@ -560,7 +572,7 @@ int launch(GemmParams p, int batch, hipStream_t stream, const char *family) {
         attr_done = true;
     }
     p.tiles_m = la::cdiv(p.M, CF::TM);
-    if (getenv("LA_GELU_PK")) p.epilogue |= 4096;
+    if (const char *g = getenv("LA_GELU_PK")) p.epilogue |= atoi(g) == 2 ? 8192 : 4096;
     la::TimerScope ts(family, stream);
     hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, batch), dim3(CF::THREADS), CF::LDS, stream, p);
     LA_LAUNCH_CHECK();

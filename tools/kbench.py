@@ -38,11 +38,11 @@ def bench_gemm_variants(iters, variants, rounds=5):
         outs = {v: torch.empty(M, N, device="cuda", dtype=torch.float32 if f32out else torch.bfloat16) for v in variants}
 
         def run(v):
-            if v == 1000:                      # pseudo-variant: default main loop, erfc-form GELU on the packed pipe (LA_GELU_PK)
-                os.environ["LA_GELU_PK"] = "1"
+            if v in (1000, 1001):              # pseudo-variants: default main loop; LA_GELU_PK=1 erfc-form GELU on the packed pipe,
+                os.environ["LA_GELU_PK"] = "1" if v == 1000 else "2"       # =2 the sigmoid form one value at a time
             else:
                 os.environ.pop("LA_GELU_PK", None)
-            os.environ["LA_PP_DBG"] = str(0 if v == 1000 else v)
+            os.environ["LA_PP_DBG"] = str(0 if v >= 1000 else v)
             ops.gemm(a, w, outs[v], bias=bias, residual=res, gelu="gelu" in name, out_f32=f32out)
 
         times = {v: [] for v in variants}
@@ -96,8 +96,9 @@ def bench_attn(iters):
     fl = 4.0 * T * T * H * 64 * B
     ref = None
     for rd in range(3):
-        for nw, msum in (("4", False), ("8", False), ("4", True)):
+        for nw, msum, thr in (("4", False, "0"), ("4", False, "8"), ("8", False, "8"), ("4", True, "8")):
             os.environ["LA_ATTN_NW"] = nw
+            os.environ["LA_ATTN_THR"] = thr
             if msum:
                 os.environ["LA_ATTN_MSUM"] = "1"
             else:
@@ -106,9 +107,26 @@ def bench_attn(iters):
             if ref is None:
                 ref = out.clone()
             dmax = float((out.float() - ref.float()).abs().max())
-            print(f"attention B={B} T={T} H={H} waves/workgroup {nw} msum {int(msum)}: median {med*1e3:.1f} us  min {mn*1e3:.1f} us  {fl/med/1e9:.1f} TF/s  "
+            print(f"attention B={B} T={T} H={H} waves/workgroup {nw} msum {int(msum)} defer-thr {thr}: median {med*1e3:.1f} us  min {mn*1e3:.1f} us  {fl/med/1e9:.1f} TF/s  "
                   f"max abs diff to the first run: {dmax:.3e}", flush=True)
-    os.environ.pop("LA_ATTN_NW", None); os.environ.pop("LA_ATTN_MSUM", None)
+    os.environ.pop("LA_ATTN_NW", None); os.environ.pop("LA_ATTN_MSUM", None); os.environ.pop("LA_ATTN_THR", None)
+
+
+def bench_attn_knockout(iters):
+    """Diagnostic build only (LA_EXTRA_CXXFLAGS=-DLA_ATTN_KNOCKOUT python -m lyricalignment_amd.build): the tile loop with parts
+    left out -- 1 exponentials, 2 V^T fragment reads, 4 K fragment reads, 8 staging, 16 MFMAs (bit mask); results are garbage."""
+    B, T, H = 32, 1500, 16
+    qkv = rnd(B * T, 3 * H * 64)
+    qkv[:, : H * 64] *= 0.125
+    out = torch.empty(B * T, H * 64, device="cuda", dtype=torch.bfloat16)
+    names = {0: "full", 1: "no exp", 2: "no V reads", 4: "no K reads", 6: "no K/V reads", 8: "no staging", 14: "no LDS traffic at all",
+             16: "no MFMA", 17: "no MFMA, no exp", 7: "no exp, no K/V reads", 15: "no exp, no LDS traffic", 30: "no MFMA, no LDS traffic"}
+    for rd in range(2):
+        for ko, nm in names.items():
+            os.environ["LA_ATTN_KO"] = str(ko)
+            med, mn = timeit(lambda: ops.attention(qkv, B, T, H, out=out), iters)
+            print(f"attention knockout {ko:2d} ({nm}): median {med*1e3:.1f} us  min {mn*1e3:.1f} us", flush=True)
+    os.environ.pop("LA_ATTN_KO", None)
 
 
 def bench_gru(iters):
@@ -144,5 +162,6 @@ if __name__ == "__main__":
         sys.exit(0)
     if a.what in ("gemm", "all"): bench_gemm(a.iters)
     if a.what in ("attn", "all"): bench_attn(a.iters)
+    if a.what == "attn_ko": bench_attn_knockout(a.iters)
     if a.what in ("gru", "all"): bench_gru(a.iters)
     if a.what in ("fc", "all"): bench_fc(a.iters)
