@@ -32,12 +32,14 @@ template <> struct Half16<bf16_t> {
     typedef bf16x8 vec8;
     typedef __bf16 elem;
     static constexpr unsigned kOnes = 0x3F803F80u;   // two 1.0
+    static constexpr float kPLimit = 0x1p30f;        // optimistic softmax: largest row partial sum (hence P) taken without a redo
     __device__ static __forceinline__ f32x16 mfma32(vec8 a, vec8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 };
 template <> struct Half16<la::f16_t> {
     typedef f16x8 vec8;
     typedef _Float16 elem;
     static constexpr unsigned kOnes = 0x3C003C00u;
+    static constexpr float kPLimit = 0x1p13f;        // f16 tops out at 65504
     __device__ static __forceinline__ f32x16 mfma32(vec8 a, vec8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 };
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -128,8 +130,15 @@ __device__ __forceinline__ void stage_kv_bf16(const bf16_t *kbase, const bf16_t 
 // KO (diagnostic builds only, -DLA_ATTN_KNOCKOUT, results are garbage): a bit mask of the parts left out, to see which of the three
 // pipes the tile time follows -- 1 no exponentials, 2 no V^T fragment reads, 4 no K fragment reads, 8 no staging after tile 0,
 // 16 no MFMAs.
-template <typename T16, int NW = 4, bool MSUM = false, int KO = 0>
+// OPT: optimistic softmax -- no per-tile maximum.  P = exp2(s log2 e - m_run) is formed against the running maximum as it
+// stands and the row sums (needed anyway) are tested: only if some lane's partial sum is not <= LIMIT (a score rose far above
+// the running maximum, or the first tile, where m_run = -inf gives +inf / NaN) is the tile redone the textbook way -- scores
+// recomputed from the K tile still in LDS, maximum, rescale.  LIMIT keeps P inside the 16-bit type (2^30 for bf16, 2^13 for
+// f16); the f32 accumulators and the final O / l are exact in the scale.
+// PRIO (diagnostic builds): 1 = the S MFMA phase at raised wave priority, 2 = S and PV raised (softmax at 0), 3 = softmax raised
+template <typename T16, int NW = 4, bool MSUM = false, int KO = 0, bool OPT = false, int PRIO = 0>
 __global__ __launch_bounds__(64 * NW, 2) void attention_bf16_kernel(AttnParams p) {
+    static_assert(!(OPT && MSUM), "the optimistic form tests the vector-pipe row sums");
     constexpr int QT = 32 * NW, PER = 8 / NW;
     typedef Half16<T16> HT;
     typedef typename HT::vec8 vec8;
@@ -201,70 +210,86 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_bf16_kernel(AttnParams p
         // all eight K fragments are requested before the first MFMA (32 VGPRs; the kernel has room): the reads return under
         // the MFMAs instead of one ds_read -> wait -> MFMA round trip per fragment
         f32x16 s[2];
-        uint4 kf[2][4];
+        typedef std::integral_constant<int, 0> Sub0;
+        typedef std::integral_constant<int, 1> Sub1;
+        typedef std::integral_constant<int, 2> SubBoth;
+        // scores of sub-tile `which` (2 = both).  serial: the redo path -- one fragment pair in flight (few live registers)
+        auto scores = [&](auto serialc, auto whichc) {
+            constexpr bool serial = decltype(serialc)::value;
+            constexpr int lo = decltype(whichc)::value == 2 ? 0 : decltype(whichc)::value;
+            constexpr int hi = decltype(whichc)::value == 2 ? 2 : lo + 1;
+            uint4 kf[2][4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
+            for (int sub = lo; sub < hi; ++sub)
 #pragma unroll
-            for (int sub = 0; sub < 2; ++sub) {
-                const int row = sub * 32 + i32;
-                if constexpr (KO & 4) kf[sub][c] = qf[(c + sub) & 3];
-                else kf[sub][c] = *reinterpret_cast<const uint4 *>(kl + row * 128 + (((2 * c + h) ^ kswz(row)) << 4));
+                for (int r = 0; r < 16; ++r) s[sub][r] = 0.f;
+            if constexpr (!serial) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int sub = lo; sub < hi; ++sub) {
+                        const int row = sub * 32 + i32;
+                        if constexpr (KO & 4) kf[sub][c] = qf[(c + sub) & 3];
+                        else kf[sub][c] = *reinterpret_cast<const uint4 *>(kl + row * 128 + (((2 * c + h) ^ kswz(row)) << 4));
+                    }
             }
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
+            for (int c = 0; c < 4; ++c) {
+                if constexpr (serial) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[sub][r] = 0.f;
+                    for (int sub = lo; sub < hi; ++sub) {
+                        const int row = sub * 32 + i32;
+                        kf[sub][c] = *reinterpret_cast<const uint4 *>(kl + row * 128 + (((2 * c + h) ^ kswz(row)) << 4));
+                    }
+                }
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
+                for (int sub = lo; sub < hi; ++sub)
+                    if constexpr (KO & 16) s[sub][c] += __builtin_bit_cast(float, kf[sub][c].x) + __builtin_bit_cast(float, kf[sub][c].w);
+                    else s[sub] = HT::mfma32(__builtin_bit_cast(vec8, kf[sub][c]), __builtin_bit_cast(vec8, qf[c]), s[sub]);
+                if constexpr (serial) __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- mask keys >= kv_len (last tile) and, for the causal decoder self-attention, keys after the query ----
+            if ((t + 1) * KT > T || p.causal) {
+                const int kmax = p.causal ? min(T - 1, qrow) : T - 1;
 #pragma unroll
-            for (int sub = 0; sub < 2; ++sub)
-                if constexpr (KO & 16) s[sub][c] += __builtin_bit_cast(float, kf[sub][c].x) + __builtin_bit_cast(float, kf[sub][c].w);
-                else s[sub] = HT::mfma32(__builtin_bit_cast(vec8, kf[sub][c]), __builtin_bit_cast(vec8, qf[c]), s[sub]);
-        // ---- mask keys >= kv_len (last tile) and, for the causal decoder self-attention, keys after the query ----
-        if ((t + 1) * KT > T || p.causal) {
-            const int kmax = p.causal ? min(T - 1, qrow) : T - 1;
+                for (int sub = lo; sub < hi; ++sub)
 #pragma unroll
-            for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (t * KT + sub * 32 + acc_row(r, h) > kmax) s[sub][r] = -INFINITY;
-        }
-        // ---- online softmax (exp2 domain) ----
-        float mx = -INFINITY;
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[sub][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        // Deferred maximum (cdna guide T13): the running maximum m_run only moves when some query's tile maximum exceeds it by
-        // more than THR (in the exp2 domain); until then p = exp2(s - m_run) may reach 2^THR instead of 1 -- harmless in the f32
-        // accumulators and scale-free for the 16-bit rounding of P -- and the whole rescale of O (and of the running sum) is
-        // skipped.  With scores of a few units the maximum of 1500 keys settles inside the first tile or two, so the rescale
-        // block (32 multiplies per lane) runs on the first tiles only instead of on nearly every one.  thr <= 0: always move.
-        const float mx2 = mx * kLog2e;
-        float m_new = m_run, alpha = 1.0f;
-        if (__builtin_amdgcn_ballot_w64(mx2 > m_run + p.defer_thr) != 0) {     // wave-uniform
-            m_new = fmaxf(m_run, mx2);
-            alpha = __builtin_amdgcn_exp2f(m_run - m_new);          // exp2(-inf) = 0 on the first tile
-        }
-        m_run = m_new;
-        // exponent arguments and the row sum two at a time (v_pk_fma_f32 / v_pk_add_f32: 16 + 16 instructions instead of 32 + 32)
+                    for (int r = 0; r < 16; ++r)
+                        if (t * KT + sub * 32 + acc_row(r, h) > kmax) s[sub][r] = -INFINITY;
+            }
+        };
+        // s <- exp2(s log2 e - m), returns this lane's partial row sum
+        // (two at a time: v_pk_fma_f32 / v_pk_add_f32, 16 + 16 instructions instead of 32 + 32)
         typedef float f32x2 __attribute__((ext_vector_type(2)));
-        f32x2 psum2 = {0.f, 0.f};
-        const f32x2 l2e2 = {kLog2e, kLog2e}, mneg2 = {-m_new, -m_new};
+        auto exponentials = [&](float m, auto whichc) -> float {
+            constexpr int lo = decltype(whichc)::value == 2 ? 0 : decltype(whichc)::value;
+            constexpr int hi = decltype(whichc)::value == 2 ? 2 : lo + 1;
+            f32x2 psum2 = {0.f, 0.f};
+            const f32x2 l2e2 = {kLog2e, kLog2e}, mneg2 = {-m, -m};
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
+            for (int sub = lo; sub < hi; ++sub)
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const f32x2 sv = {s[sub][r], s[sub][r + 1]};
-                const f32x2 a2 = __builtin_elementwise_fma(sv, l2e2, mneg2);
-                const f32x2 pv = (KO & 1) ? a2 : f32x2{__builtin_amdgcn_exp2f(a2.x), __builtin_amdgcn_exp2f(a2.y)};
-                s[sub][r] = pv.x;
-                s[sub][r + 1] = pv.y;
-                if constexpr (!MSUM) psum2 += pv;
-            }
-        if constexpr (!MSUM) l_part = l_part * alpha + (psum2.x + psum2.y);
-        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {   // wave-uniform; exact: alpha == 1 changes nothing
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2 sv = {s[sub][r], s[sub][r + 1]};
+                    const f32x2 a2 = __builtin_elementwise_fma(sv, l2e2, mneg2);
+                    const f32x2 pv = (KO & 1) ? a2 : f32x2{__builtin_amdgcn_exp2f(a2.x), __builtin_amdgcn_exp2f(a2.y)};
+                    s[sub][r] = pv.x;
+                    s[sub][r + 1] = pv.y;
+                    if constexpr (!MSUM) psum2 += pv;
+                }
+            return psum2.x + psum2.y;
+        };
+        auto tile_max = [&](auto whichc) -> float {
+            constexpr int lo = decltype(whichc)::value == 2 ? 0 : decltype(whichc)::value;
+            constexpr int hi = decltype(whichc)::value == 2 ? 2 : lo + 1;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int sub = lo; sub < hi; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[sub][r]);
+            return fmaxf(mx, __shfl_xor(mx, 32)) * kLog2e;
+        };
+        auto rescale = [&](float alpha) {
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -273,10 +298,10 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_bf16_kernel(AttnParams p
 #pragma unroll
                 for (int r = 0; r < 16; ++r) osum[r] *= alpha;
             }
-        }
-        // ---- O^T += V^T P^T ----
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
+        };
+        // ---- O^T += V^T P^T for one 32-key sub-tile ----
+        auto pv_sub = [&](auto subc) {
+            constexpr int sub = decltype(subc)::value;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 vec8 pf;  // element j <-> accumulator register 8*ks + j <-> key sub*32 + 16ks + 8(j>>2) + 4h + (j&3)
@@ -303,6 +328,56 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_bf16_kernel(AttnParams p
                     else o[b] = HT::mfma32(__builtin_bit_cast(vec8, vf), pf, o[b]);
                 }
             }
+        };
+        // the textbook step for sub-tile(s) `which`, scores recomputed from the K tile in LDS (the optimistic form's redo path)
+        auto redo = [&](auto whichc) -> float {
+            scores(std::true_type{}, whichc);
+            const float m_new = fmaxf(m_run, tile_max(whichc));
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);    // exp2(-inf) = 0 on the first tile
+            m_run = m_new;
+            rescale(alpha);
+            l_part *= alpha;
+            return exponentials(m_new, whichc);
+        };
+        if constexpr (PRIO == 1 || PRIO == 2) __builtin_amdgcn_s_setprio(3);
+        scores(std::false_type{}, SubBoth{});
+        if constexpr (PRIO == 1 || PRIO == 2) __builtin_amdgcn_s_setprio(0);
+        if constexpr (PRIO == 3) __builtin_amdgcn_s_setprio(3);
+        if constexpr (OPT) {
+            // per 32-key sub-tile, so that sub-tile 1's exponentials and sub-tile 0's PV MFMAs share a basic block (hipcc
+            // interleaves them, as it does in the textbook form)
+            float ps0 = exponentials(m_run, Sub0{});
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(ps0 <= HT::kPLimit)) != 0, 0)) ps0 = redo(Sub0{});   // wave-uniform, rare
+            l_part += ps0;
+            float ps1 = exponentials(m_run, Sub1{});
+            pv_sub(Sub0{});
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(ps1 <= HT::kPLimit)) != 0, 0)) ps1 = redo(Sub1{});
+            l_part += ps1;
+            if constexpr (PRIO == 3) __builtin_amdgcn_s_setprio(0);
+            if constexpr (PRIO == 2) __builtin_amdgcn_s_setprio(3);
+            pv_sub(Sub1{});
+            if constexpr (PRIO == 2) __builtin_amdgcn_s_setprio(0);
+        } else {
+            // ---- online softmax (exp2 domain) ----
+            // Deferred maximum (cdna guide T13): the running maximum m_run only moves when some query's tile maximum exceeds it by
+            // more than THR (in the exp2 domain); until then p = exp2(s - m_run) may reach 2^THR instead of 1 -- harmless in the
+            // f32 accumulators and scale-free for the 16-bit rounding of P -- and the whole rescale of O (and of the running sum)
+            // is skipped.  With scores of a few units the maximum of 1500 keys settles inside the first tile or two, so the
+            // rescale block (32 multiplies per lane) runs on the first tiles only instead of on nearly every one.
+            // thr <= 0: always move.
+            const float mx2 = tile_max(SubBoth{});
+            float m_new = m_run, alpha = 1.0f;
+            if (__builtin_amdgcn_ballot_w64(mx2 > m_run + p.defer_thr) != 0) {     // wave-uniform
+                m_new = fmaxf(m_run, mx2);
+                alpha = __builtin_amdgcn_exp2f(m_run - m_new);          // exp2(-inf) = 0 on the first tile
+            }
+            m_run = m_new;
+            const float ps = exponentials(m_new, SubBoth{});
+            if constexpr (!MSUM) l_part = l_part * alpha + ps;
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) rescale(alpha);   // wave-uniform; exact: alpha == 1 changes nothing
+            pv_sub(Sub0{});
+            pv_sub(Sub1{});
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     };
@@ -485,14 +560,23 @@ static int attention_launch(int dtype, AttnParams p, int batch, hipStream_t stre
                 LA_KO_CASE(1) LA_KO_CASE(2) LA_KO_CASE(4) LA_KO_CASE(6) LA_KO_CASE(8) LA_KO_CASE(14) LA_KO_CASE(16) LA_KO_CASE(17)
                 LA_KO_CASE(7) LA_KO_CASE(15) LA_KO_CASE(30)
 #undef LA_KO_CASE
+#define LA_KO_OPT(n, ko) case n: hipLaunchKernelGGL((attention_bf16_kernel<bf16_t, 4, false, ko, true>), grid, block, 0, stream, p); break;
+                LA_KO_OPT(100, 0) LA_KO_OPT(101, 1) LA_KO_OPT(106, 6) LA_KO_OPT(108, 8) LA_KO_OPT(114, 14) LA_KO_OPT(116, 16) LA_KO_OPT(130, 30)
+#undef LA_KO_OPT
+#define LA_KO_PRIO(n, pr) case n: hipLaunchKernelGGL((attention_bf16_kernel<bf16_t, 4, false, 0, true, pr>), grid, block, 0, stream, p); break;
+                LA_KO_PRIO(201, 1) LA_KO_PRIO(202, 2) LA_KO_PRIO(203, 3)
+#undef LA_KO_PRIO
                 default: hipLaunchKernelGGL((attention_bf16_kernel<bf16_t, 4>), grid, block, 0, stream, p);
             }
 #endif
         } else if (getenv("LA_ATTN_MSUM")) {                 // developer A/B: softmax denominator on the matrix pipe
             if (dtype == LA_F16) hipLaunchKernelGGL((attention_bf16_kernel<la::f16_t, 4, true>), grid, block, 0, stream, p);
             else hipLaunchKernelGGL((attention_bf16_kernel<bf16_t, 4, true>), grid, block, 0, stream, p);
-        } else if (dtype == LA_F16) hipLaunchKernelGGL((attention_bf16_kernel<la::f16_t, 4>), grid, block, 0, stream, p);
-        else hipLaunchKernelGGL((attention_bf16_kernel<bf16_t, 4>), grid, block, 0, stream, p);
+        } else if (const char *opt = getenv("LA_ATTN_OPT"); opt && atoi(opt) == 0) {   // developer A/B: per-tile maximum (deferred, LA_ATTN_THR)
+            if (dtype == LA_F16) hipLaunchKernelGGL((attention_bf16_kernel<la::f16_t, 4>), grid, block, 0, stream, p);
+            else hipLaunchKernelGGL((attention_bf16_kernel<bf16_t, 4>), grid, block, 0, stream, p);
+        } else if (dtype == LA_F16) hipLaunchKernelGGL((attention_bf16_kernel<la::f16_t, 4, false, 0, true>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((attention_bf16_kernel<bf16_t, 4, false, 0, true>), grid, block, 0, stream, p);
     } else {
         static bool attr_done = false;
         if (!attr_done) {

@@ -152,7 +152,9 @@ def test_attention_online_rescale_spike():
     qkv[7, :64] = 0.0; qkv[7, 0] = 4.0           # query 7 looks at feature 0
     qkv[:, 64] = 0.0; qkv[250, 64] = 10.0         # key 250 spikes on feature 0 (tile 3), key 10 a smaller spike (tile 0)
     qkv[10, 64] = 5.0
-    for dtype, tol in ((torch.float32, 2e-5), (torch.bfloat16, 2e-2)):
+    qkv[130, 64] = 7.5                             # and an intermediate one in the FIRST half of tile 2 (both redo paths of the
+    qkv[9, :64] = 0.0; qkv[9, 0] = -4.0            # optimistic softmax); query 9 looks the other way: its scores only fall
+    for dtype, tol in ((torch.float32, 2e-5), (torch.bfloat16, 2e-2), (torch.float16, 4e-3)):
         x = qkv.to(dtype)
         out = ops.attention(x.cuda(), 1, T, H).float().cpu()
         xd = x.double()

@@ -96,8 +96,12 @@ def bench_attn(iters):
     fl = 4.0 * T * T * H * 64 * B
     ref = None
     for rd in range(3):
-        for nw, msum, thr in (("4", False, "0"), ("4", False, "8"), ("8", False, "8"), ("4", True, "8")):
+        for nw, msum, thr in (("4", False, "0"), ("4", False, "8"), ("4", False, "opt"), ("8", False, "8"), ("4", True, "8")):
             os.environ["LA_ATTN_NW"] = nw
+            if thr == "opt":                       # the default: optimistic softmax, no per-tile maximum
+                os.environ.pop("LA_ATTN_OPT", None)
+            else:
+                os.environ["LA_ATTN_OPT"] = "0"
             os.environ["LA_ATTN_THR"] = thr
             if msum:
                 os.environ["LA_ATTN_MSUM"] = "1"
@@ -109,7 +113,7 @@ def bench_attn(iters):
             dmax = float((out.float() - ref.float()).abs().max())
             print(f"attention B={B} T={T} H={H} waves/workgroup {nw} msum {int(msum)} defer-thr {thr}: median {med*1e3:.1f} us  min {mn*1e3:.1f} us  {fl/med/1e9:.1f} TF/s  "
                   f"max abs diff to the first run: {dmax:.3e}", flush=True)
-    os.environ.pop("LA_ATTN_NW", None); os.environ.pop("LA_ATTN_MSUM", None); os.environ.pop("LA_ATTN_THR", None)
+    os.environ.pop("LA_ATTN_NW", None); os.environ.pop("LA_ATTN_MSUM", None); os.environ.pop("LA_ATTN_THR", None); os.environ.pop("LA_ATTN_OPT", None)
 
 
 def bench_attn_knockout(iters):
@@ -120,7 +124,10 @@ def bench_attn_knockout(iters):
     qkv[:, : H * 64] *= 0.125
     out = torch.empty(B * T, H * 64, device="cuda", dtype=torch.bfloat16)
     names = {0: "full", 1: "no exp", 2: "no V reads", 4: "no K reads", 6: "no K/V reads", 8: "no staging", 14: "no LDS traffic at all",
-             16: "no MFMA", 17: "no MFMA, no exp", 7: "no exp, no K/V reads", 15: "no exp, no LDS traffic", 30: "no MFMA, no LDS traffic"}
+             16: "no MFMA", 17: "no MFMA, no exp", 7: "no exp, no K/V reads", 15: "no exp, no LDS traffic", 30: "no MFMA, no LDS traffic",
+             100: "optimistic softmax, full", 101: "optimistic, no exp", 106: "optimistic, no K/V reads", 108: "optimistic, no staging",
+             114: "optimistic, no LDS traffic", 116: "optimistic, no MFMA", 130: "optimistic, no MFMA, no LDS traffic",
+             201: "optimistic, S phase at raised priority", 202: "optimistic, S and PV raised", 203: "optimistic, softmax raised"}
     for rd in range(2):
         for ko, nm in names.items():
             os.environ["LA_ATTN_KO"] = str(ko)
