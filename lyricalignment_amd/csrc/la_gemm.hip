@@ -229,41 +229,17 @@ template <int DBG> struct PPGeom {
     static constexpr int TM = HALF ? KH::TM : PP::TM, THREADS = HALF ? KH::THREADS : PP::THREADS;
     static constexpr int LDS = HALF ? KH::LDS : ((DBG >= 20 && DBG != 24 && DBG < 32) ? K2<5>::LDS : PP::LDS);
 };
-template <bool OUT_F32, int DBG, typename T16, int LNM = 0>
-__global__ __launch_bounds__(PPGeom<DBG>::THREADS, 2) void gemm_pp_kernel(GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    const int nwg = p.tiles_m * p.tiles_n;
-    const int tile = xcd_remap(blockIdx.x, nwg);
-    const TileCoord tc = tile_coord(tile, p.tiles_m, p.tiles_n, p.group);
-    const int m0 = tc.tm * PPGeom<DBG>::TM, n0 = tc.tn * PP::TN;
-    const int z = blockIdx.y;
-    const T16 *A = reinterpret_cast<const T16 *>(p.A) + (int64_t)z * p.strideA;
-    const T16 *W = reinterpret_cast<const T16 *>(p.W) + (int64_t)z * p.strideW;
-    const float *bias = p.bias ? p.bias + (int64_t)z * p.strideBias : nullptr;
-
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wr = wave >> 2, wc = wave & 3;
+// Epilogue of one wave's 128x64 output tile (rows wrow0.., columns wcol0..) held in the MFMA accumulator layout acc[mi][ni][j]
+// = C[wrow0 + 16 mi + r][wcol0 + 16 ni + 4 q + j]: LayerNorm fold / bias, GELU, f32 residual, stores (wide, through the wave's
+// own 32 x EPI_PITCH bytes of LDS at `reg`), the 16-bit copy and the per-segment row statistics.  bias_l / csum_l: the bias and
+// the LN column sum of column wcol0 + lane, requested by the caller BEFORE its main loop.  Shared by the 8-wave ping-pong
+// kernel (one call per wave) and the one-wave-per-SIMD kernel (two calls per wave, one per 64-column half).
+constexpr int EPI_PITCH = 272;
+template <bool OUT_F32, typename T16, int LNM>
+__device__ __forceinline__ void wave_epilogue(const GemmParams &p, int z, f32x4 (&acc)[8][4], int wrow0, int wcol0, bool has_bias,
+                                              float bias_l, float csum_l, unsigned char *reg) {
+    const int lane = threadIdx.x & 63;
     const int r = lane & 15, q = lane >> 4;
-    const bool has_bias = (p.epilogue & LA_EPI_BIAS) && bias;
-    // Per-column epilogue operands are requested BEFORE the main loop, one column per lane (this wave's 64 columns), and
-    // handed to the accumulator layout with ds_bpermute afterwards: all eight waves reach the epilogue together, so a load
-    // issued there is a fully exposed L2 round trip per tile.
-    const int ncol = min(n0 + wc * 64 + lane, p.N - 1);
-    const float bias_l = has_bias ? bias[ncol] : 0.f;
-    float csum_l = 0.f;
-    if constexpr (LNM == 2) csum_l = p.ln_csum[ncol];
-
-    f32x4 acc[8][4];
-    if constexpr (DBG == 8 && std::is_same<T16, bf16_t>::value) mainloop_flat256(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
-    else if constexpr (DBG == 80) mainloop_k2p<T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
-    else if constexpr (DBG == 64) mainloop_half<T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
-    else if constexpr (DBG == 24) mainloop_k2f<4, T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
-    else if constexpr (DBG == 25) mainloop_k2f<5, T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
-    else if constexpr (DBG >= 32) mainloop_pp<DBG, T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
-    else if constexpr (DBG >= 20) mainloop_k2<DBG & 3, 5, T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
-    else if constexpr (DBG >= 16) mainloop_k2<DBG & 3, 4, T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
-    else mainloop_pp<DBG, T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc, p.stamps);
-
     typedef typename std::conditional<OUT_F32, float, T16>::type TC;
     TC *C = reinterpret_cast<TC *>(p.C) + (int64_t)z * p.strideC;
     const float *R = p.residual ? p.residual + (int64_t)z * p.strideR : nullptr;
@@ -278,7 +254,7 @@ __global__ __launch_bounds__(PPGeom<DBG>::THREADS, 2) void gemm_pp_kernel(GemmPa
         float rs[8], bm[8];
 #pragma unroll
         for (int mi = 0; mi < 8; ++mi) {
-            const float2 st = reinterpret_cast<const float2 *>(p.ln_stats)[min(m0 + wr * 128 + mi * 16 + r, p.M - 1)];
+            const float2 st = reinterpret_cast<const float2 *>(p.ln_stats)[min(wrow0 + mi * 16 + r, p.M - 1)];
             rs[mi] = st.y; bm[mi] = -st.x * st.y;
         }
 #pragma unroll
@@ -325,10 +301,7 @@ __global__ __launch_bounds__(PPGeom<DBG>::THREADS, 2) void gemm_pp_kernel(GemmPa
                 }
             }
     }
-    constexpr int PITCH = 272;
-    __syncthreads();
-    unsigned char *reg = lds + wave * (32 * PITCH);
-    const int wrow0 = m0 + wr * 128, wcol0 = n0 + wc * 64;
+    constexpr int PITCH = EPI_PITCH;
     const bool fast_c = ((p.ldc * (int64_t)sizeof(TC)) % 16 == 0) && ((uintptr_t)C % 16 == 0);
     const bool fast_r = do_res && (p.ldr % 4 == 0) && ((uintptr_t)R % 16 == 0);
     // Interior wave tiles (all but the last row / column of tiles): straight-line code, no bounds or alignment branches, so
@@ -431,66 +404,237 @@ __global__ __launch_bounds__(PPGeom<DBG>::THREADS, 2) void gemm_pp_kernel(GemmPa
     }
 }
 
-// Developer experiment (LA_PP_DBG=72): the "mono" main loop (one wave per SIMD, 128x128 wave tiles) with a plain epilogue --
-// bias, GELU, f32 residual, f32 or 16-bit result -- enough to time the loop on the encoder's shapes.
-template <bool OUT_F32, typename T16>
+template <bool OUT_F32, int DBG, typename T16, int LNM = 0>
+__global__ __launch_bounds__(PPGeom<DBG>::THREADS, 2) void gemm_pp_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int tile = xcd_remap(blockIdx.x, nwg);
+    const TileCoord tc = tile_coord(tile, p.tiles_m, p.tiles_n, p.group);
+    const int m0 = tc.tm * PPGeom<DBG>::TM, n0 = tc.tn * PP::TN;
+    const int z = blockIdx.y;
+    const T16 *A = reinterpret_cast<const T16 *>(p.A) + (int64_t)z * p.strideA;
+    const T16 *W = reinterpret_cast<const T16 *>(p.W) + (int64_t)z * p.strideW;
+    const float *bias = p.bias ? p.bias + (int64_t)z * p.strideBias : nullptr;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 2, wc = wave & 3;
+    const int r = lane & 15, q = lane >> 4;
+    const bool has_bias = (p.epilogue & LA_EPI_BIAS) && bias;
+    // Per-column epilogue operands are requested BEFORE the main loop, one column per lane (this wave's 64 columns), and
+    // handed to the accumulator layout with ds_bpermute afterwards: all eight waves reach the epilogue together, so a load
+    // issued there is a fully exposed L2 round trip per tile.
+    const int ncol = min(n0 + wc * 64 + lane, p.N - 1);
+    const float bias_l = has_bias ? bias[ncol] : 0.f;
+    float csum_l = 0.f;
+    if constexpr (LNM == 2) csum_l = p.ln_csum[ncol];
+
+    f32x4 acc[8][4];
+    if constexpr (DBG == 8 && std::is_same<T16, bf16_t>::value) mainloop_flat256(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
+    else if constexpr (DBG == 80) mainloop_k2p<T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
+    else if constexpr (DBG == 64) mainloop_half<T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
+    else if constexpr (DBG == 24) mainloop_k2f<4, T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
+    else if constexpr (DBG == 25) mainloop_k2f<5, T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
+    else if constexpr (DBG >= 32) mainloop_pp<DBG, T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
+    else if constexpr (DBG >= 20) mainloop_k2<DBG & 3, 5, T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
+    else if constexpr (DBG >= 16) mainloop_k2<DBG & 3, 4, T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
+    else mainloop_pp<DBG, T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc, p.stamps);
+
+    __syncthreads();
+    wave_epilogue<OUT_F32, T16, LNM>(p, z, acc, m0 + wr * 128, n0 + wc * 64, has_bias, bias_l, csum_l, lds + wave * (32 * EPI_PITCH));
+}
+
+// Epilogue of the one-wave-per-SIMD kernel: one wave's 128x128 tile, accumulators in the AGPRs.  Per pass of 32 rows the wave
+// writes its accumulator tuples STRAIGHT from the AGPRs into its own 32 x 528 bytes of LDS (ds_write_b128 takes AGPR data: no
+// v_accvgpr_read, no VGPR copy of the tile) and reads them back row-major -- lane (lane >> 5, lane & 31) = (row parity, four
+// consecutive columns), two whole 512-byte rows per instruction -- where the LayerNorm fold / bias, GELU, the f32 residual,
+// the stores, the 16-bit copy and the per-segment row statistics are applied in the same order and with the same operations
+// as wave_epilogue (bit-identical results).  The lane's four columns are fixed, so its bias / column-sum values (b4, cs4) are
+// loaded once by the caller before the main loop; the pass's residual rows and LayerNorm row statistics are requested before
+// the staging, 16 rows in flight per lane.
+constexpr int MONO_PITCH = 528;
+template <int OFF> __device__ __forceinline__ void ds_write128_agpr(unsigned addr, const f32x4 &a) {
+    asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(addr), "a"(a), "n"(OFF) : "memory");
+}
+template <bool OUT_F32, typename T16, int LNM>
+__device__ __forceinline__ void mono_epilogue(const GemmParams &p, int z, f32x4 (&acc)[8][8], int wrow0, int wcol0, bool has_bias,
+                                              const float (&b4)[4], const float (&cs4)[4], unsigned char *reg) {
+    constexpr int PITCH = MONO_PITCH;
+    const int lane = threadIdx.x & 63;
+    const int r = lane & 15, q = lane >> 4, c = lane & 31, rp = lane >> 5;
+    typedef typename std::conditional<OUT_F32, float, T16>::type TC;
+    TC *C = reinterpret_cast<TC *>(p.C) + (int64_t)z * p.strideC;
+    const float *R = p.residual ? p.residual + (int64_t)z * p.strideR : nullptr;
+    const bool do_gelu = p.epilogue & LA_EPI_GELU;
+    const bool do_res = (p.epilogue & LA_EPI_RESIDUAL) && R;
+    const bool fast_c = ((p.ldc * (int64_t)sizeof(TC)) % 16 == 0) && ((uintptr_t)C % 16 == 0);
+    const bool fast_r = do_res && (p.ldr % 4 == 0) && ((uintptr_t)R % 16 == 0);
+    const bool full = wrow0 + 128 <= p.M && wcol0 + 128 <= p.N && fast_c && (!do_res || fast_r);     // wave-uniform
+    const int n = wcol0 + c * 4;
+    T16 *C2 = nullptr;
+    if constexpr (LNM == 1 && OUT_F32) C2 = reinterpret_cast<T16 *>(p.C2) + (int64_t)z * p.strideC;
+    const unsigned wr_addr = la::lds_addr_u32(reg) + (unsigned)(r * PITCH + q * 16);
+    const unsigned char *rd = reg + rp * PITCH + c * 16;
+    // the 16 accumulator tuples of pass h -> LDS (the AGPR names are compile-time: one arm per pass)
+    auto stage = [&](auto hc) __attribute__((always_inline)) {
+        constexpr int h = decltype(hc)::value;
+        la::gemm::static_for<0, 16>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value, mm = i >> 3, ni = i & 7;
+            ds_write128_agpr<mm * 16 * PITCH + ni * 64>(wr_addr, acc[2 * h + mm][ni]);
+        });
+    };
+    // one pass of 32 rows; the row code exists once per (FULL, RES) -- the passes are a run-time loop around it, so the whole
+    // epilogue stays a few thousand instructions (fully unrolled it was 45 k: every wave then streams its code from L2)
+    auto pass = [&](int h, auto fullc, auto resc) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(fullc)::value, RES = decltype(resc)::value;
+        const int row0 = wrow0 + h * 32;
+        float4 t[16];
+        float2 st[16];
+        // (row addresses by pointer increments: a 64-bit multiply per row costs more vector cycles than the row's arithmetic)
+        if constexpr (FULL && RES) {
+            const float *rr = R + (int64_t)(row0 + rp) * p.ldr + n;
+            const int64_t rstep = 2 * p.ldr;
+#pragma unroll
+            for (int it = 0; it < 16; ++it) { t[it] = *reinterpret_cast<const float4 *>(rr); rr += rstep; }
+        }
+        const int64_t cstep = 2 * p.ldc;
+        int64_t off = (int64_t)(row0 + rp) * p.ldc + n - cstep;
+        if constexpr (LNM == 2) {
+#pragma unroll
+            for (int it = 0; it < 16; ++it) st[it] = reinterpret_cast<const float2 *>(p.ln_stats)[min(row0 + it * 2 + rp, p.M - 1)];
+        }
+        switch (h) {
+            case 0: stage(std::integral_constant<int, 0>{}); break;
+            case 1: stage(std::integral_constant<int, 1>{}); break;
+            case 2: stage(std::integral_constant<int, 2>{}); break;
+            default: stage(std::integral_constant<int, 3>{}); break;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            f32x4 v = *reinterpret_cast<const f32x4 *>(rd + it * 2 * PITCH);
+            const int m = row0 + it * 2 + rp;
+            off += cstep;
+            if constexpr (LNM == 2) {
+                const float rs = st[it].y, bm = -st[it].x * st[it].y;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = fmaf(v[j], rs, fmaf(bm, cs4[j], b4[j]));
+            } else if (has_bias) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += b4[j];
+            }
+            if (do_gelu) {
+                if constexpr (!OUT_F32) {
+                    const la::f32x2 lo = la::gelu_sig2(la::f32x2{v[0], v[1]}), hi = la::gelu_sig2(la::f32x2{v[2], v[3]});
+                    v = f32x4{lo.x, lo.y, hi.x, hi.y};
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = la::gelu_erf(v[j]);
+                }
+            }
+            if constexpr (FULL) {
+                if constexpr (RES) { v[0] += t[it].x; v[1] += t[it].y; v[2] += t[it].z; v[3] += t[it].w; }
+                if ((p.epilogue & 2048) && v[0] != 12345.678f) continue;      // developer probe: the epilogue without its stores
+                if constexpr (sizeof(TC) == 4) {
+                    *reinterpret_cast<float4 *>(C + off) = make_float4(v[0], v[1], v[2], v[3]);
+                    if constexpr (LNM == 1) {
+                        const ushort4 pk = la::Pack4<T16>::run(v[0], v[1], v[2], v[3]);
+                        *reinterpret_cast<ushort4 *>(C2 + off) = pk;
+                        if (p.ln_part) {
+                            const float2 sg = segment_stats<T16>(pk);
+                            if (r == 0) reinterpret_cast<float2 *>(p.ln_part)[(int64_t)((wcol0 >> 6) + (c >> 4)) * p.M + m] = sg;
+                        }
+                    }
+                } else {
+                    *reinterpret_cast<ushort4 *>(C + off) = la::Pack4<TC>::run(v[0], v[1], v[2], v[3]);
+                }
+            } else {
+                // ragged tile / unaligned operands (wave_epilogue's generic path, same order of operations)
+                const bool in = m < p.M && n < p.N;
+                const int nv = in ? min(4, p.N - n) : 0;
+                if (do_res && in) {
+                    const float *rr = R + (int64_t)m * p.ldr + n;
+                    if (fast_r && nv == 4) {
+                        const float4 tt = *reinterpret_cast<const float4 *>(rr);
+                        v[0] += tt.x; v[1] += tt.y; v[2] += tt.z; v[3] += tt.w;
+                    } else {
+                        for (int j = 0; j < nv; ++j) v[j] += rr[j];
+                    }
+                }
+                if (in) {
+                    TC *cc = C + off;
+                    if (fast_c && nv == 4) {
+                        if constexpr (sizeof(TC) == 4) *reinterpret_cast<float4 *>(cc) = make_float4(v[0], v[1], v[2], v[3]);
+                        else *reinterpret_cast<ushort4 *>(cc) = la::Pack4<TC>::run(v[0], v[1], v[2], v[3]);
+                    } else {
+                        for (int j = 0; j < nv; ++j) la::Elem<TC>::store(cc + j, v[j]);
+                    }
+                }
+                if constexpr (LNM == 1) {
+                    if (in) {
+                        for (int j = 0; j < nv; ++j) la::Elem<T16>::store(C2 + off + j, v[j]);
+                    }
+                    if (p.ln_part) {       // N % 64 == 0 on this path (host check): a segment's 16 lanes are in or out together
+                        const float2 sg = segment_stats<T16>(la::Pack4<T16>::run(v[0], v[1], v[2], v[3]));
+                        if (r == 0 && in) reinterpret_cast<float2 *>(p.ln_part)[(int64_t)((wcol0 >> 6) + (c >> 4)) * p.M + m] = sg;
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);       // one pass's loads and rows in flight at a time (register budget)
+    };
+    typedef std::true_type TT;
+    typedef std::false_type FF;
+    if (full) {
+        if (do_res) {
+#pragma nounroll
+            for (int h = 0; h < 4; ++h) pass(h, TT{}, TT{});
+        } else {
+#pragma nounroll
+            for (int h = 0; h < 4; ++h) pass(h, TT{}, FF{});
+        }
+    } else {
+#pragma nounroll
+        for (int h = 0; h < 4; ++h) pass(h, FF{}, FF{});
+    }
+}
+
+// The one-wave-per-SIMD kernel: 256x256 tile, 4 waves x 128x128 wave tiles, hand-placed main loop (mainloop_mono_asm; ASM = 0:
+// the hipcc-scheduled loop, 2 / 3: timing probes), accumulators in the AGPRs from the first MFMA to the epilogue's ds_write.
+template <bool OUT_F32, typename T16, int ASM = 1, int LNM = 0>
 __global__ __launch_bounds__(MONO::THREADS, 1) void gemm_mono_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int nwg = p.tiles_m * p.tiles_n;
     const int tile = xcd_remap(blockIdx.x, nwg);
     const TileCoord tc = tile_coord(tile, p.tiles_m, p.tiles_n, p.group);
     const int m0 = tc.tm * 256, n0 = tc.tn * 256;
-    const T16 *A = reinterpret_cast<const T16 *>(p.A), *W = reinterpret_cast<const T16 *>(p.W);
-    f32x4 acc[8][8];
-    mainloop_mono<T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
-    typedef typename std::conditional<OUT_F32, float, T16>::type TC;
-    TC *C = reinterpret_cast<TC *>(p.C);
+    const int z = blockIdx.y;
+    const T16 *A = reinterpret_cast<const T16 *>(p.A) + (int64_t)z * p.strideA;
+    const T16 *W = reinterpret_cast<const T16 *>(p.W) + (int64_t)z * p.strideW;
+    const float *bias = p.bias ? p.bias + (int64_t)z * p.strideBias : nullptr;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wr = wave >> 1, wc = wave & 1, r = lane & 15, q = lane >> 4;
-    const bool has_bias = (p.epilogue & LA_EPI_BIAS) && p.bias, do_gelu = p.epilogue & LA_EPI_GELU, do_res = (p.epilogue & LA_EPI_RESIDUAL) && p.residual;
-    constexpr int PITCH = 528;                                   // 128 f32 + 16 B
-    unsigned char *reg = lds + wave * (32 * PITCH);
-    const int wrow0 = m0 + wr * 128, wcol0 = n0 + wc * 128;
+    const int wr = wave >> 1, wc = wave & 1;
+    const bool has_bias = (p.epilogue & LA_EPI_BIAS) && bias;
+    // per-column epilogue operands of this lane's four columns, requested before the main loop
+    float b4[4], cs4[4];
 #pragma unroll
-    for (int h = 0; h < 4; ++h) {
-#pragma unroll
-        for (int mm = 0; mm < 2; ++mm)
-#pragma unroll
-            for (int ni = 0; ni < 8; ++ni) {
-                f32x4 v = acc[2 * h + mm][ni];
-                if (has_bias) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] += p.bias[min(wcol0 + ni * 16 + q * 4 + j, p.N - 1)];
-                }
-                if (do_gelu) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = OUT_F32 ? la::gelu_erf(v[j]) : la::gelu_sig(v[j]);
-                }
-                *reinterpret_cast<f32x4 *>(reg + (mm * 16 + r) * PITCH + (ni * 16 + q * 4) * 4) = v;
-            }
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int rl = it * 4 + q, m = wrow0 + h * 32 + rl;
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const int n = wcol0 + half * 64 + r * 4;
-                f32x4 v = *reinterpret_cast<const f32x4 *>(reg + rl * PITCH + half * 256 + r * 16);
-                if (m >= p.M || n + 3 >= p.N) continue;         // experiment: whole float4s only (N % 4 == 0 shapes)
-                if (do_res) {
-                    const float4 t = *reinterpret_cast<const float4 *>(p.residual + (int64_t)m * p.ldr + n);
-                    v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
-                }
-                TC *c = C + (int64_t)m * p.ldc + n;
-                if constexpr (sizeof(TC) == 4) *reinterpret_cast<float4 *>(c) = make_float4(v[0], v[1], v[2], v[3]);
-                else *reinterpret_cast<ushort4 *>(c) = la::Pack4<T16>::run(v[0], v[1], v[2], v[3]);
-            }
-        }
+    for (int j = 0; j < 4; ++j) {
+        const int ncol = min(n0 + wc * 128 + (lane & 31) * 4 + j, p.N - 1);
+        b4[j] = has_bias ? bias[ncol] : 0.f;
+        cs4[j] = 0.f;
+        if constexpr (LNM == 2) cs4[j] = p.ln_csum[ncol];
     }
+    f32x4 acc[8][8];
+    if constexpr (ASM != 0) mainloop_mono_asm<T16, ASM - 1>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
+    else mainloop_mono<T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
+    if constexpr (ASM != 0) {
+        if (p.epilogue & 256) return;        // developer probe (KB_NOSTORE): the main loop (volatile asm: not removable) alone
+    }
+    mono_epilogue<OUT_F32, T16, LNM>(p, z, acc, m0 + wr * 128, n0 + wc * 128, has_bias, b4, cs4, lds + wave * (32 * MONO_PITCH));
 }
 
-template <bool OUT_F32, typename T16>
+template <bool OUT_F32, typename T16, int ASM = 1, int LNM = 0>
 int launch_mono(GemmParams p, int batch, hipStream_t stream) {
-    auto kern = gemm_mono_kernel<OUT_F32, T16>;
+    auto kern = gemm_mono_kernel<OUT_F32, T16, ASM, LNM>;
     static bool attr_done = false;
     if (!attr_done) {
         LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, MONO::LDS));
@@ -498,11 +642,21 @@ int launch_mono(GemmParams p, int batch, hipStream_t stream) {
     }
     p.tiles_m = la::cdiv(p.M, 256);
     p.tiles_n = la::cdiv(p.N, 256);
-    p.group = std::min(p.tiles_n, std::max(4, p.group / 2));
+    p.group = getenv("LA_GEMM_GROUP") ? std::min(p.group, p.tiles_n) : std::min(p.tiles_n, std::max(4, p.group / 2));
     la::TimerScope ts("gemm_bf16", stream);
-    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, 1), dim3(MONO::THREADS), MONO::LDS, stream, p);
+    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, batch), dim3(MONO::THREADS), MONO::LDS, stream, p);
     LA_LAUNCH_CHECK();
     return LA_OK;
+}
+
+// the one-wave-per-SIMD kernel by epilogue mode (the same three the ping-pong kernel has)
+template <bool OUT_F32, typename T16, int ASM>
+int launch_mono_modes(GemmParams p, int batch, hipStream_t stream) {
+    if (p.ln_stats) return launch_mono<OUT_F32, T16, ASM, 2>(p, batch, stream);
+    if constexpr (OUT_F32) {
+        if (p.C2) return launch_mono<OUT_F32, T16, ASM, 1>(p, batch, stream);
+    }
+    return launch_mono<OUT_F32, T16, ASM, 0>(p, batch, stream);
 }
 
 template <bool OUT_F32, int DBG, typename T16, int LNM = 0>
@@ -513,7 +667,12 @@ int launch_pp(GemmParams p, int batch, hipStream_t stream) {
     const char *dbg_env = getenv("LA_PP_DBG");               // read per launch: tools/kbench.py flips it between rounds of one process
     const int dbg = dbg_env ? atoi(dbg_env) : 0;
     if constexpr (std::is_same<T16, bf16_t>::value) {       // the developer probes exist for the bf16 instantiation
-        if (dbg == 72 && batch == 1 && p.N % 4 == 0 && !p.C2 && !p.ln_stats) return launch_mono<OUT_F32, T16>(p, batch, stream);
+        if (p.K % 128 == 0 && p.K >= 256) {
+            if (dbg == 72) return launch_mono<OUT_F32, T16, 0>(p, batch, stream);
+            if (dbg == 73) return launch_mono_modes<OUT_F32, T16, 1>(p, batch, stream);
+            if (dbg == 74) return launch_mono<OUT_F32, T16, 2>(p, batch, stream);
+            if (dbg == 75) return launch_mono<OUT_F32, T16, 3>(p, batch, stream);
+        }
         switch (dbg) {
             case 16: return launch_pp_dbg<OUT_F32, 16, T16>(p, batch, stream);
             case 20: return launch_pp_dbg<OUT_F32, 20, T16>(p, batch, stream);

@@ -792,5 +792,156 @@ __device__ __forceinline__ void mainloop_mono(const T16 *A, int64_t lda, int M, 
     LA_PP_BARRIER();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// "mono", hand-placed (LA_PP_DBG=73): the same tile, stages and ring as mainloop_mono, but EVERY instruction of the k-loop is
+// an `asm volatile` statement, so hipcc keeps the source order (it only allocates registers): per k-step (K = 32) the wave
+// issues its 64 MFMAs back to back and drops into their gaps -- one instruction per gap, so the matrix pipe never waits for
+// the issue port -- the 16 ds_read_b128 of the NEXT k-step's fragments (second register set, j = 2, 5, .., 47), its 8 LDS-DMA
+// pieces of stage s + 4 (j = 4, 11, .., 53), one counted wait (j = 56) and the k-step's only barrier (j = 58).  The 8x8
+// accumulators live in the 256 AGPRs.  tools/mfma_ceiling.hip runs exactly this stream on random data: 2.0 PFLOP/s.
+//   Timeline (stage = k-step = 32 of K; ring slot = stage % 4; prefetch distance 4 = the whole ring):
+//     k-step s computes on the fragments of stage s (in registers since k-step s - 1), reads the fragments of stage s + 1 and
+//     issues the DMA of stage s + 4 into the slot of stage s itself.
+//     RAW: stage s + 1 was issued during k-step s - 3; at j = 56 of k-step s - 1 every wave retires its pieces of it (the 16 of
+//       stages s + 2 and s + 3 may stay in flight: vmcnt(16)), and the barrier at j = 58 publishes that.
+//     WAR: the fragments of stage s were requested during k-step s - 1 (the last at j = 47) and retired by the lgkmcnt(0) at
+//       j = 56 of that k-step in every wave, i.e. before the wave reached the barrier of k-step s - 1; the refill of that slot
+//       is issued after it (j >= 4 of k-step s).
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+template <typename T> struct MmaAsm;
+template <> struct MmaAsm<bf16_t> {
+    __device__ static __forceinline__ void run(const u32x4 &w, const u32x4 &a, f32x4 &acc) {
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(w), "v"(a));
+    }
+};
+template <> struct MmaAsm<_Float16> {
+    __device__ static __forceinline__ void run(const u32x4 &w, const u32x4 &a, f32x4 &acc) {
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(w), "v"(a));
+    }
+};
+template <int I, int N, typename F> __device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+template <int OFF> __device__ __forceinline__ void ds_read128_asm(u32x4 &d, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+}
+
+// PROBE (timing only, wrong results): 1 = no DMA inside the loop, 2 = every refill re-reads stage 0's columns (L2-resident)
+template <typename T16 = bf16_t, int PROBE = 0>
+__device__ __forceinline__ void mainloop_mono_asm(const T16 *A, int64_t lda, int M, const T16 *W, int64_t ldw, int N, int K,
+                                                  int m0, int n0, unsigned char *lds, f32x4 (&acc)[8][8]) {
+    constexpr int STAGE = 32768, OPS = 16384, SB = 64;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int r = lane & 15, q = lane >> 4;
+    const int ns = K / 32;
+    const int64_t lda_b = lda * 2, ldw_b = ldw * 2;
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 8; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // this wave's pieces of every stage: 4 of W (rows 64 wave .. + 63) and 4 of A
+    unsigned voff_a[4], voff_w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rt = (4 * wave + i) * 16 + (lane >> 2);
+        const int sw = ((lane & 3) ^ swz2(rt)) << 4;
+        int ra = m0 + rt; ra = ra > M - 1 ? M - 1 : ra;
+        int rw = n0 + rt; rw = rw > N - 1 ? N - 1 : rw;
+        voff_a[i] = (unsigned)((int64_t)(ra - m0) * lda_b) + sw;
+        voff_w[i] = (unsigned)((int64_t)(rw - n0) * ldw_b) + sw;
+    }
+    const unsigned char *a_row0 = reinterpret_cast<const unsigned char *>(A) + (int64_t)m0 * lda_b;
+    const unsigned char *w_row0 = reinterpret_cast<const unsigned char *>(W) + (int64_t)n0 * ldw_b;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_u32(lds));
+    const unsigned piece0 = lds0 + (4 * wave) * 1024;
+    // piece i (0..3 of W, 4..7 of A) of this wave's share of the stage whose K offset is kb bytes, into ring slot `slot`
+    auto issue1 = [&](const unsigned char *w_src, const unsigned char *a_src, int slot, int i) __attribute__((always_inline)) {
+        const unsigned dst = piece0 + slot * STAGE + (i < 4 ? OPS : 0) + (i & 3) * 1024;
+        if (i < 4) glds16_so(voff_w[i], w_src, dst);
+        else glds16_so(voff_a[i - 4], a_src, dst);
+    };
+    // fragment addresses: lane part + slot * 32 KiB + tile * 1 KiB (swz2 does not depend on the 16-row tile index); the
+    // ds_read offset field holds 16 bits, so slots 2 and 3 go through a second base register
+    const unsigned fa_lo = lds0 + (unsigned)((wr * 128 + r) * SB + ((q ^ swz2(r)) << 4)), fa_hi = fa_lo + 2 * STAGE;
+    const unsigned fw_lo = lds0 + OPS + (unsigned)((wc * 128 + r) * SB + ((q ^ swz2(r)) << 4)), fw_hi = fw_lo + 2 * STAGE;
+
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) issue1(w_row0 + st * SB, a_row0 + st * SB, st, i);
+    }
+    // stages 0 and 1 landed (own pieces; everyone's after the barrier): the 16 pieces of stages 2 and 3 may stay in flight
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    LA_PP_BARRIER();
+    u32x4 fa[2][8], fw[2][8];
+    ds_read128_asm<0 * 1024>(fw[0][0], fw_lo); ds_read128_asm<1 * 1024>(fw[0][1], fw_lo); ds_read128_asm<2 * 1024>(fw[0][2], fw_lo);
+    ds_read128_asm<3 * 1024>(fw[0][3], fw_lo); ds_read128_asm<4 * 1024>(fw[0][4], fw_lo); ds_read128_asm<5 * 1024>(fw[0][5], fw_lo);
+    ds_read128_asm<6 * 1024>(fw[0][6], fw_lo); ds_read128_asm<7 * 1024>(fw[0][7], fw_lo);
+    ds_read128_asm<0 * 1024>(fa[0][0], fa_lo); ds_read128_asm<1 * 1024>(fa[0][1], fa_lo); ds_read128_asm<2 * 1024>(fa[0][2], fa_lo);
+    ds_read128_asm<3 * 1024>(fa[0][3], fa_lo); ds_read128_asm<4 * 1024>(fa[0][4], fa_lo); ds_read128_asm<5 * 1024>(fa[0][5], fa_lo);
+    ds_read128_asm<6 * 1024>(fa[0][6], fa_lo); ds_read128_asm<7 * 1024>(fa[0][7], fa_lo);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { fa[1][i] = fa[0][i]; fw[1][i] = fw[0][i]; }     // (defined values for the never-used first set)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // slot 0 is refilled in k-step 0: every wave's stage-0 fragments
+    LA_PP_BARRIER();                                       // are in registers first
+
+    // one k-step.  NX: there is a stage s + 1 (its fragments are read), PF: there is a stage s + 4 (its DMA is issued), VM: the
+    // pieces this wave may leave in flight at the k-step's vmcnt -- all compile-time: the steady loop has (1, 1, 16), the four
+    // peeled last k-steps (1,0,8), (1,0,0), (1,0,0), (0,0,0); no branch anywhere.
+    auto kstep = [&](int s, auto nxc, auto pfc, auto vmc, auto curc, auto slotc) __attribute__((always_inline)) {
+        constexpr bool NX = decltype(nxc)::value, PF = decltype(pfc)::value && PROBE != 1;
+        constexpr int VM = decltype(vmc)::value;
+        constexpr int CUR = decltype(curc)::value, SLOT = decltype(slotc)::value;
+        constexpr int SN = (SLOT + 1) & 3, SW = SLOT;            // stage s + 4 takes the slot of stage s (free since barrier s - 1)
+        constexpr int OFFN = (SN & 1) * STAGE;                   // offset of slot SN from its base register
+        const unsigned fan = SN >= 2 ? fa_hi : fa_lo, fwn = SN >= 2 ? fw_hi : fw_lo;
+        const unsigned char *w_src = w_row0 + (PROBE == 2 ? 0 : (int64_t)(s + 4) * SB), *a_src = a_row0 + (PROBE == 2 ? 0 : (int64_t)(s + 4) * SB);
+        static_for<0, 64>([&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value, mi = j >> 3, ni = j & 7;
+            MmaAsm<T16>::run(fw[CUR][ni], fa[CUR][mi], acc[mi][ni]);
+            if constexpr (NX && j % 3 == 2 && j / 3 < 16) {
+                constexpr int i = j / 3;                   // fragments of the next k-step: W 0..7, then A 0..7
+                if constexpr (i < 8) ds_read128_asm<OFFN + i * 1024>(fw[CUR ^ 1][i], fwn);
+                else ds_read128_asm<OFFN + (i - 8) * 1024>(fa[CUR ^ 1][i - 8], fan);
+            }
+            if constexpr (PF && j % 7 == 4 && j / 7 < 8) issue1(w_src, a_src, SW, j / 7);
+            if constexpr (j == 56) {
+                // stage s + 2 (read during k-step s + 1) has landed; the next stage's fragments (last requested 9 MFMAs ago)
+                // are in registers, so its slot may be refilled after the barrier
+                if constexpr (VM == 16) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+                else if constexpr (VM == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            }
+            if constexpr (j == 58) asm volatile("s_barrier" ::: "memory");
+        });
+    };
+    typedef std::false_type F;
+    typedef std::true_type TT;
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    typedef std::integral_constant<int, 2> I2;
+    typedef std::integral_constant<int, 3> I3;
+    typedef std::integral_constant<int, 8> V8;
+    typedef std::integral_constant<int, 16> V16;
+    int s = 0;                              // ns is a multiple of 4, >= 8 (host check)
+    for (; s + 4 < ns; s += 4) {            // every k-step here has a stage s + 4
+        kstep(s, TT{}, TT{}, V16{}, I0{}, I0{});
+        kstep(s + 1, TT{}, TT{}, V16{}, I1{}, I1{});
+        kstep(s + 2, TT{}, TT{}, V16{}, I0{}, I2{});
+        kstep(s + 3, TT{}, TT{}, V16{}, I1{}, I3{});
+    }
+    kstep(s, TT{}, F{}, V8{}, I0{}, I0{});
+    kstep(s + 1, TT{}, F{}, I0{}, I1{}, I1{});
+    kstep(s + 2, TT{}, F{}, I0{}, I0{}, I2{});
+    kstep(s + 3, F{}, F{}, I0{}, I1{}, I3{});
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    LA_PP_BARRIER();
+}
+
 }  // namespace gemm
 }  // namespace la

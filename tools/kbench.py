@@ -81,7 +81,7 @@ def bench_gemm(iters):
             fn = lambda: ops.gemm(a, w, out, bias=bias, gelu="gelu" in name)
         if os.environ.get("KB_NOSTORE"):
             from lyricalignment_amd._lib import lib, ptr, stream_ptr
-            epi = 1 | 256 | (8 if f32out else 0) | (2 if "gelu" in name else 0)
+            epi = 1 | {0: 0, 1: 256, 2: 2048}[int(os.environ["KB_NOSTORE"])] | (8 if f32out else 0) | (2 if "gelu" in name else 0)   # 1: no epilogue, 2: no stores
             fn = lambda: lib().la_gemm(1, M, N, K, 1, ptr(a), K, 0, ptr(w), ptr(out), N, 0, ptr(bias), 0, 0, 0, epi, stream_ptr())
         med, mn = timeit(fn, iters)
         fl = 2.0 * M * N * K

@@ -115,6 +115,110 @@ __global__ __launch_bounds__(512, 2) void loop_kernel(const uint4 *seed, float *
     if (acc_out == 12345.678f) sink[blockIdx.x] = acc_out;   // keeps the accumulators live
 }
 
+// mono: ONE wave per SIMD (256-thread workgroup), 128x128 wave tile = 8x8 accumulators of 16x16x32 in the 256 AGPRs, every
+// instruction of the k-loop placed by hand (all asm volatile, so hipcc keeps the order): per k-step (K = 32) the wave's 64 MFMAs
+// carry the 16 ds_read_b128 of the NEXT k-step's fragments (second register set) and its 8 LDS-DMA pieces in their gaps.
+//   MODE 0: MFMAs only (fragments never reloaded)   1: + the fragment reads   2: + the DMA pieces   3: + one s_barrier per k-step
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+__device__ __forceinline__ void mfma16_asm(f32x4 &acc, const u32x4 &b, const u32x4 &a) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(b), "v"(a));
+}
+__device__ __forceinline__ void dsread_asm(u32x4 &dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr) : "memory");
+}
+template <int MODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void mono_kernel(const uint4 *seed, float *sink, Stamp *stamps, int iters, const unsigned char *panel) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < 128 * 1024 / 16; i += 256) reinterpret_cast<uint4 *>(lds)[i] = seed[(blockIdx.x * 131 + i) & 4095];
+    __syncthreads();
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(const __attribute__((address_space(3))) void *)lds);
+    const int wm = wave >> 1, wn = wave & 1;
+    // fragment addresses: stage (64 KiB) = A image [256 rows][128 B] + W image [256 rows][128 B], K = 64 per row, XOR-swizzled
+    // 16-byte slots; fragment i of k-step ks: rows 16 i .. 16 i + 15, slot (4 ks + (lane >> 4)) ^ ((lane >> 1) & 7)
+    unsigned a_addr[2], b_addr[2];       // per k-step; + i * 2048 per fragment, + stage * 65536
+    for (int ks = 0; ks < 2; ++ks) {
+        const unsigned in_row = (unsigned)((lane & 15) * 128 + ((((ks * 4 + (lane >> 4)) ^ ((lane >> 1) & 7))) << 4));
+        a_addr[ks] = lds0 + wm * 16384 + in_row;
+        b_addr[ks] = lds0 + 32768 + wn * 16384 + in_row;
+    }
+    unsigned voff[8];
+    for (int i = 0; i < 8; ++i) voff[i] = (unsigned)(((8 * wave + i) * 8 + (lane >> 3)) * 2048 + ((lane & 7) << 4));
+    const unsigned char *pa = panel + (size_t)(blockIdx.x % 64) * 256 * 2048, *pw = panel + (size_t)(64 + (blockIdx.x / 8) % 4) * 256 * 2048;
+    f32x4 acc[8][8];
+    for (int m = 0; m < 8; ++m) for (int n = 0; n < 8; ++n) acc[m][n] = f32x4{0, 0, 0, 0};
+    u32x4 fa[2][8], fb[2][8];
+    for (int i = 0; i < 8; ++i) { dsread_asm(fa[0][i], a_addr[0] + i * 2048); dsread_asm(fb[0][i], b_addr[0] + i * 2048); }
+    for (int i = 0; i < 8; ++i) { fa[1][i] = fa[0][i]; fb[1][i] = fb[0][i]; }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+        const unsigned rd_stage = (unsigned)(it & 1) * 65536u, wr_stage = 65536u - rd_stage;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            // fragments of this k-step were requested during the previous one; the last request is >= 16 MFMAs old
+            if constexpr (MODE >= 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const unsigned na = a_addr[ks ^ 1] + (ks ? wr_stage : rd_stage), nb = b_addr[ks ^ 1] + (ks ? wr_stage : rd_stage);
+            const unsigned char *src = (ks ? pw : pa) + (it & 15) * 128;
+            const unsigned dst = lds0 + wr_stage + (ks ? 32768u : 0u) + wave * 8192;
+#pragma unroll
+            for (int j = 0; j < 64; ++j) {
+                const int m = j >> 3, n = j & 7;
+                mfma16_asm(acc[m][n], fb[ks][n], fa[ks][m]);
+                if constexpr (MODE >= 1) {
+                    if (j % 3 == 2 && j / 3 < 16) {          // j = 2, 5, ..., 47: the 16 reads of the next k-step
+                        const int i = j / 3;
+                        if (i < 8) dsread_asm(fa[ks ^ 1][i], na + i * 2048);
+                        else dsread_asm(fb[ks ^ 1][i - 8], nb + (i - 8) * 2048);
+                    }
+                }
+                if constexpr (MODE >= 2) {
+                    if (j % 7 == 4 && j / 7 < 8) glds16_so(voff[j / 7], src, dst + (j / 7) * 1024);   // j = 4, 11, ..., 53
+                    if (j == 56) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                }
+                if constexpr (MODE >= 3) {
+                    if (j == 58) asm volatile("s_barrier" ::: "memory");
+                }
+            }
+        }
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    float acc_out = 0.f;
+    for (int m = 0; m < 8; ++m) for (int n = 0; n < 8; ++n) acc_out += acc[m][n][0] + acc[m][n][3];
+    if (lane == 0 && wave == 0) stamps[blockIdx.x] = Stamp{c1 - c0, r1 - r0};
+    if (acc_out == 12345.678f) sink[blockIdx.x] = acc_out;
+}
+
+template <int MODE>
+void run_mono(const char *name, const uint4 *seed, float *sink, Stamp *stamps, int blocks, const unsigned char *panel) {
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(mono_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+    const int iters = 4000;
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    for (int w = 0; w < 40; ++w) hipLaunchKernelGGL((mono_kernel<MODE>), dim3(blocks), dim3(256), 131072, 0, seed, sink, stamps, iters, panel);
+    CHECK(hipDeviceSynchronize());
+    std::vector<float> ms;
+    for (int r = 0; r < 7; ++r) {
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL((mono_kernel<MODE>), dim3(blocks), dim3(256), 131072, 0, seed, sink, stamps, iters, panel);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        float t; CHECK(hipEventElapsedTime(&t, e0, e1)); ms.push_back(t);
+    }
+    std::sort(ms.begin(), ms.end());
+    std::vector<Stamp> h(blocks);
+    CHECK(hipMemcpy(h.data(), stamps, blocks * sizeof(Stamp), hipMemcpyDeviceToHost));
+    std::vector<double> clk, cyc;
+    for (auto &s : h) { clk.push_back((double)s.cyc / (double)s.rt * 100.0); cyc.push_back((double)s.cyc); }
+    std::sort(clk.begin(), clk.end()); std::sort(cyc.begin(), cyc.end());
+    const double flops = (double)blocks * 4 * iters * (128.0 * 128 * 64 * 2);
+    printf("%-14s  %8.1f TFLOP/s (median of 7; min-time %8.1f)   cycles/MFMA/SIMD %.2f (one wave per SIMD)   in-kernel clock %.0f MHz\n",
+           name, flops / (ms[3] * 1e-3) / 1e12, flops / (ms[0] * 1e-3) / 1e12, cyc[blocks / 2] / ((double)iters * 128), clk[blocks / 2]);
+    fflush(stdout);
+}
+
 template <int SHAPE, bool LDS, bool DMA = false>
 void run(const char *name, const uint4 *seed, float *sink, Stamp *stamps, int blocks, const unsigned char *panel = nullptr) {
     CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(loop_kernel<SHAPE, LDS, DMA>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
@@ -170,5 +274,10 @@ int main() {
     CHECK(hipMemset(panel, 0x3c, (size_t)68 * 256 * 2048));
     run<16, true, true>("lds16+dma", seed, sink, stamps, blocks, panel);
     run<16, false, true>("reg16+dma", seed, sink, stamps, blocks, panel);
+    printf("one wave per SIMD, 128x128 wave tiles, hand-placed k-loop (asm volatile):\n");
+    run_mono<0>("mono mfma", seed, sink, stamps, blocks, panel);
+    run_mono<1>("mono +reads", seed, sink, stamps, blocks, panel);
+    run_mono<2>("mono +dma", seed, sink, stamps, blocks, panel);
+    run_mono<3>("mono +barrier", seed, sink, stamps, blocks, panel);
     return 0;
 }
