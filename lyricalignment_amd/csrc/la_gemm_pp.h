@@ -943,5 +943,130 @@ __device__ __forceinline__ void mainloop_mono_asm(const T16 *A, int64_t lda, int
     LA_PP_BARRIER();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// "duo", hand-placed (LA_PP_DBG=81): the ping-pong kernel's geometry -- 8 waves = 2 (M) x 4 (N), 128x64 wave tiles, two waves
+// per SIMD -- with the k2 stages (K = 32, ring of 4) and the hand-placed instruction stream of mainloop_mono_asm instead of
+// the LOAD / COMPUTE role alternation: every wave runs the same program, per k-step its 32 MFMAs with the next k-step's 12
+// fragment reads (4 of W, 8 of A; j = 1, 3, .., 23), its 4 LDS-DMA pieces of stage s + 4 (j = 2, 10, 18, 26), one counted wait
+// (j = 28) and one barrier (j = 29) in their gaps.  The partner wave of the SIMD covers a wave's DMA-issue and barrier time
+// with its own MFMAs.  Accumulators in VGPRs (128) + two fragment sets (96): the epilogue is the ping-pong kernel's.
+//   Timeline as in mainloop_mono_asm (prefetch distance 4 on the ring of 4; vmcnt counts are per wave: 4 pieces per stage).
+template <typename T> struct MmaAsmV;
+template <> struct MmaAsmV<bf16_t> {
+    __device__ static __forceinline__ void run(const u32x4 &w, const u32x4 &a, f32x4 &acc) {
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(a));
+    }
+};
+template <> struct MmaAsmV<_Float16> {
+    __device__ static __forceinline__ void run(const u32x4 &w, const u32x4 &a, f32x4 &acc) {
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(a));
+    }
+};
+
+template <typename T16 = bf16_t>
+__device__ __forceinline__ void mainloop_duo_asm(const T16 *A, int64_t lda, int M, const T16 *W, int64_t ldw, int N, int K,
+                                                 int m0, int n0, unsigned char *lds, f32x4 (&acc)[8][4]) {
+    constexpr int STAGE = 32768, OPS = 16384, SB = 64;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int r = lane & 15, q = lane >> 4;
+    const int ns = K / 32;
+    const int64_t lda_b = lda * 2, ldw_b = ldw * 2;
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // this wave's 4 pieces of every stage: waves 0..3 carry the W image (rows 64 wave .. + 63), waves 4..7 the A image
+    const bool is_w = wave < 4;
+    const int pw = wave & 3;
+    unsigned voff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rt = (4 * pw + i) * 16 + (lane >> 2);
+        const int sw = ((lane & 3) ^ swz2(rt)) << 4;
+        int rg = (is_w ? n0 : m0) + rt;
+        const int lim = (is_w ? N : M) - 1;
+        rg = rg > lim ? lim : rg;
+        voff[i] = (unsigned)((int64_t)(rg - (is_w ? n0 : m0)) * (is_w ? ldw_b : lda_b)) + sw;
+    }
+    const unsigned char *src0 = is_w ? reinterpret_cast<const unsigned char *>(W) + (int64_t)n0 * ldw_b
+                                     : reinterpret_cast<const unsigned char *>(A) + (int64_t)m0 * lda_b;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_u32(lds));
+    const unsigned piece0 = lds0 + (is_w ? OPS : 0) + (4 * pw) * 1024;
+    auto issue1 = [&](const unsigned char *src, int slot, int i) __attribute__((always_inline)) {
+        glds16_so(voff[i], src, piece0 + slot * STAGE + i * 1024);
+    };
+    const unsigned fa_lo = lds0 + (unsigned)((wr * 128 + r) * SB + ((q ^ swz2(r)) << 4)), fa_hi = fa_lo + 2 * STAGE;
+    const unsigned fw_lo = lds0 + OPS + (unsigned)((wc * 64 + r) * SB + ((q ^ swz2(r)) << 4)), fw_hi = fw_lo + 2 * STAGE;
+
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) issue1(src0 + st * SB, st, i);
+    }
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // stages 0 and 1 landed; the 8 pieces of stages 2 and 3 may stay in flight
+    LA_PP_BARRIER();
+    u32x4 fa[2][8], fw[2][4];
+    ds_read128_asm<0 * 1024>(fw[0][0], fw_lo); ds_read128_asm<1 * 1024>(fw[0][1], fw_lo); ds_read128_asm<2 * 1024>(fw[0][2], fw_lo);
+    ds_read128_asm<3 * 1024>(fw[0][3], fw_lo);
+    ds_read128_asm<0 * 1024>(fa[0][0], fa_lo); ds_read128_asm<1 * 1024>(fa[0][1], fa_lo); ds_read128_asm<2 * 1024>(fa[0][2], fa_lo);
+    ds_read128_asm<3 * 1024>(fa[0][3], fa_lo); ds_read128_asm<4 * 1024>(fa[0][4], fa_lo); ds_read128_asm<5 * 1024>(fa[0][5], fa_lo);
+    ds_read128_asm<6 * 1024>(fa[0][6], fa_lo); ds_read128_asm<7 * 1024>(fa[0][7], fa_lo);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) fa[1][i] = fa[0][i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fw[1][i] = fw[0][i];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    LA_PP_BARRIER();
+
+    auto kstep = [&](int s, auto nxc, auto pfc, auto vmc, auto curc, auto slotc) __attribute__((always_inline)) {
+        constexpr bool NX = decltype(nxc)::value, PF = decltype(pfc)::value;
+        constexpr int VM = decltype(vmc)::value;
+        constexpr int CUR = decltype(curc)::value, SLOT = decltype(slotc)::value;
+        constexpr int SN = (SLOT + 1) & 3, SW = SLOT;
+        constexpr int OFFN = (SN & 1) * STAGE;
+        const unsigned fan = SN >= 2 ? fa_hi : fa_lo, fwn = SN >= 2 ? fw_hi : fw_lo;
+        const unsigned char *src = src0 + (int64_t)(s + 4) * SB;
+        static_for<0, 32>([&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value, mi = j >> 2, ni = j & 3;
+            MmaAsmV<T16>::run(fw[CUR][ni], fa[CUR][mi], acc[mi][ni]);
+            if constexpr (NX && (j & 1) == 1 && j / 2 < 12) {
+                constexpr int i = j / 2;                   // fragments of the next k-step: W 0..3, then A 0..7
+                if constexpr (i < 4) ds_read128_asm<OFFN + i * 1024>(fw[CUR ^ 1][i], fwn);
+                else ds_read128_asm<OFFN + (i - 4) * 1024>(fa[CUR ^ 1][i - 4], fan);
+            }
+            if constexpr (PF && (j & 7) == 2) issue1(src, SW, j >> 3);
+            if constexpr (j == 28) {
+                if constexpr (VM == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+                else if constexpr (VM == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            }
+            if constexpr (j == 29) asm volatile("s_barrier" ::: "memory");
+        });
+    };
+    typedef std::false_type F;
+    typedef std::true_type TT;
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    typedef std::integral_constant<int, 2> I2;
+    typedef std::integral_constant<int, 3> I3;
+    typedef std::integral_constant<int, 4> V4;
+    typedef std::integral_constant<int, 8> V8;
+    int s = 0;                              // ns is a multiple of 4, >= 8 (host check)
+    for (; s + 4 < ns; s += 4) {
+        kstep(s, TT{}, TT{}, V8{}, I0{}, I0{});
+        kstep(s + 1, TT{}, TT{}, V8{}, I1{}, I1{});
+        kstep(s + 2, TT{}, TT{}, V8{}, I0{}, I2{});
+        kstep(s + 3, TT{}, TT{}, V8{}, I1{}, I3{});
+    }
+    kstep(s, TT{}, F{}, V4{}, I0{}, I0{});
+    kstep(s + 1, TT{}, F{}, I0{}, I1{}, I1{});
+    kstep(s + 2, TT{}, F{}, I0{}, I0{}, I2{});
+    kstep(s + 3, F{}, F{}, I0{}, I1{}, I3{});
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    LA_PP_BARRIER();
+}
+
 }  // namespace gemm
 }  // namespace la

@@ -75,7 +75,9 @@ __global__ __launch_bounds__(C::THREADS, 2) void fc_lse_kernel(LseParams p) {
 }
 
 // The same reduction on the 256x256 ping-pong main loop (bf16, large row counts): a wave owns 128 rows x one 64-column strip.
-template <typename T16>
+// DUO: the hand-placed flat main loop (mainloop_duo_asm; K a multiple of 128, >= 256) instead of the quadrant ping-pong -- same
+// tile, same accumulation order, same bits.
+template <typename T16, bool DUO = false>
 __global__ __launch_bounds__(PP::THREADS, 2) void fc_lse_pp_kernel(LseParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
@@ -83,7 +85,8 @@ __global__ __launch_bounds__(PP::THREADS, 2) void fc_lse_pp_kernel(LseParams p) 
     const int tn = tc.tn;
     const int m0 = tc.tm * PP::TM, n0 = tn * PP::TN;
     f32x4 acc[8][4];
-    mainloop_pp<0, T16>(reinterpret_cast<const T16 *>(p.A), p.lda, p.M, reinterpret_cast<const T16 *>(p.W), p.K, p.N, p.K, m0, n0, lds, acc);
+    if constexpr (DUO) mainloop_duo_asm<T16>(reinterpret_cast<const T16 *>(p.A), p.lda, p.M, reinterpret_cast<const T16 *>(p.W), p.K, p.N, p.K, m0, n0, lds, acc);
+    else mainloop_pp<0, T16>(reinterpret_cast<const T16 *>(p.A), p.lda, p.M, reinterpret_cast<const T16 *>(p.W), p.K, p.N, p.K, m0, n0, lds, acc);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave >> 2, wc = wave & 3;
@@ -276,13 +279,20 @@ extern "C" int la_fc_emissions(int32_t dtype, const void *act, int64_t ld_act, c
             if (!attr_pp) {
                 LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fc_lse_pp_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, PP::LDS));
                 LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fc_lse_pp_kernel<la::f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, PP::LDS));
+                LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fc_lse_pp_kernel<bf16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, PP::LDS));
+                LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fc_lse_pp_kernel<la::f16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, PP::LDS));
                 attr_pp = true;
             }
             lp.tiles_m = la::cdiv(rows, PP::TM);
             lp.tiles_n = la::cdiv(vocab, PP::TN);
             lp.group = std::max(1, pick_group(in_dim, es, la::cdiv(vocab, BN)) / 2);
             la::TimerScope ts("fc_lse_bf16", stream);
-            if (dtype == LA_F16) hipLaunchKernelGGL(fc_lse_pp_kernel<la::f16_t>, dim3(lp.tiles_m * lp.tiles_n), dim3(PP::THREADS), PP::LDS, stream, lp);
+            const char *dbg_env = getenv("LA_PP_DBG");               // 99 forces the ping-pong loop (developer A/B, read per launch)
+            const bool duo = in_dim % 128 == 0 && in_dim >= 256 && !(dbg_env && atoi(dbg_env) == 99);
+            if (duo) {
+                if (dtype == LA_F16) hipLaunchKernelGGL((fc_lse_pp_kernel<la::f16_t, true>), dim3(lp.tiles_m * lp.tiles_n), dim3(PP::THREADS), PP::LDS, stream, lp);
+                else hipLaunchKernelGGL((fc_lse_pp_kernel<bf16_t, true>), dim3(lp.tiles_m * lp.tiles_n), dim3(PP::THREADS), PP::LDS, stream, lp);
+            } else if (dtype == LA_F16) hipLaunchKernelGGL(fc_lse_pp_kernel<la::f16_t>, dim3(lp.tiles_m * lp.tiles_n), dim3(PP::THREADS), PP::LDS, stream, lp);
             else hipLaunchKernelGGL(fc_lse_pp_kernel<bf16_t>, dim3(lp.tiles_m * lp.tiles_n), dim3(PP::THREADS), PP::LDS, stream, lp);
         } else if (dtype == LA_BF16 && rows >= 4096 && getenv("LA_GEMM_TILE") && atoi(getenv("LA_GEMM_TILE")) == 256) {
             if (!attr_bf16_big) {

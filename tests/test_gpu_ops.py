@@ -329,7 +329,7 @@ def test_colsum_deterministic():
     np.testing.assert_allclose(ht.colsum(v).cpu().double().numpy(), v.double().sum(0).cpu().numpy(), rtol=0, atol=3e-4)
 
 
-@pytest.mark.parametrize("variant", [16, 20, 24, 32, 40, 48, 64, 72, 73, 80])
+@pytest.mark.parametrize("variant", [16, 20, 24, 32, 40, 48, 64, 72, 73, 80, 81, 99])
 def test_gemm_main_loop_ab_variants_are_bit_identical(variant, monkeypatch):
     """The developer A/B main loops of the 256x256 kernel (LA_PP_DBG: 16 / 20 = one-k-step phases on a ring of 4 / 5 stages,
     24 = the same stages without the ping-pong, 32 / 40 / 48 = DMA placement probes of the default loop, 64 = 128x256 half tiles,
