@@ -963,7 +963,14 @@ template <> struct MmaAsmV<_Float16> {
     }
 };
 
-template <typename T16 = bf16_t>
+// PLACE (compile-time A/B, measured once and left in the source): where the reads / DMA pieces / wait / barrier sit among the
+// 32 MFMAs.  All four land within +-1 % of each other on the encoder's shapes -- the loop is LDS-bandwidth-bound (96 KiB of
+// fragment reads + 32 KiB of DMA writes per k-step = the 128 B per clock of a 1024-cycle k-step), not placement-bound.
+//   0: reads j = 1, 3, .., 23; DMA j = 2, 10, 18, 26; wait 28; barrier 29 (shipped)
+//   1: reads j = 0 .. 11 (one per MFMA, early); DMA j = 13, 17, 21, 25; wait 28; barrier 29
+//   2: reads j = 1, 3, .., 23; DMA j = 0, 2, 4, 6 (early burst); wait 28; barrier 29
+//   3: as 0 with the wait at 30 and the barrier at 31 (end of the k-step)
+template <typename T16 = bf16_t, int PLACE = 0>
 __device__ __forceinline__ void mainloop_duo_asm(const T16 *A, int64_t lda, int M, const T16 *W, int64_t ldw, int N, int K,
                                                  int m0, int n0, unsigned char *lds, f32x4 (&acc)[8][4]) {
     constexpr int STAGE = 32768, OPS = 16384, SB = 64;
@@ -1031,18 +1038,21 @@ __device__ __forceinline__ void mainloop_duo_asm(const T16 *A, int64_t lda, int 
         static_for<0, 32>([&](auto jc) __attribute__((always_inline)) {
             constexpr int j = decltype(jc)::value, mi = j >> 2, ni = j & 3;
             MmaAsmV<T16>::run(fw[CUR][ni], fa[CUR][mi], acc[mi][ni]);
-            if constexpr (NX && (j & 1) == 1 && j / 2 < 12) {
-                constexpr int i = j / 2;                   // fragments of the next k-step: W 0..3, then A 0..7
+            constexpr bool rd_here = PLACE == 1 ? j < 12 : ((j & 1) == 1 && j / 2 < 12);
+            if constexpr (NX && rd_here) {
+                constexpr int i = PLACE == 1 ? j : j / 2;  // fragments of the next k-step: W 0..3, then A 0..7
                 if constexpr (i < 4) ds_read128_asm<OFFN + i * 1024>(fw[CUR ^ 1][i], fwn);
                 else ds_read128_asm<OFFN + (i - 4) * 1024>(fa[CUR ^ 1][i - 4], fan);
             }
-            if constexpr (PF && (j & 7) == 2) issue1(src, SW, j >> 3);
-            if constexpr (j == 28) {
+            constexpr bool dma_here = PLACE == 1 ? (j >= 13 && j <= 25 && (j - 13) % 4 == 0) : PLACE == 2 ? (j < 8 && (j & 1) == 0) : (j & 7) == 2;
+            constexpr int dma_i = PLACE == 1 ? (j - 13) / 4 : PLACE == 2 ? j / 2 : j >> 3;
+            if constexpr (PF && dma_here) issue1(src, SW, dma_i);
+            if constexpr (j == (PLACE == 3 ? 30 : 28)) {
                 if constexpr (VM == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
                 else if constexpr (VM == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             }
-            if constexpr (j == 29) asm volatile("s_barrier" ::: "memory");
+            if constexpr (j == (PLACE == 3 ? 31 : 29)) asm volatile("s_barrier" ::: "memory");
         });
     };
     typedef std::false_type F;
