@@ -970,6 +970,8 @@ template <> struct MmaAsmV<_Float16> {
 //   1: reads j = 0 .. 11 (one per MFMA, early); DMA j = 13, 17, 21, 25; wait 28; barrier 29
 //   2: reads j = 1, 3, .., 23; DMA j = 0, 2, 4, 6 (early burst); wait 28; barrier 29
 //   3: as 0 with the wait at 30 and the barrier at 31 (end of the k-step)
+//   4: as 0 for the waves wr = 0; their SIMD partners (wr = 1) read at even j and issue their DMA pieces at j = 5, 13, 21, 26
+//      (so that the two waves of a SIMD are not held at an LDS-DMA issue together): 2.5 % SLOWER on the K = 1024 shapes
 template <typename T16 = bf16_t, int PLACE = 0>
 __device__ __forceinline__ void mainloop_duo_asm(const T16 *A, int64_t lda, int M, const T16 *W, int64_t ldw, int N, int K,
                                                  int m0, int n0, unsigned char *lds, f32x4 (&acc)[8][4]) {
@@ -1027,10 +1029,14 @@ __device__ __forceinline__ void mainloop_duo_asm(const T16 *A, int64_t lda, int 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     LA_PP_BARRIER();
 
-    auto kstep = [&](int s, auto nxc, auto pfc, auto vmc, auto curc, auto slotc) __attribute__((always_inline)) {
+    // STAG (PLACE == 4): the two waves of a SIMD (wave w and w + 4, i.e. wr = 0 / 1) carry their reads and DMA pieces in
+    // different MFMA gaps -- wr = 1 has its reads at even j and its DMA pieces four MFMAs later -- so that they are not
+    // both held at an LDS-DMA issue at the same moment
+    auto kstep = [&](int s, auto nxc, auto pfc, auto vmc, auto curc, auto slotc, auto stagc) __attribute__((always_inline)) {
         constexpr bool NX = decltype(nxc)::value, PF = decltype(pfc)::value;
         constexpr int VM = decltype(vmc)::value;
         constexpr int CUR = decltype(curc)::value, SLOT = decltype(slotc)::value;
+        constexpr bool STAG = decltype(stagc)::value;
         constexpr int SN = (SLOT + 1) & 3, SW = SLOT;
         constexpr int OFFN = (SN & 1) * STAGE;
         const unsigned fan = SN >= 2 ? fa_hi : fa_lo, fwn = SN >= 2 ? fw_hi : fw_lo;
@@ -1038,14 +1044,15 @@ __device__ __forceinline__ void mainloop_duo_asm(const T16 *A, int64_t lda, int 
         static_for<0, 32>([&](auto jc) __attribute__((always_inline)) {
             constexpr int j = decltype(jc)::value, mi = j >> 2, ni = j & 3;
             MmaAsmV<T16>::run(fw[CUR][ni], fa[CUR][mi], acc[mi][ni]);
-            constexpr bool rd_here = PLACE == 1 ? j < 12 : ((j & 1) == 1 && j / 2 < 12);
+            constexpr bool rd_here = PLACE == 1 ? j < 12 : STAG ? ((j & 1) == 0 && j / 2 < 12) : ((j & 1) == 1 && j / 2 < 12);
             if constexpr (NX && rd_here) {
                 constexpr int i = PLACE == 1 ? j : j / 2;  // fragments of the next k-step: W 0..3, then A 0..7
                 if constexpr (i < 4) ds_read128_asm<OFFN + i * 1024>(fw[CUR ^ 1][i], fwn);
                 else ds_read128_asm<OFFN + (i - 4) * 1024>(fa[CUR ^ 1][i - 4], fan);
             }
-            constexpr bool dma_here = PLACE == 1 ? (j >= 13 && j <= 25 && (j - 13) % 4 == 0) : PLACE == 2 ? (j < 8 && (j & 1) == 0) : (j & 7) == 2;
-            constexpr int dma_i = PLACE == 1 ? (j - 13) / 4 : PLACE == 2 ? j / 2 : j >> 3;
+            constexpr bool dma_here = PLACE == 1 ? (j >= 13 && j <= 25 && (j - 13) % 4 == 0) : PLACE == 2 ? (j < 8 && (j & 1) == 0)
+                                      : STAG ? (j == 5 || j == 13 || j == 21 || j == 26) : (j & 7) == 2;
+            constexpr int dma_i = PLACE == 1 ? (j - 13) / 4 : PLACE == 2 ? j / 2 : (STAG && j == 26) ? 3 : j >> 3;
             if constexpr (PF && dma_here) issue1(src, SW, dma_i);
             if constexpr (j == (PLACE == 3 ? 30 : 28)) {
                 if constexpr (VM == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
@@ -1063,17 +1070,24 @@ __device__ __forceinline__ void mainloop_duo_asm(const T16 *A, int64_t lda, int 
     typedef std::integral_constant<int, 3> I3;
     typedef std::integral_constant<int, 4> V4;
     typedef std::integral_constant<int, 8> V8;
-    int s = 0;                              // ns is a multiple of 4, >= 8 (host check)
-    for (; s + 4 < ns; s += 4) {
-        kstep(s, TT{}, TT{}, V8{}, I0{}, I0{});
-        kstep(s + 1, TT{}, TT{}, V8{}, I1{}, I1{});
-        kstep(s + 2, TT{}, TT{}, V8{}, I0{}, I2{});
-        kstep(s + 3, TT{}, TT{}, V8{}, I1{}, I3{});
+    auto run = [&](auto stagc) __attribute__((always_inline)) {
+        int s = 0;                              // ns is a multiple of 4, >= 8 (host check)
+        for (; s + 4 < ns; s += 4) {
+            kstep(s, TT{}, TT{}, V8{}, I0{}, I0{}, stagc);
+            kstep(s + 1, TT{}, TT{}, V8{}, I1{}, I1{}, stagc);
+            kstep(s + 2, TT{}, TT{}, V8{}, I0{}, I2{}, stagc);
+            kstep(s + 3, TT{}, TT{}, V8{}, I1{}, I3{}, stagc);
+        }
+        kstep(s, TT{}, F{}, V4{}, I0{}, I0{}, stagc);
+        kstep(s + 1, TT{}, F{}, I0{}, I1{}, I1{}, stagc);
+        kstep(s + 2, TT{}, F{}, I0{}, I0{}, I2{}, stagc);
+        kstep(s + 3, F{}, F{}, I0{}, I1{}, I3{}, stagc);
+    };
+    if constexpr (PLACE == 4) {
+        if (wr == 0) run(F{}); else run(TT{});          // wave-uniform: both arms execute the same number of barriers
+    } else {
+        run(F{});
     }
-    kstep(s, TT{}, F{}, V4{}, I0{}, I0{});
-    kstep(s + 1, TT{}, F{}, I0{}, I1{}, I1{});
-    kstep(s + 2, TT{}, F{}, I0{}, I0{}, I2{});
-    kstep(s + 3, F{}, F{}, I0{}, I1{}, I3{});
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     LA_PP_BARRIER();
 }
