@@ -264,20 +264,22 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_bf16_kernel(AttnParams p
         auto exponentials = [&](float m, auto whichc) -> float {
             constexpr int lo = decltype(whichc)::value == 2 ? 0 : decltype(whichc)::value;
             constexpr int hi = decltype(whichc)::value == 2 ? 2 : lo + 1;
-            f32x2 psum2 = {0.f, 0.f};
-            const f32x2 l2e2 = {kLog2e, kLog2e}, mneg2 = {-m, -m};
+            // plain v_fma_f32 / v_add_f32, two independent partial sums -- NOT packed f32: v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32
+            // do not run beside the matrix pipe at all (tools/valu_mfma_overlap.hip: 0 % of a block of them hides under MFMAs,
+            // 45-70 % of any other vector instruction does) and cost 1.8x a plain instruction for 2x the work; measured here:
+            // 344 us plain against 349 us packed
+            float ps0 = 0.f, ps1 = 0.f;
 #pragma unroll
             for (int sub = lo; sub < hi; ++sub)
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
-                    const f32x2 sv = {s[sub][r], s[sub][r + 1]};
-                    const f32x2 a2 = __builtin_elementwise_fma(sv, l2e2, mneg2);
-                    const f32x2 pv = (KO & 1) ? a2 : f32x2{__builtin_amdgcn_exp2f(a2.x), __builtin_amdgcn_exp2f(a2.y)};
-                    s[sub][r] = pv.x;
-                    s[sub][r + 1] = pv.y;
-                    if constexpr (!MSUM) psum2 += pv;
+                    const float a0 = fmaf(s[sub][r], kLog2e, -m), a1 = fmaf(s[sub][r + 1], kLog2e, -m);
+                    const float p0 = (KO & 1) ? a0 : __builtin_amdgcn_exp2f(a0), p1 = (KO & 1) ? a1 : __builtin_amdgcn_exp2f(a1);
+                    s[sub][r] = p0;
+                    s[sub][r + 1] = p1;
+                    if constexpr (!MSUM) { ps0 += p0; ps1 += p1; }
                 }
-            return psum2.x + psum2.y;
+            return ps0 + ps1;
         };
         auto tile_max = [&](auto whichc) -> float {
             constexpr int lo = decltype(whichc)::value == 2 ? 0 : decltype(whichc)::value;
@@ -379,7 +381,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_bf16_kernel(AttnParams p
             pv_sub(Sub1{});
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if constexpr (!(KO & 32)) __syncthreads();       // (KO 32: the tile loop without its barrier -- timing only)
     };
     for (int t = 0; t < nkv; t += 2) {
         tile(t, std::integral_constant<int, 0>{});
@@ -560,8 +562,10 @@ static int attention_launch(int dtype, AttnParams p, int batch, hipStream_t stre
                 LA_KO_CASE(1) LA_KO_CASE(2) LA_KO_CASE(4) LA_KO_CASE(6) LA_KO_CASE(8) LA_KO_CASE(14) LA_KO_CASE(16) LA_KO_CASE(17)
                 LA_KO_CASE(7) LA_KO_CASE(15) LA_KO_CASE(30)
 #undef LA_KO_CASE
-#define LA_KO_OPT(n, ko) case n: hipLaunchKernelGGL((attention_bf16_kernel<bf16_t, 4, false, ko, true>), grid, block, 0, stream, p); break;
-                LA_KO_OPT(100, 0) LA_KO_OPT(101, 1) LA_KO_OPT(106, 6) LA_KO_OPT(108, 8) LA_KO_OPT(114, 14) LA_KO_OPT(116, 16) LA_KO_OPT(130, 30)
+            // LA_ATTN_LDSPAD=<bytes> of unused dynamic LDS per workgroup: 0 -> 4 workgroups per CU, 20480 -> 3, 49152 -> 2, 102400 -> 1
+#define LA_KO_OPT(n, ko) case n: { const char *pad = getenv("LA_ATTN_LDSPAD"); \
+        hipLaunchKernelGGL((attention_bf16_kernel<bf16_t, 4, false, ko, true>), grid, block, pad ? atoi(pad) : 0, stream, p); } break;
+                LA_KO_OPT(132, 32) LA_KO_OPT(140, 40) LA_KO_OPT(100, 0) LA_KO_OPT(101, 1) LA_KO_OPT(106, 6) LA_KO_OPT(108, 8) LA_KO_OPT(114, 14) LA_KO_OPT(116, 16) LA_KO_OPT(130, 30)
 #undef LA_KO_OPT
 #define LA_KO_PRIO(n, pr) case n: hipLaunchKernelGGL((attention_bf16_kernel<bf16_t, 4, false, 0, true, pr>), grid, block, 0, stream, p); break;
                 LA_KO_PRIO(201, 1) LA_KO_PRIO(202, 2) LA_KO_PRIO(203, 3)

@@ -98,7 +98,7 @@ def bench_attn(iters):
     for rd in range(3):
         for nw, msum, thr in (("4", False, "0"), ("4", False, "8"), ("4", False, "opt"), ("8", False, "8"), ("4", True, "8")):
             os.environ["LA_ATTN_NW"] = nw
-            if thr == "opt":                       # the default: optimistic softmax, no per-tile maximum
+            if thr.startswith("opt"):              # the default: optimistic softmax, no per-tile maximum
                 os.environ.pop("LA_ATTN_OPT", None)
             else:
                 os.environ["LA_ATTN_OPT"] = "0"
@@ -126,7 +126,7 @@ def bench_attn_knockout(iters):
     names = {0: "full", 1: "no exp", 2: "no V reads", 4: "no K reads", 6: "no K/V reads", 8: "no staging", 14: "no LDS traffic at all",
              16: "no MFMA", 17: "no MFMA, no exp", 7: "no exp, no K/V reads", 15: "no exp, no LDS traffic", 30: "no MFMA, no LDS traffic",
              100: "optimistic softmax, full", 101: "optimistic, no exp", 106: "optimistic, no K/V reads", 108: "optimistic, no staging",
-             114: "optimistic, no LDS traffic", 116: "optimistic, no MFMA", 130: "optimistic, no MFMA, no LDS traffic",
+             132: "optimistic, no tile barrier", 140: "optimistic, no tile barrier, no staging", 114: "optimistic, no LDS traffic", 116: "optimistic, no MFMA", 130: "optimistic, no MFMA, no LDS traffic",
              201: "optimistic, S phase at raised priority", 202: "optimistic, S and PV raised", 203: "optimistic, softmax raised"}
     for rd in range(2):
         for ko, nm in names.items():
@@ -134,6 +134,21 @@ def bench_attn_knockout(iters):
             med, mn = timeit(lambda: ops.attention(qkv, B, T, H, out=out), iters)
             print(f"attention knockout {ko:2d} ({nm}): median {med*1e3:.1f} us  min {mn*1e3:.1f} us", flush=True)
     os.environ.pop("LA_ATTN_KO", None)
+
+
+def bench_attn_occupancy(iters):
+    """Diagnostic build (-DLA_ATTN_KNOCKOUT): the shipped attention kernel at 4 / 3 / 2 / 1 workgroups (= waves per SIMD) per CU,
+    forced by unused dynamic LDS."""
+    B, T, H = 32, 1500, 16
+    qkv = rnd(B * T, 3 * H * 64)
+    qkv[:, : H * 64] *= 0.125
+    out = torch.empty(B * T, H * 64, device="cuda", dtype=torch.bfloat16)
+    os.environ["LA_ATTN_KO"] = "100"
+    for pad, occ in ((0, 4), (20480, 3), (49152, 2), (102400, 1)):
+        os.environ["LA_ATTN_LDSPAD"] = str(pad)
+        med, mn = timeit(lambda: ops.attention(qkv, B, T, H, out=out), iters)
+        print(f"attention at {occ} waves per SIMD: median {med*1e3:.1f} us  min {mn*1e3:.1f} us", flush=True)
+    os.environ.pop("LA_ATTN_KO", None); os.environ.pop("LA_ATTN_LDSPAD", None)
 
 
 def bench_gru(iters):
@@ -170,5 +185,6 @@ if __name__ == "__main__":
     if a.what in ("gemm", "all"): bench_gemm(a.iters)
     if a.what in ("attn", "all"): bench_attn(a.iters)
     if a.what == "attn_ko": bench_attn_knockout(a.iters)
+    if a.what == "attn_occ": bench_attn_occupancy(a.iters)
     if a.what in ("gru", "all"): bench_gru(a.iters)
     if a.what in ("fc", "all"): bench_fc(a.iters)
