@@ -163,6 +163,44 @@ def test_attention_online_rescale_spike():
         np.testing.assert_allclose(out.double().numpy(), ref.numpy(), rtol=0, atol=tol)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_gemm_hand_placed_loop_matches_ping_pong_in_every_epilogue_mode(dtype, monkeypatch):
+    """The default main loop of the 256x256 kernel (hand-placed flat stream, K % 128 == 0) against the quadrant ping-pong
+    (LA_PP_DBG=99) -- same bits -- in the epilogue modes the encoder uses beyond the plain ones: the LayerNorm-consumer epilogue
+    (row statistics + column sums), the producer epilogue (f32 result + 16-bit copy + per-segment statistics), a batched launch,
+    ragged last row / column tiles, both 16-bit operand types, K = 256 (two ring turns: prologue + peeled tail only) and K = 1280."""
+    from lyricalignment_amd import ops
+    for M, N, K in ((256 * 24 + 72, 2048 + 128, 1280), (256 * 16, 3072, 256)):       # >= 192 tiles: the 256x256 kernel's domain
+        a = _rand(M, K, seed=191).to(dtype).cuda()
+        w = _rand(N, K, seed=192, scale=K ** -0.5).to(dtype).cuda()
+        bias = _rand(N, seed=193).cuda()
+        res = _rand(M, N, seed=194).cuda()
+        stats = torch.stack([_rand(M, seed=195) * 0.1, _rand(M, seed=196).abs() + 0.5], dim=1).contiguous().cuda()
+        csum = _rand(N, seed=197).cuda()
+
+        def run_all():
+            outs = [ops.gemm(a, w, bias=bias, gelu=True, ln_stats=stats, ln_csum=csum).clone()]
+            o32 = torch.empty(M, N, device="cuda")
+            o16 = torch.empty(M, N, device="cuda", dtype=dtype)
+            part = torch.zeros(N // 64, M, 2, device="cuda")
+            ops.gemm(a, w, o32, bias=bias, residual=res, out_f32=True, out16=o16, ln_part=part)
+            outs += [o32.clone(), o16.clone(), part.clone()]
+            ab = a[: (M // 2 // 16) * 16 * 2].reshape(2, -1, K)              # two batch slots of equal row count
+            mb = ab.shape[1]
+            ob = torch.empty(2, mb, N, device="cuda", dtype=dtype)
+            ops.gemm(ab.reshape(-1, K), w, ob.reshape(-1, N), bias=bias, M=mb, lda=K, batch=2, stride_a=mb * K, stride_c=mb * N)
+            outs.append(ob.clone())
+            return outs
+
+        monkeypatch.delenv("LA_PP_DBG", raising=False)
+        new = run_all()
+        monkeypatch.setenv("LA_PP_DBG", "99")
+        old = run_all()
+        for x, y in zip(new, old):
+            assert torch.equal(x, y)
+        monkeypatch.delenv("LA_PP_DBG", raising=False)
+
+
 @pytest.mark.parametrize("B,T,H", [(1, 1, 64), (3, 7, 64), (32, 50, 128), (40, 23, 384), (2, 300, 384), (20, 11, 128)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_gru_layer(B, T, H, dtype):
