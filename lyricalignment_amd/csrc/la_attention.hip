@@ -553,8 +553,12 @@ static int attention_launch(int dtype, AttnParams p, int batch, hipStream_t stre
         const char *nw_env = getenv("LA_ATTN_NW");        // developer A/B (read per launch): 8 = 256-query workgroups
         if (nw_env && atoi(nw_env) == 8 && p.q_len >= 256) {
             const dim3 grid8(la::cdiv(p.q_len, 256) * p.n_head * batch), block8(512);
-            if (dtype == LA_F16) hipLaunchKernelGGL((attention_bf16_kernel<la::f16_t, 8>), grid8, block8, 0, stream, p);
-            else hipLaunchKernelGGL((attention_bf16_kernel<bf16_t, 8>), grid8, block8, 0, stream, p);
+            const char *opt8 = getenv("LA_ATTN_OPT");
+            if (opt8 && atoi(opt8) == 0) {
+                if (dtype == LA_F16) hipLaunchKernelGGL((attention_bf16_kernel<la::f16_t, 8>), grid8, block8, 0, stream, p);
+                else hipLaunchKernelGGL((attention_bf16_kernel<bf16_t, 8>), grid8, block8, 0, stream, p);
+            } else if (dtype == LA_F16) hipLaunchKernelGGL((attention_bf16_kernel<la::f16_t, 8, false, 0, true>), grid8, block8, 0, stream, p);
+            else hipLaunchKernelGGL((attention_bf16_kernel<bf16_t, 8, false, 0, true>), grid8, block8, 0, stream, p);
 #ifdef LA_ATTN_KNOCKOUT
         } else if (const char *ko = getenv("LA_ATTN_KO")) {  // diagnostic build: parts of the tile loop left out (bf16 only)
             switch (atoi(ko)) {

@@ -96,7 +96,7 @@ def bench_attn(iters):
     fl = 4.0 * T * T * H * 64 * B
     ref = None
     for rd in range(3):
-        for nw, msum, thr in (("4", False, "0"), ("4", False, "8"), ("4", False, "opt"), ("8", False, "8"), ("4", True, "8")):
+        for nw, msum, thr in (("4", False, "0"), ("4", False, "8"), ("4", False, "opt"), ("8", False, "opt"), ("8", False, "8"), ("4", True, "8")):
             os.environ["LA_ATTN_NW"] = nw
             if thr.startswith("opt"):              # the default: optimistic softmax, no per-tile maximum
                 os.environ.pop("LA_ATTN_OPT", None)
