@@ -147,23 +147,74 @@ def dims_for(name: str) -> ModelDimensions:
     return ModelDimensions(n_audio_state=d, n_audio_head=h, n_audio_layer=l, n_text_state=d, n_text_head=h, n_text_layer=l)
 
 
+class HostIndependentRng:
+    """Synthetic-weight generator whose values are the same BITS on every host.
+
+    torch.randn's CPU kernel is vectorised per CPU capability (AVX2 / AVX512 Box-Muller paths whose log / cos differ in the
+    last place, and whose fill order differs), and nn.Module default initialisation draws from the unseeded global
+    generator: "seed 0" weights differed between the build container and the GPU boxes (tools/weights_fingerprint.py,
+    profiles/r3_selfcheck_diagnosis.md).  Here every value is an integer function of the raw PCG64 stream
+    (numpy BitGenerator.random_raw: a documented, platform-independent sequence) followed by ONE float32 multiply:
+    normal()  = (sum of four uint16 - 131070) / sqrt((65536^2 - 1) / 3)   Irwin-Hall(4): mean 0, variance 1, |x| <= 3.46
+    uniform() = (uint32 >> 8) * 2^-23 - 1                                  uniform on [-1, 1)"""
+
+    _NORM = np.float32(1.0 / np.sqrt((65536.0 ** 2 - 1.0) / 3.0))
+
+    def __init__(self, seed: int):
+        self._bg = np.random.PCG64(int(seed))
+
+    def normal(self, shape) -> torch.Tensor:
+        n = int(np.prod(shape)) if len(shape) else 1
+        x = torch.from_numpy(self._bg.random_raw(n).view(np.int64))
+        m = 0x0000FFFF0000FFFF                                  # lane sums in integer arithmetic (exact, thread-count independent)
+        x = (x & m) + ((x >> 16) & m)
+        k = ((x & 0xFFFFFFFF) + (x >> 32) - 131070).to(torch.float32)
+        return (k * float(self._NORM)).reshape(tuple(shape))
+
+    def uniform(self, shape) -> torch.Tensor:
+        n = int(np.prod(shape)) if len(shape) else 1
+        raw = self._bg.random_raw((n + 1) // 2).view(np.uint32)[:n]
+        return torch.from_numpy(((raw >> 8).astype(np.float32) * np.float32(2.0 ** -23) - np.float32(1.0)).reshape(tuple(shape)))
+
+
 def build_model(name: str = "tiny", seed: int = 0, with_decoder: bool = False, std: float = 0.02,
                 dims: Optional[ModelDimensions] = None) -> Whisper:
-    """Random-init weights of the named architecture (no checkpoints are reachable offline)."""
+    """Random-init weights of the named architecture (no checkpoints are reachable offline); bit-identical on every host
+    (HostIndependentRng), so a bench or test that names a seed means the same model on the build container, the
+    builder's GPU box and the driver's."""
     dims = dims or dims_for(name)
-    model = Whisper(dims, with_decoder=with_decoder)
-    g = torch.Generator().manual_seed(seed)
+    with torch.device("meta"):                      # every parameter is assigned below: skip nn.Module's own initialisation
+        model = Whisper(dims, with_decoder=with_decoder)
+    model = model.to_empty(device="cpu")
+    with torch.no_grad():
+        model.encoder.positional_embedding.copy_(sinusoids(dims.n_audio_ctx, dims.n_audio_state))
+    g = HostIndependentRng(seed)
     with torch.no_grad():
         for n, p in model.named_parameters():
             if n.endswith("_ln.weight") or n.endswith("ln_post.weight") or n.endswith("ln.weight"):
-                p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g))
+                p.copy_(1.0 + 0.1 * g.normal(p.shape))
             elif "ln" in n.split(".")[-2] and n.endswith("bias"):
-                p.copy_(0.1 * torch.randn(p.shape, generator=g))
+                p.copy_(0.1 * g.normal(p.shape))
             elif n.startswith("encoder.conv1.weight"):
-                p.copy_(0.05 * torch.randn(p.shape, generator=g))
+                p.copy_(0.05 * g.normal(p.shape))
             else:
-                p.copy_(std * torch.randn(p.shape, generator=g))
+                p.copy_(std * g.normal(p.shape))
     return model
+
+
+def init_align_head(model, seed: int = 7, fc_scale: float = 12.0, rnn_scale: float = 1.5) -> None:
+    """Synthetic weights for AlignModel.align_rnn (module/align_model.py:11-40), bit-identical on every host: uniform on
+    +-scale / sqrt(hidden), GRU matrices and biases with rnn_scale, the output Linear's weight with fc_scale.  fc_scale ~ 12
+    gives frame posteriors as peaked as a trained head's (|logit| <= ~20); nn.Module's default initialisation
+    (fc_scale ~ 0.6) leaves all 21129 classes within +-0.8 of each other, and on such near-flat emissions the best lattice
+    path is decided by differences far below the 16-bit modes' rounding -- boundaries of a flat head are not comparable
+    between precisions (tests/test_gpu_parity_full.py docstring; profiles/r3_selfcheck_diagnosis.md)."""
+    g = HostIndependentRng(seed)
+    hidden = model.align_rnn.rnn.hidden_size
+    with torch.no_grad():
+        for n, p in model.align_rnn.named_parameters():
+            s = fc_scale if n.startswith("fc.weight") else rnn_scale
+            p.copy_(g.uniform(p.shape) * (s / hidden ** 0.5))
 
 
 def load_model(name_or_path: str, device: str = "cuda", **_) -> Whisper:

@@ -1,0 +1,130 @@
+"""The bench's OWN configuration against the oracle (BASELINE configs[1]: Whisper-medium, bfloat16, 32 x 30 s clips, the
+LayerNorm-folded 256x256 GEMMs, the head over 64 clips, two streams) -- round-2 verdict item 1.
+
+BENCH_r02's self-check read 1.087 s on the driver's box and 0.0 on the builder's.  Diagnosis (profiles/r3_selfcheck_diagnosis.md):
+the bench's head came from nn.Module's default initialisation out of the UNSEEDED global generator, whose stream differs from
+host to host (tools/weights_fingerprint.py), and a default-initialised head on featureless noise gives near-flat posteriors:
+the best lattice path then leads the runner-up by ~1e-4 of a total of ~1100, so which boundaries the bf16 path and the fp32
+oracle agree on was a draw per host.  The device side is deterministic: every pipeline shape / warm-up count / repeat gives
+bit-identical frames (first test below).  Since round 3 bench.py's weights and inputs are host-independent bits, the head is
+peaked and the labels are the head's own top classes; these tests hold that configuration to the oracle
+(utils/alignment.py:121-188, inference_alignment.py:159-177)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+N_ORACLE_CLIPS = 4
+
+
+@pytest.fixture(scope="module")
+def headline():
+    import bench
+    from lyricalignment_amd import whisper_compat as wc
+    from lyricalignment_amd.module.align_model import AlignModel
+    from oracle import alignment_oracle as ao, model_oracle as mo
+    ao.build()
+    dims = wc.dims_for(bench.MODEL)
+    model = AlignModel(wc.build_model(bench.MODEL, seed=0), embed_dim=dims.n_audio_state, hidden_dim=bench.HIDDEN, output_dim=bench.VOCAB,
+                       device="cuda:0", compute_dtype=torch.bfloat16).eval()
+    wc.init_align_head(model, seed=7, fc_scale=bench.HEAD_FC_SCALE)
+    with torch.no_grad():
+        eng = model.engine()
+    device = torch.device("cuda", 0)
+    mel, labels, n_labels, Ls = bench.build_inputs(device, eng=eng)
+    with torch.no_grad():
+        ref = eng.align_mel(mel, labels, n_labels, n_frames=bench.T_FRAMES, use_ctc=True)
+    torch.cuda.synchronize()
+    assert int((ref[3] != 0).sum()) == 0
+    # the fp32 oracle's own end-to-end result on the first clips (one ~2.5 s CPU pass each)
+    torch.set_num_threads(bench.usable_cores())
+    p = {"encoder." + k: v.detach().float().cpu() for k, v in model.whisper_model.encoder.state_dict().items()}
+    p.update({"align_rnn." + k: v.detach().float().cpu() for k, v in model.align_rnn.state_dict().items()})
+    oracle = []
+    for b in range(N_ORACLE_CLIPS):
+        L = int(Ls[b])
+        with torch.no_grad():
+            logits = mo.gru_head_forward(p, mo.encoder_forward(p, mel[b:b + 1].cpu(), n_head=dims.n_audio_head))
+            lp, ls = mo.emission_prep_ctc(logits)
+            secs = ao.perform_viterbi_ctc(logits, labels[b:b + 1, :L].cpu().long())[0]
+        oracle.append(dict(L=L, lp=lp[0], ls=ls[0], on=np.array([s[0] for s in secs]), off=np.array([s[1] for s in secs])))
+    return dict(bench=bench, eng=eng, mel=mel, labels=labels, n_labels=n_labels, Ls=Ls, oracle=oracle,
+                ref=[t.cpu().numpy().copy() for t in ref[:2]])
+
+
+def _run_pipeline(h, submits, head_group=2):
+    """submits: list of batch counts, one drain() after each -> list of (onset, offset) numpy arrays, one per submitted batch."""
+    from lyricalignment_amd.engine import PipelinedAligner
+    bench = h["bench"]
+    pipe = PipelinedAligner(h["eng"], head_group=head_group)
+    got = []
+    with torch.no_grad():
+        for n in submits:
+            outs = [pipe.submit(h["mel"], h["labels"], h["n_labels"], n_frames=bench.T_FRAMES, use_ctc=True) for _ in range(n)]
+            pipe.drain()
+            torch.cuda.synchronize()
+            got += [(o[0].cpu().numpy(), o[1].cpu().numpy(), o[3].cpu().numpy()) for o in outs]
+    return got
+
+
+def test_pipeline_with_partial_flush_is_bit_identical_to_single_stream(headline):
+    """5 + 4 submits through PipelinedAligner(head_group=2): head launch sets of 64, 64, 32 (partial flush at the drain), 64, 64
+    clips on stream H beside the next encoders on stream E.  Every batch's frames == the single-stream align_mel result: the
+    pipeline changes which kernels are in flight together, never a result (the driver's --warmup 5 --steps 20 shape)."""
+    mask = np.arange(headline["labels"].shape[1])[None, :] < headline["Ls"][:, None]
+    got = _run_pipeline(headline, [5, 4])
+    assert len(got) == 9
+    for i, (on, off, st) in enumerate(got):
+        assert (st == 0).all()
+        assert (on[mask] == headline["ref"][0][mask]).all() and (off[mask] == headline["ref"][1][mask]).all(), f"batch {i} differs"
+
+
+def test_headline_batch_boundaries_and_emissions_against_oracle(headline):
+    """The first clips of the B = 32 bf16 batch against alignment_oracle.perform_viterbi_ctc(oracle logits): emissions within
+    the bf16 bounds calibrated at full depth (tests/test_gpu_parity_full.py), boundary MAE within bench.py's self-check
+    tolerance (one frame) and >= 95 % of the boundaries equal."""
+    from lyricalignment_amd import _lib
+    bench, eng = headline["bench"], headline["eng"]
+    n = N_ORACLE_CLIPS
+    with torch.no_grad():
+        feats = eng.encode(headline["mel"])
+        em = eng.emissions(feats, bench.BATCH, bench.T_FRAMES, bench.T_FRAMES, headline["labels"], headline["n_labels"], _lib.LA_VARIANT_CTC)[:n].cpu()
+    on_err, off_err, em_err = [], [], []
+    for b, o in enumerate(headline["oracle"]):
+        L = o["L"]
+        idx = headline["labels"][b, :L].cpu().long() - 1
+        em_err.append(torch.cat([(em[b, :, 1:1 + L] - o["lp"][:, idx]).abs().flatten(), (em[b, :, 0] - o["ls"][:, 0]).abs()]))
+        on_err.append(np.abs(headline["ref"][0][b, :L] * 0.02 - o["on"]))
+        off_err.append(np.abs(headline["ref"][1][b, :L] * 0.02 - o["off"]))
+    em_err = torch.cat(em_err)
+    on_err, off_err = np.concatenate(on_err), np.concatenate(off_err)
+    both = np.concatenate([on_err, off_err])
+    print(f"bf16 B=32: emission error mean {float(em_err.mean()):.4f} max {float(em_err.max()):.4f}; boundaries equal "
+          f"{float((both < 1e-9).mean()):.3f}, onset MAE {on_err.mean():.4f} s, max deviation {both.max():.2f} s")
+    assert float(em_err.mean()) < 0.06 and float(em_err.max()) < 0.35
+    assert on_err.mean() <= bench.SELFCHECK_TOL_S and off_err.mean() <= bench.SELFCHECK_TOL_S
+    assert float((both < 1e-9).mean()) >= 0.95
+
+
+def test_headline_pipeline_repeats_beside_a_side_stream_load_are_bit_identical(headline):
+    """Ten runs of the two-stream pipeline while a third stream keeps the chip busy with unrelated GEMMs (different CU
+    availability, different interleaving of the persistent GRU recurrence with the encoder's tiles): frames bit-identical
+    every time -- a result that moved with timing would be a race."""
+    from lyricalignment_amd import ops
+    mask = np.arange(headline["labels"].shape[1])[None, :] < headline["Ls"][:, None]
+    side = torch.cuda.Stream()
+    a = torch.randn((8192, 2048), device="cuda").to(torch.bfloat16)
+    w = torch.randn((2048, 2048), device="cuda").to(torch.bfloat16)
+    c = torch.empty((8192, 2048), dtype=torch.bfloat16, device="cuda")
+    torch.cuda.synchronize()
+    for rep in range(10):
+        with torch.cuda.stream(side):
+            for _ in range(40 + 10 * rep):                    # a different amount of foreign work each time
+                ops.gemm(a, w, c)
+        got = _run_pipeline(headline, [3], head_group=2 if rep % 2 == 0 else 1)
+        side.synchronize()
+        for on, off, st in got:
+            assert (st == 0).all()
+            assert (on[mask] == headline["ref"][0][mask]).all() and (off[mask] == headline["ref"][1][mask]).all(), f"repeat {rep} differs"
+    headline["eng"].check_gru()
