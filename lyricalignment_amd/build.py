@@ -9,7 +9,10 @@ from __future__ import annotations
 
 import concurrent.futures
 import glob
+import hashlib
+import json
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -22,6 +25,16 @@ ARCH = "gfx950"
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
             "-fno-fast-math", "-ffp-contract=on"] + os.environ.get("LA_EXTRA_CXXFLAGS", "").split()
+# every object is stamped with the flags it was compiled with: an A/B build (LA_EXTRA_CXXFLAGS=-D...) never reuses a stale one
+FLAGS_TAG = hashlib.sha256(" ".join([HIPCC] + CXXFLAGS).encode()).hexdigest()[:12]
+
+# Kernels whose main loop is a hand-placed `asm volatile` stream (la_gemm_pp.h): the fragment registers are written by one asm
+# statement and waited for in another ~27 MFMAs later, so a register-allocator spill or copy between the two would read stale
+# data without any error.  The build fails if one of them has spilled registers or scratch (round-2 advisor finding: the
+# LayerNorm-consumer instantiations sat at 256 VGPRs with 107-127 spills).  The one-wave-per-SIMD experiment (LA_PP_DBG=73) is
+# only reported: its spills are in the hipcc-scheduled epilogue, after the loop's last wait.
+NO_SPILL_KERNELS = re.compile(r"gemm_pp_kernel|fc_lse_pp_kernel")
+REPORT_KERNELS = re.compile(r"gemm_mono_kernel")
 
 
 def _sources():
@@ -32,17 +45,59 @@ def _headers():
     return glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
 
 
+def _parse_resource_usage(stderr: str) -> dict:
+    """-Rpass-analysis=kernel-resource-usage remarks -> {mangled kernel name: {"VGPRs": n, "VGPRs Spill": n, ...}}."""
+    usage, cur = {}, None
+    for line in stderr.splitlines():
+        m = re.search(r"remark: Function Name: (\S+)", line)
+        if m:
+            cur = usage.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+([A-Za-z \[\]/]+): (\S+) \[-Rpass-analysis", line)
+        if m and cur is not None:
+            try:
+                cur[m.group(1).strip()] = int(m.group(2))
+            except ValueError:
+                cur[m.group(1).strip()] = m.group(2)
+    return usage
+
+
+def check_spills(usage: dict, src: str) -> None:
+    bad = []
+    for name, u in usage.items():
+        spilled = u.get("VGPRs Spill", 0) or u.get("SGPRs Spill", 0) or u.get("ScratchSize [bytes/lane]", 0)
+        if spilled and NO_SPILL_KERNELS.search(name):
+            bad.append(f"{name}: VGPRs {u.get('VGPRs')}, spilled {u.get('VGPRs Spill')}, scratch {u.get('ScratchSize [bytes/lane]')} B/lane")
+        elif spilled and REPORT_KERNELS.search(name):
+            sys.stderr.write(f"[build] note: {name} spills {u.get('VGPRs Spill')} VGPRs (developer variant, not gated)\n")
+    if bad:
+        raise RuntimeError(f"{os.path.basename(src)}: hand-placed-loop kernels must not spill (stale-fragment hazard):\n  " + "\n  ".join(bad))
+
+
 def _compile(src: str, force: bool) -> str:
     obj = os.path.join(OBJ, os.path.basename(src) + ".o")
+    meta = obj + ".json"                                  # flags tag + per-kernel register usage of the compile that made obj
     newest = max([os.path.getmtime(src)] + [os.path.getmtime(h) for h in _headers()])
-    if not force and os.path.exists(obj) and os.path.getmtime(obj) >= newest:
-        return obj
-    cmd = [HIPCC, *CXXFLAGS, "-x", "hip", "-c", src, "-o", obj]
+    if not force and os.path.exists(obj) and os.path.exists(meta) and os.path.getmtime(obj) >= newest:
+        try:
+            with open(meta) as f:
+                m = json.load(f)
+            if m.get("flags") == FLAGS_TAG:
+                check_spills(m.get("usage", {}), src)
+                return obj
+        except (OSError, ValueError):
+            pass
+    cmd = [HIPCC, *CXXFLAGS, "-Rpass-analysis=kernel-resource-usage", "-x", "hip", "-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
-    if r.stderr.strip():
-        sys.stderr.write(r.stderr)
+    usage = _parse_resource_usage(r.stderr)
+    rest = "\n".join(l for l in r.stderr.splitlines() if "-Rpass-analysis=kernel-resource-usage" not in l and not re.match(r"^\s*(\d+ \||\|)", l))
+    if rest.strip():
+        sys.stderr.write(rest + "\n")
+    with open(meta, "w") as f:
+        json.dump({"flags": FLAGS_TAG, "usage": usage}, f)
+    check_spills(usage, src)
     return obj
 
 
@@ -57,7 +112,10 @@ def build(force: bool = False, jobs: int | None = None) -> str:
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
-    build_example(force)
+    try:                                   # the C++ consumer example is a check of the header, not a part of the library:
+        build_example(force)               # tests/test_gpu_surface.py asserts that it builds, links and runs
+    except RuntimeError as e:
+        sys.stderr.write(f"[build] warning: {e}\n")
     return LIB
 
 

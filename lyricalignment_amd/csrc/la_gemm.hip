@@ -32,7 +32,6 @@ struct GemmParams {
     const float *ln_stats = nullptr;   // consumer: per-row (mean, rstd) of the raw A rows, [M][2]
     const float *ln_csum = nullptr;    // consumer: c[n] = sum_k W'[n][k] of the gamma-folded weights, [N]
     int K_tail = 0;                    // split-K: K of the LAST batch slot when the chunks are uneven (0 = p.K)
-    unsigned *stamps = nullptr;        // diagnostic build (-DLA_PP_STAMPS): per-segment s_memtime of one K-tile, [64 workgroups][8 waves][32]
     float *ln_part = nullptr;          // producer (optional): per-row partial statistics of the 16-bit copy, [N/64][M][2] =
                                        // (mean, sum of squared deviations) of each 64-column segment (la_ln_stats_finalize)
 };
@@ -222,19 +221,55 @@ __device__ __forceinline__ float2 segment_stats(const ushort4 pk) {
 
 // LNM: 0 = plain; 1 = producer of the LayerNorm fold (second, 16-bit copy of the f32 rows); 2 = consumer (LayerNorm epilogue).
 // Separate instantiations: one body with run-time switches for all three spilled 40-48 VGPRs in every mode.
-// DBG selects the main loop (developer A/B, LA_PP_DBG): 0 ping-pong quadrants (default) | 1, 2, 4 its probes | 8 flat256 |
-// 16-18 k2 ring of 4 | 20, 21 k2 ring of 5 | 24, 25 k2f ring of 4 / 5 | 64 half tile (128 x 256, 4 waves, two workgroups per CU)
-template <int DBG> struct PPGeom {
-    static constexpr bool HALF = DBG == 64;
-    static constexpr int TM = HALF ? KH::TM : PP::TM, THREADS = HALF ? KH::THREADS : PP::THREADS;
-    static constexpr int LDS = HALF ? KH::LDS : ((DBG >= 20 && DBG != 24 && DBG < 32) ? K2<5>::LDS : PP::LDS);
-};
+// DUO selects the main loop: true = the hand-placed flat stream (mainloop_duo_asm), false = the quadrant ping-pong (mainloop_pp,
+// for K that is not a multiple of 128 or below 256; LA_PP_DBG=99 forces it: the bit-identical A/B partner).
 // Epilogue of one wave's 128x64 output tile (rows wrow0.., columns wcol0..) held in the MFMA accumulator layout acc[mi][ni][j]
 // = C[wrow0 + 16 mi + r][wcol0 + 16 ni + 4 q + j]: LayerNorm fold / bias, GELU, f32 residual, stores (wide, through the wave's
 // own 32 x EPI_PITCH bytes of LDS at `reg`), the 16-bit copy and the per-segment row statistics.  bias_l / csum_l: the bias and
 // the LN column sum of column wcol0 + lane, requested by the caller BEFORE its main loop.  Shared by the 8-wave ping-pong
 // kernel (one call per wave) and the one-wave-per-SIMD kernel (two calls per wave, one per 64-column half).
 constexpr int EPI_PITCH = 272;
+// One row-major quad (4 consecutive columns of one row) through the epilogue arithmetic, in the order every GEMM kernel of this
+// file uses: LayerNorm fold (rstd (acc - mean c) + b' as two FMAs) or bias, activation.  b4 / cs4: bias and LN column sums of
+// the lane's four columns; st = (mean, rstd) of the row.
+template <bool OUT_F32, int LNM>
+__device__ __forceinline__ void epi_quad(f32x4 &v, const float (&b4)[4], const float (&cs4)[4], float2 st, bool has_bias, bool do_gelu, int epilogue) {
+    if constexpr (LNM == 2) {
+        // A held the RAW rows x (16-bit copy of the residual stream) and W the gamma-folded weights W' = gamma o W:
+        // LN(x) W^T + b = rstd (x W'^T - mean c) + b'
+        const float rs = st.y, bm = -st.x * st.y;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaf(v[j], rs, fmaf(bm, cs4[j], b4[j]));
+    } else if (has_bias) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += b4[j];
+    }
+    if (do_gelu) {
+        if constexpr (!OUT_F32) {                        // result is rounded to 16 bits: the 11-slot sigmoid form
+            if (epilogue & 4096) {                       // developer A/B (LA_GELU_PK=1): the erfc form on the packed pipe
+                const la::f32x2 lo = la::gelu_pk(la::f32x2{v[0], v[1]}), hi = la::gelu_pk(la::f32x2{v[2], v[3]});
+                v = f32x4{lo.x, lo.y, hi.x, hi.y};
+            } else if (epilogue & 8192) {                // developer A/B (LA_GELU_PK=2): one value at a time
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = la::gelu_sig(v[j]);
+            } else {
+                const la::f32x2 lo = la::gelu_sig2(la::f32x2{v[0], v[1]}), hi = la::gelu_sig2(la::f32x2{v[2], v[3]});
+                v = f32x4{lo.x, lo.y, hi.x, hi.y};
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = la::gelu_erf(v[j]);
+        }
+    }
+}
+
+// The wave's 128x64 tile leaves the accumulator layout FIRST: per pass of 32 rows the 8 accumulator tuples go through the wave's
+// LDS region and come back row-major (lane (r, q) = columns 4r..4r+3 of row 4 it + q), and the whole epilogue arithmetic runs
+// there, where a lane's four columns are fixed for the tile (bias / column sums: 8 registers, fetched from the one-column-per-
+// lane values the caller requested before its main loop) and the pass's row operands (residual rows, LayerNorm statistics) are
+// requested together before the staging.  Round 2 applied the LayerNorm fold and the GELU in the accumulator layout, before the
+// staging: 16 row statistics + 32 broadcast column operands live beside the 128 accumulators -- the LayerNorm-consumer
+// instantiations (QKV, MLP-up) sat at 256 VGPRs with 107-127 spilled registers and 112 B of scratch per lane.
 template <bool OUT_F32, typename T16, int LNM>
 __device__ __forceinline__ void wave_epilogue(const GemmParams &p, int z, f32x4 (&acc)[8][4], int wrow0, int wcol0, bool has_bias,
                                               float bias_l, float csum_l, unsigned char *reg) {
@@ -245,68 +280,21 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams &p, int z, f32x4 
     const float *R = p.residual ? p.residual + (int64_t)z * p.strideR : nullptr;
     const bool do_gelu = p.epilogue & LA_EPI_GELU;
     const bool do_res = (p.epilogue & LA_EPI_RESIDUAL) && R;
-    const int q16 = q * 16;                                   // byte address of lane 4q for ds_bpermute
-    auto lane_bcast = [](float v, int byte_addr) { return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_addr, __float_as_int(v))); };
-    if constexpr (LNM == 2) {
-        // A held the RAW rows x (16-bit copy of the residual stream) and W the gamma-folded weights W' = gamma o W:
-        // LN(x) W^T + b = rstd (x W'^T - mean c) + b'.  acc row = mi*16 + r, col = ni*16 + 4q + j.  Statistics, column sums
-        // and bias are requested together (one exposed round trip per tile, not three) and applied as two FMAs per element.
-        float rs[8], bm[8];
+    const int epi = p.epilogue;
+    // the lane's four columns 4r .. 4r+3 of the wave's 64: from the lanes that hold them (bias_l / csum_l = column `lane`)
+    float b4[4], cs4[4];
 #pragma unroll
-        for (int mi = 0; mi < 8; ++mi) {
-            const float2 st = reinterpret_cast<const float2 *>(p.ln_stats)[min(wrow0 + mi * 16 + r, p.M - 1)];
-            rs[mi] = st.y; bm[mi] = -st.x * st.y;
-        }
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float c = lane_bcast(csum_l, q16 + (ni * 16 + j) * 4), b = lane_bcast(bias_l, q16 + (ni * 16 + j) * 4);
-#pragma unroll
-                for (int mi = 0; mi < 8; ++mi) acc[mi][ni][j] = fmaf(acc[mi][ni][j], rs[mi], fmaf(bm[mi], c, b));
-            }
-    } else if (has_bias) {
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float b = lane_bcast(bias_l, q16 + (ni * 16 + j) * 4);
-#pragma unroll
-                for (int mi = 0; mi < 8; ++mi) acc[mi][ni][j] += b;
-            }
+    for (int j = 0; j < 4; ++j) {
+        b4[j] = __int_as_float(__builtin_amdgcn_ds_bpermute((r * 4 + j) * 4, __float_as_int(bias_l)));
+        cs4[j] = LNM == 2 ? __int_as_float(__builtin_amdgcn_ds_bpermute((r * 4 + j) * 4, __float_as_int(csum_l))) : 0.f;
     }
-    if (do_gelu) {
-#pragma unroll
-        for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                if constexpr (!OUT_F32) {                        // result is rounded to 16 bits: the 11-slot sigmoid form
-                    if (p.epilogue & 4096) {                     // developer A/B (LA_GELU_PK=1): the erfc form on the packed pipe
-                        const la::f32x2 lo = la::gelu_pk(la::f32x2{acc[mi][ni][0], acc[mi][ni][1]});
-                        const la::f32x2 hi = la::gelu_pk(la::f32x2{acc[mi][ni][2], acc[mi][ni][3]});
-                        acc[mi][ni] = f32x4{lo.x, lo.y, hi.x, hi.y};
-                    } else {
-                        if (p.epilogue & 8192) {                 // developer A/B (LA_GELU_PK=2): one value at a time
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) acc[mi][ni][j] = la::gelu_sig(acc[mi][ni][j]);
-                        } else {
-                            const la::f32x2 lo = la::gelu_sig2(la::f32x2{acc[mi][ni][0], acc[mi][ni][1]});
-                            const la::f32x2 hi = la::gelu_sig2(la::f32x2{acc[mi][ni][2], acc[mi][ni][3]});
-                            acc[mi][ni] = f32x4{lo.x, lo.y, hi.x, hi.y};
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[mi][ni][j] = la::gelu_erf(acc[mi][ni][j]);
-                }
-            }
-    }
+    const float2 *stats = reinterpret_cast<const float2 *>(p.ln_stats);
     constexpr int PITCH = EPI_PITCH;
     const bool fast_c = ((p.ldc * (int64_t)sizeof(TC)) % 16 == 0) && ((uintptr_t)C % 16 == 0);
     const bool fast_r = do_res && (p.ldr % 4 == 0) && ((uintptr_t)R % 16 == 0);
     // Interior wave tiles (all but the last row / column of tiles): straight-line code, no bounds or alignment branches, so
-    // the residual loads of four rows are in flight together (the generic loop below waited out one HBM round trip per row:
-    // 32 dependent round trips per wave and tile, most of the 54 us the residual GEMMs lost to their epilogue).
+    // the residual loads of a pass's rows are in flight together (a generic loop waits out one HBM round trip per row:
+    // 32 dependent round trips per wave and tile, most of the 54 us the residual GEMMs once lost to their epilogue).
     if (wrow0 + 128 <= p.M && wcol0 + 64 <= p.N && fast_c && (!do_res || fast_r)) {
         TC *cw = C + (int64_t)wrow0 * p.ldc + wcol0 + r * 4;
         const float *rw = do_res ? R + (int64_t)wrow0 * p.ldr + wcol0 + r * 4 : nullptr;
@@ -322,9 +310,14 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams &p, int z, f32x4 
 #pragma unroll
             for (int h = 0; h < 4; ++h) {
                 float4 t[8];
+                float2 st[8];
                 if constexpr (RES) {
 #pragma unroll
                     for (int it = 0; it < 8; ++it) t[it] = *reinterpret_cast<const float4 *>(rw + (int64_t)(h * 32 + it * 4 + q) * p.ldr);
+                }
+                if constexpr (LNM == 2) {
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) st[it] = stats[wrow0 + h * 32 + it * 4 + q];
                 }
 #pragma unroll
                 for (int mm = 0; mm < 2; ++mm)
@@ -335,6 +328,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams &p, int z, f32x4 
                 for (int it = 0; it < 8; ++it) {
                     const int rl = it * 4 + q;
                     f32x4 v = *reinterpret_cast<const f32x4 *>(reg + rl * PITCH + r * 16);
+                    epi_quad<OUT_F32, LNM>(v, b4, cs4, LNM == 2 ? st[it] : make_float2(0.f, 0.f), has_bias, do_gelu, epi);
                     if constexpr (RES) { v[0] += t[it].x; v[1] += t[it].y; v[2] += t[it].z; v[3] += t[it].w; }
                     const int64_t off = (int64_t)(h * 32 + rl) * p.ldc;
                     TC *c = cw + off;
@@ -344,8 +338,8 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams &p, int z, f32x4 
                             const ushort4 pk = la::Pack4<T16>::run(v[0], v[1], v[2], v[3]);
                             *reinterpret_cast<ushort4 *>(c2w + off) = pk;
                             if (part) {
-                                const float2 st = segment_stats<T16>(pk);
-                                if (r == 0) part[h * 32 + rl] = st;
+                                const float2 sg = segment_stats<T16>(pk);
+                                if (r == 0) part[h * 32 + rl] = sg;
                             }
                         }
                     } else {
@@ -372,6 +366,9 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams &p, int z, f32x4 
             const int m = wrow0 + h * 32 + rl;
             const int n = wcol0 + r * 4;
             f32x4 v = *reinterpret_cast<const f32x4 *>(reg + rl * PITCH + r * 16);
+            float2 st = make_float2(0.f, 0.f);
+            if constexpr (LNM == 2) st = stats[min(m, p.M - 1)];
+            epi_quad<OUT_F32, LNM>(v, b4, cs4, st, has_bias, do_gelu, epi);
             if (m >= p.M || n >= p.N) continue;
             const int nv = min(4, p.N - n);
             if (do_res) {
@@ -396,21 +393,21 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams &p, int z, f32x4 
             if constexpr (LNM == 1) {
                 for (int j = 0; j < nv; ++j) la::Elem<T16>::store(C2 + (int64_t)m * p.ldc + n + j, v[j]);
                 if (p.ln_part) {                             // N % 64 == 0 on this path (host check): the 16 lanes of the row are all here
-                    const float2 st = segment_stats<T16>(la::Pack4<T16>::run(v[0], v[1], v[2], v[3]));
-                    if (r == 0) reinterpret_cast<float2 *>(p.ln_part)[(int64_t)(wcol0 >> 6) * p.M + m] = st;
+                    const float2 sg = segment_stats<T16>(la::Pack4<T16>::run(v[0], v[1], v[2], v[3]));
+                    if (r == 0) reinterpret_cast<float2 *>(p.ln_part)[(int64_t)(wcol0 >> 6) * p.M + m] = sg;
                 }
             }
         }
     }
 }
 
-template <bool OUT_F32, int DBG, typename T16, int LNM = 0>
-__global__ __launch_bounds__(PPGeom<DBG>::THREADS, 2) void gemm_pp_kernel(GemmParams p) {
+template <bool OUT_F32, bool DUO, typename T16, int LNM = 0>
+__global__ __launch_bounds__(PP::THREADS, 2) void gemm_pp_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int nwg = p.tiles_m * p.tiles_n;
     const int tile = xcd_remap(blockIdx.x, nwg);
     const TileCoord tc = tile_coord(tile, p.tiles_m, p.tiles_n, p.group);
-    const int m0 = tc.tm * PPGeom<DBG>::TM, n0 = tc.tn * PP::TN;
+    const int m0 = tc.tm * PP::TM, n0 = tc.tn * PP::TN;
     const int z = blockIdx.y;
     const T16 *A = reinterpret_cast<const T16 *>(p.A) + (int64_t)z * p.strideA;
     const T16 *W = reinterpret_cast<const T16 *>(p.W) + (int64_t)z * p.strideW;
@@ -418,10 +415,9 @@ __global__ __launch_bounds__(PPGeom<DBG>::THREADS, 2) void gemm_pp_kernel(GemmPa
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave >> 2, wc = wave & 3;
-    const int r = lane & 15, q = lane >> 4;
     const bool has_bias = (p.epilogue & LA_EPI_BIAS) && bias;
     // Per-column epilogue operands are requested BEFORE the main loop, one column per lane (this wave's 64 columns), and
-    // handed to the accumulator layout with ds_bpermute afterwards: all eight waves reach the epilogue together, so a load
+    // handed to the row-major epilogue layout with ds_bpermute afterwards: all eight waves reach the epilogue together, so a load
     // issued there is a fully exposed L2 round trip per tile.
     const int ncol = min(n0 + wc * 64 + lane, p.N - 1);
     const float bias_l = has_bias ? bias[ncol] : 0.f;
@@ -429,16 +425,8 @@ __global__ __launch_bounds__(PPGeom<DBG>::THREADS, 2) void gemm_pp_kernel(GemmPa
     if constexpr (LNM == 2) csum_l = p.ln_csum[ncol];
 
     f32x4 acc[8][4];
-    if constexpr (DBG == 8 && std::is_same<T16, bf16_t>::value) mainloop_flat256(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
-    else if constexpr (DBG == 81) mainloop_duo_asm<T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
-    else if constexpr (DBG == 80) mainloop_k2p<T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
-    else if constexpr (DBG == 64) mainloop_half<T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
-    else if constexpr (DBG == 24) mainloop_k2f<4, T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
-    else if constexpr (DBG == 25) mainloop_k2f<5, T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
-    else if constexpr (DBG >= 32) mainloop_pp<DBG, T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
-    else if constexpr (DBG >= 20) mainloop_k2<DBG & 3, 5, T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
-    else if constexpr (DBG >= 16) mainloop_k2<DBG & 3, 4, T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
-    else mainloop_pp<DBG, T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc, p.stamps);
+    if constexpr (DUO) mainloop_duo_asm<T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
+    else mainloop_pp<T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
 
     __syncthreads();
     wave_epilogue<OUT_F32, T16, LNM>(p, z, acc, m0 + wr * 128, n0 + wc * 64, has_bias, bias_l, csum_l, lds + wave * (32 * EPI_PITCH));
@@ -599,9 +587,9 @@ __device__ __forceinline__ void mono_epilogue(const GemmParams &p, int z, f32x4 
     }
 }
 
-// The one-wave-per-SIMD kernel: 256x256 tile, 4 waves x 128x128 wave tiles, hand-placed main loop (mainloop_mono_asm; ASM = 0:
-// the hipcc-scheduled loop, 2 / 3: timing probes), accumulators in the AGPRs from the first MFMA to the epilogue's ds_write.
-template <bool OUT_F32, typename T16, int ASM = 1, int LNM = 0>
+// The one-wave-per-SIMD kernel (LA_PP_DBG=73): 256x256 tile, 4 waves x 128x128 wave tiles, hand-placed main loop
+// (mainloop_mono_asm), accumulators in the AGPRs from the first MFMA to the epilogue's ds_write.
+template <bool OUT_F32, typename T16, int LNM = 0>
 __global__ __launch_bounds__(MONO::THREADS, 1) void gemm_mono_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int nwg = p.tiles_m * p.tiles_n;
@@ -625,17 +613,14 @@ __global__ __launch_bounds__(MONO::THREADS, 1) void gemm_mono_kernel(GemmParams 
         if constexpr (LNM == 2) cs4[j] = p.ln_csum[ncol];
     }
     f32x4 acc[8][8];
-    if constexpr (ASM != 0) mainloop_mono_asm<T16, ASM - 1>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
-    else mainloop_mono<T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
-    if constexpr (ASM != 0) {
-        if (p.epilogue & 256) return;        // developer probe (KB_NOSTORE): the main loop (volatile asm: not removable) alone
-    }
+    mainloop_mono_asm<T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
+    if (p.epilogue & 256) return;            // developer probe (KB_NOSTORE): the main loop (volatile asm: not removable) alone
     mono_epilogue<OUT_F32, T16, LNM>(p, z, acc, m0 + wr * 128, n0 + wc * 128, has_bias, b4, cs4, lds + wave * (32 * MONO_PITCH));
 }
 
-template <bool OUT_F32, typename T16, int ASM = 1, int LNM = 0>
+template <bool OUT_F32, typename T16, int LNM = 0>
 int launch_mono(GemmParams p, int batch, hipStream_t stream) {
-    auto kern = gemm_mono_kernel<OUT_F32, T16, ASM, LNM>;
+    auto kern = gemm_mono_kernel<OUT_F32, T16, LNM>;
     static bool attr_done = false;
     if (!attr_done) {
         LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, MONO::LDS));
@@ -651,81 +636,54 @@ int launch_mono(GemmParams p, int batch, hipStream_t stream) {
 }
 
 // the one-wave-per-SIMD kernel by epilogue mode (the same three the ping-pong kernel has)
-template <bool OUT_F32, typename T16, int ASM>
-int launch_mono_modes(GemmParams p, int batch, hipStream_t stream) {
-    if (p.ln_stats) return launch_mono<OUT_F32, T16, ASM, 2>(p, batch, stream);
-    if constexpr (OUT_F32) {
-        if (p.C2) return launch_mono<OUT_F32, T16, ASM, 1>(p, batch, stream);
-    }
-    return launch_mono<OUT_F32, T16, ASM, 0>(p, batch, stream);
-}
-
-template <bool OUT_F32, int DBG, typename T16, int LNM = 0>
-int launch_pp_dbg(GemmParams p, int batch, hipStream_t stream);
-
 template <bool OUT_F32, typename T16>
-int launch_pp(GemmParams p, int batch, hipStream_t stream) {
-    const char *dbg_env = getenv("LA_PP_DBG");               // read per launch: tools/kbench.py flips it between rounds of one process
-    const int dbg = dbg_env ? atoi(dbg_env) : 0;
-    if constexpr (std::is_same<T16, bf16_t>::value) {       // the developer probes exist for the bf16 instantiation
-        if (p.K % 128 == 0 && p.K >= 256) {
-            if (dbg == 72) return launch_mono<OUT_F32, T16, 0>(p, batch, stream);
-            if (dbg == 73) return launch_mono_modes<OUT_F32, T16, 1>(p, batch, stream);
-            if (dbg == 74) return launch_mono<OUT_F32, T16, 2>(p, batch, stream);
-            if (dbg == 75) return launch_mono<OUT_F32, T16, 3>(p, batch, stream);
-        }
-        switch (dbg) {
-            case 16: return launch_pp_dbg<OUT_F32, 16, T16>(p, batch, stream);
-            case 20: return launch_pp_dbg<OUT_F32, 20, T16>(p, batch, stream);
-            case 24: return launch_pp_dbg<OUT_F32, 24, T16>(p, batch, stream);
-            case 32: return launch_pp_dbg<OUT_F32, 32, T16>(p, batch, stream);
-            case 40: return launch_pp_dbg<OUT_F32, 40, T16>(p, batch, stream);
-            case 48: return launch_pp_dbg<OUT_F32, 48, T16>(p, batch, stream);
-            case 64: return launch_pp_dbg<OUT_F32, 64, T16>(p, batch, stream);
-            case 80: return launch_pp_dbg<OUT_F32, 80, T16>(p, batch, stream);
-            case 81: if (p.K % 128 == 0 && p.K >= 256) return launch_pp_dbg<OUT_F32, 81, T16>(p, batch, stream); break;
-            case 1: return launch_pp_dbg<OUT_F32, 1, T16>(p, batch, stream);
-            case 2: return launch_pp_dbg<OUT_F32, 2, T16>(p, batch, stream);
-            case 3: return launch_pp_dbg<OUT_F32, 3, T16>(p, batch, stream);
-            case 4: return launch_pp_dbg<OUT_F32, 4, T16>(p, batch, stream);
-            case 8: return launch_pp_dbg<OUT_F32, 8, T16>(p, batch, stream);
-            default: break;
-        }
-    }
-    // Main loop: the hand-placed flat stream (mainloop_duo_asm, "81") where its k-step structure fits -- K a multiple of 128
-    // (four k-steps of 32 per ring turn), at least 256 -- else the quadrant ping-pong; LA_PP_DBG=99 forces the ping-pong.
-    // Same tile, same epilogue, same accumulation order: the two give identical bits.
-    const bool duo = p.K % 128 == 0 && p.K >= 256 && dbg != 99;
-    if (p.ln_stats) return duo ? launch_pp_dbg<OUT_F32, 81, T16, 2>(p, batch, stream) : launch_pp_dbg<OUT_F32, 0, T16, 2>(p, batch, stream);
+int launch_mono_modes(GemmParams p, int batch, hipStream_t stream) {
+    if (p.ln_stats) return launch_mono<OUT_F32, T16, 2>(p, batch, stream);
     if constexpr (OUT_F32) {
-        if (p.C2) return duo ? launch_pp_dbg<OUT_F32, 81, T16, 1>(p, batch, stream) : launch_pp_dbg<OUT_F32, 0, T16, 1>(p, batch, stream);
+        if (p.C2) return launch_mono<OUT_F32, T16, 1>(p, batch, stream);
     }
-    return duo ? launch_pp_dbg<OUT_F32, 81, T16>(p, batch, stream) : launch_pp_dbg<OUT_F32, 0, T16>(p, batch, stream);
+    return launch_mono<OUT_F32, T16, 0>(p, batch, stream);
 }
 
-template <bool OUT_F32, int DBG, typename T16, int LNM>
-int launch_pp_dbg(GemmParams p, int batch, hipStream_t stream) {
-    auto kern = gemm_pp_kernel<OUT_F32, DBG, T16, LNM>;
-    typedef PPGeom<DBG> G;
+template <bool OUT_F32, bool DUO, typename T16, int LNM = 0>
+int launch_pp_loop(GemmParams p, int batch, hipStream_t stream) {
+    auto kern = gemm_pp_kernel<OUT_F32, DUO, T16, LNM>;
     static bool attr_done = false;
     if (!attr_done) {
-        LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+        LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, PP::LDS));
         attr_done = true;
     }
-    p.tiles_m = la::cdiv(p.M, G::TM);
+    p.tiles_m = la::cdiv(p.M, PP::TM);
     p.tiles_n = la::cdiv(p.N, PP::TN);
     // column tiles that walk the M dimension together (their W panels share the XCD's L2 with the streaming A panel).
     // At least 4: with fewer, the K=4096 GEMM (N = 4 tiles) re-reads its 2 MB-per-row-block A panel once per column tile
     // (in-pipeline sweep: 1 -> 46.1 ms/step, 4 -> 45.7, 8 -> 45.9, 16 -> 46.4).
     p.group = getenv("LA_GEMM_GROUP") ? std::min(p.group, p.tiles_n) : std::min(p.tiles_n, std::max(4, p.group / 2));
     if (const char *g = getenv("LA_GELU_PK")) p.epilogue |= atoi(g) == 2 ? 8192 : 4096;
-#ifdef LA_PP_STAMPS
-    if (const char *sp = getenv("LA_STAMP_PTR")) p.stamps = reinterpret_cast<unsigned *>(strtoull(sp, nullptr, 0));
-#endif
     la::TimerScope ts("gemm_bf16", stream);
-    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, batch), dim3(G::THREADS), G::LDS, stream, p);
+    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, batch), dim3(PP::THREADS), PP::LDS, stream, p);
     LA_LAUNCH_CHECK();
     return LA_OK;
+}
+
+// Main loop: the hand-placed flat stream (mainloop_duo_asm) where its k-step structure fits -- K a multiple of 128 (four k-steps
+// of 32 per ring turn), at least 256 -- else the quadrant ping-pong; LA_PP_DBG=99 forces the ping-pong, 73 selects the
+// one-wave-per-SIMD kernel (read per launch: tools/kbench.py flips it between rounds of one process).  Same tile, same
+// accumulation order, same epilogue arithmetic: all three give identical bits.
+template <bool OUT_F32, typename T16>
+int launch_pp(GemmParams p, int batch, hipStream_t stream) {
+    const char *dbg_env = getenv("LA_PP_DBG");
+    const int dbg = dbg_env ? atoi(dbg_env) : 0;
+    const bool fits = p.K % 128 == 0 && p.K >= 256;
+    if constexpr (std::is_same<T16, bf16_t>::value) {       // the one-wave-per-SIMD experiment exists for bf16
+        if (dbg == 73 && fits) return launch_mono_modes<OUT_F32, T16>(p, batch, stream);
+    }
+    const bool duo = fits && dbg != 99;
+    if (p.ln_stats) return duo ? launch_pp_loop<OUT_F32, true, T16, 2>(p, batch, stream) : launch_pp_loop<OUT_F32, false, T16, 2>(p, batch, stream);
+    if constexpr (OUT_F32) {
+        if (p.C2) return duo ? launch_pp_loop<OUT_F32, true, T16, 1>(p, batch, stream) : launch_pp_loop<OUT_F32, false, T16, 1>(p, batch, stream);
+    }
+    return duo ? launch_pp_loop<OUT_F32, true, T16>(p, batch, stream) : launch_pp_loop<OUT_F32, false, T16>(p, batch, stream);
 }
 
 template <typename T, bool OUT_F32, typename CF, bool TA = false, bool TW = false>

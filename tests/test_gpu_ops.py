@@ -367,12 +367,12 @@ def test_colsum_deterministic():
     np.testing.assert_allclose(ht.colsum(v).cpu().double().numpy(), v.double().sum(0).cpu().numpy(), rtol=0, atol=3e-4)
 
 
-@pytest.mark.parametrize("variant", [16, 20, 24, 32, 40, 48, 64, 72, 73, 80, 81, 99])
+@pytest.mark.parametrize("variant", [73, 99])
 def test_gemm_main_loop_ab_variants_are_bit_identical(variant, monkeypatch):
-    """The developer A/B main loops of the 256x256 kernel (LA_PP_DBG: 16 / 20 = one-k-step phases on a ring of 4 / 5 stages,
-    24 = the same stages without the ping-pong, 32 / 40 / 48 = DMA placement probes of the default loop, 64 = 128x256 half tiles,
-    two 4-wave workgroups per CU, 72 = one wave per SIMD with 128x128 wave tiles, 80 = flat loop with software-pipelined fragment reads) walk k in the same order
-    per accumulator as the default quadrant ping-pong: identical bits, including the ragged last row / column of tiles."""
+    """The A/B partners of the 256x256 kernel's default hand-placed loop that stay in the library (LA_PP_DBG: 99 = the quadrant
+    ping-pong, 73 = one wave per SIMD with 128x128 wave tiles and its own AGPR-direct epilogue; the other round-2 structures
+    were measured, recorded in DESIGN.md and removed) walk k in the same order per accumulator and apply the same epilogue
+    arithmetic: identical bits, including the ragged last row / column of tiles."""
     from lyricalignment_amd import ops
     M, N, K = 256 * 49 + 40, 1024 + 64, 1024
     a = _rand(M, K, seed=91).bfloat16().cuda()
