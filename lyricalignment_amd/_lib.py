@@ -12,7 +12,8 @@ from ctypes import POINTER, c_char_p, c_double, c_int32, c_int64, c_size_t, c_vo
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "liblyricalign_hip.so")
+# LA_LIB_PATH: another build of the same library (same-box A/B of two builds; tools/ab_bench.sh)
+LIB_PATH = os.environ.get("LA_LIB_PATH") or os.path.join(HERE, "liblyricalign_hip.so")
 
 LA_OK, LA_EINVAL, LA_EINFEASIBLE, LA_EEMPTY, LA_EHIP, LA_ETIMEOUT, LA_EUNSUPPORTED = range(7)
 LA_F32, LA_BF16, LA_F16 = 0, 1, 2

@@ -116,10 +116,14 @@ __device__ __forceinline__ void mma_step(const uint4 &a, const uint4 &w, f32x4 &
 //     every storing wave drains vmcnt, one lane signals with a relaxed agent-scope add; consumers poll that counter with
 //     an sc1 load, pass a workgroup barrier and read h with sc1 16-byte buffer loads only -> no release / acquire fence
 //     (each costs ~1.7 us per step here).  WT = true is the default; LA_GRU_FENCE=1 selects the fence form (WT = false).
-template <typename T, int MAXKS, bool WT, int MT>
-__global__ __launch_bounds__(GruTraits<T>::NW * 64, 1) void gru_kernel(GruParams p) {
+// NW: waves per workgroup.  16-bit modes: 8 where hidden is a multiple of 128 (two waves per SIMD at <= 256 registers each: a
+//     wave's W_hh slice is 12 * MAXKS registers, 144 at hidden <= 384) -- one (direction, 16-clip group) is then hidden / 128
+//     workgroups = CUs instead of hidden / 64: the resident recurrence takes 24 instead of 48 CUs from the encoder's GEMMs at 64
+//     clips, and a step's hand-off has 3 instead of 6 participants.  (768-thread workgroups -- 16 CUs -- do not fit: three waves
+//     per SIMD leave 168 registers per wave, 144 of which the W slice takes; acc + gates + prefetched inputs need ~50 more.)
+template <typename T, int MAXKS, bool WT, int MT, int NW = GruTraits<T>::NW>
+__global__ __launch_bounds__(NW * 64, 1) void gru_kernel(GruParams p) {
     typedef GruTraits<T> TR;
-    constexpr int NW = TR::NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int slice = blockIdx.x, dir = blockIdx.y, group = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -226,7 +230,7 @@ __global__ __launch_bounds__(GruTraits<T>::NW * 64, 1) void gru_kernel(GruParams
                 unsigned char *hl = lds + 16;
                 // all of this thread's requests go out before the first one is waited for (a rolled load -> LDS-store loop
                 // serialised 3 / 6 memory round trips: that, not the distance to the other XCDs, was the 2.7-3.7 us fetch)
-                constexpr int NREQ = (16 * MT * MAXKS * 4) / (NW * 64);
+                constexpr int NREQ = (16 * MT * MAXKS * 4 + NW * 64 - 1) / (NW * 64);
                 uint4 hv[NREQ];
 #pragma unroll
                 for (int k = 0; k < NREQ; ++k) {
@@ -452,11 +456,14 @@ static int gru_forward(int32_t dtype, const float *gi, const void *w_hh, const f
     la_gru_workspace_bytes(batch, frames, hidden, &need);
     LA_CHECK_ARG(workspace_bytes >= need, "gru_layer: workspace too small (%zu < %zu)", workspace_bytes, need);
     const int groups = gru_groups(batch);
-    const int nw = dtype == LA_F32 ? 2 : 4;
     if (hidden % 64 != 0 || (dtype != LA_F32 && hidden > 512) || (dtype == LA_F32 && hidden > 384)) {
         la::set_error("gru_layer: hidden=%d unsupported (multiple of 64; bf16 <= 512, f32 <= 384)", hidden);
         return LA_EUNSUPPORTED;
     }
+    // 16-bit modes: 8-wave workgroups (128 hidden units each) where hidden allows; LA_GRU_NW=4 keeps the 4-wave form (A/B)
+    static const bool force_nw4 = getenv("LA_GRU_NW") && atoi(getenv("LA_GRU_NW")) == 4;
+    const bool wide = dtype != LA_F32 && hidden % 128 == 0 && hidden <= 384 && !force_nw4;   // (a 192-register W slice spills at 256)
+    const int nw = dtype == LA_F32 ? 2 : (wide ? 8 : 4);
     const int nsplit = hidden / (16 * nw);
     if (nsplit * 2 * groups > 224) {
         la::set_error("gru_layer: %d co-resident workgroups needed (batch too large for one launch; split the batch)", nsplit * 2 * groups);
@@ -476,18 +483,25 @@ static int gru_forward(int32_t dtype, const float *gi, const void *w_hh, const f
         la::TimerScope ts("gru_bf16", stream);
         const int mt = (batch <= 16 || GROUP == 16) ? 1 : 2;
         const size_t lds_b = 16 + (size_t)16 * mt * (hidden * 2 + 16);          // flag + the staged h rows of the batch tiles
-#define LA_GRU_LAUNCH16(T_)                                                                                                \
+        // MAXKS = the W slice's compile-time k-steps: 12 with 8 waves (hidden <= 384, 144 registers), 16 with 4 (hidden <= 512, 192)
+#define LA_GRU_LAUNCH16_(T_, KS_, NW_)                                                                                     \
     do {                                                                                                                   \
         if (mt == 1) {                                                                                                     \
-            if (use_fence) hipLaunchKernelGGL((gru_kernel<T_, 16, false, 1>), grid, dim3(256), lds_b, stream, p);          \
-            else hipLaunchKernelGGL((gru_kernel<T_, 16, true, 1>), grid, dim3(256), lds_b, stream, p);                     \
+            if (use_fence) hipLaunchKernelGGL((gru_kernel<T_, KS_, false, 1, NW_>), grid, dim3(NW_ * 64), lds_b, stream, p); \
+            else hipLaunchKernelGGL((gru_kernel<T_, KS_, true, 1, NW_>), grid, dim3(NW_ * 64), lds_b, stream, p);          \
         } else {                                                                                                           \
-            if (use_fence) hipLaunchKernelGGL((gru_kernel<T_, 16, false, 2>), grid, dim3(256), lds_b, stream, p);          \
-            else hipLaunchKernelGGL((gru_kernel<T_, 16, true, 2>), grid, dim3(256), lds_b, stream, p);                     \
+            if (use_fence) hipLaunchKernelGGL((gru_kernel<T_, KS_, false, 2, NW_>), grid, dim3(NW_ * 64), lds_b, stream, p); \
+            else hipLaunchKernelGGL((gru_kernel<T_, KS_, true, 2, NW_>), grid, dim3(NW_ * 64), lds_b, stream, p);          \
         }                                                                                                                  \
+    } while (0)
+#define LA_GRU_LAUNCH16(T_)                                                                                                \
+    do {                                                                                                                   \
+        if (wide) LA_GRU_LAUNCH16_(T_, 12, 8);                                                                             \
+        else LA_GRU_LAUNCH16_(T_, 16, 4);                                                                                  \
     } while (0)
         if (dtype == LA_F16) LA_GRU_LAUNCH16(la::f16_t); else LA_GRU_LAUNCH16(bf16_t);
 #undef LA_GRU_LAUNCH16
+#undef LA_GRU_LAUNCH16_
     } else {
         const size_t lds_bytes = 16 + (size_t)2 * 3 * 16 * hidden * 4;
         static bool attr_done = false;
