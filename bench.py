@@ -295,6 +295,8 @@ def finetune_mode(args, rank, world, local_rank, device, dist):
                        "sharding": "clips over ranks; one all-reduce (sum) per flat gradient bucket per optimizer step"},
             "micro_step_ms": (elapsed / args.steps * 1e3 - ar_ms) / args.accum,
             "allreduce_ms_per_step": ar_ms,
+            # bus bandwidth of the ring all-reduce: 2 (N - 1) / N x the gradient bytes cross every rank's links per step
+            "allreduce_GBps": (2.0 * (world - 1) / world * grad_bytes / (ar_ms * 1e-3) / 1e9) if (world > 1 and ar_ms > 0) else None,
             "roofline": {"bound": "mfma", "kernel": "gemm_kernel<float> (v_mfma_f32_16x16x4_f32; every Linear forward + both backward products)",
                          "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s", "frac": achieved / 157.3, "traffic": None,
                          "launches_per_step": launches.value / max(args.steps, 1), "avg_launch_ms": total_ms.value / max(launches.value, 1)},

@@ -170,10 +170,16 @@ int la_logmel_f32(const float *audio, int32_t batch, int32_t n_samples,
 /* epilogue flags for la_gemm */
 enum {
     LA_EPI_BIAS = 1,      /* + bias[n] (f32)                                          */
-    LA_EPI_GELU = 2,      /* exact erf GELU after the bias                            */
+    LA_EPI_GELU = 2,      /* GELU after the bias.  f32 results (float32 mode, LA_EPI_OUT_F32): the erf form, |error| <= 1.2e-7.
+                           * 16-bit results: x * sigmoid(x (a + b x^2 + c x^4)), a minimax fit to x Phi(x): max ABSOLUTE error 2.5e-5
+                           * (below half a bf16 ulp for |gelu| >= 1e-2; the relative error is unbounded in the negative tail, where
+                           * |gelu| < 1e-2 -- whisper's F.gelu is the erf form).  LA_EPI_GELU_ERF selects the erf form there too. */
     LA_EPI_RESIDUAL = 4,  /* + residual[m][n] (f32, own strides; batch stride may be 0) */
     LA_EPI_OUT_F32 = 8,   /* C is f32 regardless of the operand dtype                 */
     LA_EPI_MISH = 16,     /* x * tanh(softplus(x)) after the bias                     */
+    LA_EPI_GELU_ERF = 4096, /* with LA_EPI_GELU and a 16-bit result: the erfc-based form (relative error <= 2.8e-5 = 1/140 bf16 ulp,
+                           * 1/17 f16 ulp) instead of the sigmoid fit; ~40 % more epilogue issue slots.  (LA_GELU_PK=1 in the
+                           * environment sets it on every launch: the developer A/B switch.) */
     /* operand layout flags of la_gemm_ex (float32 only), OR-ed into the same word: the operand is stored TRANSPOSED,
      * [K][rows] with pitch lda / ldw >= rows (rows % 4 == 0).  With a flag set K may be any length (a K-contiguous operand
      * must then have a pitch >= K rounded up to 32); both set = the weight-gradient shape
@@ -257,10 +263,10 @@ int la_mel_to_rows(const float *mel, int64_t mel_batch_stride, int64_t mel_row_s
  * projections W_ih x + b_ih of both directions; w_hh [2][3H][H] (`dtype`),
  * b_hh [2][3H] f32.  out [batch][frames][2H] (`dtype`) receives h_t (forward in
  * columns 0..H-1, reverse in H..2H-1); out_mish (optional, same shape) receives
- * Mish(h_t) (module/align_model.py:37).  Persistent kernel: 2 * H/64 (bf16) workgroups
+ * Mish(h_t) (module/align_model.py:37).  Persistent kernel: 2 * H/128 (16-bit modes, H % 128 == 0, H <= 384; else 2 * H/64) workgroups
  * per 16 clips exchange h through `out` with write-through (sc1) stores and per-step
  * arrival counters in `workspace` (zeroed on the stream by this call).  H % 64 == 0;
- * at most 224 workgroups may be co-resident (bf16, H=384: batch <= 288).
+ * at most 224 workgroups may be co-resident (16-bit modes, H=384: 8-wave workgroups, 2 * 3 per 16 clips).
  * `timeout_flag` (device int32, optional) is set non-zero if a bounded wait
  * gave up; the host wrapper maps it to LA_ETIMEOUT.
  */
@@ -460,7 +466,7 @@ typedef struct la_head_weights {
  * logits: feats rows [.][ld_feats] (compute dtype), clip b at rows b*clip_stride_rows .. +frames -> 2 x {input-projection
  * GEMM, persistent BiGRU recurrence} -> Mish -> fused Linear + emission prep -> batched DP -> onset / offset frames
  * (same outputs as la_viterbi_batch).  emissions_out (optional) [batch][frames][max_labels+1] f32 receives the compact
- * emissions.  More clips than one launch set of the recurrence takes (288 in the 16-bit modes at hidden 384) run as
+ * emissions.  More clips than one launch set of the recurrence takes (256; 144 in float32 at hidden 384) run as
  * consecutive slices inside this call.  `timeout_flag`: see la_gru_layer.
  */
 int la_align_head_workspace_bytes(const la_head_weights *w, int32_t batch, int32_t frames, int32_t max_labels, size_t *bytes);

@@ -19,6 +19,7 @@ LA_OK, LA_EINVAL, LA_EINFEASIBLE, LA_EEMPTY, LA_EHIP, LA_ETIMEOUT, LA_EUNSUPPORT
 LA_F32, LA_BF16, LA_F16 = 0, 1, 2
 LA_VARIANT_PLAIN, LA_VARIANT_CTC = 0, 1
 EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_OUT_F32, EPI_MISH = 1, 2, 4, 8, 16
+EPI_GELU_ERF = 4096
 GEMM_TRANS_A, GEMM_TRANS_W = 512, 1024        # la_gemm_ex operand layout flags (float32)
 
 # every symbol include/lyricalign.h declares: (name, restype, argtypes)

@@ -158,18 +158,20 @@ struct HeadBufs {
 int carve_head(void *ws, const la_head_weights *w, int batch, int frames, int max_labels, HeadBufs *b) {
     Carve c(ws);
     const size_t es = esize(w->dtype);
+    // every buffer is sized for ONE slice of clips (bb): GRU, FC and DP run slice by slice, so a 4608-clip batch (BASELINE
+    // configs[3]) holds 256 clips' worth of Mish(GRU) and emissions here, not the whole batch's (10.6 GB of `act` in round 2)
     const int H = w->hidden, cap = head_clip_cap(w, frames), bb = batch < cap ? batch : cap;
     b->gi = static_cast<float *>(c.take((size_t)bb * frames * 6 * H * 4));
     b->gru[0] = c.take((size_t)bb * frames * 2 * H * es);
     b->gru[1] = c.take((size_t)bb * frames * 2 * H * es);
-    b->act = c.take((size_t)batch * frames * 2 * H * es);
-    b->em = static_cast<float *>(c.take((size_t)batch * frames * (max_labels + 1) * 4));
-    b->n_frames = static_cast<int32_t *>(c.take((size_t)batch * 4));
+    b->act = c.take((size_t)bb * frames * 2 * H * es);
+    b->em = static_cast<float *>(c.take((size_t)bb * frames * (max_labels + 1) * 4));
+    b->n_frames = static_cast<int32_t *>(c.take((size_t)bb * 4));
     LA_TRY(la_gru_workspace_bytes(bb, frames, H, &b->gru_ws_bytes));
     b->gru_ws = c.take(b->gru_ws_bytes);
-    LA_TRY(la_fc_emissions_workspace_bytes(w->dtype, batch, frames, 2 * H, w->vocab, max_labels, &b->fc_ws_bytes));
+    LA_TRY(la_fc_emissions_workspace_bytes(w->dtype, bb, frames, 2 * H, w->vocab, max_labels, &b->fc_ws_bytes));
     b->fc_ws = c.take(b->fc_ws_bytes);
-    LA_TRY(la_viterbi_workspace_bytes(batch, frames, max_labels, &b->vit_ws_bytes));
+    LA_TRY(la_viterbi_workspace_bytes(bb, frames, max_labels, &b->vit_ws_bytes));
     b->vit_ws = c.take(b->vit_ws_bytes > 16 ? b->vit_ws_bytes : 16);
     b->total = c.off;
     return LA_OK;
@@ -202,6 +204,8 @@ extern "C" int la_align_head_forward(const la_head_weights *w, const void *feats
     const size_t es = esize(dt);
     const int out_f32 = dt == LA_F32 ? 0 : LA_EPI_OUT_F32;
     const int cap = head_clip_cap(w, frames);
+    LA_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(b.n_frames), frames, batch < cap ? batch : cap, stream));
+    const int64_t em_clip = (int64_t)frames * (max_labels + 1);
     for (int b0 = 0; b0 < batch; b0 += cap) {        // the persistent recurrence takes one launch set of clips at a time
         const int nb = batch - b0 < cap ? batch - b0 : cap;
         const unsigned char *x = static_cast<const unsigned char *>(feats) + (size_t)b0 * clip_stride_rows * ld_feats * es;
@@ -210,16 +214,19 @@ extern "C" int la_align_head_forward(const la_head_weights *w, const void *feats
         for (int layer = 0; layer < 2; ++layer) {
             LA_TRY(la_gemm(dt, frames, 6 * H, in_dim, nb, x, lda, stride_a, w->w_ih[layer], b.gi, 6 * H, (int64_t)frames * 6 * H, w->b_ih[layer],
                            nullptr, 0, 0, LA_EPI_BIAS | out_f32, stream));
-            void *mish = layer == 1 ? static_cast<unsigned char *>(b.act) + (size_t)b0 * frames * 2 * H * es : nullptr;
-            LA_TRY(la_gru_layer(dt, b.gi, w->w_hh[layer], w->b_hh[layer], b.gru[layer], mish, nb, frames, H, b.gru_ws, b.gru_ws_bytes, timeout_flag, stream));
+            LA_TRY(la_gru_layer(dt, b.gi, w->w_hh[layer], w->b_hh[layer], b.gru[layer], layer == 1 ? b.act : nullptr, nb, frames, H, b.gru_ws,
+                                b.gru_ws_bytes, timeout_flag, stream));
             x = static_cast<const unsigned char *>(b.gru[layer]);
             lda = 2 * H; stride_a = (int64_t)frames * 2 * H; in_dim = 2 * H;
         }
+        // the slice's fused Linear + emission prep and its DP, on the slice's rows of the caller's label / result arrays
+        float *em = emissions_out ? emissions_out + (int64_t)b0 * em_clip : b.em;
+        const int32_t *lab = labels + (int64_t)b0 * labels_stride;
+        LA_TRY(la_fc_emissions(dt, b.act, 2 * H, w->w_fc, w->b_fc, nb, frames, 2 * H, w->vocab, variant, lab, labels_stride, n_labels + b0, max_labels,
+                               em, em_clip, max_labels + 1, b.fc_ws, b.fc_ws_bytes, stream));
+        LA_TRY(la_viterbi_batch(em, em_clip, max_labels + 1, lab, labels_stride, n_labels + b0, b.n_frames, nb, frames, max_labels,
+                                onset + (int64_t)b0 * out_stride, offset + (int64_t)b0 * out_stride, out_stride, final_score + b0, status + b0,
+                                b.vit_ws, b.vit_ws_bytes, stream));
     }
-    float *em = emissions_out ? emissions_out : b.em;
-    LA_TRY(la_fc_emissions(dt, b.act, 2 * H, w->w_fc, w->b_fc, batch, frames, 2 * H, w->vocab, variant, labels, labels_stride, n_labels, max_labels,
-                           em, (int64_t)frames * (max_labels + 1), max_labels + 1, b.fc_ws, b.fc_ws_bytes, stream));
-    LA_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(b.n_frames), frames, batch, stream));
-    return la_viterbi_batch(em, (int64_t)frames * (max_labels + 1), max_labels + 1, labels, labels_stride, n_labels, b.n_frames, batch, frames,
-                            max_labels, onset, offset, out_stride, final_score, status, b.vit_ws, b.vit_ws_bytes, stream);
+    return LA_OK;
 }

@@ -364,9 +364,11 @@ bool plan_viterbi(int batch, int max_frames, int max_labels, VitPlan *pl) {
 template <int NW, bool DPP>
 int launch_viterbi(const VitParams &p, const VitPlan &pl, int batch, hipStream_t stream) {
     auto kern = viterbi_kernel<NW, DPP>;
-    if (pl.lds_bytes > 48 * 1024)
-        LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)pl.lds_bytes));
+    static bool attr_done = false;            // once per instantiation, to the planner's budget (pl.lds_bytes never exceeds it)
+    if (pl.lds_bytes > 48 * 1024 && !attr_done) {
+        LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+        attr_done = true;
+    }
     la::TimerScope ts("viterbi", stream);
     hipLaunchKernelGGL(kern, dim3(batch), dim3(NW * 64), pl.lds_bytes, stream, p);
     LA_LAUNCH_CHECK();
@@ -413,11 +415,16 @@ extern "C" int la_viterbi_batch(const float *em, int64_t em_batch_stride, int64_
     if (pl.strip) {
         la::TimerScope ts("viterbi", stream);
 #define LA_STRIP_CASE(RV)                                                                                                  \
-    case RV:                                                                                                               \
-        LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(viterbi_strip_kernel<RV>),                               \
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes));                        \
+    case RV: {                                                                                                             \
+        static bool attr_done = false;                                                                                     \
+        if (!attr_done) {                                                                                                  \
+            LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(viterbi_strip_kernel<RV>),                           \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));                      \
+            attr_done = true;                                                                                              \
+        }                                                                                                                  \
         hipLaunchKernelGGL(viterbi_strip_kernel<RV>, dim3(batch), dim3(1024), pl.lds_bytes, stream, p);                    \
-        break;
+        break;                                                                                                             \
+    }
         switch (pl.strip) {
             LA_STRIP_CASE(2) LA_STRIP_CASE(4) LA_STRIP_CASE(8)
             default: return LA_EUNSUPPORTED;

@@ -519,9 +519,12 @@ class AlignEngine:
     # ---- head: align_rnn up to Mish ------------------------------------------------------
     def head_clip_cap(self, T: int) -> int:
         """Clips one launch set of the persistent GRU recurrence can take: every workgroup of the launch must be resident
-        (la_gru.hip: 2 directions x hidden/(16 * waves) workgroups per 16 clips, at most 224 per launch -> 288 clips in the
-        16-bit modes, 144 in float32 at hidden 384) and the out buffer is addressed through a 2 GiB buffer descriptor."""
+        (la_gru.hip: 2 directions x hidden/(16 * waves) workgroups per 16 clips, at most 224 per launch -> 288 clips with 4-wave
+        workgroups, 144 in float32 at hidden 384), the out buffer is addressed through a 2 GiB buffer descriptor, and both
+        this sequence and la_align_head_forward clamp to HEAD_CLIPS_MAX = 256."""
         hw = self.head
+        if hw.hidden < 64 or hw.hidden % 64 != 0:
+            raise NotImplementedError(f"liblyricalign_hip unsupported shape: GRU hidden={hw.hidden} (a multiple of 64 is required)")
         es = 4 if hw.dtype == torch.float32 else 2
         nsplit = hw.hidden // (16 * (2 if hw.dtype == torch.float32 else 4))
         by_cus = (224 // (2 * nsplit)) * 16

@@ -104,8 +104,11 @@ def allreduce_mean_(buckets: Sequence[torch.Tensor], world: int) -> None:
     if world == 1:
         return
     import torch.distributed as dist
-    for b in buckets:
-        dist.all_reduce(b, op=dist.ReduceOp.SUM)
+    # both buckets are handed to the backend before either is waited for (RCCL: back-to-back ring passes on its own stream;
+    # ~0.1 % of the 3.14 GB is the small second bucket, so this only saves its launch latency)
+    works = [dist.all_reduce(b, op=dist.ReduceOp.SUM, async_op=True) for b in buckets]
+    for w in works:
+        w.wait()
 
 
 def linear_warmup_scale(step: int, warmup_steps: int, train_steps: int) -> float:

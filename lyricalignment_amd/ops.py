@@ -10,7 +10,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import (EPI_BIAS, EPI_GELU, EPI_MISH, EPI_OUT_F32, EPI_RESIDUAL, LA_BF16, LA_F32, LA_VARIANT_CTC,
+from ._lib import (EPI_BIAS, EPI_GELU, EPI_GELU_ERF, EPI_MISH, EPI_OUT_F32, EPI_RESIDUAL, LA_BF16, LA_F32, LA_VARIANT_CTC,
                    LA_VARIANT_PLAIN, check, dtype_code, lib, ptr, stream_ptr)
 
 
@@ -122,6 +122,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None, *
         epi |= EPI_RESIDUAL
     if gelu:
         epi |= EPI_GELU
+        if gelu == "erf":                # 16-bit results: the erfc-based form instead of the sigmoid fit (LA_EPI_GELU_ERF)
+            epi |= EPI_GELU_ERF
     if mish:
         epi |= EPI_MISH
     if c_dtype == torch.float32 and dt != LA_F32:

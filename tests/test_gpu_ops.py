@@ -367,6 +367,26 @@ def test_colsum_deterministic():
     np.testing.assert_allclose(ht.colsum(v).cpu().double().numpy(), v.double().sum(0).cpu().numpy(), rtol=0, atol=3e-4)
 
 
+@pytest.mark.parametrize("dtype,ulp", [(torch.bfloat16, 2.0 ** -8), (torch.float16, 2.0 ** -11)])
+def test_gemm_gelu_forms_of_the_16_bit_epilogue(dtype, ulp):
+    """include/lyricalign.h's contract for LA_EPI_GELU with a 16-bit result: the default sigmoid fit is within 2.5e-5 ABSOLUTE
+    (+ the output rounding) of the erf GELU (whisper's F.gelu); LA_EPI_GELU_ERF (gelu="erf") is within one output ulp
+    RELATIVE of it everywhere, negative tail included."""
+    from lyricalignment_amd import ops
+    M, N, K = 256 * 48, 1024, 256
+    a = (_rand(M, K, seed=71) * 1.5).to(dtype).cuda()
+    w = _rand(N, K, seed=72, scale=K ** -0.5).to(dtype).cuda()
+    bias = _rand(N, seed=73).cuda()
+    pre = a.double() @ w.double().T + bias.double()
+    ref = torch.nn.functional.gelu(pre)                       # erf form, float64
+    fit = ops.gemm(a, w, bias=bias, gelu=True).double()
+    erf = ops.gemm(a, w, bias=bias, gelu="erf").double()
+    tol_round = ref.abs() * ulp                                # half an ulp would do for round-to-nearest; leave one
+    assert float(((fit - ref).abs() - tol_round).max()) < 2.5e-5 + 1e-6
+    assert float(((erf - ref).abs() / ref.abs().clamp_min(1e-30))[ref.abs() > 1e-6].max()) < ulp * 1.05 + 2.8e-5
+    assert not torch.equal(fit, erf)                           # the flag does select another form
+
+
 @pytest.mark.parametrize("variant", [73, 99])
 def test_gemm_main_loop_ab_variants_are_bit_identical(variant, monkeypatch):
     """The A/B partners of the 256x256 kernel's default hand-placed loop that stay in the library (LA_PP_DBG: 99 = the quadrant

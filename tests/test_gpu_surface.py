@@ -297,6 +297,28 @@ def test_finetune_bench_two_ranks_run_the_gradient_allreduce():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["mode"] == "finetune" and out["value"] > 0
     assert out["allreduce_ms_per_step"] >= 0 and out["config"]["grad_bytes_per_step"] > 0
+    assert out["allreduce_GBps"] is None or out["allreduce_GBps"] > 0        # bus bandwidth of the one exchange step
+
+
+@pytest.mark.parametrize("mode_args", [["--mode", "longform", "--songs", "4"], ["--mode", "largev2", "--clips", "64"]])
+def test_other_config_bench_modes_two_ranks(mode_args):
+    """BASELINE configs[4] (long form) and configs[3] (large-v2 float16) through bench.py with 2 ranks over gloo on one device:
+    the dress rehearsal of the driver's N > 1 launch for the modes the align / finetune tests above do not cover (songs / clips
+    sharded over ranks, no data-path collective, whole-job aggregate in `value`)."""
+    env = dict(os.environ, LA_BENCH_SAME_DEVICE="1", LA_BENCH_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", *mode_args, "--steps", "2", "--warmup", "1"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]
+    out = json.loads(lines[0])
+    units, unit_s = (4, 180.0) if mode_args[1] == "longform" else (64, 30.0)
+    assert out["n_gpus"] == 2 and out["config"]["mode"] == mode_args[1] and out["scaling"] == "weak" and out["cpu_baseline"] is None
+    assert abs(out["value"] - 2 * units * unit_s * 2 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
+    assert out["roofline"]["frac"] > 0
 
 
 # ------------------------------------------------------------------------------------------------ pipeline label lifetime
