@@ -177,9 +177,9 @@ enum {
     LA_EPI_RESIDUAL = 4,  /* + residual[m][n] (f32, own strides; batch stride may be 0) */
     LA_EPI_OUT_F32 = 8,   /* C is f32 regardless of the operand dtype                 */
     LA_EPI_MISH = 16,     /* x * tanh(softplus(x)) after the bias                     */
-    LA_EPI_GELU_ERF = 4096, /* with LA_EPI_GELU and a 16-bit result: the erfc-based form (relative error <= 2.8e-5 = 1/140 bf16 ulp,
-                           * 1/17 f16 ulp) instead of the sigmoid fit; ~40 % more epilogue issue slots.  (LA_GELU_PK=1 in the
-                           * environment sets it on every launch: the developer A/B switch.) */
+    LA_EPI_GELU_ERF = 4096, /* with LA_EPI_GELU and a 16-bit result: the erfc-based form (max absolute error 1.3e-6, 20 x closer to
+                           * F.gelu than the sigmoid fit) at ~40 % more epilogue issue slots.  (LA_GELU_PK=1 in the environment sets
+                           * it on every launch: the developer A/B switch.) */
     /* operand layout flags of la_gemm_ex (float32 only), OR-ed into the same word: the operand is stored TRANSPOSED,
      * [K][rows] with pitch lda / ldw >= rows (rows % 4 == 0).  With a flag set K may be any length (a K-contiguous operand
      * must then have a pitch >= K rounded up to 32); both set = the weight-gradient shape

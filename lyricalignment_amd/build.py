@@ -65,12 +65,15 @@ def _parse_resource_usage(stderr: str) -> dict:
 def check_spills(usage: dict, src: str) -> None:
     bad = []
     for name, u in usage.items():
-        spilled = u.get("VGPRs Spill", 0) or u.get("SGPRs Spill", 0) or u.get("ScratchSize [bytes/lane]", 0)
+        # (SGPR spills go to lanes of a reserved VGPR by v_writelane -- no memory, nothing asynchronous: not a hazard)
+        spilled = u.get("VGPRs Spill", 0) or u.get("ScratchSize [bytes/lane]", 0)
         if spilled and NO_SPILL_KERNELS.search(name):
             bad.append(f"{name}: VGPRs {u.get('VGPRs')}, spilled {u.get('VGPRs Spill')}, scratch {u.get('ScratchSize [bytes/lane]')} B/lane")
         elif spilled and REPORT_KERNELS.search(name):
             sys.stderr.write(f"[build] note: {name} spills {u.get('VGPRs Spill')} VGPRs (developer variant, not gated)\n")
-    if bad:
+    if bad and os.environ.get("LA_ALLOW_SPILLS") == "1":          # developer experiments only
+        sys.stderr.write("[build] SPILLS (allowed by LA_ALLOW_SPILLS=1):\n  " + "\n  ".join(bad) + "\n")
+    elif bad:
         raise RuntimeError(f"{os.path.basename(src)}: hand-placed-loop kernels must not spill (stale-fragment hazard):\n  " + "\n  ".join(bad))
 
 
