@@ -88,6 +88,11 @@ int la_timer_enable(const char *name);
 int la_timer_disable(void);
 int la_timer_read(double *total_ms, int64_t *launches);
 int la_timer_reset(void);
+/* Sampling: bracket every `period`-th launch of the family only (an event record is a barrier packet of its own: ~6.6 us of stream
+ * idle time each between back-to-back kernels).  la_timer_read_work also returns the summed work (flops for the GEMM families:
+ * 2 M N K batch) of the bracketed launches and the number of launches of the family seen since the reset. */
+int la_timer_sample(int32_t period);
+int la_timer_read_work(double *total_ms, int64_t *timed_launches, double *timed_work, int64_t *all_launches);
 
 /* ------------------------------------------------------------------------- */
 /* forced-alignment DP   (replaces utils/alignment.py:73-119 + :141-185)      */

@@ -32,6 +32,8 @@ SYMBOLS = {
     "la_timer_disable": (c_int32, []),
     "la_timer_read": (c_int32, [POINTER(c_double), POINTER(c_int64)]),
     "la_timer_reset": (c_int32, []),
+    "la_timer_sample": (c_int32, [c_int32]),
+    "la_timer_read_work": (c_int32, [POINTER(c_double), POINTER(c_int64), POINTER(c_double), POINTER(c_int64)]),
     "la_viterbi_workspace_bytes": (c_int32, [_I32, _I32, _I32, POINTER(_SZ)]),
     "la_viterbi_batch": (c_int32, [_P, _I64, _I64, _P, _I32, _P, _P, _I32, _I32, _I32, _P, _P, _I32, _P, _P, _P, _SZ, _P]),
     "la_viterbi_core": (c_int32, [_P, _I64, _P, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),

@@ -47,7 +47,7 @@ void *stream_scratch(hipStream_t stream, int purpose, size_t bytes);
 struct TimerScope {
     bool active;
     hipStream_t stream;
-    TimerScope(const char *family, hipStream_t s);
+    TimerScope(const char *family, hipStream_t s, double work = 0.0);   // work: flops (or bytes) of the launch, summed for bracketed launches
     ~TimerScope();
 };
 

@@ -629,7 +629,7 @@ int launch_mono(GemmParams p, int batch, hipStream_t stream) {
     p.tiles_m = la::cdiv(p.M, 256);
     p.tiles_n = la::cdiv(p.N, 256);
     p.group = getenv("LA_GEMM_GROUP") ? std::min(p.group, p.tiles_n) : std::min(p.tiles_n, std::max(4, p.group / 2));
-    la::TimerScope ts("gemm_bf16", stream);
+    la::TimerScope ts("gemm_bf16", stream, 2.0 * p.M * p.N * p.K * batch);
     hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, batch), dim3(MONO::THREADS), MONO::LDS, stream, p);
     LA_LAUNCH_CHECK();
     return LA_OK;
@@ -660,7 +660,7 @@ int launch_pp_loop(GemmParams p, int batch, hipStream_t stream) {
     // (in-pipeline sweep: 1 -> 46.1 ms/step, 4 -> 45.7, 8 -> 45.9, 16 -> 46.4).
     p.group = getenv("LA_GEMM_GROUP") ? std::min(p.group, p.tiles_n) : std::min(p.tiles_n, std::max(4, p.group / 2));
     if (const char *g = getenv("LA_GELU_PK")) p.epilogue |= atoi(g) == 2 ? 8192 : 4096;
-    la::TimerScope ts("gemm_bf16", stream);
+    la::TimerScope ts("gemm_bf16", stream, 2.0 * p.M * p.N * p.K * batch);
     hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, batch), dim3(PP::THREADS), PP::LDS, stream, p);
     LA_LAUNCH_CHECK();
     return LA_OK;
@@ -696,7 +696,7 @@ int launch(GemmParams p, int batch, hipStream_t stream, const char *family) {
     }
     p.tiles_m = la::cdiv(p.M, CF::TM);
     if (const char *g = getenv("LA_GELU_PK")) p.epilogue |= atoi(g) == 2 ? 8192 : 4096;
-    la::TimerScope ts(family, stream);
+    la::TimerScope ts(family, stream, 2.0 * p.M * p.N * (p.K_tail ? (double)((batch - 1) * (int64_t)p.K + p.K_tail) : (double)p.K * batch));
     hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, batch), dim3(CF::THREADS), CF::LDS, stream, p);
     LA_LAUNCH_CHECK();
     return LA_OK;

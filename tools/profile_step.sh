@@ -9,6 +9,7 @@ trace=$(find $out -name "*kernel_trace.csv" | head -1)
 stats=$(find $out -name "*kernel_stats.csv" | head -1)
 python3 tools/trace_by_shape.py "$trace" > gpurun_out/${tag}_kernel_by_shape.csv
 head -25 "$stats" > gpurun_out/${tag}_kernel_stats.csv
+python3 tools/trace_gaps.py "$trace" > gpurun_out/${tag}_trace_gaps.txt
 rm -rf $out
 tail -2 gpurun_out/${tag}_bench_under_rocprof.log | cut -c1-300
-cat gpurun_out/${tag}_kernel_by_shape.csv
+cat gpurun_out/${tag}_trace_gaps.txt
