@@ -237,9 +237,12 @@ def finetune_mode(args, rank, world, local_rank, device, dist):
     dec_out = torch.from_numpy(rs.randint(0, 50000, size=(B, n_tok)))
     ar_events = []
 
+    micro = dict(audios=audios, ctc_labels=labels, frame_labels=fl, decoder_input=dec_in, decoder_output=dec_out)
+
     def step(timed):
-        for _ in range(args.accum):
-            tuner.micro_step(audios, labels, fl, dec_in, dec_out, accum_grad_steps=args.accum)
+        # the accumulation loop of train_step: fused = ONE forward / backward over the accum x 2 clips, per-micro-batch losses
+        # (FineTuner.accumulate; --accum-mode loop = accum separate micro-steps, the round-1/2 form)
+        tuner.accumulate([micro] * args.accum, accum_grad_steps=args.accum, fused=args.accum_mode == "fused")
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         ft.allreduce_mean_(tuner.grad, tuner.world)          # the one exchange step of the data-parallel path
@@ -290,7 +293,7 @@ def finetune_mode(args, rank, world, local_rank, device, dist):
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (Gaussian waveforms, random class-id / frame / token labels, random-init weights)",
             "config": {"workload": f"whisper-{args.model} multitask fine-tune step, per-GPU micro-batch {B} x 30 s x accum {args.accum} "
-                                   "(BASELINE.json configs[2])", "mode": "finetune", "micro_batch": B, "accum": args.accum,
+                                   "(BASELINE.json configs[2])", "mode": "finetune", "micro_batch": B, "accum": args.accum, "accum_mode": args.accum_mode,
                        "decoder_tokens": n_tok, "grad_bytes_per_step": grad_bytes,
                        "sharding": "clips over ranks; one all-reduce (sum) per flat gradient bucket per optimizer step"},
             "micro_step_ms": (elapsed / args.steps * 1e3 - ar_ms) / args.accum,
@@ -425,6 +428,8 @@ def main():
     ap.add_argument("--songs", type=int, default=16, help="longform mode: 180 s songs per GPU and step")
     ap.add_argument("--model", default=MODEL, help="finetune mode only: whisper architecture (medium = configs[2])")
     ap.add_argument("--accum", type=int, default=8, help="finetune mode: micro-steps per optimizer step (reference default 8)")
+    ap.add_argument("--accum-mode", choices=["fused", "loop"], default="fused",
+                    help="finetune mode: the accum micro-batches as one fused forward / backward (per-micro-batch losses) or as a loop")
     ap.add_argument("--timer-period", type=int, default=7,
                     help="align mode: the roofline leg brackets every n-th launch of the GEMM family with HIP events (1 = every launch; odd and not a divisor of the 199 launches per pair of batches, so every shape is sampled alike)")
     args = ap.parse_args()

@@ -397,8 +397,8 @@ int la_softmax_bwd_rows_f32(const float *p, float *dp, int64_t ld, int64_t rows,
  * gradient of token + learned positional embedding (dtok accumulates, dpos [n][d] is written), and
  * F.cross_entropy(logits [rows][vocab], target, ignore_index=-100, 'mean'): loss2[0] = loss, loss2[1] = 1/count;
  * row_ws holds 2*rows floats; dlogits (optional) = scale * dloss/dlogits. */
-int la_embed_tokens_bwd_f32(const float *dx, const int64_t *tokens, int32_t batch, int32_t n, int32_t d, float *dtok, float *dpos,
-                            void *stream);
+int la_embed_tokens_bwd_f32(const float *dx, const int64_t *tokens, int32_t batch, int32_t n, int32_t d, int32_t n_vocab, float *dtok,
+                            float *dpos, void *stream);      /* ids clamped to [0, n_vocab) like la_embed_tokens */
 int la_cross_entropy_f32(const float *logits, int64_t ld, int32_t rows, int32_t vocab, const int64_t *target, float scale,
                          float *loss2, float *row_ws, float *dlogits, int64_t ld_d, void *stream);
 int la_col2im3_f32(const float *dcols, int32_t batch, int32_t t_out, int32_t stride, int32_t channels, float *out,

@@ -182,7 +182,9 @@ __global__ void col2im3_kernel(const float *dcols, int T_out, int stride, int C,
 
 // gradient of x[b][i][:] = tok_emb[tokens[b][i]][:] + pos[i][:]:  dtok rows accumulate (atomics: a token may repeat),
 // dpos[i] = sum over the batch (written, deterministic order)
-__global__ void embed_bwd_kernel(const float *dx, const int64_t *tokens, int B, int n, int d, float *dtok, float *dpos) {
+// token ids are clamped to [0, n_vocab) exactly as embed_tokens_kernel clamps them in the forward pass (an out-of-range id in user
+// data must not become an out-of-bounds atomic)
+__global__ void embed_bwd_kernel(const float *dx, const int64_t *tokens, int B, int n, int d, int n_vocab, float *dtok, float *dpos) {
     const int64_t total = (int64_t)n * d;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % d), pos_i = (int)(i / d);
@@ -190,7 +192,9 @@ __global__ void embed_bwd_kernel(const float *dx, const int64_t *tokens, int B, 
         for (int b = 0; b < B; ++b) {
             const float g = dx[((int64_t)b * n + pos_i) * d + c];
             acc += g;
-            atomicAdd(dtok + tokens[(int64_t)b * n + pos_i] * d + c, g);
+            int64_t tk = tokens[(int64_t)b * n + pos_i];
+            tk = tk < 0 ? 0 : (tk >= n_vocab ? n_vocab - 1 : tk);
+            atomicAdd(dtok + tk * d + c, g);
         }
         dpos[i] = acc;
     }
@@ -368,10 +372,10 @@ extern "C" int la_scale_f32(const float *x, float alpha, float *y, int64_t n, vo
     return LA_OK;
 }
 
-extern "C" int la_embed_tokens_bwd_f32(const float *dx, const int64_t *tokens, int32_t batch, int32_t n, int32_t d, float *dtok,
-                                       float *dpos, void *stream_) {
-    LA_CHECK_ARG(dx && tokens && dtok && dpos && batch > 0 && n > 0 && d > 0, "embed_tokens_bwd: bad arguments");
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3(ew_grid((int64_t)n * d)), dim3(256), 0, (hipStream_t)stream_, dx, tokens, batch, n, d, dtok, dpos);
+extern "C" int la_embed_tokens_bwd_f32(const float *dx, const int64_t *tokens, int32_t batch, int32_t n, int32_t d, int32_t n_vocab,
+                                       float *dtok, float *dpos, void *stream_) {
+    LA_CHECK_ARG(dx && tokens && dtok && dpos && batch > 0 && n > 0 && d > 0 && n_vocab > 0, "embed_tokens_bwd: bad arguments");
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(ew_grid((int64_t)n * d)), dim3(256), 0, (hipStream_t)stream_, dx, tokens, batch, n, d, n_vocab, dtok, dpos);
     LA_LAUNCH_CHECK();
     return LA_OK;
 }

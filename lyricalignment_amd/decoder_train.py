@@ -133,7 +133,7 @@ class DecoderFunction(torch.autograd.Function):
         # embeddings: token rows accumulate on top of the tied-projection gradient, positions are summed over the batch
         dtok = dtok.contiguous()
         dpos = torch.zeros((n_pos, d), dtype=torch.float32, device=dev)
-        check(lib().la_embed_tokens_bwd_f32(ptr(dx), ptr(tokens), B, n, d, ptr(dtok), ptr(dpos), stream_ptr()), "embed_tokens_bwd")
+        check(lib().la_embed_tokens_bwd_f32(ptr(dx), ptr(tokens), B, n, d, int(dtok.shape[0]), ptr(dtok), ptr(dpos), stream_ptr()), "embed_tokens_bwd")
         grads[0], grads[1] = dtok, dpos
         return (None, dxa.view(B, Ta, d) if dxa is not None else None, None, *grads_to(grads, ctx.param_devices))
 

@@ -246,6 +246,75 @@ class FineTuner:
         self._check_grad_views()
         return out
 
+    def accumulate(self, micro_batches, accum_grad_steps: Optional[int] = None, get_orig_len: bool = False, fused: bool = True,
+                   decoder_pad_id: int = 0):
+        """The accumulation loop of train_step (train_multitask.py:240-326: `accum_grad_steps` micro-batches, each loss divided
+        by accum_grad_steps, gradients summed) for a list of MULTITASK micro-batches, each a dict with the keyword arguments of
+        micro_step (audios, ctc_labels, frame_labels, decoder_input, decoder_output).
+        fused=True runs the micro-batches as ONE forward / backward over all their clips -- the activations of 8 x 2 clips of
+        Whisper-medium are ~80 GB of the 288 GB -- with every loss still taken per micro-batch slice (its own means, its own
+        1 / accum factor), so the accumulated gradient is the same sum: the GEMMs see 8 x the rows (M = 24000 instead of
+        3000: the float32 kernel fills the chip), the two persistent GRU sweeps per layer run once over 16 clips instead of
+        eight times over 2, and ~8 x fewer kernels are launched.  Dropout masks are drawn over the fused batch (a different
+        random stream than eight separate draws, the same distribution).  fused=False is the loop of micro_step() calls.
+        decoder_pad_id: any valid token id (it fills prompt positions whose targets are -100 and which no earlier position
+        attends to).  Returns the summed (un-scaled) loss vector like micro_step."""
+        accum = int(accum_grad_steps or len(micro_batches))
+        if not fused or len(micro_batches) == 1:
+            out = None
+            for mb in micro_batches:
+                l = self.micro_step(accum_grad_steps=accum, get_orig_len=get_orig_len, **mb)
+                out = l if out is None else out + l
+            return out
+        m = self.model
+        m.train()
+        from .decoder_train import cross_entropy
+        dev = self.flat[0].device
+        out = torch.zeros((4,), dtype=torch.float32, device=dev)
+        s = 1.0 / float(accum)
+        audios = [a for mb in micro_batches for a in mb["audios"]]
+        sizes = [len(mb["audios"]) for mb in micro_batches]
+        want_dec = m.train_transcript and all(mb.get("decoder_input") is not None for mb in micro_batches)
+        y_in = None
+        n_tok = 0
+        if want_dec:                                            # one [sum B, n_tok] prompt: shorter micro-batches are padded on the
+            n_tok = max(int(mb["decoder_input"].shape[1]) for mb in micro_batches)       # right (causal decoder: earlier positions are
+            rows = []                                                                     # unaffected; the padded targets are -100)
+            for mb in micro_batches:
+                di = mb["decoder_input"]
+                pad = n_tok - int(di.shape[1])
+                rows.append(torch.nn.functional.pad(di, (0, pad), value=decoder_pad_id) if pad else di)
+            y_in = torch.cat(rows, dim=0)
+        align_logit, trans_logit = m.frame_manual_forward(audios, y_in, get_orig_len=get_orig_len)
+        roots, grads = [], []
+        if align_logit is not None and m.train_alignment:
+            al = align_logit.detach()
+            parts, b0, any_part = [], 0, False
+            for mb, nb in zip(micro_batches, sizes):
+                sl_roots, sl_grads = [], []
+                self._align_losses(al[b0:b0 + nb], mb.get("frame_labels"), mb.get("ctc_labels"), s, out, sl_roots, sl_grads)
+                parts.append(sl_grads[0] if sl_grads else torch.zeros_like(al[b0:b0 + nb]))
+                any_part |= bool(sl_grads)
+                b0 += nb
+            if any_part:
+                roots.append(align_logit); grads.append(torch.cat(parts, dim=0))
+        if trans_logit is not None and all(mb.get("decoder_output") is not None for mb in micro_batches):
+            tl = trans_logit.detach()
+            parts, b0 = [], 0
+            for mb, nb in zip(micro_batches, sizes):
+                do = mb["decoder_output"]
+                pad = n_tok - int(do.shape[1])
+                do = torch.nn.functional.pad(do, (0, pad), value=-100) if pad else do
+                l, dl = cross_entropy(tl[b0:b0 + nb].contiguous(), do, scale_grad=s)
+                out[3] += l
+                parts.append(dl)
+                b0 += nb
+            roots.append(trans_logit); grads.append(torch.cat(parts, dim=0))
+        if roots:
+            torch.autograd.backward(roots, grads)
+        self._check_grad_views()
+        return out
+
     def step(self, allreduced: bool = False) -> torch.Tensor:
         """All-reduce + clip + AdamW + schedule; returns the device scalar sum(grad^2) over the summed buckets.
         allreduced=True: the caller has already run allreduce_mean_(self.grad, self.world) (bench.py times it separately)."""

@@ -450,6 +450,54 @@ def test_full_finetune_steps_reduce_the_loss():
     assert tuple(logits.shape) == (2, 50, 41) and torch.isfinite(logits).all()
 
 
+def test_fused_gradient_accumulation_equals_the_loop_of_micro_steps():
+    """FineTuner.accumulate(fused=True): the accumulation loop of train_step (train_multitask.py:240-326) as ONE forward /
+    backward over all micro-batches' clips, every loss taken per micro-batch slice with its own means and 1 / accum factor.
+    Three micro-batches of different sizes, label counts and decoder lengths (dropout 0: the masks are the only thing that
+    may differ): the accumulated gradient buckets and the loss vector equal the loop of micro_step() calls."""
+    from lyricalignment_amd import finetune as ft
+    audios, labels, frame_labels, dec_in, dec_out = _tiny_batch()
+    rs = np.random.RandomState(92)
+    a3 = (rs.randn(14000) * 0.1).astype(np.float32)
+    fl3 = torch.full((1, 50), -100, dtype=torch.long); fl3[0, 2:40] = 11
+    mbs = [
+        dict(audios=audios, ctc_labels=labels, frame_labels=frame_labels, decoder_input=dec_in, decoder_output=dec_out),
+        dict(audios=[a3], ctc_labels=torch.tensor([[11, 4, 30]]), frame_labels=fl3, decoder_input=torch.tensor([[1, 55, 2]]),
+             decoder_output=torch.tensor([[55, 2, -100]])),
+        dict(audios=audios[::-1], ctc_labels=labels.flip(0), frame_labels=frame_labels.flip(0), decoder_input=dec_in.flip(0),
+             decoder_output=dec_out.flip(0)),
+    ]
+    grads, losses = [], []
+    for fused in (False, True):
+        model = _tiny_full_model(dropout=0.0)
+        torch.manual_seed(3)
+        with torch.no_grad():                                   # identical head in both runs (it is drawn from the global generator)
+            for p_ in model.align_rnn.parameters():
+                p_.copy_(torch.randn(p_.shape) * 0.1)
+        tuner = ft.FineTuner(model, vocab_size=40, world=1)
+        losses.append(tuner.accumulate(mbs, fused=fused).cpu())
+        grads.append([g.clone().cpu() for g in tuner.grad])
+    # (float32 forward with other GEMM shapes -- other tile / split-K decisions, other summation orders: 1e-4 relative)
+    np.testing.assert_allclose(losses[1].numpy(), losses[0].numpy(), rtol=3e-4, atol=1e-6)
+    for g_loop, g_fused in zip(*grads):
+        scale = float(g_loop.abs().max())
+        assert scale > 0
+        np.testing.assert_allclose(g_fused.numpy(), g_loop.numpy(), rtol=0, atol=3e-4 * scale)
+
+
+def test_out_of_vocabulary_token_ids_are_clamped_not_faulted():
+    """A decoder prompt with ids outside [0, n_vocab) (bad user data; the reference would raise from nn.Embedding) must not become
+    an out-of-bounds gather / atomic on the device: la_embed_tokens and la_embed_tokens_bwd_f32 clamp the id the same way."""
+    from lyricalignment_amd import finetune as ft
+    model = _tiny_full_model(dropout=0.0)
+    audios, labels, frame_labels, dec_in, dec_out = _tiny_batch()
+    bad = dec_in.clone(); bad[0, 2] = 10 ** 6; bad[1, 1] = -7
+    tuner = ft.FineTuner(model, vocab_size=40, world=1)
+    losses = tuner.micro_step(audios, labels, frame_labels, bad, dec_out, accum_grad_steps=1)
+    torch.cuda.synchronize()
+    assert torch.isfinite(losses).all() and all(torch.isfinite(g).all() for g in tuner.grad)
+
+
 def _dp_worker(rank, world, port, out_dir):
     import os
     import torch.distributed as dist
