@@ -260,19 +260,27 @@ class FineTuner:
         decoder_pad_id: any valid token id (it fills prompt positions whose targets are -100 and which no earlier position
         attends to).  Returns the summed (un-scaled) loss vector like micro_step."""
         accum = int(accum_grad_steps or len(micro_batches))
-        if not fused or len(micro_batches) == 1:
+        m = self.model
+        mel = None
+        if fused and len(micro_batches) > 1 and not get_orig_len and not m._encoder_frozen():
+            # the log-mel of every micro-batch on its own (zero-padding to ITS longest clip, clamp at ITS maximum - 8: the reference
+            # computes one log-mel per batch, module/align_model.py:78-84), then one batch of 30 s windows
+            from .whisper_compat import N_FRAMES, pad_or_trim
+            with torch.no_grad():
+                mels = [m._mel_of(mb["audios"]) for mb in micro_batches]
+            if all(x.shape[-1] <= N_FRAMES for x in mels):
+                mel = torch.cat([pad_or_trim(x, N_FRAMES) for x in mels], dim=0)
+        if mel is None:                                         # not fusable (ragged frame counts, long-form chunks, frozen encoder): the loop
             out = None
             for mb in micro_batches:
                 l = self.micro_step(accum_grad_steps=accum, get_orig_len=get_orig_len, **mb)
                 out = l if out is None else out + l
             return out
-        m = self.model
         m.train()
         from .decoder_train import cross_entropy
         dev = self.flat[0].device
         out = torch.zeros((4,), dtype=torch.float32, device=dev)
         s = 1.0 / float(accum)
-        audios = [a for mb in micro_batches for a in mb["audios"]]
         sizes = [len(mb["audios"]) for mb in micro_batches]
         want_dec = m.train_transcript and all(mb.get("decoder_input") is not None for mb in micro_batches)
         y_in = None
@@ -285,7 +293,7 @@ class FineTuner:
                 pad = n_tok - int(di.shape[1])
                 rows.append(torch.nn.functional.pad(di, (0, pad), value=decoder_pad_id) if pad else di)
             y_in = torch.cat(rows, dim=0)
-        align_logit, trans_logit = m.frame_manual_forward(audios, y_in, get_orig_len=get_orig_len)
+        align_logit, trans_logit = m.frame_manual_forward(None, y_in, get_orig_len=False, mel=mel)
         roots, grads = [], []
         if align_logit is not None and m.train_alignment:
             al = align_logit.detach()

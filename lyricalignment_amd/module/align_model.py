@@ -204,12 +204,16 @@ class AlignModel(torch.nn.Module):
         feats = eng.encode(song_major_chunks(mel, plan))
         return feats, B, sum(k for _, _, k in plan), len(plan) * N_CTX
 
-    def frame_manual_forward(self, audios: List[np.ndarray], y_in=None, get_orig_len: bool = True):
+    def frame_manual_forward(self, audios: List[np.ndarray], y_in=None, get_orig_len: bool = True, mel: Optional[torch.Tensor] = None):
+        """(:72-123).  `mel` (addition, training path only): a ready log-mel batch instead of `audios` -- FineTuner.accumulate
+        computes it per micro-batch (the reference's log-mel clamps at the BATCH maximum - 8, :84, so a micro-batch's features
+        depend on which clips it holds) and runs the micro-batches as one batch from there."""
         train = self._wants_grad()
         if train and not self._encoder_frozen():                            # whole-model fine-tune (train_multitask.py default)
             from ..head_train import HeadFunction, head_params
-            with torch.no_grad():
-                mel = self._mel_of(audios)
+            if mel is None:
+                with torch.no_grad():
+                    mel = self._mel_of(audios)
             embed, embed_pad = self._encoder_train_features(mel, get_orig_len)
             align_logit = transcribe_logit = None
             if self.train_alignment:
