@@ -393,6 +393,18 @@ int la_layernorm_bwd_f32(const float *x, const float *dy, const float *gamma, in
 /* causal_q_len > 0: row r is query (r mod causal_q_len) and sees keys 0 .. (r mod causal_q_len) + cols - causal_q_len */
 int la_softmax_rows_f32(float *s, int64_t ld, int64_t rows, int32_t cols, int32_t causal_q_len, void *stream);
 int la_softmax_bwd_rows_f32(const float *p, float *dp, int64_t ld, int64_t rows, int32_t cols, void *stream);
+/* Fused float32 attention backward, head_dim 64 (the gradient of whisper/model.py MultiHeadAttention.qkv_attention, reached from
+ * train_multitask.py:325-326): q [batch*q_len][ld_q] (pre-scaled by head_dim^-0.5, as la_attention takes it), k / v
+ * [batch*kv_len][ld_kv], o = the forward output and dout its gradient [batch*q_len][ld_o / ld_do]; head h owns columns
+ * 64 h .. 64 h + 63 of every operand.  Writes dq [batch*q_len][ld_dq] (w.r.t. the pre-scaled q) and dk / dv [batch*kv_len][ld_dkv].
+ * Nothing of size q_len x kv_len is materialised: scores are recomputed per 64 x 64 tile (three launches: row statistics,
+ * a key-block sweep for dk / dv, a query-block sweep for dq).  workspace: la_attention_bwd_workspace_bytes (2 floats per
+ * query row and head).  causal != 0: key j is visible to queries i >= j (q_len == kv_len). */
+int la_attention_bwd_workspace_bytes(int32_t batch, int32_t q_len, int32_t n_head, size_t *bytes);
+int la_attention_bwd_f32(const float *q, int64_t ld_q, const float *k, const float *v, int64_t ld_kv, const float *o, int64_t ld_o,
+                         const float *dout, int64_t ld_do, float *dq, int64_t ld_dq, float *dk, float *dv, int64_t ld_dkv,
+                         int32_t batch, int32_t q_len, int32_t kv_len, int32_t n_head, int32_t causal, void *workspace,
+                         size_t workspace_bytes, void *stream);
 /* Text-decoder training pieces (whisper/model.py TextDecoder; train_multitask.py:285,308 decoder cross-entropy):
  * gradient of token + learned positional embedding (dtok accumulates, dpos [n][d] is written), and
  * F.cross_entropy(logits [rows][vocab], target, ignore_index=-100, 'mean'): loss2[0] = loss, loss2[1] = 1/count;

@@ -111,7 +111,7 @@ class DecoderFunction(torch.autograd.Function):
             dac = gemm_nn(dx2, woc)
             dqc = torch.empty((M, d), dtype=torch.float32, device=dev)
             dkv = torch.empty((B * Ta, 2 * d), dtype=torch.float32, device=dev)
-            attention_bwd_ex(qc, kv[:, :d], kv[:, d:], dac, dqc, dkv[:, :d], dkv[:, d:], B, n, Ta, H, causal=False)
+            attention_bwd_ex(qc, kv[:, :d], kv[:, d:], dac, dqc, dkv[:, :d], dkv[:, d:], B, n, Ta, H, causal=False, o=ac)
             G[11], G[12] = scale(gemm_tn(dqc, hc), 0.125), scale(colsum(dqc), 0.125)
             dwkv, dbkv = gemm_tn(dkv, xa2), colsum(dkv)
             G[13], G[14], G[15] = dwkv[:d], dwkv[d:], dbkv[d:]
@@ -122,7 +122,7 @@ class DecoderFunction(torch.autograd.Function):
             dx1 = add(dx2, dln)
             # causal self-attention
             G[7], G[8] = gemm_tn(dx1, a), colsum(dx1)
-            dqkv = attention_bwd(qkv, gemm_nn(dx1, wo), B, n, H, causal=True)
+            dqkv = attention_bwd(qkv, gemm_nn(dx1, wo), B, n, H, causal=True, att=a)
             dwqkv, dbqkv = gemm_tn(dqkv, h1), colsum(dqkv)
             G[2], G[3] = scale(dwqkv[:d], 0.125), scale(dbqkv[:d], 0.125)
             G[4], G[5], G[6] = dwqkv[d:2 * d], dwqkv[2 * d:], dbqkv[2 * d:]

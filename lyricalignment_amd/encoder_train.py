@@ -17,6 +17,8 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional, Sequence
 
+import os
+
 import torch
 
 from . import _lib, ops
@@ -85,10 +87,24 @@ def transpose_batched(src, ld_in, bs_in, rows, cols, out, ld_out, bs_out, out_ro
                                              batch, stream_ptr()), "transpose_pad_batched")
 
 
-def attention_bwd_ex(q, k, v, do, dq, dk, dv, B: int, Tq: int, Tk: int, H: int, causal: bool = False) -> None:
+ATTN_BWD_COMPOSED = os.environ.get("LA_ATTN_BWD", "fused") == "composed"     # developer A/B: the round-1 composition of batched GEMMs
+
+
+def attention_bwd_ex(q, k, v, do, dq, dk, dv, B: int, Tq: int, Tk: int, H: int, causal: bool = False, o=None) -> None:
     """Row views q/do/dq [B*Tq, >=64H], k/v/dk/dv [B*Tk, >=64H] (column slices of packed projections are fine; q pre-scaled
-    by 1/8).  Per clip, for all heads at once: S = q k^T and P = softmax(S) are recomputed (the forward kernel keeps no P),
+    by 1/8).  With the forward output `o` given: the fused kernel la_attention_bwd_f32 (scores recomputed per 64 x 64 tile, nothing
+    of size Tq x Tk materialised, all clips in three launches).  Without it (or LA_ATTN_BWD=composed), per clip, for all heads
+    at once: S = q k^T and P = softmax(S) are recomputed as whole [H, Tq, Tk] tiles,
     dP = dO v^T, dS = P o (dP - rowsum(dP o P)), dQ = dS k, dK = dS^T q, dV = P^T dO."""
+    if o is not None and not ATTN_BWD_COMPOSED and k.stride(0) == v.stride(0) and dk.stride(0) == dv.stride(0):
+        import ctypes
+        need = ctypes.c_size_t(0)
+        check(lib().la_attention_bwd_workspace_bytes(B, Tq, H, ctypes.byref(need)), "attention_bwd_workspace_bytes")
+        ws = torch.empty((need.value // 4,), dtype=torch.float32, device=q.device)
+        check(lib().la_attention_bwd_f32(ptr(q), q.stride(0), ptr(k), ptr(v), k.stride(0), ptr(o), o.stride(0), ptr(do), do.stride(0),
+                                         ptr(dq), dq.stride(0), ptr(dk), ptr(dv), dk.stride(0), B, Tq, Tk, H, 1 if causal else 0,
+                                         ptr(ws), need.value, stream_ptr()), "attention_bwd")
+        return
     Tqp, Tkp = _rup(Tq), _rup(Tk)
     f = dict(dtype=torch.float32, device=q.device)
     P = torch.empty((H, Tq, Tkp), **f)
@@ -125,11 +141,13 @@ def attention_bwd_ex(q, k, v, do, dq, dk, dv, B: int, Tq: int, Tk: int, H: int, 
         gemm_ex(Tk, 64, Tqp, H, Pt, Tqp, Tk * Tqp, dOt, Tqp, 64 * Tqp, dvb, dv.stride(0), 64)      # dV
 
 
-def attention_bwd(qkv: torch.Tensor, datt: torch.Tensor, B: int, T: int, H: int, causal: bool = False) -> torch.Tensor:
-    """Self-attention over a packed projection: qkv [B*T, 3d] (q pre-scaled), datt [B*T, d] -> dqkv [B*T, 3d]."""
+def attention_bwd(qkv: torch.Tensor, datt: torch.Tensor, B: int, T: int, H: int, causal: bool = False, att=None) -> torch.Tensor:
+    """Self-attention over a packed projection: qkv [B*T, 3d] (q pre-scaled), datt [B*T, d] -> dqkv [B*T, 3d];
+    att = the forward output [B*T, d] (selects the fused kernel)."""
     d = 64 * H
     dqkv = torch.empty((B * T, 3 * d), dtype=torch.float32, device=qkv.device)
-    attention_bwd_ex(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], datt, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], B, T, T, H, causal)
+    attention_bwd_ex(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], datt.contiguous(), dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], B, T, T, H,
+                     causal, o=att)
     return dqkv
 
 
@@ -214,7 +232,7 @@ class EncoderFunction(torch.autograd.Function):
             dx_mid = add(dx, dln)
             # x_mid = x + att Wo^T + bo
             G[7], G[8] = gemm_tn(dx_mid, att), colsum(dx_mid)
-            dqkv = attention_bwd(qkv, gemm_nn(dx_mid, wo), B, N_CTX, H)
+            dqkv = attention_bwd(qkv, gemm_nn(dx_mid, wo), B, N_CTX, H, att=att)
             dwqkv, dbqkv = gemm_tn(dqkv, h1), colsum(dqkv)
             G[2], G[3] = scale(dwqkv[:d], 0.125), scale(dbqkv[:d], 0.125)
             G[4], G[5], G[6] = dwqkv[d:2 * d], dwqkv[2 * d:], dbqkv[2 * d:]

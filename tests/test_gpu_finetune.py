@@ -160,9 +160,11 @@ def _rel(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
 
 
-@pytest.mark.parametrize("B,T,H", [(1, 96, 2), (2, 1500, 1), (1, 333, 3)])
-def test_attention_backward_matches_torch_autograd(B, T, H):
-    """dQ/dK/dV from recomputed score tiles (batched f32 MFMA GEMMs + row softmax kernels) against torch autograd."""
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("B,T,H", [(1, 96, 2), (2, 1500, 1), (1, 333, 3), (3, 64, 2), (2, 130, 1)])
+def test_attention_backward_matches_torch_autograd(B, T, H, fused):
+    """dQ/dK/dV against torch autograd: the fused kernel la_attention_bwd_f32 (forward output given: scores recomputed per 64 x 64
+    tile) and the round-1 composition (batched f32 MFMA GEMMs over whole score tiles + row softmax kernels)."""
     from lyricalignment_amd import encoder_train as et
     d = 64 * H
     g = torch.Generator().manual_seed(T)
@@ -173,9 +175,34 @@ def test_attention_backward_matches_torch_autograd(B, T, H):
     q, k, v = [t.view(B, T, H, 64).permute(0, 2, 1, 3) for t in ref_in.split(d, dim=1)]
     o = (torch.softmax(q @ k.transpose(-1, -2), dim=-1) @ v).permute(0, 2, 1, 3).reshape(B * T, d)
     o.backward(datt)
-    got = et.attention_bwd(qkv.cuda(), datt.cuda(), B, T, H).cpu()
+    got = et.attention_bwd(qkv.cuda(), datt.cuda(), B, T, H, att=o.detach().cuda() if fused else None).cpu()
     for name, sl in (("dq", slice(0, d)), ("dk", slice(d, 2 * d)), ("dv", slice(2 * d, 3 * d))):
         assert _rel(got[:, sl], ref_in.grad[:, sl]) < 2e-4, name     # float32 tolerance (north_star: 1e-3)
+
+
+@pytest.mark.parametrize("B,Tq,Tk,H,causal", [(2, 37, 37, 2, True), (2, 5, 1500, 2, False), (1, 70, 200, 1, False), (3, 129, 129, 1, True)])
+def test_fused_attention_backward_causal_and_cross_shapes(B, Tq, Tk, H, causal):
+    """la_attention_bwd_f32 on the text decoder's shapes: causal self-attention and cross-attention (q_len != kv_len, ragged last
+    tiles, operands as column slices of packed projections) against torch autograd."""
+    from lyricalignment_amd import encoder_train as et
+    d = 64 * H
+    g = torch.Generator().manual_seed(Tq * 7 + Tk)
+    q0 = (torch.randn(B * Tq, d, generator=g) * 0.35).requires_grad_(True)
+    kv0 = torch.randn(B * Tk, 2 * d, generator=g).requires_grad_(True)
+    do = torch.randn(B * Tq, d, generator=g)
+    q = q0.view(B, Tq, H, 64).permute(0, 2, 1, 3)
+    k, v = [t.view(B, Tk, H, 64).permute(0, 2, 1, 3) for t in kv0.split(d, dim=1)]
+    s = q @ k.transpose(-1, -2)
+    if causal:
+        s = s + torch.full((Tq, Tk), float("-inf")).triu(1)
+    o = (torch.softmax(s, dim=-1) @ v).permute(0, 2, 1, 3).reshape(B * Tq, d)
+    o.backward(do)
+    qd, kvd = q0.detach().cuda(), kv0.detach().cuda()
+    dq = torch.empty_like(qd)
+    dkv = torch.empty_like(kvd)
+    et.attention_bwd_ex(qd, kvd[:, :d], kvd[:, d:], do.cuda(), dq, dkv[:, :d], dkv[:, d:], B, Tq, Tk, H, causal=causal, o=o.detach().cuda())
+    assert _rel(dq.cpu(), q0.grad) < 2e-4
+    assert _rel(dkv.cpu()[:, :d], kv0.grad[:, :d]) < 2e-4 and _rel(dkv.cpu()[:, d:], kv0.grad[:, d:]) < 2e-4
 
 
 @pytest.mark.parametrize("d,H,L,B", [(64, 1, 1, 1), (128, 2, 2, 2)])
