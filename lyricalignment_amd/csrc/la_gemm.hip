@@ -829,8 +829,11 @@ static int gemm_run_ldw(int dtype, int M, int N, int K, int batch, const void *A
         // a partial last round of tiles (192 or 384 tiles on 256 CUs) -> S = 4 / 2 makes the rounds finer (768 quarter / half
         // tiles = 3 full rounds) when K is long enough to pay for the partial-sum pass.
         const int ksteps = la::cdiv(K, 32);
+        // (two 128x128 workgroups fit a CU, so 512 slots would fill it twice over: LA_GEMM_SPLIT_SLOTS=512 measured no
+        //  difference on the fused fine-tune step, 868 vs 868 ms; one workgroup per CU stays the limit)
+        static const int kSlots = getenv("LA_GEMM_SPLIT_SLOTS") ? atoi(getenv("LA_GEMM_SPLIT_SLOTS")) : 256;
         int S = 1;
-        while (S < 16 && tiles * S * 2 <= 256 && ksteps / (S * 2) >= 4) S *= 2;
+        while (S < 16 && tiles * S * 2 <= kSlots && ksteps / (S * 2) >= 4) S *= 2;
         if (S == 1 && K >= 1024 && (int64_t)M * N <= ((int64_t)4 << 20)) {
             if (tiles * 4 % 256 == 0 && tiles % 256 != 0 && tiles < 256) S = 4;
             else if (tiles * 2 % 256 == 0 && tiles % 256 != 0 && tiles < 512) S = 2;
