@@ -399,12 +399,16 @@ int la_softmax_bwd_rows_f32(const float *p, float *dp, int64_t ld, int64_t rows,
  * 64 h .. 64 h + 63 of every operand.  Writes dq [batch*q_len][ld_dq] (w.r.t. the pre-scaled q) and dk / dv [batch*kv_len][ld_dkv].
  * Nothing of size q_len x kv_len is materialised: scores are recomputed per 64 x 64 tile (three launches: row statistics,
  * a key-block sweep for dk / dv, a query-block sweep for dq).  workspace: la_attention_bwd_workspace_bytes (2 floats per
- * query row and head).  causal != 0: key j is visible to queries i >= j (q_len == kv_len). */
+ * query row and head).  lse: the forward's row statistic (la_attention_lse_f32) or NULL.  causal != 0: key j is visible to queries i >= j (q_len == kv_len). */
 int la_attention_bwd_workspace_bytes(int32_t batch, int32_t q_len, int32_t n_head, size_t *bytes);
 int la_attention_bwd_f32(const float *q, int64_t ld_q, const float *k, const float *v, int64_t ld_kv, const float *o, int64_t ld_o,
                          const float *dout, int64_t ld_do, float *dq, int64_t ld_dq, float *dk, float *dv, int64_t ld_dkv,
-                         int32_t batch, int32_t q_len, int32_t kv_len, int32_t n_head, int32_t causal, void *workspace,
-                         size_t workspace_bytes, void *stream);
+                         int32_t batch, int32_t q_len, int32_t kv_len, int32_t n_head, int32_t causal, const float *lse,
+                         void *workspace, size_t workspace_bytes, void *stream);
+/* The float32 training forward: la_attention_ex(LA_F32, ...) that also writes lse [batch][n_head][q_len] = log sum_j exp(s_ij);
+ * handed to la_attention_bwd_f32 (`lse`; NULL there = recomputed by one more sweep over the scores). */
+int la_attention_lse_f32(const float *q, int64_t ld_q, const float *k, const float *v, int64_t ld_kv, float *out, int64_t ld_out,
+                         int32_t batch, int32_t q_len, int32_t kv_len, int32_t n_head, int32_t causal, float *lse, void *stream);
 /* Text-decoder training pieces (whisper/model.py TextDecoder; train_multitask.py:285,308 decoder cross-entropy):
  * gradient of token + learned positional embedding (dtok accumulates, dpos [n][d] is written), and
  * F.cross_entropy(logits [rows][vocab], target, ignore_index=-100, 'mean'): loss2[0] = loss, loss2[1] = 1/count;

@@ -57,6 +57,7 @@ struct AttnParams {
     int64_t q_bs, kv_bs, out_bs;   // rows from one clip to the next (== q_len / kv_len / q_len unless the caller says otherwise)
     int batch;
     float defer_thr;               // 16-bit kernels: deferred-maximum threshold (exp2 domain); 0 = the textbook online softmax
+    float *lse = nullptr;          // float32 kernel, training forward: log sum_j exp(s_ij) per query row, [batch][n_head][q_len] (la_attention_bwd_f32)
 };
 
 // Block -> (query tile, head, clip).  Workgroups are dealt round-robin over the 8 XCDs in launch order and every XCD has its
@@ -530,6 +531,8 @@ __global__ __launch_bounds__(256, 2) void attention_f32_kernel(AttnParams p) {
 
     const float l = l_part + __shfl_xor(l_part, 32);
     const float inv = 1.0f / l;
+    if (p.lse && q_valid && h == 0)          // m_run is in the exp2 domain: lse = m ln 2 + ln l
+        p.lse[((int64_t)clip * p.n_head + head) * p.q_len + qrow] = fmaf(m_run, 0.6931471805599453f, __logf(l));
     if (q_valid) {
         float *orow = reinterpret_cast<float *>(p.out) + ((int64_t)clip * p.out_bs + qrow) * p.ld_out + head * 64;
 #pragma unroll
@@ -630,6 +633,22 @@ extern "C" int la_attention_ex(int32_t dtype, const void *q, int64_t ld_q, const
                  "attention_ex: rows must be 16-byte aligned");
     AttnParams p{q, k, v, ld_q, ld_kv, out, ld_out, q_len, kv_len, n_head, causal ? 1 : 0, q_len, kv_len, q_len, 0};
     return attention_launch(dtype, p, batch, stream);
+}
+
+// The float32 forward of the TRAINING path: la_attention_ex that also hands over the row statistic the fused backward needs
+// (lse [batch][n_head][q_len]), so that la_attention_bwd_f32 does not recompute the scores once more just for it.
+extern "C" int la_attention_lse_f32(const float *q, int64_t ld_q, const float *k, const float *v, int64_t ld_kv, float *out, int64_t ld_out,
+                                    int32_t batch, int32_t q_len, int32_t kv_len, int32_t n_head, int32_t causal, float *lse, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (batch == 0 || q_len == 0) return LA_OK;
+    LA_CHECK_ARG(q && k && v && out && lse && batch > 0 && q_len > 0 && kv_len > 0 && n_head > 0, "attention_lse: bad arguments");
+    LA_CHECK_ARG(!causal || q_len == kv_len, "attention_lse: causal masking is defined for self-attention (q_len == kv_len)");
+    LA_CHECK_ARG(ld_q >= n_head * 64 && ld_kv >= n_head * 64 && ld_out >= n_head * 64, "attention_lse: leading dimensions too small");
+    LA_CHECK_ARG(ld_q % 4 == 0 && ld_kv % 4 == 0 && ld_out % 4 == 0 && (uintptr_t)q % 16 == 0 && (uintptr_t)k % 16 == 0 && (uintptr_t)v % 16 == 0 &&
+                     (uintptr_t)out % 16 == 0, "attention_lse: rows must be 16-byte aligned");
+    AttnParams p{q, k, v, ld_q, ld_kv, out, ld_out, q_len, kv_len, n_head, causal ? 1 : 0, q_len, kv_len, q_len, 0};
+    p.lse = lse;
+    return attention_launch(LA_F32, p, batch, stream);
 }
 
 // Attention against a key / value CACHE (autoregressive decoding, whisper/decoding.py's kv_cache): clip b's keys are rows

@@ -32,6 +32,7 @@ struct BwdParams {
     int64_t ld_q, ld_kv, ld_o, ld_do, ld_dq, ld_dkv;
     int B, Tq, Tk, H, causal;
     float *lse, *dvec;          // [B][H][Tq]
+    int have_lse;               // lse was handed over by the forward kernel (la_attention_lse_f32): the statistics sweep only takes D
 };
 
 // Workgroup shape of the two sweep kernels: NT threads = NT / 64 waves as 2 (row halves of 32) x WN (column strips of 64 / WN);
@@ -48,6 +49,24 @@ __device__ __forceinline__ void load_tile(float *T, const float *src, int64_t ld
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (row0 + row < limit) v = *reinterpret_cast<const float4 *>(src + (int64_t)(row0 + row) * ld + c4 * 4);
         *reinterpret_cast<float4 *>(T + row * PITCH + c4 * 4) = v;
+    }
+}
+// the same in two halves, so that the global loads of the NEXT tile are in flight while the current one is computed on
+template <int NTH>
+__device__ __forceinline__ void fetch_tile(float4 (&v)[1024 / NTH], const float *src, int64_t ld, int row0, int limit, int tid) {
+#pragma unroll
+    for (int it = 0; it < 1024 / NTH; ++it) {
+        const int idx = tid + it * NTH, row = idx >> 4, c4 = idx & 15;
+        v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row0 + row < limit) v[it] = *reinterpret_cast<const float4 *>(src + (int64_t)(row0 + row) * ld + c4 * 4);
+    }
+}
+template <int NTH>
+__device__ __forceinline__ void put_tile(float *T, const float4 (&v)[1024 / NTH], int tid) {
+#pragma unroll
+    for (int it = 0; it < 1024 / NTH; ++it) {
+        const int idx = tid + it * NTH, row = idx >> 4, c4 = idx & 15;
+        *reinterpret_cast<float4 *>(T + row * PITCH + c4 * 4) = v[it];
     }
 }
 __device__ __forceinline__ uint4 frag_n(const float *T, int row, int k0) {      // 4 consecutive k of one row
@@ -143,10 +162,11 @@ __global__ __launch_bounds__(256) void attn_stats_kernel(BwdParams p) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, q = lane >> 4;
     const float *qb = p.q + (int64_t)b * p.Tq * p.ld_q + h * 64;
     const float *kb = p.k + (int64_t)b * p.Tk * p.ld_kv + h * 64;
-    load_tile<256>(Qt, qb, p.ld_q, i0, p.Tq, tid);
     const int row = 16 * w + r, qg = i0 + row;       // this lane's query row (shared by the 4 lanes q = 0..3)
     float m_run = -INFINITY, l_run = 0.f;
     int nkb = (p.Tk + BT - 1) / BT;
+    if (p.have_lse) nkb = 0;
+    else load_tile<256>(Qt, qb, p.ld_q, i0, p.Tq, tid);
     if (p.causal) nkb = min(nkb, (min(p.Tq, i0 + BT) - 1) / BT + 1);
     for (int jb = 0; jb < nkb; ++jb) {
         const int j0 = jb * BT;
@@ -202,7 +222,7 @@ __global__ __launch_bounds__(256) void attn_stats_kernel(BwdParams p) {
     dsum += __shfl_xor(dsum, 32);
     if (q == 0 && qg < p.Tq) {
         const int64_t idx = ((int64_t)b * p.H + h) * p.Tq + qg;
-        p.lse[idx] = m_run + __logf(l_run);
+        if (!p.have_lse) p.lse[idx] = m_run + __logf(l_run);
         p.dvec[idx] = dsum;
     }
 }
@@ -234,14 +254,22 @@ __global__ __launch_bounds__(NT) void attn_bwd_kv_kernel(BwdParams p) {
     zero(dK);
     zero(dV);
     const int nqb = (p.Tq + BT - 1) / BT;
-    for (int ib = p.causal ? j0 / BT : 0; ib < nqb; ++ib) {         // causal: queries before this key block see none of its keys
+    const int ib0 = p.causal ? j0 / BT : 0;                         // causal: queries before this key block see none of its keys
+    float4 qn[1024 / NT], don[1024 / NT];                           // the next query block's Q / dO rows, in flight under the products
+    fetch_tile<NT>(qn, qb, p.ld_q, ib0 * BT, p.Tq, tid);
+    fetch_tile<NT>(don, dob, p.ld_do, ib0 * BT, p.Tq, tid);
+    for (int ib = ib0; ib < nqb; ++ib) {
         const int i0 = ib * BT;
         __syncthreads();                                            // the previous iteration's reads of Qt / dOt / Pt / dSt
-        load_tile<NT>(Qt, qb, p.ld_q, i0, p.Tq, tid);
-        load_tile<NT>(dOt, dob, p.ld_do, i0, p.Tq, tid);
+        put_tile<NT>(Qt, qn, tid);
+        put_tile<NT>(dOt, don, tid);
         float lse[2], dv[2];
         row_scalars(p, b, h, i0, wm, r, lse, dv);
         __syncthreads();
+        if (ib + 1 < nqb) {
+            fetch_tile<NT>(qn, qb, p.ld_q, i0 + BT, p.Tq, tid);
+            fetch_tile<NT>(don, dob, p.ld_do, i0 + BT, p.Tq, tid);
+        }
         f32x4 P[2][NI], dS[2][NI];
         tile_p_ds(p, Qt, dOt, Kt, Vt, i0, j0, lse, dv, wm, wn, r, q, P, dS);
         store_acc_tile(Pt, P, wm, wn, r, q);
@@ -270,12 +298,19 @@ __global__ __launch_bounds__(NT) void attn_bwd_q_kernel(BwdParams p) {
     zero(dQ);
     int nkb = (p.Tk + BT - 1) / BT;
     if (p.causal) nkb = min(nkb, (min(p.Tq, i0 + BT) - 1) / BT + 1);
+    float4 kn[1024 / NT], vn[1024 / NT];                            // the next key block's K / V rows, in flight under the products
+    fetch_tile<NT>(kn, kb, p.ld_kv, 0, p.Tk, tid);
+    fetch_tile<NT>(vn, vb, p.ld_kv, 0, p.Tk, tid);
     for (int jb = 0; jb < nkb; ++jb) {
         const int j0 = jb * BT;
         __syncthreads();
-        load_tile<NT>(Kt, kb, p.ld_kv, j0, p.Tk, tid);
-        load_tile<NT>(Vt, vb, p.ld_kv, j0, p.Tk, tid);
+        put_tile<NT>(Kt, kn, tid);
+        put_tile<NT>(Vt, vn, tid);
         __syncthreads();
+        if (jb + 1 < nkb) {
+            fetch_tile<NT>(kn, kb, p.ld_kv, j0 + BT, p.Tk, tid);
+            fetch_tile<NT>(vn, vb, p.ld_kv, j0 + BT, p.Tk, tid);
+        }
         f32x4 P[2][NI], dS[2][NI];
         tile_p_ds(p, Qt, dOt, Kt, Vt, i0, j0, lse, dv, wm, wn, r, q, P, dS);
         store_acc_tile(dSt, dS, wm, wn, r, q);
@@ -295,8 +330,8 @@ extern "C" int la_attention_bwd_workspace_bytes(int32_t batch, int32_t q_len, in
 
 extern "C" int la_attention_bwd_f32(const float *q, int64_t ld_q, const float *k, const float *v, int64_t ld_kv, const float *o, int64_t ld_o,
                                     const float *dout, int64_t ld_do, float *dq, int64_t ld_dq, float *dk, float *dv, int64_t ld_dkv,
-                                    int32_t batch, int32_t q_len, int32_t kv_len, int32_t n_head, int32_t causal, void *workspace,
-                                    size_t workspace_bytes, void *stream_) {
+                                    int32_t batch, int32_t q_len, int32_t kv_len, int32_t n_head, int32_t causal, const float *lse_in,
+                                    void *workspace, size_t workspace_bytes, void *stream_) {
     if (batch == 0 || q_len == 0 || kv_len == 0) return LA_OK;
     LA_CHECK_ARG(q && k && v && o && dout && dq && dk && dv && workspace, "attention_bwd: null pointer");
     LA_CHECK_ARG(batch > 0 && q_len > 0 && kv_len > 0 && n_head > 0, "attention_bwd: bad sizes");
@@ -311,7 +346,7 @@ extern "C" int la_attention_bwd_f32(const float *q, int64_t ld_q, const float *k
     hipStream_t stream = (hipStream_t)stream_;
     float *lse = static_cast<float *>(workspace);
     BwdParams p{q, k, v, o, dout, dq, dk, dv, ld_q, ld_kv, ld_o, ld_do, ld_dq, ld_dkv, batch, q_len, kv_len, n_head, causal ? 1 : 0,
-                lse, lse + (size_t)batch * n_head * q_len};
+                lse_in ? const_cast<float *>(lse_in) : lse, lse + (size_t)batch * n_head * q_len, lse_in ? 1 : 0};
     static bool attr_done = false;
     if (!attr_done) {
         LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_kv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * TILE * 4));

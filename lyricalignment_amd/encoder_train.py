@@ -90,7 +90,7 @@ def transpose_batched(src, ld_in, bs_in, rows, cols, out, ld_out, bs_out, out_ro
 ATTN_BWD_COMPOSED = os.environ.get("LA_ATTN_BWD", "fused") == "composed"     # developer A/B: the round-1 composition of batched GEMMs
 
 
-def attention_bwd_ex(q, k, v, do, dq, dk, dv, B: int, Tq: int, Tk: int, H: int, causal: bool = False, o=None) -> None:
+def attention_bwd_ex(q, k, v, do, dq, dk, dv, B: int, Tq: int, Tk: int, H: int, causal: bool = False, o=None, lse=None) -> None:
     """Row views q/do/dq [B*Tq, >=64H], k/v/dk/dv [B*Tk, >=64H] (column slices of packed projections are fine; q pre-scaled
     by 1/8).  With the forward output `o` given: the fused kernel la_attention_bwd_f32 (scores recomputed per 64 x 64 tile, nothing
     of size Tq x Tk materialised, all clips in three launches).  Without it (or LA_ATTN_BWD=composed), per clip, for all heads
@@ -103,7 +103,7 @@ def attention_bwd_ex(q, k, v, do, dq, dk, dv, B: int, Tq: int, Tk: int, H: int, 
         ws = torch.empty((need.value // 4,), dtype=torch.float32, device=q.device)
         check(lib().la_attention_bwd_f32(ptr(q), q.stride(0), ptr(k), ptr(v), k.stride(0), ptr(o), o.stride(0), ptr(do), do.stride(0),
                                          ptr(dq), dq.stride(0), ptr(dk), ptr(dv), dk.stride(0), B, Tq, Tk, H, 1 if causal else 0,
-                                         ptr(ws), need.value, stream_ptr()), "attention_bwd")
+                                         ptr(lse) if lse is not None else None, ptr(ws), need.value, stream_ptr()), "attention_bwd")
         return
     Tqp, Tkp = _rup(Tq), _rup(Tk)
     f = dict(dtype=torch.float32, device=q.device)
@@ -141,13 +141,13 @@ def attention_bwd_ex(q, k, v, do, dq, dk, dv, B: int, Tq: int, Tk: int, H: int, 
         gemm_ex(Tk, 64, Tqp, H, Pt, Tqp, Tk * Tqp, dOt, Tqp, 64 * Tqp, dvb, dv.stride(0), 64)      # dV
 
 
-def attention_bwd(qkv: torch.Tensor, datt: torch.Tensor, B: int, T: int, H: int, causal: bool = False, att=None) -> torch.Tensor:
+def attention_bwd(qkv: torch.Tensor, datt: torch.Tensor, B: int, T: int, H: int, causal: bool = False, att=None, lse=None) -> torch.Tensor:
     """Self-attention over a packed projection: qkv [B*T, 3d] (q pre-scaled), datt [B*T, d] -> dqkv [B*T, 3d];
     att = the forward output [B*T, d] (selects the fused kernel)."""
     d = 64 * H
     dqkv = torch.empty((B * T, 3 * d), dtype=torch.float32, device=qkv.device)
     attention_bwd_ex(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], datt.contiguous(), dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], B, T, T, H,
-                     causal, o=att)
+                     causal, o=att, lse=lse)
     return dqkv
 
 
@@ -198,12 +198,13 @@ class EncoderFunction(torch.autograd.Function):
             bqkv = torch.cat([scale(bq, 0.125), torch.zeros_like(bq), bv], 0).contiguous()
             h1 = ops.layernorm(x, g1, be1, torch.float32)
             qkv = ops.gemm(h1, wqkv, bias=bqkv)
-            att = ops.attention(qkv, B, N_CTX, H)
+            lse = torch.empty((B, H, N_CTX), dtype=torch.float32, device=qkv.device)        # row statistic for the fused backward
+            att = ops.attention_ex(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, N_CTX, N_CTX, H, lse=lse)
             x_mid = ops.gemm(att, wo, bias=bo, residual=x)
             h2 = ops.layernorm(x_mid, g2, be2, torch.float32)
             u_pre = ops.gemm(h2, w1, bias=b1)
             x_next = ops.gemm(gelu(u_pre), w2, bias=b2, residual=x_mid)
-            saved.append((x, h1, qkv, att, x_mid, h2, u_pre))
+            saved.append((x, h1, qkv, att, x_mid, h2, u_pre, lse))
             packed.append((g1, wqkv, wo, g2, w1, w2))
             x = x_next
         y = ops.layernorm(x, P[-2], P[-1], torch.float32)
@@ -221,7 +222,7 @@ class EncoderFunction(torch.autograd.Function):
         grads: List[Optional[torch.Tensor]] = [None] * (6 + 15 * n_layer)
         dx, grads[-2], grads[-1] = layernorm_bwd(ctx.x_last, dyf, ctx.lnp_g)
         for i in reversed(range(n_layer)):
-            x, h1, qkv, att, x_mid, h2, u_pre = ctx.saved[i]
+            x, h1, qkv, att, x_mid, h2, u_pre, lse = ctx.saved[i]
             g1, wqkv, wo, g2, w1, w2 = ctx.packed[i]
             G = [None] * 15
             # x_next = x_mid + gelu(u_pre) W2^T + b2
@@ -232,7 +233,7 @@ class EncoderFunction(torch.autograd.Function):
             dx_mid = add(dx, dln)
             # x_mid = x + att Wo^T + bo
             G[7], G[8] = gemm_tn(dx_mid, att), colsum(dx_mid)
-            dqkv = attention_bwd(qkv, gemm_nn(dx_mid, wo), B, N_CTX, H, att=att)
+            dqkv = attention_bwd(qkv, gemm_nn(dx_mid, wo), B, N_CTX, H, att=att, lse=lse)
             dwqkv, dbqkv = gemm_tn(dqkv, h1), colsum(dqkv)
             G[2], G[3] = scale(dwqkv[:d], 0.125), scale(dbqkv[:d], 0.125)
             G[4], G[5], G[6] = dwqkv[d:2 * d], dwqkv[2 * d:], dbqkv[2 * d:]

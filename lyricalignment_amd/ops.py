@@ -291,7 +291,7 @@ def fc_emissions(act: torch.Tensor, w_fc: torch.Tensor, b_fc: torch.Tensor, batc
 
 
 def attention_ex(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, q_len: int, kv_len: int, n_head: int,
-                 causal: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 causal: bool = False, out: Optional[torch.Tensor] = None, lse: Optional[torch.Tensor] = None) -> torch.Tensor:
     """General attention for the text decoder: q [batch*q_len, >=d] / k, v [batch*kv_len, >=d] row views (column slices of
     packed projections are fine: only the row pitch and the 16-byte alignment matter), q pre-scaled by 1/8."""
     for name, t in (("q", q), ("k", k), ("v", v)):
@@ -306,6 +306,13 @@ def attention_ex(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, 
         raise ValueError("attention_ex: views smaller than batch*len x n_head*64")
     if out is None:
         out = torch.empty((batch * q_len, d), dtype=q.dtype, device=q.device)
+    if lse is not None:                 # float32 training forward: also the row statistic for la_attention_bwd_f32
+        _dev(lse, "lse", torch.float32)
+        if q.dtype != torch.float32 or lse.numel() < batch * n_head * q_len or not lse.is_contiguous():
+            raise ValueError("attention_ex: lse goes with float32 operands, [batch, n_head, q_len] contiguous")
+        check(lib().la_attention_lse_f32(ptr(q), q.stride(0), ptr(k), ptr(v), k.stride(0), ptr(out), out.stride(0), batch, q_len, kv_len,
+                                         n_head, 1 if causal else 0, ptr(lse), stream_ptr()), "attention_lse")
+        return out
     check(lib().la_attention_ex(dt, ptr(q), q.stride(0), ptr(k), ptr(v), k.stride(0), ptr(out), out.stride(0), batch, q_len,
                                 kv_len, n_head, 1 if causal else 0, stream_ptr()), "attention_ex")
     return out

@@ -175,7 +175,15 @@ def test_attention_backward_matches_torch_autograd(B, T, H, fused):
     q, k, v = [t.view(B, T, H, 64).permute(0, 2, 1, 3) for t in ref_in.split(d, dim=1)]
     o = (torch.softmax(q @ k.transpose(-1, -2), dim=-1) @ v).permute(0, 2, 1, 3).reshape(B * T, d)
     o.backward(datt)
-    got = et.attention_bwd(qkv.cuda(), datt.cuda(), B, T, H, att=o.detach().cuda() if fused else None).cpu()
+    lse = None
+    if fused and T % 2 == 0:      # half of the shapes: the row statistic comes from the forward kernel (la_attention_lse_f32), as in training
+        from lyricalignment_amd import ops
+        qd = qkv.cuda()
+        lse = torch.empty((B, H, T), dtype=torch.float32, device="cuda")
+        o_dev = ops.attention_ex(qd[:, :d], qd[:, d:2 * d], qd[:, 2 * d:], B, T, T, H, lse=lse)
+        np.testing.assert_allclose(lse.cpu().numpy(), torch.logsumexp(q @ k.transpose(-1, -2), dim=-1).detach().numpy(), rtol=0, atol=2e-5)
+        np.testing.assert_allclose(o_dev.cpu().numpy(), o.detach().numpy(), rtol=0, atol=2e-5)
+    got = et.attention_bwd(qkv.cuda(), datt.cuda(), B, T, H, att=o.detach().cuda() if fused else None, lse=lse).cpu()
     for name, sl in (("dq", slice(0, d)), ("dk", slice(d, 2 * d)), ("dv", slice(2 * d, 3 * d))):
         assert _rel(got[:, sl], ref_in.grad[:, sl]) < 2e-4, name     # float32 tolerance (north_star: 1e-3)
 
