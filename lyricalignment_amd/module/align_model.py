@@ -303,10 +303,11 @@ def encoder_only_engine(whisper_model, mel: torch.Tensor) -> torch.Tensor:
     return eng.encode(mel, out_dtype=torch.float32).view(mel.shape[0], N_CTX, eng.enc.d).clone()
 
 
-def decoder_engine(whisper_model, tokens: torch.Tensor, audio_features: torch.Tensor, greedy=None) -> torch.Tensor:
-    """Whisper.logits for a bare whisper_compat.Whisper (float32 compute): packs encoder + decoder weights once.
-    greedy = (max_new_tokens, eot): run the greedy token loop from the prompt `tokens` instead and return the tokens."""
+def decoder_engine_of(whisper_model) -> AlignEngine:
+    """The float32 encoder + decoder engine of a bare whisper_compat.Whisper (packed once, re-packed when parameters change)."""
     _lib.require_gpu()
+    if whisper_model.decoder is None:
+        raise RuntimeError("this Whisper object was built without a decoder")
     cache = getattr(whisper_model, "_la_dec_engine", None)
     key = tuple(p._version for p in whisper_model.parameters())
     if cache is None or cache[0] != key:
@@ -317,7 +318,13 @@ def decoder_engine(whisper_model, tokens: torch.Tensor, audio_features: torch.Te
                           dec=pack_decoder(dec_sd, int(whisper_model.dims.n_text_head), torch.float32, dev))
         cache = (key, eng)
         whisper_model._la_dec_engine = cache
-    eng = cache[1]
+    return cache[1]
+
+
+def decoder_engine(whisper_model, tokens: torch.Tensor, audio_features: torch.Tensor, greedy=None) -> torch.Tensor:
+    """Whisper.logits for a bare whisper_compat.Whisper (float32 compute): packs encoder + decoder weights once.
+    greedy = (max_new_tokens, eot): run the greedy token loop from the prompt `tokens` instead and return the tokens."""
+    eng = decoder_engine_of(whisper_model)
     B, n_audio, d = audio_features.shape
     xa = audio_features.to(device=eng.device, dtype=torch.float32).contiguous().view(B * n_audio, d)
     if greedy is not None and len(greedy) == 3:

@@ -135,9 +135,21 @@ class Whisper(nn.Module):
         from .module.align_model import decoder_engine
         return decoder_engine(self, prompt, audio_features, greedy=(int(max_new_tokens), int(eot), int(beam_size)))
 
-    def transcribe(self, *a, **k):
-        raise NotImplementedError("whisper's transcribe (temperature fallback, timestamp rules, token suppression, tokenizer) is "
-                                  "not rebuilt here; decode_greedy() / decode_beam() run the decoder's token loop on the device")
+    def decode(self, mel_or_features: torch.Tensor, options=None, tokenizer=None):
+        """whisper.decode on 30 s windows: mel [B, 80, 3000] (or encoder outputs [B, 1500, d]) -> list of DecodingResult
+        (lyricalignment_amd.transcribe: logit filters, greedy / sampling / beam search; token ids, text only with a tokenizer)."""
+        from .transcribe import decode
+        x = mel_or_features
+        if x.dim() == 3 and x.shape[1] == self.dims.n_mels and x.shape[2] == N_FRAMES:
+            x = self.embed_audio(x)
+        return decode(self, x, options, tokenizer)
+
+    def transcribe(self, audio, **kwargs):
+        """whisper's transcribe (inference_transcript.py:88-91): sliding 30 s windows, temperature fallback, timestamp rules,
+        no-speech skipping, conditioning on the previous text -- lyricalignment_amd.transcribe.transcribe.  The vocabulary is not
+        in this image: result["text"] needs `tokenizer=TokenizerSpec(codec=...)`, result["tokens"] / ["segments"] do not."""
+        from .transcribe import transcribe
+        return transcribe(self, audio, **kwargs)
 
 
 def dims_for(name: str) -> ModelDimensions:

@@ -406,3 +406,31 @@ def test_gemm_main_loop_ab_variants_are_bit_identical(variant, monkeypatch):
     for _ in range(3):
         assert torch.equal(ops.gemm(a, w, bias=bias, gelu=True), ref16)
         assert torch.equal(ops.gemm(a, w, bias=bias, residual=res, out_f32=True), ref32)
+
+
+def test_kernel_timer_sampling_and_work_accounting():
+    """la_timer_sample / la_timer_read_work (bench.py's roofline leg): with period 3, launches 0, 3, 6 of the family are bracketed
+    by HIP events, their 2 M N K is summed, every launch is counted, other families are ignored."""
+    import ctypes
+    from lyricalignment_amd import _lib, ops
+    L = _lib.lib()
+    a = _rand(512, 256, seed=1).bfloat16().cuda()
+    w = _rand(384, 256, seed=2, scale=0.06).bfloat16().cuda()
+    x = _rand(64, 128, seed=3).cuda()
+    L.la_timer_reset()
+    assert L.la_timer_sample(0) != 0                  # period must be >= 1
+    assert L.la_timer_sample(3) == 0
+    L.la_timer_enable(b"gemm_bf16")
+    try:
+        for i in range(7):
+            ops.gemm(a, w)
+            ops.layernorm(x, torch.ones(128, device="cuda"), torch.zeros(128, device="cuda"), torch.float32)   # another family
+        torch.cuda.synchronize()
+    finally:
+        L.la_timer_disable()
+    ms, timed, work, seen = ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_int64(0)
+    assert L.la_timer_read_work(ctypes.byref(ms), ctypes.byref(timed), ctypes.byref(work), ctypes.byref(seen)) == 0
+    assert (timed.value, seen.value) == (3, 7) and ms.value > 0
+    assert work.value == 3 * 2.0 * 512 * 384 * 256
+    L.la_timer_reset()
+    L.la_timer_sample(1)

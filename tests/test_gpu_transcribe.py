@@ -1,0 +1,149 @@
+"""whisper's decoding rules and transcribe loop on the HIP decoder (lyricalignment_amd.transcribe; reference call site
+inference_transcript.py:88-91).  openai-whisper is not in this image: the rules are held to hand-worked cases of the published
+algorithm (whisper/decoding.py ApplyTimestampRules / SuppressBlank / SuppressTokens, whisper/transcribe.py) and to their invariants
+on sequences the device decoder actually produces."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def model():
+    from lyricalignment_amd import whisper_compat as wc
+    dims = wc.ModelDimensions(n_audio_state=128, n_audio_head=2, n_audio_layer=2, n_text_state=128, n_text_head=2, n_text_layer=2,
+                              n_vocab=51865, n_text_ctx=448)
+    return wc.build_model(dims=dims, seed=21, std=0.05, with_decoder=True)
+
+
+def _tok():
+    from lyricalignment_amd.transcribe import TokenizerSpec
+    return TokenizerSpec()
+
+
+def test_special_token_ids_of_both_vocabularies():
+    from lyricalignment_amd.transcribe import TokenizerSpec
+    m, e = TokenizerSpec(), TokenizerSpec(multilingual=False)
+    assert (m.eot, m.sot, m.language_token("en"), m.language_token("zh"), m.translate, m.transcribe, m.sot_lm, m.sot_prev, m.no_speech,
+            m.no_timestamps, m.timestamp_begin) == (50257, 50258, 50259, 50260, 50358, 50359, 50360, 50361, 50362, 50363, 50364)
+    assert m.timestamp_begin + 1501 == 51865 and e.timestamp_begin + 1501 == 51864          # 0.00 .. 30.00 s fill the vocabulary
+    assert m.sot_sequence("zh", "transcribe") == (50258, 50260, 50359) and e.sot_sequence(None, "transcribe") == (50257,)
+
+
+def test_timestamp_rules_on_hand_worked_cases():
+    """ApplyTimestampRules case by case: first token must be a timestamp <= max_initial; after text+timestamp the pair must be
+    closed or the text ended; after a closed pair no third timestamp; timestamps never decrease; timestamp mass beats text."""
+    from lyricalignment_amd.transcribe import apply_timestamp_rules_
+    tok = _tok()
+    tb, eot, V = tok.timestamp_begin, tok.eot, 51865
+    def fresh(n):
+        return torch.zeros((n, V), dtype=torch.float32, device="cuda")
+    # (a) nothing sampled yet
+    lg = fresh(2)
+    apply_timestamp_rules_(lg, [[], []], tok, 50)
+    finite = torch.isfinite(lg[0]).nonzero()[:, 0]
+    assert int(finite.min()) == tb and int(finite.max()) == tb + 50
+    # (b) text then ONE timestamp (an open pair): only timestamps >= it or <|endoftext|> ... i.e. no text token
+    lg = fresh(1)
+    lg[0, eot] = 50.0                                      # (a confident <|endoftext|>, so the probability-mass rule does not fire)
+    apply_timestamp_rules_(lg, [[tb + 10, 1000, 1001, tb + 60]], tok, 50)
+    assert not torch.isfinite(lg[0, :eot]).any() and torch.isfinite(lg[0, eot])
+    assert not torch.isfinite(lg[0, tb: tb + 60]).any() and torch.isfinite(lg[0, tb + 60]) and torch.isfinite(lg[0, tb + 61])
+    # (c) two timestamps in a row (a closed pair): the next token is text, never a third timestamp
+    lg = fresh(1)
+    lg[0, 1234] = 50.0                                     # a confident text token, so the probability-mass rule does not fire
+    apply_timestamp_rules_(lg, [[tb + 10, 1000, tb + 60, tb + 60]], tok, 50)
+    assert not torch.isfinite(lg[0, tb:]).any() and torch.isfinite(lg[0, 1234]) and not torch.isfinite(lg[0, tok.no_timestamps])
+    # (d) text after a timestamp: later timestamps must be strictly greater than the last one
+    lg = fresh(1)
+    lg[0, 1234] = 50.0
+    apply_timestamp_rules_(lg, [[tb + 10, 1000]], tok, 50)
+    assert not torch.isfinite(lg[0, tb: tb + 11]).any() and torch.isfinite(lg[0, tb + 11]) and torch.isfinite(lg[0, 1000])
+    # (e) flat logits over 1501 timestamps vs 50364 text tokens: every text token has 1 / 51865, the timestamps 1501 / 51865 together
+    lg = fresh(1)
+    apply_timestamp_rules_(lg, [[tb + 10, 1000]], tok, 50)
+    assert not torch.isfinite(lg[0, :tb]).any() and torch.isfinite(lg[0, tb + 11:]).all()
+
+
+def test_suppression_lists():
+    from lyricalignment_amd.transcribe import DecodingOptions, TokenizerSpec, suppress_blank_, suppressed_token_ids
+    tok = TokenizerSpec(non_speech_ids=(11, 13, 2437))
+    ids = suppressed_token_ids(DecodingOptions(), tok)                    # "-1" -> non-speech symbols + the specials
+    assert set((11, 13, 2437, tok.sot, tok.translate, tok.transcribe, tok.sot_lm, tok.sot_prev, tok.no_speech)) == set(ids)
+    assert set(suppressed_token_ids(DecodingOptions(suppress_tokens=[5, 6]), tok)) >= {5, 6, tok.sot} and 11 not in suppressed_token_ids(DecodingOptions(suppress_tokens=[5, 6]), tok)
+    lg = torch.zeros((2, 51865), device="cuda")
+    suppress_blank_(lg, 0, tok)
+    assert not torch.isfinite(lg[:, tok.blank_id]).any() and not torch.isfinite(lg[:, tok.eot]).any()
+    lg = torch.zeros((2, 51865), device="cuda")
+    suppress_blank_(lg, 3, tok)
+    assert torch.isfinite(lg).all()
+
+
+def _check_timestamp_grammar(tokens, tok):
+    """The invariants ApplyTimestampRules enforces on any sampled sequence."""
+    tb = tok.timestamp_begin
+    assert tokens and tokens[0] >= tb and tokens[0] <= tb + 50
+    last = -1
+    run = 0
+    for t in tokens:
+        if t >= tb:
+            run += 1
+            assert run <= 2 and t >= last
+            last = t
+        else:
+            run = 0
+    assert tok.no_timestamps not in tokens and tok.sot not in tokens and tok.no_speech not in tokens
+
+
+@pytest.mark.parametrize("mode", ["greedy", "beam", "sample"])
+def test_decode_obeys_the_rules_and_matches_the_plain_loops_without_them(model, mode):
+    from lyricalignment_amd.transcribe import DecodingOptions, decode
+    tok = _tok()
+    rs = np.random.RandomState(5)
+    feats = torch.from_numpy(rs.randn(2, 1500, 128).astype(np.float32) * 0.5).cuda()
+    o = DecodingOptions(language="zh", sample_len=24)
+    if mode == "beam":
+        o.beam_size = 3
+    if mode == "sample":
+        o.temperature, o.best_of = 0.7, 2
+    res = decode(model, feats, o, tok, rng=torch.Generator(device="cuda").manual_seed(3))
+    assert len(res) == 2
+    for r in res:
+        _check_timestamp_grammar(r.tokens, tok)
+        assert 0.0 <= r.no_speech_prob <= 1.0 and np.isfinite(r.avg_logprob) and r.avg_logprob <= 0 and r.text is None
+        assert all(t != tok.blank_id for t in r.tokens[:1])
+    if mode == "greedy":
+        # with every rule off the loop is AlignEngine.decode_greedy (argmax fed back), token for token
+        plain = DecodingOptions(language="zh", sample_len=24, suppress_tokens=None, suppress_blank=False, without_timestamps=True)
+        got = decode(model, feats, plain, tok)
+        prompt = torch.tensor([list(tok.sot_sequence("zh", "transcribe")) + [tok.no_timestamps]] * 2)
+        ref = model.decode_greedy(prompt, feats, 24, tok.eot).cpu().tolist()
+        for r, row in zip(got, ref):
+            body = row[4:]
+            body = body[: body.index(tok.eot)] if tok.eot in body else body
+            assert r.tokens == body
+
+
+def test_transcribe_windows_fallback_and_segments(model):
+    """70 s of audio: three windows; segments are ordered, inside the recording, their tokens obey the grammar; forcing the
+    log-probability threshold walks the whole temperature ladder; a no-speech threshold of 0 skips every window."""
+    from lyricalignment_amd.transcribe import transcribe
+    tok = _tok()
+    rs = np.random.RandomState(9)
+    t = np.arange(70 * 16000) / 16000.0
+    audio = (0.3 * np.sin(2 * np.pi * 220 * t) + 0.05 * rs.randn(t.size)).astype(np.float32)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    out = transcribe(model, audio, language="zh", beam_size=2, tokenizer=tok, rng=g, logprob_threshold=None, compression_ratio_threshold=None)
+    assert out["language"] == "zh" and out["text"] is None and len(out["segments"]) >= 1
+    prev_end = 0.0
+    for seg in out["segments"]:
+        assert 0.0 <= seg["start"] <= seg["end"] <= 70.0 + 30.0 and seg["start"] >= prev_end - 1e-6 and seg["temperature"] == 0.0
+        prev_end = seg["start"]
+    assert sum(len(s["tokens"]) for s in out["segments"]) == len(out["tokens"])
+    # every window fails an impossible threshold at every temperature: the last rung of the ladder is what is kept
+    out2 = transcribe(model, audio[: 16000 * 20], language="zh", tokenizer=tok, rng=g, logprob_threshold=0.0, compression_ratio_threshold=None,
+                      no_speech_threshold=None, temperature=(0.0, 0.5, 1.0))
+    assert all(s["temperature"] == 1.0 for s in out2["segments"]) and out2["segments"]
+    out3 = transcribe(model, audio[: 16000 * 20], language="zh", tokenizer=tok, rng=g, no_speech_threshold=-1.0, logprob_threshold=0.0)
+    assert out3["segments"] == [] and out3["tokens"] == []
