@@ -256,6 +256,7 @@ def finetune_mode(args, rank, world, local_rank, device, dist):
     torch.cuda.synchronize()
     L = _lib.lib()
     L.la_timer_reset()
+    L.la_timer_sample(args.timer_period)      # (every launch bracketed = two barrier packets each: ~40 ms of a 0.8 s step)
     L.la_timer_enable(os.environ.get("LA_BENCH_TIMER", "gemm_f32").encode())
     if dist is not None:
         dist.barrier()
@@ -273,16 +274,17 @@ def finetune_mode(args, rank, world, local_rank, device, dist):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     import ctypes
-    total_ms, launches = ctypes.c_double(0.0), ctypes.c_int64(0)
-    _lib.check(L.la_timer_read(ctypes.byref(total_ms), ctypes.byref(launches)), "timer_read")
+    total_ms, launches, work, seen = ctypes.c_double(0.0), ctypes.c_int64(0), ctypes.c_double(0.0), ctypes.c_int64(0)
+    _lib.check(L.la_timer_read_work(ctypes.byref(total_ms), ctypes.byref(launches), ctypes.byref(work), ctypes.byref(seen)), "timer_read_work")
     d, nl = dims.n_audio_state, dims.n_audio_layer
     T = T_FRAMES
     # algorithmic GEMM flops of one micro-step (forward + the two backward products of every Linear = 3 x forward):
     # encoder Linears / convs, GRU input projections + FC, decoder (cross-attention K/V projections over 1500 frames dominate)
     fwd = (2 * 3000 * 80 * 3 * d + 2 * T * d * 3 * d + nl * 24 * T * d * d) + (2 * (2 * T * d * 3 * HIDDEN) + 2 * (2 * T * 2 * HIDDEN * 3 * HIDDEN)
            + 2 * T * 2 * HIDDEN * VOCAB) + dims.n_text_layer * (2 * T * d * 2 * d + n_tok * 22 * d * d) + 2 * n_tok * d * 51865
-    gemm_flops_step = 3.0 * fwd * B * args.accum
-    achieved = gemm_flops_step * args.steps / (total_ms.value * 1e-3) / 1e12 if total_ms.value > 0 else 0.0
+    gemm_flops_step = 3.0 * fwd * B * args.accum          # (analytic count of the Linear layers, for reference: "linear_gflop_per_step")
+    # achieved = 2 M N K of the bracketed float32 GEMM launches (summed by the library) / their HIP-event durations
+    achieved = work.value / (total_ms.value * 1e-3) / 1e12 if total_ms.value > 0 else 0.0
     ar_ms = float(np.mean([a.elapsed_time(b) for a, b in ar_events])) if ar_events else 0.0
     grad_bytes = int(sum(g.numel() for g in tuner.grad) * 4)
     if rank == 0:
@@ -302,7 +304,8 @@ def finetune_mode(args, rank, world, local_rank, device, dist):
             "allreduce_GBps": (2.0 * (world - 1) / world * grad_bytes / (ar_ms * 1e-3) / 1e9) if (world > 1 and ar_ms > 0) else None,
             "roofline": {"bound": "mfma", "kernel": "gemm_kernel<float> (v_mfma_f32_16x16x4_f32; every Linear forward + both backward products)",
                          "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s", "frac": achieved / 157.3, "traffic": None,
-                         "launches_per_step": launches.value / max(args.steps, 1), "avg_launch_ms": total_ms.value / max(launches.value, 1)},
+                         "launches_per_step": seen.value / max(args.steps, 1), "avg_launch_ms": total_ms.value / max(launches.value, 1),
+                         "timed_launches": launches.value, "linear_gflop_per_step": gemm_flops_step / 1e9},
             "cpu_baseline": None,
             "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9}), flush=True)
     if dist is not None:
