@@ -37,7 +37,8 @@ struct BwdParams {
 
 // Workgroup shape of the two sweep kernels: NT threads = NT / 64 waves as 2 (row halves of 32) x WN (column strips of 64 / WN);
 // a wave holds 2 x NI accumulator tiles of 16 x 16 per product.  8 waves (two per SIMD, one workgroup per CU: the kv sweep's
-// six tiles are 102 KB of LDS) hide the fragment-read latency that 4 waves leave exposed: 10.1 -> see DESIGN ms per layer.
+// six tiles are 102 KB of LDS) hide the fragment-read latency that 4 waves leave exposed: 10.1 -> 7.65 ms per layer for 16 clips
+// of Whisper-medium (then 6.0 with the next block's tiles fetched into registers under the current block's products).
 constexpr int NT = 512, WN = NT / 128, NI = 4 / WN;
 
 // rows row0 .. row0 + 63 of a row-major matrix (64 columns from `src`), zero beyond `limit`, into an LDS tile
