@@ -356,3 +356,52 @@ def test_song_major_chunks_layout():
     # Python's round() (banker's) on the last chunk, as the reference computes it
     assert frame_plan(6301, True)[-1][2] == 150 and frame_plan(6303, True)[-1][2] == 152
     assert frame_plan(2001, True) == [(0, 2001, 1000)] and frame_plan(9000, False) == [(0, 3000, 1500)]
+
+
+# ------------------------------------------------------------------------------------------------ round 3: synthetic inputs, self-check
+def test_synthetic_weights_and_mel_are_pinned_bits():
+    """whisper_compat.HostIndependentRng / build_model and bench.synthetic_mel are integer functions of documented PRNG streams
+    followed by exactly-rounded float operations: "seed 0" is the same bits on every host (the rounds 1-2 bench head was not --
+    profiles/r3_selfcheck_diagnosis.md).  Known answers recorded in the build container; the GPU boxes reproduce them
+    (tools/weights_fingerprint.py)."""
+    import hashlib
+    import bench
+    from lyricalignment_amd import whisper_compat as wc
+    g = wc.HostIndependentRng(5)
+    assert g.normal((4,)).tolist() == [1.8091176748275757, -0.6242265105247498, 0.06731465458869934, -1.3636040687561035]
+    assert g.uniform((3,)).tolist() == [0.9590473175048828, -0.8921386003494263, -0.4441525936126709]
+    m = wc.build_model("tiny", seed=0)
+    h = hashlib.sha256()
+    for _, v in sorted(dict(m.named_parameters()).items()):
+        h.update(v.detach().numpy().tobytes())
+    assert h.hexdigest()[:16] == "9e3fa492c4e37f77"
+    w = m.encoder.blocks[0].mlp[0].weight
+    assert abs(float(w.std()) - 0.02) < 2e-4 and abs(float(w.mean())) < 2e-4                      # Irwin-Hall(4): unit variance, zero mean
+    mel = bench.synthetic_mel(4, 3000, 2)
+    assert mel.shape == (4, 80, 3000) and mel.dtype == np.float32 and float(mel.min()) >= -1.0 and float(mel.max()) <= 1.0
+    assert hashlib.sha256(mel.tobytes()).hexdigest()[:16] == "8615eadc7753240a"
+
+
+def test_bench_selfcheck_arithmetic():
+    """bench.selfcheck: seconds = frame * 0.02 on the device side, the oracle's [onset, offset] pairs on the other; MAE over
+    all labels of the checked clips, per-clip breakdown, boundaries_equal counts onsets and offsets."""
+    import bench
+    on = np.array([[10, 20, 30, 0], [5, 6, 0, 0]], dtype=np.int32)
+    off = np.array([[15, 25, 40, 0], [6, 9, 0, 0]], dtype=np.int32)
+    cpu = [[[0.2, 0.3], [0.4, 0.5], [0.6, 0.9]], [[0.1, 0.12], [0.12, 0.2]]]          # clip 0: last offset 0.1 s late on the device
+    chk = bench.selfcheck(on, off, cpu, np.array([3, 2]))
+    assert chk["clips"] == 2 and chk["tol_s"] == bench.SELFCHECK_TOL_S
+    assert abs(chk["onset_mae_s"]) < 1e-12
+    assert abs(chk["offset_mae_s"] - (0.1 + 0.02) / 5) < 1e-9 and abs(chk["max_dev_s"] - 0.1) < 1e-9
+    assert chk["per_clip"][0]["boundaries_equal"] == 5 and chk["per_clip"][1]["boundaries_equal"] == 3
+
+
+def test_whisper_special_token_ids():
+    """lyricalignment_amd.transcribe.TokenizerSpec: the special-token ids of whisper's two vocabularies (constants of the
+    published tokenizer: 99 language tokens, six task tokens, 1501 timestamps from 0.00 to 30.00 s)."""
+    from lyricalignment_amd.transcribe import LANGUAGES, TokenizerSpec
+    m, e = TokenizerSpec(), TokenizerSpec(multilingual=False)
+    assert len(LANGUAGES) == 99 and LANGUAGES[:3] == ["en", "zh", "de"] and LANGUAGES[-1] == "su"
+    assert (m.eot, m.sot, m.language_token("zh"), m.translate, m.transcribe, m.no_speech, m.no_timestamps, m.timestamp_begin) == \
+        (50257, 50258, 50260, 50358, 50359, 50362, 50363, 50364)
+    assert m.timestamp_begin + 1501 == 51865 and e.timestamp_begin + 1501 == 51864
