@@ -375,7 +375,7 @@ def test_synthetic_weights_and_mel_are_pinned_bits():
     for _, v in sorted(dict(m.named_parameters()).items()):
         h.update(v.detach().numpy().tobytes())
     assert h.hexdigest()[:16] == "9e3fa492c4e37f77"
-    w = m.encoder.blocks[0].mlp[0].weight
+    w = m.encoder.blocks[0].mlp[0].weight.detach()
     assert abs(float(w.std()) - 0.02) < 2e-4 and abs(float(w.mean())) < 2e-4                      # Irwin-Hall(4): unit variance, zero mean
     mel = bench.synthetic_mel(4, 3000, 2)
     assert mel.shape == (4, 80, 3000) and mel.dtype == np.float32 and float(mel.min()) >= -1.0 and float(mel.max()) <= 1.0
