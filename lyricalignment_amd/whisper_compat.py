@@ -199,7 +199,14 @@ def build_model(name: str = "tiny", seed: int = 0, with_decoder: bool = False, s
         model = Whisper(dims, with_decoder=with_decoder)
     model = model.to_empty(device="cpu")
     with torch.no_grad():
-        model.encoder.positional_embedding.copy_(sinusoids(dims.n_audio_ctx, dims.n_audio_state))
+        # whisper's sinusoids() with its float32 rounding points (the argument t * inv_timescale is a float32 product), but exp / sin /
+        # cos evaluated in float64 and rounded once: torch's float32 transcendentals differ in the last place between hosts (vendor
+        # math libraries), a double-precision value rounded to float32 practically never does
+        n_ctx, ch = dims.n_audio_ctx, dims.n_audio_state
+        inc = np.float32(np.log(10000.0) / (ch // 2 - 1))
+        inv = np.exp((-inc * np.arange(ch // 2, dtype=np.float32)).astype(np.float64)).astype(np.float32)
+        st = (np.arange(n_ctx, dtype=np.float32)[:, None] * inv[None, :]).astype(np.float64)
+        model.encoder.positional_embedding.copy_(torch.from_numpy(np.concatenate([np.sin(st), np.cos(st)], axis=1).astype(np.float32)))
     g = HostIndependentRng(seed)
     with torch.no_grad():
         for n, p in model.named_parameters():

@@ -6,9 +6,11 @@ the bench's head came from nn.Module's default initialisation out of the UNSEEDE
 host to host (tools/weights_fingerprint.py), and a default-initialised head on featureless noise gives near-flat posteriors:
 the best lattice path then leads the runner-up by ~1e-4 of a total of ~1100, so which boundaries the bf16 path and the fp32
 oracle agree on was a draw per host.  The device side is deterministic: every pipeline shape / warm-up count / repeat gives
-bit-identical frames (first test below).  Since round 3 bench.py's weights and inputs are host-independent bits, the head is
-peaked and the labels are the head's own top classes; these tests hold that configuration to the oracle
-(utils/alignment.py:121-188, inference_alignment.py:159-177)."""
+bit-identical frames (first test below).  Since round 3 bench.py's weights and inputs are host-independent bits and the task is
+well-posed: the clips are synthetic songs (notes of 40 timbres), the transcript is what was sung, and the head's 40 syllable rows are
+a linear probe fitted on other songs (bench.fit_head) -- the lattice's best path leads by nats per frame, as a trained model's does on
+its own data.  These tests hold that configuration to the oracle (utils/alignment.py:121-188, inference_alignment.py:159-177) and to
+the note edges the songs were synthesised with."""
 import numpy as np
 import pytest
 import torch
@@ -28,11 +30,11 @@ def headline():
     dims = wc.dims_for(bench.MODEL)
     model = AlignModel(wc.build_model(bench.MODEL, seed=0), embed_dim=dims.n_audio_state, hidden_dim=bench.HIDDEN, output_dim=bench.VOCAB,
                        device="cuda:0", compute_dtype=torch.bfloat16).eval()
-    wc.init_align_head(model, seed=7, fc_scale=bench.HEAD_FC_SCALE)
+    device = torch.device("cuda", 0)
+    fit = bench.fit_head(model, device)
     with torch.no_grad():
         eng = model.engine()
-    device = torch.device("cuda", 0)
-    mel, labels, n_labels, Ls = bench.build_inputs(device, eng=eng)
+    mel, labels, n_labels, Ls, plans = bench.build_inputs(device)
     with torch.no_grad():
         ref = eng.align_mel(mel, labels, n_labels, n_frames=bench.T_FRAMES, use_ctc=True)
     torch.cuda.synchronize()
@@ -49,7 +51,7 @@ def headline():
             lp, ls = mo.emission_prep_ctc(logits)
             secs = ao.perform_viterbi_ctc(logits, labels[b:b + 1, :L].cpu().long())[0]
         oracle.append(dict(L=L, lp=lp[0], ls=ls[0], on=np.array([s[0] for s in secs]), off=np.array([s[1] for s in secs])))
-    return dict(bench=bench, eng=eng, mel=mel, labels=labels, n_labels=n_labels, Ls=Ls, oracle=oracle,
+    return dict(bench=bench, eng=eng, mel=mel, labels=labels, n_labels=n_labels, Ls=Ls, oracle=oracle, plans=plans, fit=fit,
                 ref=[t.cpu().numpy().copy() for t in ref[:2]])
 
 
@@ -81,18 +83,21 @@ def test_pipeline_with_partial_flush_is_bit_identical_to_single_stream(headline)
 
 
 def test_headline_batch_boundaries_and_emissions_against_oracle(headline):
-    """The first clips of the B = 32 bf16 batch against alignment_oracle.perform_viterbi_ctc(oracle logits): emissions within
-    the bf16 bounds calibrated at full depth (tests/test_gpu_parity_full.py), boundary MAE within bench.py's self-check
-    tolerance (one frame) and >= 95 % of the boundaries equal."""
+    """The first clips of the B = 32 bf16 batch against alignment_oracle.perform_viterbi_ctc(oracle logits): emission log-probs
+    (range 0 .. -35 with the fitted head) within bf16 bounds (measured: mean 0.035, max 0.30), boundary MAE within bench.py's
+    self-check tolerance (one frame; measured 0.0005 s, no boundary further than one frame), >= 90 % of the boundaries equal
+    (measured 97.6 %; 94.5 ... 100 % per clip over 16 clips, tools/selfcheck_repro.py), and the device's onsets within 0.1 s MAE of
+    the note edges the songs were synthesised with (measured 0.020 s = one frame)."""
     from lyricalignment_amd import _lib
     bench, eng = headline["bench"], headline["eng"]
     n = N_ORACLE_CLIPS
     with torch.no_grad():
         feats = eng.encode(headline["mel"])
         em = eng.emissions(feats, bench.BATCH, bench.T_FRAMES, bench.T_FRAMES, headline["labels"], headline["n_labels"], _lib.LA_VARIANT_CTC)[:n].cpu()
-    on_err, off_err, em_err = [], [], []
+    on_err, off_err, em_err, true_err = [], [], [], []
     for b, o in enumerate(headline["oracle"]):
         L = o["L"]
+        true_err.append(np.abs(headline["ref"][0][b, :L] * 0.02 - headline["plans"][b][0][:-1] * 0.01))
         idx = headline["labels"][b, :L].cpu().long() - 1
         em_err.append(torch.cat([(em[b, :, 1:1 + L] - o["lp"][:, idx]).abs().flatten(), (em[b, :, 0] - o["ls"][:, 0]).abs()]))
         on_err.append(np.abs(headline["ref"][0][b, :L] * 0.02 - o["on"]))
@@ -101,10 +106,13 @@ def test_headline_batch_boundaries_and_emissions_against_oracle(headline):
     on_err, off_err = np.concatenate(on_err), np.concatenate(off_err)
     both = np.concatenate([on_err, off_err])
     print(f"bf16 B=32: emission error mean {float(em_err.mean()):.4f} max {float(em_err.max()):.4f}; boundaries equal "
-          f"{float((both < 1e-9).mean()):.3f}, onset MAE {on_err.mean():.4f} s, max deviation {both.max():.2f} s")
-    assert float(em_err.mean()) < 0.06 and float(em_err.max()) < 0.35
+          f"{float((both < 1e-9).mean()):.3f}, onset MAE {on_err.mean():.4f} s, max deviation {both.max():.2f} s; device onsets vs the "
+          f"songs' note edges: MAE {np.concatenate(true_err).mean():.4f} s; head fit {headline['fit']}")
+    assert headline["fit"]["fit_frame_accuracy"] > 0.9
+    assert float(em_err.mean()) < 0.06 and float(em_err.max()) < 0.6
     assert on_err.mean() <= bench.SELFCHECK_TOL_S and off_err.mean() <= bench.SELFCHECK_TOL_S
-    assert float((both < 1e-9).mean()) >= 0.95
+    assert float((both < 1e-9).mean()) >= 0.90 and both.max() <= 0.2
+    assert np.concatenate(true_err).mean() <= 0.1
 
 
 def test_headline_pipeline_repeats_beside_a_side_stream_load_are_bit_identical(headline):

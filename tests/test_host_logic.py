@@ -360,7 +360,7 @@ def test_song_major_chunks_layout():
 
 # ------------------------------------------------------------------------------------------------ round 3: synthetic inputs, self-check
 def test_synthetic_weights_and_mel_are_pinned_bits():
-    """whisper_compat.HostIndependentRng / build_model and bench.synthetic_mel are integer functions of documented PRNG streams
+    """whisper_compat.HostIndependentRng / build_model and bench.note_plan / timbre_bank / synthetic_mel are integer functions of documented PRNG streams
     followed by exactly-rounded float operations: "seed 0" is the same bits on every host (the rounds 1-2 bench head was not --
     profiles/r3_selfcheck_diagnosis.md).  Known answers recorded in the build container; the GPU boxes reproduce them
     (tools/weights_fingerprint.py)."""
@@ -377,9 +377,18 @@ def test_synthetic_weights_and_mel_are_pinned_bits():
     assert h.hexdigest()[:16] == "9e3fa492c4e37f77"
     w = m.encoder.blocks[0].mlp[0].weight.detach()
     assert abs(float(w.std()) - 0.02) < 2e-4 and abs(float(w.mean())) < 2e-4                      # Irwin-Hall(4): unit variance, zero mean
-    mel = bench.synthetic_mel(4, 3000, 2)
+    # the sinusoid buffer: float32 rounding points of whisper's sinusoids(), transcendentals in float64 rounded once
+    assert hashlib.sha256(m.encoder.positional_embedding.numpy().tobytes()).hexdigest()[:16] == "33269a1ce89889f7"
+    env, ids = bench.timbre_bank()
+    assert env.shape == (bench.N_TIMBRES, 80) and len(set(ids.tolist())) == bench.N_TIMBRES and ids.min() >= 2 and ids.max() <= bench.VOCAB - 3
+    assert ids[:4].tolist() == [229, 248, 736, 1546] and hashlib.sha256(env.tobytes()).hexdigest()[:16] == "84a22b23a32ff3ed"
+    plans = bench.note_plan(np.array([15, 8, 13, 5]), 3000, 2)
+    assert plans[3][0].tolist() == [0, 549, 943, 1622, 2273, 3000] and plans[3][1].tolist() == [37, 5, 23, 30, 39]
+    for edges, timbre in plans:
+        assert (np.diff(edges) > 0).all() and (timbre[1:] != timbre[:-1]).all()                  # no empty note, no repeated syllable
+    mel = bench.synthetic_mel(plans, 3000, 2)
     assert mel.shape == (4, 80, 3000) and mel.dtype == np.float32 and float(mel.min()) >= -1.0 and float(mel.max()) <= 1.0
-    assert hashlib.sha256(mel.tobytes()).hexdigest()[:16] == "8615eadc7753240a"
+    assert hashlib.sha256(mel.tobytes()).hexdigest()[:16] == "c0d9833081663b9d"
 
 
 def test_bench_selfcheck_arithmetic():
@@ -394,6 +403,10 @@ def test_bench_selfcheck_arithmetic():
     assert abs(chk["onset_mae_s"]) < 1e-12
     assert abs(chk["offset_mae_s"] - (0.1 + 0.02) / 5) < 1e-9 and abs(chk["max_dev_s"] - 0.1) < 1e-9
     assert chk["per_clip"][0]["boundaries_equal"] == 5 and chk["per_clip"][1]["boundaries_equal"] == 3
+    # with the songs' note plans: both sides against the synthesised note edges (mel frames of 10 ms)
+    plans = [(np.array([20, 40, 62, 100]), np.zeros(3, dtype=np.int64)), (np.array([10, 12, 30]), np.zeros(2, dtype=np.int64))]
+    chk = bench.selfcheck(on, off, cpu, np.array([3, 2]), plans)
+    assert abs(chk["gpu_onset_vs_note_edges_mae_s"] - 0.02 / 5) < 1e-9 and abs(chk["cpu_onset_vs_note_edges_mae_s"] - 0.02 / 5) < 1e-9
 
 
 def test_whisper_special_token_ids():

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--uniform-mel", action="store_true", help="uniform[-1,1] noise mel (the rounds 1-2 bench input)")
     ap.add_argument("--warmups", default="5,2,1,3,4,5")
     ap.add_argument("--tag", default="")
+    ap.add_argument("--unfitted-head", action="store_true")
     ap.add_argument("--random-labels", action="store_true", help="random class ids instead of the head's own top classes")
     args = ap.parse_args()
     from lyricalignment_amd import _lib, whisper_compat as wc
@@ -45,11 +46,17 @@ def main():
         torch.manual_seed(0)
         for m_ in (model.align_rnn.rnn, model.align_rnn.fc):
             m_.reset_parameters()                     # nn.Module's default initialisation: the rounds 1-2 bench head
+    elif args.unfitted_head:
+        wc.init_align_head(model, seed=7, fc_scale=args.fc_scale)     # peaked but knows nothing of the songs' timbres
     else:
-        wc.init_align_head(model, seed=7, fc_scale=args.fc_scale)
+        print(json.dumps({"head_fit": bench.fit_head(model, device)}), flush=True)     # bench.py's head
     with torch.no_grad():
         eng = model.engine()
-    mel, labels, n_labels, Ls = bench.build_inputs(device, eng=None if args.random_labels else eng)
+    mel, labels, n_labels, Ls, plans = bench.build_inputs(device)
+    if args.random_labels:
+        rl = np.random.RandomState(4)
+        for b, L in enumerate(Ls):
+            labels[b, :L] = torch.from_numpy(rl.randint(2, 403, size=L).astype(np.int32)).to(device)
     if args.uniform_mel:
         mel = torch.from_numpy(np.random.RandomState(2).uniform(-1.0, 1.0, size=(bench.BATCH, 80, 3000)).astype(np.float32)).to(device)
     B = bench.BATCH
@@ -128,6 +135,10 @@ def main():
 
             rec = {"clip": b, "L": L, "onset_mae_s": float(np.abs(cpu_on - gpu_on).mean()), "offset_mae_s": float(np.abs(cpu_off - gpu_off).mean()),
                    "n_equal": int((np.abs(cpu_on - gpu_on) < 1e-9).sum() + (np.abs(cpu_off - gpu_off) < 1e-9).sum()), "n_bound": 2 * L,
+                   "n_within2": int((np.abs(cpu_on - gpu_on) < 0.041).sum() + (np.abs(cpu_off - gpu_off) < 0.041).sum()),
+                   "max_dev_s": float(max(np.abs(cpu_on - gpu_on).max(), np.abs(cpu_off - gpu_off).max())),
+                   "mean_frames_per_label": float(np.mean(cpu_off - cpu_on) / 0.02),
+                   "onset_vs_note_edge_mae_s": float(np.abs(cpu_on - plans[b][0][:-1] * 0.01).mean()),
                    "oracle_path_score": path_score(np.round(cpu_on / 0.02), np.round(cpu_off / 0.02)),
                    "device_path_score_on_oracle_emissions": path_score(ref_on[b, :L], ref_off[b, :L]),
                    "logit_absmax": float(lg.abs().max()), "logit_std": float(lg.std())}
