@@ -89,7 +89,7 @@ int main(int argc, char **argv) {
 
     hipStream_t stream;
     HIP_OK(hipStreamCreate(&stream));
-    const size_t es = enc.dtype == LA_F32 ? 4 : 2;
+    const size_t es = (enc.dtype & 0xff) == LA_F32 ? 4 : 2;   // (LA_Q_LOG2 may ride on the weights' dtype)
     size_t ws_e = 0, ws_h = 0;
     LA_CALL(la_encoder_workspace_bytes(&enc, B, &ws_e));
     LA_CALL(la_align_head_workspace_bytes(&head, B, frames, Lmax, &ws_h));
@@ -101,7 +101,7 @@ int main(int argc, char **argv) {
     HIP_OK(hipMalloc(&onset, (size_t)B * Lmax * 4)); HIP_OK(hipMalloc(&offset, (size_t)B * Lmax * 4));
     HIP_OK(hipMalloc(&status, (size_t)B * 4)); HIP_OK(hipMalloc(&score, (size_t)B * 8)); HIP_OK(hipMalloc(&flag, 4));
     HIP_OK(hipMemsetAsync(flag, 0, 4, stream));
-    LA_CALL(la_encoder_forward(&enc, mel, (int64_t)enc.n_mels * 3000, 3000, B, feats, enc.d, enc.dtype, wse, ws_e, stream));
+    LA_CALL(la_encoder_forward(&enc, mel, (int64_t)enc.n_mels * 3000, 3000, B, feats, enc.d, enc.dtype & 0xff, wse, ws_e, stream));
     LA_CALL(la_align_head_forward(&head, feats, enc.d, 1500, B, frames, variant, labels, Lmax, n_labels, Lmax, onset, offset, Lmax, score,
                                   status, nullptr, wsh, ws_h, flag, stream));
     HIP_OK(hipStreamSynchronize(stream));

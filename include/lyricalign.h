@@ -67,6 +67,16 @@ typedef enum la_dtype {
                     +-65504 -- Whisper was trained in fp16, so its activations fit                                   */
 } la_dtype;
 
+/*
+ * Modifier bit on the dtype argument of la_attention / la_attention_ex / la_attention_cached and on la_encoder_weights.dtype
+ * (16-bit dtypes): the q operand -- the q rows of wqkv and of bqkv -- carries head_dim^-0.5 * log2(e) instead of
+ * head_dim^-0.5 (whisper/model.py MultiHeadAttention.qkv_attention scales q and k by head_dim^-0.25 each), so the scores
+ * leave the matrix pipe in the exp2 domain.  With LA_BF16 the attention kernel then also starts its running maximum at 0
+ * and subtracts nothing until a query needs it (la_attention.hip, FOLD): one vector instruction less per score.
+ */
+#define LA_Q_LOG2 0x100
+
+
 typedef enum la_variant {
     LA_VARIANT_PLAIN = 0, /* perform_viterbi:      log_softmax over all V, silence = col 0          */
     LA_VARIANT_CTC = 1    /* perform_viterbi_ctc:  log_softmax over cols 1..V-2, silence = sigmoid  */

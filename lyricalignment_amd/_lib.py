@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("LA_LIB_PATH") or os.path.join(HERE, "liblyricalign_hi
 
 LA_OK, LA_EINVAL, LA_EINFEASIBLE, LA_EEMPTY, LA_EHIP, LA_ETIMEOUT, LA_EUNSUPPORTED = range(7)
 LA_F32, LA_BF16, LA_F16 = 0, 1, 2
+LA_Q_LOG2 = 0x100        # modifier on the attention entry points' dtype / la_encoder_weights.dtype (include/lyricalign.h)
 LA_VARIANT_PLAIN, LA_VARIANT_CTC = 0, 1
 EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_OUT_F32, EPI_MISH = 1, 2, 4, 8, 16
 EPI_GELU_ERF = 4096

@@ -29,7 +29,7 @@ def write_weights(engine, path: str) -> None:
         raise ValueError("capi_export: the engine needs the 2-layer head")
     with open(path, "wb") as f:
         f.write(struct.pack("<i", MAGIC))
-        f.write(struct.pack("<5i", _lib.dtype_code(e.dtype), e.d, e.n_head, len(e.blocks), e.n_mels))
+        f.write(struct.pack("<5i", _lib.dtype_code(e.dtype) | (_lib.LA_Q_LOG2 if e.q_log2 else 0), e.d, e.n_head, len(e.blocks), e.n_mels))
         for t in (e.conv1_w, e.conv1_b, e.conv2_w, e.conv2_b, e.pos, e.lnp_g, e.lnp_b):
             _tensor(f, t)
         for b in e.blocks:

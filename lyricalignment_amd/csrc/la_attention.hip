@@ -58,6 +58,7 @@ struct AttnParams {
     int batch;
     float defer_thr;               // 16-bit kernels: deferred-maximum threshold (exp2 domain); 0 = the textbook online softmax
     float *lse = nullptr;          // float32 kernel, training forward: log sum_j exp(s_ij) per query row, [batch][n_head][q_len] (la_attention_bwd_f32)
+    float score_scale = 1.4426950408889634f;   // 16-bit kernels: log2(e), or 1 when q already carries it (LA_Q_LOG2)
 };
 
 // Block -> (query tile, head, clip).  Workgroups are dealt round-robin over the 8 XCDs in launch order and every XCD has its
@@ -137,9 +138,18 @@ __device__ __forceinline__ void stage_kv_bf16(const bf16_t *kbase, const bf16_t 
 // recomputed from the K tile still in LDS, maximum, rescale.  LIMIT keeps P inside the 16-bit type (2^30 for bf16, 2^13 for
 // f16); the f32 accumulators and the final O / l are exact in the scale.
 // PRIO (diagnostic builds): 1 = the S MFMA phase at raised wave priority, 2 = S and PV raised (softmax at 0), 3 = softmax raised
-template <typename T16, int NW = 4, bool MSUM = false, int KO = 0, bool OPT = false, int PRIO = 0>
-__global__ __launch_bounds__(64 * NW, 2) void attention_bf16_kernel(AttnParams p) {
+// FOLD (bf16, LA_Q_LOG2: q carries head_dim^-0.5 log2 e, so the scores arrive in the exp2 domain): the optimistic form with the
+// running maximum STARTING AT 0 and, while no query of the wave has needed one, no subtraction at all -- P = exp2(s) as the scores
+// come out of the matrix pipe.  bf16 has float32's exponent range, so P in 2^-126 .. 2^30 is as precise relative to its row as
+// exp2(s - max) is; the float32 accumulators and the final O / l do not care about the common scale.  Per score that leaves
+// v_exp_f32 + v_add_f32 (row sum) + half a v_cvt_pk on the vector pipe, the busier one here, instead of v_fma_f32 + those
+// (337 -> 315 us per Whisper-medium layer).  Scores above 2^30 take the same redo path as before (it installs a maximum; from
+// then on the wave subtracts it); a query whose scores ALL lie below ~2^-100 would underflow its sum: the block then repeats its
+// sweep the textbook way (block-uniform decision after the sweep; never seen on real activations, forced in the tests).
+template <typename T16, int NW = 4, bool MSUM = false, int KO = 0, bool OPT = false, int PRIO = 0, bool FOLD = false>
+__global__ __launch_bounds__(64 * NW, FOLD ? 4 : 2) void attention_bf16_kernel(AttnParams p) {
     static_assert(!(OPT && MSUM), "the optimistic form tests the vector-pipe row sums");
+    static_assert(!FOLD || OPT, "the log2-domain form is a variant of the optimistic one");
     constexpr int QT = 32 * NW, PER = 8 / NW;
     typedef Half16<T16> HT;
     typedef typename HT::vec8 vec8;
@@ -168,7 +178,9 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_bf16_kernel(AttnParams p
     for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[b][r] = 0.f;
-    float m_run = -INFINITY, l_part = 0.f;
+    float m_run = FOLD ? 0.f : -INFINITY, l_part = 0.f;
+    int plain = FOLD ? 1 : 0;               // FOLD: no query of this wave has needed a maximum yet: P = exp2(s) as it stands (wave-uniform)
+    const float kScale = FOLD ? 1.0f : p.score_scale;
     f32x16 osum;
 #pragma unroll
     for (int r = 0; r < 16; ++r) osum[r] = 0.f;
@@ -199,7 +211,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_bf16_kernel(AttnParams p
     const int g = lane >> 4, q4 = (lane & 15) >> 2, pp = lane & 3;
 
     // the tile body is instantiated once per LDS buffer so every fragment address is (loop-invariant VGPR) + immediate
-    auto tile = [&](int t, auto curc) {
+    auto tile = [&](int t, auto curc) __attribute__((always_inline)) {
         constexpr int cur = decltype(curc)::value;
         const unsigned char *kl = lds + cur * (2 * KT * 128);
         const unsigned char *vl = kl + KT * 128;
@@ -270,16 +282,24 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_bf16_kernel(AttnParams p
             // 45-70 % of any other vector instruction does) and cost 1.8x a plain instruction for 2x the work; measured here:
             // 344 us plain against 349 us packed
             float ps0 = 0.f, ps1 = 0.f;
+            auto body = [&](auto subtract_m) {
 #pragma unroll
-            for (int sub = lo; sub < hi; ++sub)
+                for (int sub = lo; sub < hi; ++sub)
 #pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    const float a0 = fmaf(s[sub][r], kLog2e, -m), a1 = fmaf(s[sub][r + 1], kLog2e, -m);
-                    const float p0 = (KO & 1) ? a0 : __builtin_amdgcn_exp2f(a0), p1 = (KO & 1) ? a1 : __builtin_amdgcn_exp2f(a1);
-                    s[sub][r] = p0;
-                    s[sub][r + 1] = p1;
-                    if constexpr (!MSUM) { ps0 += p0; ps1 += p1; }
-                }
+                    for (int r = 0; r < 16; r += 2) {
+                        float a0, a1;
+                        if constexpr (FOLD) {
+                            a0 = s[sub][r]; a1 = s[sub][r + 1];
+                            if constexpr (decltype(subtract_m)::value) { a0 -= m; a1 -= m; }
+                        } else { a0 = fmaf(s[sub][r], kScale, -m); a1 = fmaf(s[sub][r + 1], kScale, -m); }
+                        const float p0 = (KO & 1) ? a0 : __builtin_amdgcn_exp2f(a0), p1 = (KO & 1) ? a1 : __builtin_amdgcn_exp2f(a1);
+                        s[sub][r] = p0;
+                        s[sub][r + 1] = p1;
+                        if constexpr (!MSUM) { ps0 += p0; ps1 += p1; }
+                    }
+            };
+            if (FOLD && plain) body(std::false_type{});      // wave-uniform (an SGPR): only the redo path clears it
+            else body(std::true_type{});
             return ps0 + ps1;
         };
         auto tile_max = [&](auto whichc) -> float {
@@ -290,7 +310,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_bf16_kernel(AttnParams p
             for (int sub = lo; sub < hi; ++sub)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[sub][r]);
-            return fmaxf(mx, __shfl_xor(mx, 32)) * kLog2e;
+            return fmaxf(mx, __shfl_xor(mx, 32)) * kScale;
         };
         auto rescale = [&](float alpha) {
 #pragma unroll
@@ -338,6 +358,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_bf16_kernel(AttnParams p
             const float m_new = fmaxf(m_run, tile_max(whichc));
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);    // exp2(-inf) = 0 on the first tile
             m_run = m_new;
+            plain = 0;
             rescale(alpha);
             l_part *= alpha;
             return exponentials(m_new, whichc);
@@ -384,9 +405,29 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_bf16_kernel(AttnParams p
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if constexpr (!(KO & 32)) __syncthreads();       // (KO 32: the tile loop without its barrier -- timing only)
     };
-    for (int t = 0; t < nkv; t += 2) {
-        tile(t, std::integral_constant<int, 0>{});
-        if (t + 1 < nkv) tile(t + 1, std::integral_constant<int, 1>{});
+    auto sweep = [&]() __attribute__((always_inline)) {
+        for (int t = 0; t < nkv; t += 2) {
+            tile(t, std::integral_constant<int, 0>{});
+            if (t + 1 < nkv) tile(t + 1, std::integral_constant<int, 1>{});
+        }
+    };
+    sweep();
+    if constexpr (FOLD) {
+        // a sum outside 2^-100 .. 2^100 (all of a query's scores far below 0, or an overflow the per-tile test did not see):
+        // the whole block once more with a maximum from the first tile on (block-uniform decision, said so to the compiler;
+        // a second, cold copy of the tile loop rather than a loop around the first: that nest cost 50 VGPRs)
+        const float l0 = l_part + __shfl_xor(l_part, 32);
+        if (__builtin_amdgcn_readfirstlane(__syncthreads_or(q_valid && !(l0 >= 0x1p-100f && l0 <= 0x1p100f)))) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[b][r] = 0.f;
+            m_run = -INFINITY; l_part = 0.f; plain = 0;
+            stage_kv_bf16<PER>(kbase, vbase, p.ld_kv, 0, nkv_all == 1 ? off_last : off_full, lds0, lds0 + KT * 128, wave);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            sweep();
+        }
     }
 
     // ---- epilogue: O[q][dv] = O^T / l ----
@@ -546,7 +587,14 @@ __global__ __launch_bounds__(256, 2) void attention_f32_kernel(AttnParams p) {
 
 }  // namespace
 
-static int attention_launch(int dtype, AttnParams p, int batch, hipStream_t stream) {
+static int attention_launch(int dtype_arg, AttnParams p, int batch, hipStream_t stream) {
+    const int dtype = dtype_arg & 0xff;
+    const bool qlog2 = dtype_arg & LA_Q_LOG2;
+    if (qlog2 && dtype != LA_BF16 && dtype != LA_F16) {
+        la::set_error("attention: LA_Q_LOG2 goes with the 16-bit kernels");
+        return LA_EINVAL;
+    }
+    p.score_scale = qlog2 ? 1.0f : kLog2e;
     p.batch = batch;
     const char *thr_env = getenv("LA_ATTN_THR");              // developer A/B (read per launch)
     p.defer_thr = thr_env ? (float)atof(thr_env) : 8.0f;
@@ -586,6 +634,8 @@ static int attention_launch(int dtype, AttnParams p, int batch, hipStream_t stre
         } else if (const char *opt = getenv("LA_ATTN_OPT"); opt && atoi(opt) == 0) {   // developer A/B: per-tile maximum (deferred, LA_ATTN_THR)
             if (dtype == LA_F16) hipLaunchKernelGGL((attention_bf16_kernel<la::f16_t, 4>), grid, block, 0, stream, p);
             else hipLaunchKernelGGL((attention_bf16_kernel<bf16_t, 4>), grid, block, 0, stream, p);
+        } else if (static const bool nofold = getenv("LA_ATTN_FOLD") && atoi(getenv("LA_ATTN_FOLD")) == 0; qlog2 && dtype == LA_BF16 && !nofold) {
+            hipLaunchKernelGGL((attention_bf16_kernel<bf16_t, 4, false, 0, true, 0, true>), grid, block, 0, stream, p);   // exp2-domain scores, no maximum until one is needed
         } else if (dtype == LA_F16) hipLaunchKernelGGL((attention_bf16_kernel<la::f16_t, 4, false, 0, true>), grid, block, 0, stream, p);
         else hipLaunchKernelGGL((attention_bf16_kernel<bf16_t, 4, false, 0, true>), grid, block, 0, stream, p);
     } else {
@@ -602,12 +652,13 @@ static int attention_launch(int dtype, AttnParams p, int batch, hipStream_t stre
     return LA_OK;
 }
 
-extern "C" int la_attention(int32_t dtype, const void *qkv, int64_t ld_qkv, void *out, int64_t ld_out, int32_t batch,
+extern "C" int la_attention(int32_t dtype_arg, const void *qkv, int64_t ld_qkv, void *out, int64_t ld_out, int32_t batch,
                             int32_t frames, int32_t n_head, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (batch == 0 || frames == 0) return LA_OK;
     LA_CHECK_ARG(qkv && out && batch > 0 && frames > 0 && n_head > 0, "attention: bad arguments");
-    LA_CHECK_ARG(dtype == LA_F32 || dtype == LA_BF16 || dtype == LA_F16, "attention: bad dtype");
+    const int dtype = dtype_arg & 0xff;       // LA_Q_LOG2 may ride on it
+    LA_CHECK_ARG((dtype_arg & ~(0xff | LA_Q_LOG2)) == 0 && (dtype == LA_F32 || dtype == LA_BF16 || dtype == LA_F16), "attention: bad dtype");
     const int es = dtype == LA_F32 ? 4 : 2;
     LA_CHECK_ARG(ld_qkv >= 3 * n_head * 64 && ld_out >= n_head * 64, "attention: leading dimensions too small");
     LA_CHECK_ARG((ld_qkv * es) % 16 == 0 && (ld_out * es) % 16 == 0 && (uintptr_t)qkv % 16 == 0 && (uintptr_t)out % 16 == 0,
@@ -615,16 +666,17 @@ extern "C" int la_attention(int32_t dtype, const void *qkv, int64_t ld_qkv, void
     const char *b = reinterpret_cast<const char *>(qkv);
     const int d = n_head * 64;
     AttnParams p{b, b + (int64_t)d * es, b + (int64_t)2 * d * es, ld_qkv, ld_qkv, out, ld_out, frames, frames, n_head, 0, frames, frames, frames, 0};
-    return attention_launch(dtype, p, batch, stream);
+    return attention_launch(dtype_arg, p, batch, stream);
 }
 
-extern "C" int la_attention_ex(int32_t dtype, const void *q, int64_t ld_q, const void *k, const void *v, int64_t ld_kv,
+extern "C" int la_attention_ex(int32_t dtype_arg, const void *q, int64_t ld_q, const void *k, const void *v, int64_t ld_kv,
                                void *out, int64_t ld_out, int32_t batch, int32_t q_len, int32_t kv_len, int32_t n_head,
                                int32_t causal, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (batch == 0 || q_len == 0) return LA_OK;
     LA_CHECK_ARG(q && k && v && out && batch > 0 && q_len > 0 && kv_len > 0 && n_head > 0, "attention_ex: bad arguments");
-    LA_CHECK_ARG(dtype == LA_F32 || dtype == LA_BF16 || dtype == LA_F16, "attention_ex: bad dtype");
+    const int dtype = dtype_arg & 0xff;       // LA_Q_LOG2 may ride on it
+    LA_CHECK_ARG((dtype_arg & ~(0xff | LA_Q_LOG2)) == 0 && (dtype == LA_F32 || dtype == LA_BF16 || dtype == LA_F16), "attention_ex: bad dtype");
     LA_CHECK_ARG(!causal || q_len == kv_len, "attention_ex: causal masking is defined for self-attention (q_len == kv_len)");
     const int es = dtype == LA_F32 ? 4 : 2;
     LA_CHECK_ARG(ld_q >= n_head * 64 && ld_kv >= n_head * 64 && ld_out >= n_head * 64, "attention_ex: leading dimensions too small");
@@ -632,7 +684,7 @@ extern "C" int la_attention_ex(int32_t dtype, const void *q, int64_t ld_q, const
                      (uintptr_t)k % 16 == 0 && (uintptr_t)v % 16 == 0 && (uintptr_t)out % 16 == 0,
                  "attention_ex: rows must be 16-byte aligned");
     AttnParams p{q, k, v, ld_q, ld_kv, out, ld_out, q_len, kv_len, n_head, causal ? 1 : 0, q_len, kv_len, q_len, 0};
-    return attention_launch(dtype, p, batch, stream);
+    return attention_launch(dtype_arg, p, batch, stream);
 }
 
 // The float32 forward of the TRAINING path: la_attention_ex that also hands over the row statistic the fused backward needs
@@ -655,13 +707,14 @@ extern "C" int la_attention_lse_f32(const float *q, int64_t ld_q, const float *k
 // [b * kv_batch_rows, b * kv_batch_rows + kv_len) of k / v -- the cache has room for kv_batch_rows >= kv_len rows per clip --
 // and its queries rows [b * q_batch_rows, ... + q_len) of q; out rows are packed [b * q_len + i].  Queries are the LAST q_len
 // positions of the sequence: with causal != 0 query i sees keys 0 .. kv_len - q_len + i.
-extern "C" int la_attention_cached(int32_t dtype, const void *q, int64_t ld_q, int64_t q_batch_rows, const void *k, const void *v,
+extern "C" int la_attention_cached(int32_t dtype_arg, const void *q, int64_t ld_q, int64_t q_batch_rows, const void *k, const void *v,
                                    int64_t ld_kv, int64_t kv_batch_rows, void *out, int64_t ld_out, int32_t batch, int32_t q_len,
                                    int32_t kv_len, int32_t n_head, int32_t causal, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (batch == 0 || q_len == 0) return LA_OK;
     LA_CHECK_ARG(q && k && v && out && batch > 0 && q_len > 0 && kv_len > 0 && n_head > 0, "attention_cached: bad arguments");
-    LA_CHECK_ARG(dtype == LA_F32 || dtype == LA_BF16 || dtype == LA_F16, "attention_cached: bad dtype");
+    const int dtype = dtype_arg & 0xff;       // LA_Q_LOG2 may ride on it
+    LA_CHECK_ARG((dtype_arg & ~(0xff | LA_Q_LOG2)) == 0 && (dtype == LA_F32 || dtype == LA_BF16 || dtype == LA_F16), "attention_cached: bad dtype");
     LA_CHECK_ARG(q_batch_rows >= q_len && kv_batch_rows >= kv_len, "attention_cached: batch strides shorter than the lengths");
     LA_CHECK_ARG(!causal || q_len == 1 || q_len == kv_len, "attention_cached: causal masking needs q_len == 1 or q_len == kv_len");
     const int es = dtype == LA_F32 ? 4 : 2;
@@ -671,5 +724,5 @@ extern "C" int la_attention_cached(int32_t dtype, const void *q, int64_t ld_q, i
                  "attention_cached: rows must be 16-byte aligned");
     // one new token against the whole cache needs no mask at all
     AttnParams p{q, k, v, ld_q, ld_kv, out, ld_out, q_len, kv_len, n_head, (causal && q_len > 1) ? 1 : 0, q_batch_rows, kv_batch_rows, q_len, 0};
-    return attention_launch(dtype, p, batch, stream);
+    return attention_launch(dtype_arg, p, batch, stream);
 }

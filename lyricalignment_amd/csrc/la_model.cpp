@@ -51,7 +51,7 @@ EncBufs carve_encoder(void *ws, int dtype, int batch, int d) {
 }
 
 bool encoder_fused_ln(const la_encoder_weights *w, int batch) {
-    if (w->dtype == LA_F32 || w->n_layer < 1 || !w->blocks[0].wqkv_ln || w->d <= 128) return false;
+    if ((w->dtype & 0xff) == LA_F32 || w->n_layer < 1 || !w->blocks[0].wqkv_ln || w->d <= 128) return false;
     static const char *off = getenv("LA_LN_FUSION");
     if (off && off[0] == '0') return false;
     const int64_t M = (int64_t)batch * N_CTX;
@@ -69,7 +69,7 @@ bool encoder_fused_ln(const la_encoder_weights *w, int batch) {
 
 extern "C" int la_encoder_workspace_bytes(const la_encoder_weights *w, int32_t batch, size_t *bytes) {
     LA_CHECK_ARG(w && bytes && batch > 0 && w->d > 0, "encoder_workspace_bytes: bad arguments");
-    *bytes = carve_encoder(nullptr, w->dtype, batch, w->d).total;
+    *bytes = carve_encoder(nullptr, w->dtype & 0xff, batch, w->d).total;
     return LA_OK;
 }
 
@@ -79,11 +79,12 @@ extern "C" int la_encoder_forward(const la_encoder_weights *w, const float *mel,
     hipStream_t stream = (hipStream_t)stream_;
     if (batch == 0) return LA_OK;
     LA_CHECK_ARG(w && mel && out && workspace && batch > 0, "encoder_forward: null pointer / bad batch");
-    LA_CHECK_ARG(w->dtype == LA_F32 || w->dtype == LA_BF16 || w->dtype == LA_F16, "encoder_forward: bad compute dtype");
+    LA_CHECK_ARG(((w->dtype & 0xff) == LA_F32 && !(w->dtype & LA_Q_LOG2)) || (w->dtype & ~LA_Q_LOG2) == LA_BF16 || (w->dtype & ~LA_Q_LOG2) == LA_F16,
+                 "encoder_forward: bad compute dtype");
     LA_CHECK_ARG(w->d > 0 && w->d % 64 == 0 && w->n_head * 64 == w->d, "encoder_forward: kernels are built for head_dim 64 (d = %d, heads = %d)", w->d, w->n_head);
     LA_CHECK_ARG(w->n_mels > 0 && w->n_mels <= C_PAD && w->n_layer >= 0 && (w->n_layer == 0 || w->blocks), "encoder_forward: bad dimensions");
     LA_CHECK_ARG((uintptr_t)workspace % 256 == 0, "encoder_forward: workspace must be 256-byte aligned");
-    const int dt = w->dtype, d = w->d, M = batch * N_CTX;
+    const int dt = w->dtype & 0xff, dt_attn = w->dtype, d = w->d, M = batch * N_CTX;   // (LA_Q_LOG2 rides on the attention calls' dtype)
     const EncBufs b = carve_encoder(workspace, dt, batch, d);
     LA_CHECK_ARG(workspace_bytes >= b.total, "encoder_forward: workspace too small (%zu < %zu)", workspace_bytes, b.total);
     const size_t es = esize(dt);
@@ -114,7 +115,7 @@ extern "C" int la_encoder_forward(const la_encoder_weights *w, const float *mel,
             LA_CHECK_ARG(k.wqkv_ln && k.cqkv && k.bqkv_ln && k.w1_ln && k.c1 && k.b1_ln, "encoder_forward: block %d lacks the LayerNorm-folded weights", l);
             LA_TRY(la_gemm_fused_ln(dt, M, 3 * d, d, 1, b.h, d, 0, k.wqkv_ln, b.qkv, 3 * d, 0, k.bqkv_ln, nullptr, 0, 0, LA_EPI_BIAS, nullptr, 0, 0,
                                     b.stats, k.cqkv, nullptr, stream));
-            LA_TRY(la_attention(dt, b.qkv, 3 * d, b.att, d, batch, N_CTX, w->n_head, stream));
+            LA_TRY(la_attention(dt_attn, b.qkv, 3 * d, b.att, d, batch, N_CTX, w->n_head, stream));
             LA_TRY(la_gemm_fused_ln(dt, M, d, d, 1, b.att, d, 0, k.wo, b.x, d, 0, k.bo, b.x, d, 0, epi_res, b.h, d, 0, nullptr, nullptr, nullptr, stream));
             LA_TRY(la_row_stats16(dt, b.h, d, M, d, 1e-5f, b.stats, stream));
             LA_TRY(la_gemm_fused_ln(dt, M, 4 * d, d, 1, b.h, d, 0, k.w1_ln, b.u, 4 * d, 0, k.b1_ln, nullptr, 0, 0, LA_EPI_BIAS | LA_EPI_GELU, nullptr, 0, 0,
@@ -124,7 +125,7 @@ extern "C" int la_encoder_forward(const la_encoder_weights *w, const float *mel,
         } else {
             LA_TRY(la_layernorm(b.x, d, M, d, k.ln1_g, k.ln1_b, b.h, d, dt, stream));
             LA_TRY(la_gemm(dt, M, 3 * d, d, 1, b.h, d, 0, k.wqkv, b.qkv, 3 * d, 0, k.bqkv, nullptr, 0, 0, LA_EPI_BIAS, stream));
-            LA_TRY(la_attention(dt, b.qkv, 3 * d, b.att, d, batch, N_CTX, w->n_head, stream));
+            LA_TRY(la_attention(dt_attn, b.qkv, 3 * d, b.att, d, batch, N_CTX, w->n_head, stream));
             LA_TRY(la_gemm(dt, M, d, d, 1, b.att, d, 0, k.wo, b.x, d, 0, k.bo, b.x, d, 0, epi_res, stream));
             LA_TRY(la_layernorm(b.x, d, M, d, k.ln2_g, k.ln2_b, b.h, d, dt, stream));
             LA_TRY(la_gemm(dt, M, 4 * d, d, 1, b.h, d, 0, k.w1, b.u, 4 * d, 0, k.b1, nullptr, 0, 0, LA_EPI_BIAS | LA_EPI_GELU, stream));

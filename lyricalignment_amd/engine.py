@@ -79,6 +79,7 @@ class EncoderWeights:
     pos: torch.Tensor
     blocks: List[BlockWeights]
     lnp_g: torch.Tensor; lnp_b: torch.Tensor
+    q_log2: bool = False        # the q rows of wqkv / bqkv carry head_dim^-0.5 log2(e) (include/lyricalign.h LA_Q_LOG2)
 
 
 @dataclass
@@ -108,6 +109,11 @@ def pack_encoder(sd: Dict[str, torch.Tensor], n_head: int, dtype: torch.dtype, d
     blocks = []
     i = 0
     scale = 64 ** -0.5  # (head_dim^-0.25 on q) * (head_dim^-0.25 on k), folded into q: exact power of two
+    # bfloat16: log2(e) too, so that the scores arrive in the exp2 domain and the attention kernel's softmax needs no multiply
+    # (LA_Q_LOG2; the product is rounded to bf16 once, like the plain fold).  LA_ATTN_Q_LOG2=0: developer A/B.
+    q_log2 = dtype == torch.bfloat16 and os.environ.get("LA_ATTN_Q_LOG2", "1") != "0"
+    if q_log2:
+        scale *= 1.4426950408889634
     while f"{prefix}blocks.{i}.attn.query.weight" in sd:
         b = f"blocks.{i}."
         wq, bq = g(b + "attn.query.weight").detach().float() * scale, g(b + "attn.query.bias").detach().float() * scale
@@ -131,7 +137,7 @@ def pack_encoder(sd: Dict[str, torch.Tensor], n_head: int, dtype: torch.dtype, d
     return EncoderWeights(d, n_head, n_mels, dtype,
                           c1.reshape(d, 3 * C_PAD).to(device=device, dtype=dtype).contiguous(), _f32(g("conv1.bias"), device),
                           c2.to(device=device, dtype=dtype).contiguous(), _f32(g("conv2.bias"), device),
-                          _f32(pos, device), blocks, _f32(g("ln_post.weight"), device), _f32(g("ln_post.bias"), device))
+                          _f32(pos, device), blocks, _f32(g("ln_post.weight"), device), _f32(g("ln_post.bias"), device), q_log2)
 
 
 @dataclass
@@ -243,7 +249,7 @@ class AlignEngine:
         for i, b in enumerate(e.blocks):
             blocks[i] = _lib.EncoderBlockC(P(b.ln1_g), P(b.ln1_b), P(b.wqkv), P(b.bqkv), P(b.wo), P(b.bo), P(b.ln2_g), P(b.ln2_b),
                                            P(b.w1), P(b.b1), P(b.w2), P(b.b2), P(b.wqkv_ln), P(b.cqkv), P(b.bqkv_ln), P(b.w1_ln), P(b.c1), P(b.b1_ln))
-        c = _lib.EncoderWeightsC(_lib.dtype_code(e.dtype), e.d, e.n_head, len(e.blocks), e.n_mels, P(e.conv1_w), P(e.conv1_b), P(e.conv2_w),
+        c = _lib.EncoderWeightsC(_lib.dtype_code(e.dtype) | (_lib.LA_Q_LOG2 if e.q_log2 else 0), e.d, e.n_head, len(e.blocks), e.n_mels, P(e.conv1_w), P(e.conv1_b), P(e.conv2_w),
                                  P(e.conv2_b), P(e.pos), P(e.lnp_g), P(e.lnp_b), blocks)
         c._keep = blocks            # the struct points into this host array
         return c
@@ -315,7 +321,7 @@ class AlignEngine:
             ops.row_stats16(h, out=stats)                                                     # of the stem's output (batched GEMM)
             for blk in e.blocks:
                 ops.gemm(h, blk.wqkv_ln, qkv, bias=blk.bqkv_ln, ln_stats=stats, ln_csum=blk.cqkv)
-                ops.attention(qkv, B, N_CTX, e.n_head, out=att)
+                ops.attention(qkv, B, N_CTX, e.n_head, out=att, q_log2=e.q_log2)
                 ops.gemm(att, blk.wo, x, bias=blk.bo, residual=x, out_f32=True, out16=h, ln_part=part)   # x += out-proj; h = bf16(x)
                 row_stats()
                 ops.gemm(h, blk.w1_ln, u, bias=blk.b1_ln, gelu=True, ln_stats=stats, ln_csum=blk.c1)
@@ -325,7 +331,7 @@ class AlignEngine:
             for blk in e.blocks:
                 ops.layernorm(x, blk.ln1_g, blk.ln1_b, dt, out=h)
                 ops.gemm(h, blk.wqkv, qkv, bias=blk.bqkv)
-                ops.attention(qkv, B, N_CTX, e.n_head, out=att)
+                ops.attention(qkv, B, N_CTX, e.n_head, out=att, q_log2=e.q_log2)
                 ops.gemm(att, blk.wo, x, bias=blk.bo, residual=x, out_f32=True)          # x += out-proj (in place)
                 ops.layernorm(x, blk.ln2_g, blk.ln2_b, dt, out=h)
                 ops.gemm(h, blk.w1, u, bias=blk.b1, gelu=True)

@@ -215,8 +215,9 @@ def cast_bf16(x: torch.Tensor) -> torch.Tensor:
     return y
 
 
-def attention(qkv: torch.Tensor, batch: int, frames: int, n_head: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """qkv [batch*frames, 3*n_head*64] (q pre-scaled by 1/8) -> out [batch*frames, n_head*64], same dtype."""
+def attention(qkv: torch.Tensor, batch: int, frames: int, n_head: int, out: Optional[torch.Tensor] = None, q_log2: bool = False) -> torch.Tensor:
+    """qkv [batch*frames, 3*n_head*64] (q pre-scaled by 1/8, or by log2(e)/8 with q_log2 -- 16-bit dtypes, LA_Q_LOG2) ->
+    out [batch*frames, n_head*64], same dtype."""
     _dev(qkv, "qkv")
     dt = dtype_code(qkv.dtype)
     d = n_head * 64
@@ -226,8 +227,8 @@ def attention(qkv: torch.Tensor, batch: int, frames: int, n_head: int, out: Opti
         out = torch.empty((qkv.shape[0], d), dtype=qkv.dtype, device=qkv.device)
     if out.dtype != qkv.dtype or out.dim() != 2 or out.shape[1] != d or out.shape[0] < batch * frames or out.stride(1) != 1:
         raise ValueError("attention: bad out buffer")
-    check(lib().la_attention(dt, ptr(qkv), qkv.stride(0), ptr(out), out.stride(0), batch, frames, n_head, stream_ptr()),
-          "attention")
+    check(lib().la_attention(dt | (_lib.LA_Q_LOG2 if q_log2 else 0), ptr(qkv), qkv.stride(0), ptr(out), out.stride(0), batch, frames, n_head,
+                             stream_ptr()), "attention")
     return out
 
 

@@ -163,6 +163,59 @@ def test_attention_online_rescale_spike():
         np.testing.assert_allclose(out.double().numpy(), ref.numpy(), rtol=0, atol=tol)
 
 
+@pytest.mark.parametrize("B,T,H", [(1, 5, 1), (2, 64, 2), (1, 200, 3), (2, 1500, 2), (1, 129, 1)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_attention_q_log2(B, T, H, dtype):
+    """LA_Q_LOG2: q carries log2(e) / 8, the scores arrive in the exp2 domain (bf16: the kernel that starts its running maximum at
+    0 and subtracts nothing until a query needs it; f16: the plain kernel with a scale of 1).  Same softmax as test_attention."""
+    from lyricalignment_amd import ops
+    d = H * 64
+    qkv = _rand(B * T, 3 * d, seed=20 + T, scale=1.0)
+    qkv[:, :d] *= 0.125 * 3.0
+    x = qkv.to(dtype)
+    x2 = x.clone()
+    x2[:, :d] = (x[:, :d].double() * 1.4426950408889634).to(dtype)        # what pack_encoder's fold gives the kernel
+    out = ops.attention(x2.cuda(), B, T, H, q_log2=True).float().cpu()
+    xd = x2.double().reshape(B, T, 3, H, 64)
+    q, k, v = xd[:, :, 0].transpose(1, 2) / 1.4426950408889634, xd[:, :, 1].transpose(1, 2), xd[:, :, 2].transpose(1, 2)
+    ref = (torch.softmax(q @ k.transpose(-1, -2), dim=-1) @ v).transpose(1, 2).reshape(B * T, d)
+    np.testing.assert_allclose(out.double().numpy(), ref.numpy(), rtol=0, atol=2e-2)
+
+
+def test_attention_q_log2_extreme_scores():
+    """The exp2-domain kernel's two exits from its no-maximum fast path: scores above 2^30 (the redo path installs a maximum and
+    the wave subtracts it from then on) and queries whose scores ALL lie below 2^-100 (the sum underflows: the block repeats its
+    sweep the textbook way) -- next to ordinary queries in the same block, in the first / a middle / the last tile."""
+    from lyricalignment_amd import ops
+    T, H = 300, 1
+    qkv = _rand(T, 192, seed=33, scale=0.3)
+    qkv[:, 64] = 0.0
+    qkv[10, 64] = 4.0; qkv[130, 64] = 6.0; qkv[250, 64] = 8.0; qkv[299, 64] = 7.0      # keys that answer to feature 0
+    qkv[5, 1:64] = 0.0                                                                # (queries 5 / 7 / 9 / 200 look at feature 0 only)
+    qkv[7, :64] = 0.0; qkv[7, 0] = 12.0             # scores up to 96 (exp2 domain): above the 2^30 limit from tile 0 on, rising later
+    qkv[:, 1] = 0.0; qkv[:, 65] = 5.0               # every key answers 5 on feature 1, which only query 9 looks at:
+    qkv[9, :64] = 0.0; qkv[9, 1] = -30.0            # all of its scores are -150: the sum of exp2 underflows -> its block repeats the textbook way
+    qkv[200, :64] = 0.0; qkv[200, 0] = 5.0          # overflows only in tile 3 (key 250): a redo in the middle of the sweep
+    qkv[5, 0] = -20.0                               # underflow, but other keys (feature 0 == 0) keep the sum at ~2^0: no repeat
+    x = qkv.to(torch.bfloat16)
+    out = ops.attention(x.cuda(), 1, T, H, q_log2=True).float().cpu()
+    xd = x.double()
+    q, k, v = xd[:, :64] / 1.4426950408889634, xd[:, 64:128], xd[:, 128:]
+    ref = torch.softmax(q @ k.T, dim=-1) @ v
+    assert torch.isfinite(out).all()
+    np.testing.assert_allclose(out.double().numpy(), ref.numpy(), rtol=0, atol=2e-2)
+    # every score of every query far below zero (all blocks repeat) and far above (all redo): still the same softmax
+    for shift in (-150.0, 100.0):
+        y = _rand(T, 192, seed=34, scale=0.3)
+        y[:, 0] = shift ** 0.5 if shift > 0 else -((-shift) ** 0.5)    # q_0 k_0 = shift on every (query, key) pair
+        y[:, 64] = abs(shift) ** 0.5
+        yb = y.to(torch.bfloat16)
+        out = ops.attention(yb.cuda(), 1, T, H, q_log2=True).float().cpu()
+        yd = yb.double()
+        ref = torch.softmax((yd[:, :64] / 1.4426950408889634) @ yd[:, 64:128].T, dim=-1) @ yd[:, 128:]
+        np.testing.assert_allclose(out.double().numpy(), ref.numpy(), rtol=0, atol=2e-2)
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_gemm_hand_placed_loop_matches_ping_pong_in_every_epilogue_mode(dtype, monkeypatch):
     """The default main loop of the 256x256 kernel (hand-placed flat stream, K % 128 == 0) against the quadrant ping-pong
