@@ -449,7 +449,8 @@ int la_cast_bf16_to_f32(const void *x, float *y, int64_t n, void *stream);
  * Packed weights (device pointers; layouts = lyricalignment_amd/engine.py pack_encoder / pack_head, which build these
  * structs from an openai-whisper AudioEncoder state_dict and the reference's RNN state_dict):
  *   matrices keep nn.Linear's [out][in] layout in the compute dtype; vectors are f32;
- *   wqkv [3d][d] = rows of query (pre-scaled by head_dim^-0.5), key, value; bqkv its bias (key part zero);
+ *   wqkv [3d][d] = rows of query (pre-scaled by head_dim^-0.5; by head_dim^-0.5 log2(e) when la_encoder_weights.dtype carries
+ *   LA_Q_LOG2), key, value; bqkv its bias (key part zero, query part scaled like the rows);
  *   conv1_w [d][3][128] (tap-major, mel channels zero-padded 80 -> 128), conv2_w [d][3][d];
  *   *_ln (16-bit modes, optional): the LayerNorm-folded forms la_gemm_fused_ln consumes -- W' = gamma o W rounded to the
  *   compute dtype, c[n] = sum_k W'[n][k], b' = b + W beta; NULL = always the separate LayerNorm pass.
