@@ -9,10 +9,12 @@ image, so this is NOT pinned to it -- tests/test_gpu_transcribe.py holds the rul
     the no-speech probability from the logits at the start-of-transcript position, the maximum-likelihood ranker;
   * transcribe(): the sliding 30 s window, temperature fallback (compression-ratio / average-log-probability thresholds),
     no-speech skipping, timestamp-token segments and seeking, conditioning on the previous window's text.
-What is NOT here: the vocabulary.  whisper's tiktoken files are not in this image, so token ids cannot be turned into text unless
-the caller passes a tokenizer object (anything with `.decode(list[int]) -> str`; whisper's own `get_tokenizer(...)` qualifies).
-Without one, `text` is None, the compression ratio is taken over the token ids' byte stream, and `suppress_tokens="-1"` (whisper's
-non-speech symbol list, which is derived from the vocabulary's text) only covers the special tokens.  The special-token ids below
+What is NOT here: the vocabulary DATA.  whisper's tiktoken rank files are assets of openai-whisper and not in this image;
+lyricalignment_amd/tokenizer.py (the whisper.tokenizer stand-in: byte-pair codec + whisper's Tokenizer surface) loads them from
+$LA_WHISPER_ASSETS / an installed openai-whisper / an explicit path, and decode / transcribe pick that up by themselves
+(resolve_tokenizer); an openai-whisper Tokenizer object may be passed instead.  Without the file, `text` is None, the compression
+ratio is taken over the token ids' byte stream, and `suppress_tokens="-1"` (whisper's non-speech symbol list, which is derived
+from the vocabulary's text) only covers the special tokens.  The special-token ids below
 are constants of whisper's two vocabularies."""
 from __future__ import annotations
 
@@ -29,6 +31,19 @@ from .whisper_compat import HOP_LENGTH, N_FRAMES, SAMPLE_RATE, pad_or_trim
 LANGUAGES = ("en zh de es ru ko fr ja pt tr pl ca nl ar sv it id hi fi vi he uk el ms cs ro da hu ta no th ur hr bg lt la mi ml cy sk te "
              "fa lv bn sr az sl kn et mk br eu is hy ne mn bs kk sq sw gl mr pa si km sn yo so af oc ka be tg sd gu am yi lo uz fo ht ps "
              "tk nn mt sa lb my bo tl mg as tt haw ln ha ba jw su").split()
+# language names whisper also accepts for `language=` (whisper/tokenizer.py LANGUAGES values and TO_LANGUAGE_CODE aliases), in the
+# order of the codes above
+LANGUAGE_NAMES = dict(zip(
+    [n.replace("_", " ") for n in
+     ("english chinese german spanish russian korean french japanese portuguese turkish polish catalan dutch arabic swedish italian "
+      "indonesian hindi finnish vietnamese hebrew ukrainian greek malay czech romanian danish hungarian tamil norwegian thai urdu "
+      "croatian bulgarian lithuanian latin maori malayalam welsh slovak telugu persian latvian bengali serbian azerbaijani slovenian "
+      "kannada estonian macedonian breton basque icelandic armenian nepali mongolian bosnian kazakh albanian swahili galician marathi "
+      "punjabi sinhala khmer shona yoruba somali afrikaans occitan georgian belarusian tajik sindhi gujarati amharic yiddish lao uzbek "
+      "faroese haitian_creole pashto turkmen nynorsk maltese sanskrit luxembourgish myanmar tibetan tagalog malagasy assamese tatar "
+      "hawaiian lingala hausa bashkir javanese sundanese").split()], LANGUAGES))
+LANGUAGE_NAMES.update({"burmese": "my", "valencian": "ca", "flemish": "nl", "haitian": "ht", "letzeburgesch": "lb", "pushto": "ps",
+                       "panjabi": "pa", "moldavian": "ro", "moldovan": "ro", "sinhalese": "si", "castilian": "es", "mandarin": "zh"})
 TIME_PRECISION = 0.02          # seconds per timestamp token = 2 mel frames = one encoder frame
 INPUT_STRIDE = 2               # mel frames per encoder frame (N_FRAMES // n_audio_ctx)
 
@@ -331,13 +346,31 @@ class _Decoder:
         return nxt.cpu().tolist(), lp.cpu().tolist()
 
 
+def resolve_tokenizer(model, tokenizer=None, language: Optional[str] = None, task: Optional[str] = None) -> TokenizerSpec:
+    """What decode / transcribe work with.  None: lyricalignment_amd.tokenizer.get_tokenizer for the model's vocabulary (special
+    ids always; text and the non-speech suppression set when whisper's rank file can be found -- tokenizer.py); a
+    lyricalignment_amd.tokenizer.Tokenizer or an openai-whisper Tokenizer (anything with .decode and .non_speech_tokens): wrapped;
+    a TokenizerSpec: as it is."""
+    if isinstance(tokenizer, TokenizerSpec):
+        return tokenizer
+    multilingual = int(getattr(model.dims, "n_vocab", 51865)) >= 51865          # whisper's Whisper.is_multilingual
+    if tokenizer is None:
+        from .tokenizer import get_tokenizer
+        return get_tokenizer(multilingual, language=language if multilingual else None, task=task if multilingual else None).spec()
+    if hasattr(tokenizer, "spec"):
+        return tokenizer.spec()
+    blank = tokenizer.encode(" ") if hasattr(tokenizer, "encode") else [220]
+    return TokenizerSpec(multilingual=multilingual, codec=tokenizer, non_speech_ids=tuple(getattr(tokenizer, "non_speech_tokens", ())),
+                         blank_id=int(blank[0]) if len(blank) == 1 else 220)
+
+
 @torch.no_grad()
 def decode(model, audio_features: torch.Tensor, options: Optional[DecodingOptions] = None, tokenizer: Optional[TokenizerSpec] = None,
            rng: Optional[torch.Generator] = None) -> List[DecodingResult]:
     """whisper.decode for encoder outputs: audio_features [B, n_audio, d] -> one DecodingResult per window."""
     from .module.align_model import decoder_engine_of
     eng = decoder_engine_of(model)
-    tok = tokenizer or TokenizerSpec()
+    tok = resolve_tokenizer(model, tokenizer, (options or DecodingOptions()).language, (options or DecodingOptions()).task)
     B, n_audio, d = audio_features.shape
     xa = audio_features.to(device=eng.device, dtype=torch.float32).contiguous().view(B * n_audio, d)
     return _Decoder(eng, tok, options or DecodingOptions(), int(model.dims.n_text_ctx), rng).run(xa, n_audio)
@@ -354,11 +387,15 @@ def transcribe(model, audio, *, task: str = "transcribe", language: Optional[str
                rng: Optional[torch.Generator] = None, mel: Optional[torch.Tensor] = None) -> dict:
     """whisper.transcribe for one recording: audio float32 [N] at 16 kHz (or a ready log-mel [80, frames]).
     -> {"text", "tokens", "segments": [{seek, start, end, tokens, text, temperature, avg_logprob, compression_ratio, no_speech_prob}],
-        "language"}.  `initial_prompt` is given as token ids (no vocabulary here)."""
+        "language"}.  `initial_prompt`: token ids, or text when the vocabulary is available (tokenizer.py)."""
     from .audio_frontend import log_mel_spectrogram
     from .module.align_model import decoder_engine_of
     eng = decoder_engine_of(model)
-    tok = tokenizer or TokenizerSpec()
+    tok = resolve_tokenizer(model, tokenizer, language, task)
+    if isinstance(initial_prompt, str):                               # whisper takes text here: needs the vocabulary
+        if tok.codec is None or not hasattr(tok.codec, "encode"):
+            raise FileNotFoundError("initial_prompt as text needs whisper's vocabulary (lyricalignment_amd/tokenizer.py); pass token ids")
+        initial_prompt = tok.codec.encode(" " + initial_prompt.strip())
     if mel is None:
         mel = log_mel_spectrogram(np.asarray(audio, dtype=np.float32), device=str(eng.device))
     mel = mel.to(eng.device)

@@ -146,8 +146,8 @@ class Whisper(nn.Module):
 
     def transcribe(self, audio, **kwargs):
         """whisper's transcribe (inference_transcript.py:88-91): sliding 30 s windows, temperature fallback, timestamp rules,
-        no-speech skipping, conditioning on the previous text -- lyricalignment_amd.transcribe.transcribe.  The vocabulary is not
-        in this image: result["text"] needs `tokenizer=TokenizerSpec(codec=...)`, result["tokens"] / ["segments"] do not."""
+        no-speech skipping, conditioning on the previous text -- lyricalignment_amd.transcribe.transcribe.  result["tokens"] /
+        ["segments"] are always there; result["text"] when whisper's rank file can be found (lyricalignment_amd/tokenizer.py)."""
         from .transcribe import transcribe
         return transcribe(self, audio, **kwargs)
 

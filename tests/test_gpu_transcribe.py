@@ -147,3 +147,31 @@ def test_transcribe_windows_fallback_and_segments(model):
     assert all(s["temperature"] == 1.0 for s in out2["segments"]) and out2["segments"]
     out3 = transcribe(model, audio[: 16000 * 20], language="zh", tokenizer=tok, rng=g, no_speech_threshold=-1.0, logprob_threshold=0.0)
     assert out3["segments"] == [] and out3["tokens"] == []
+
+
+def test_transcribe_returns_text_with_a_rank_file(model, tmp_path, monkeypatch):
+    """With a byte-pair rank file of the published size under $LA_WHISPER_ASSETS (synthetic merges + filler: whisper's own file is not
+    in this image) transcribe() finds it by itself: result and segment texts are the decoded token ids, the non-speech set is
+    suppressed, the compression ratio is taken over the text, and a text initial_prompt is accepted."""
+    from tests.test_host_logic import _train_synthetic_ranks, _write_tiktoken
+    from lyricalignment_amd.tokenizer import get_tokenizer
+    from lyricalignment_amd.transcribe import transcribe
+    ranks, _ = _train_synthetic_ranks()
+    _write_tiktoken(str(tmp_path / "multilingual.tiktoken"), ranks, pad_to=50257)
+    monkeypatch.setenv("LA_WHISPER_ASSETS", str(tmp_path))
+    tok = get_tokenizer(True, language="zh", task="transcribe")
+    rs = np.random.RandomState(10)
+    t = np.arange(20 * 16000) / 16000.0
+    audio = (0.3 * np.sin(2 * np.pi * 330 * t) + 0.05 * rs.randn(t.size)).astype(np.float32)
+    g = torch.Generator(device="cuda").manual_seed(2)
+    out = transcribe(model, audio, language="zh", rng=g, logprob_threshold=None, compression_ratio_threshold=None, no_speech_threshold=None,
+                     initial_prompt="我歌唱每一座高山")
+    assert isinstance(out["text"], str) and out["segments"]
+    ns = set(tok.non_speech_tokens)
+    for seg in out["segments"]:
+        text_ids = [i for i in seg["tokens"] if i < tok.eot]
+        assert seg["text"] == tok.decode(text_ids) and not (set(text_ids) & ns)
+    assert out["text"] == tok.decode([i for i in out["tokens"] if i < tok.eot])
+    out2 = transcribe(model, audio, language="zh", rng=g, tokenizer=tok, logprob_threshold=None, compression_ratio_threshold=None,
+                      no_speech_threshold=None)                                  # the Tokenizer object itself is accepted too
+    assert isinstance(out2["text"], str)

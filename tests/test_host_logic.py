@@ -418,3 +418,133 @@ def test_whisper_special_token_ids():
     assert (m.eot, m.sot, m.language_token("zh"), m.translate, m.transcribe, m.no_speech, m.no_timestamps, m.timestamp_begin) == \
         (50257, 50258, 50260, 50358, 50359, 50362, 50363, 50364)
     assert m.timestamp_begin + 1501 == 51865 and e.timestamp_begin + 1501 == 51864
+
+
+# ------------------------------------------------------------------------------------------------ whisper.tokenizer stand-in
+def _gpt2_byte_to_unicode():
+    """GPT-2's printable stand-ins for the 256 byte values (what HF byte-level vocabularies are written in)."""
+    bs = list(range(ord("!"), ord("~") + 1)) + list(range(ord("¡"), ord("¬") + 1)) + list(range(ord("®"), ord("ÿ") + 1))
+    cs = bs[:]
+    n = 0
+    for b in range(256):
+        if b not in bs:
+            bs.append(b); cs.append(256 + n); n += 1
+    return {b: chr(c) for b, c in zip(bs, cs)}
+
+
+def _train_synthetic_ranks(n_merges=400):
+    """A small byte-pair vocabulary trained on a few sentences (English with contractions, digits, Chinese lyrics, the symbols
+    whisper suppresses): ranks 0..255 = the single bytes, then one rank per merge in training order."""
+    import collections
+    import regex
+    from lyricalignment_amd.tokenizer import _PRETOKENIZE
+    corpus = ("I'm singing in the rain, just singin' in the rain -- what a glorious feeling, we're happy again! "
+              "It's 1999 and 12 o'clock; they've said (( laughter )) [[ music ]] ♪♪ la la la ♪♪♪ <<< >>> -- --- "
+              "我和我的祖国 一刻也不能分割 无论我走到哪里 都流出一首赞歌 我歌唱每一座高山 我歌唱每一条河 "
+              "the quick brown fox jumps over the lazy dog's back 3 times; 'twas brillig, and the slithy toves \" # * + / : ; < = > @ ^ _ ` { | } ~ ") * 3
+    words = collections.Counter(m.group().encode("utf-8") for m in regex.finditer(_PRETOKENIZE, corpus))
+    seqs = {w: [bytes([b]) for b in w] for w in words}
+    merges = []
+    for _ in range(n_merges):
+        pairs = collections.Counter()
+        for w, parts in seqs.items():
+            for a, b in zip(parts, parts[1:]):
+                pairs[(a, b)] += words[w]
+        if not pairs:
+            break
+        (a, b), _cnt = max(pairs.items(), key=lambda kv: (kv[1], kv[0]))
+        merges.append((a, b))
+        for w, parts in seqs.items():
+            i, out = 0, []
+            while i < len(parts):
+                if i + 1 < len(parts) and parts[i] == a and parts[i + 1] == b:
+                    out.append(a + b); i += 2
+                else:
+                    out.append(parts[i]); i += 1
+            seqs[w] = out
+    ranks = {bytes([b]): b for b in range(256)}
+    for a, b in merges:
+        if a + b not in ranks:
+            ranks[a + b] = len(ranks)
+    return ranks, merges
+
+
+def _write_tiktoken(path, ranks, pad_to=None):
+    import base64
+    ranks = dict(ranks)
+    n = len(ranks)
+    while pad_to is not None and n < pad_to:       # filler tokens no UTF-8 text contains (bytes F8..FF never occur in UTF-8)
+        ranks[bytes([0xF8 + (n % 8), 0xF8 + ((n >> 3) % 8), 0xF8 + ((n >> 6) % 8), 0xF8 + ((n >> 9) % 8), 0xF8 + ((n >> 12) % 8), 0xF8 + ((n >> 15) % 8)])] = n
+        n += 1
+    with open(path, "wb") as f:
+        for tok, r in sorted(ranks.items(), key=lambda kv: kv[1]):
+            f.write(base64.b64encode(tok) + b" " + str(r).encode() + b"\n")
+
+
+def test_byte_pair_codec_matches_hf_tokenizers_on_a_synthetic_vocabulary(tmp_path):
+    """lyricalignment_amd.tokenizer.BytePairCodec (GPT-2 pre-tokenisation + lowest-rank-first merging over a tiktoken rank file)
+    against an independent implementation of the same scheme: HF `tokenizers` byte-level BPE built from the same merges."""
+    from tokenizers import Tokenizer as HFTokenizer, decoders, models, pre_tokenizers
+    from lyricalignment_amd.tokenizer import BytePairCodec
+    ranks, merges = _train_synthetic_ranks()
+    path = str(tmp_path / "synthetic.tiktoken")
+    _write_tiktoken(path, ranks)
+    codec = BytePairCodec.from_tiktoken_file(path)
+    assert codec.n_vocab == len(ranks) > 500
+    b2u = _gpt2_byte_to_unicode()
+    u = lambda bs: "".join(b2u[b] for b in bs)
+    hf = HFTokenizer(models.BPE(vocab={u(t): r for t, r in ranks.items()}, merges=[(u(a), u(b)) for a, b in merges]))
+    hf.pre_tokenizer = pre_tokenizers.ByteLevel(add_prefix_space=False, use_regex=True)
+    hf.decoder = decoders.ByteLevel()
+    texts = ["I'm singing in the rain", " we're happy again!  It's 12 o'clock", "我和我的祖国 一刻也不能分割", "they've  said\n\n(( laughter ))",
+             "♪♪ la la ♪♪♪", "unseen wörds: žluťoučký kůň 🎵 1234567", "   leading and trailing   ", "", "a", "\t\ttabs\tand  spaces \n"]
+    for t in texts:
+        mine = codec.encode(t)
+        assert mine == hf.encode(t).ids, t
+        assert codec.decode(mine) == t
+    assert codec.decode([ranks[bytes([0xE6])]]) == "�"          # a lone lead byte of a 3-byte character: replaced, not raised
+    with pytest.raises(ValueError):
+        BytePairCodec({b"a": 0, b"b": 1})                            # no single-byte alphabet
+
+
+def test_whisper_tokenizer_stand_in(tmp_path, monkeypatch):
+    """lyricalignment_amd.tokenizer.get_tokenizer: whisper's special-token ids and sot sequences without any asset; with a rank
+    file of the published size (synthetic merges + filler) the text side: encode / decode / decode_with_timestamps,
+    non_speech_tokens by whisper's construction, TokenizerSpec for transcribe."""
+    from lyricalignment_amd.tokenizer import get_tokenizer
+    monkeypatch.delenv("LA_WHISPER_ASSETS", raising=False)
+    tok = get_tokenizer(True, language="zh", task="transcribe")
+    assert (tok.sot, tok.eot, tok.special_tokens["<|zh|>"], tok.transcribe, tok.translate) == (50258, 50257, 50260, 50359, 50358)
+    assert (tok.sot_lm, tok.sot_prev, tok.no_speech, tok.no_timestamps, tok.timestamp_begin, tok.n_vocab) == (50360, 50361, 50362, 50363, 50364, 51865)
+    assert tok.sot_sequence == (50258, 50260, 50359) and tok.sot_sequence_including_notimestamps == (50258, 50260, 50359, 50363)
+    assert tok.special_tokens["<|30.00|>"] == 50364 + 1500 and tok.language_token == 50260 and len(tok.all_language_tokens) == 99
+    assert get_tokenizer(True).sot_sequence == (50258, 50259, 50359)                       # defaults: en, transcribe
+    assert get_tokenizer(True, language="Chinese", task="translate").sot_sequence == (50258, 50260, 50358)
+    en = get_tokenizer(False)
+    assert (en.eot, en.sot, en.sot_sequence, en.timestamp_begin, en.n_vocab) == (50256, 50257, (50257,), 50363, 51864)
+    with pytest.raises(ValueError):
+        get_tokenizer(True, language="klingon")
+    with pytest.raises(FileNotFoundError):
+        tok.encode("no vocabulary here")
+    assert tok.spec().codec is None and tok.spec().eot == 50257
+    # the text side on a rank file of the published size
+    ranks, _ = _train_synthetic_ranks()
+    _write_tiktoken(str(tmp_path / "multilingual.tiktoken"), ranks, pad_to=50257)
+    monkeypatch.setenv("LA_WHISPER_ASSETS", str(tmp_path))
+    tok = get_tokenizer(True, language="zh", task="transcribe")
+    ids = tok.encode(" 我歌唱每一座高山")
+    assert ids and max(ids) < 50257 and tok.decode(ids) == " 我歌唱每一座高山"
+    stamped = [tok.timestamp_begin] + ids + [tok.timestamp_begin + 54, tok.eot]
+    assert tok.decode(stamped) == " 我歌唱每一座高山<|endoftext|>"
+    assert tok.decode_with_timestamps(stamped) == "<|0.00|> 我歌唱每一座高山<|1.08|><|endoftext|>"
+    ns = tok.non_speech_tokens
+    codec = tok.encoding
+    assert codec.encode(" -")[0] in ns and codec.encode(" '")[0] in ns and codec.encode("♪")[0] in ns and codec.encode(" ♪")[0] in ns
+    one = codec.encode("((")
+    assert (len(one) == 1) == (one[0] in ns and codec.decode([one[0]]) == "((")           # "((" counts only as a single token
+    assert codec.encode("a")[0] not in ns and tuple(sorted(ns)) == ns
+    spec = tok.spec()
+    assert spec.codec is tok and spec.non_speech_ids == ns and spec.decode(ids + [tok.eot, tok.timestamp_begin]) == " 我歌唱每一座高山"
+    with pytest.raises(ValueError):                                                        # a rank file of the wrong size is refused
+        _write_tiktoken(str(tmp_path / "gpt2.tiktoken"), ranks, pad_to=50257)
+        get_tokenizer(False)
