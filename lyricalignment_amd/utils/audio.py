@@ -2,7 +2,7 @@
 select mono / (L+R)/2 / channel 1.  Output contract (what enters the hot path): {"speech": float32 [N], "sampling_rate": 16000}.
 
 The reference delegates to librosa.load (absent here, un-pinned there), whose resampler is soxr_hq or kaiser_best
-depending on the librosa version -- parity with IT is unpinned.  This build decodes PCM / float WAV on the host (I/O) and
+depending on the librosa version -- parity with IT is unpinned.  This build decodes WAV / AIFF / AU on the host (I/O) and
 resamples on the device with a Kaiser-windowed-sinc polyphase FIR (la_resample_poly_f32) designed exactly like
 scipy.signal.resample_poly, which is the checker the tests use.  No CPU fallback for the resampling arithmetic.
 """
@@ -54,8 +54,42 @@ def resample_to_16k(x: np.ndarray, sr: int, device="cuda") -> np.ndarray:
     return y.cpu().numpy()
 
 
+def _pcm_to_float(raw: bytes, width: int, n_channels: int, big_endian: bool) -> np.ndarray:
+    """interleaved signed PCM of `width` bytes per sample -> float32 [channels, N] in [-1, 1)"""
+    if width == 3:
+        b = np.frombuffer(raw, dtype=np.uint8).reshape(-1, 3).astype(np.int32)
+        hi, mid, lo = (b[:, 0], b[:, 1], b[:, 2]) if big_endian else (b[:, 2], b[:, 1], b[:, 0])
+        v = (hi << 16) | (mid << 8) | lo
+        v = np.where(v >= 1 << 23, v - (1 << 24), v)
+    else:
+        v = np.frombuffer(raw, dtype=np.dtype({1: "i1", 2: "i2", 4: "i4"}[width]).newbyteorder(">" if big_endian else "<"))
+    x = v.astype(np.float64) / float(1 << (8 * width - 1))
+    return np.ascontiguousarray(x.reshape(-1, n_channels).T.astype(np.float32))
+
+
 def _decode(file: str):
-    """-> (float32 [channels, N] in [-1, 1], sample rate).  WAV (PCM 8/16/24/32-bit, float32/64) via scipy.io.wavfile."""
+    """-> (float32 [channels, N] in [-1, 1], sample rate).  By the file's magic bytes: RIFF WAV (PCM 8/16/24/32-bit, float32/64)
+    via scipy.io.wavfile; AIFF / AIFF-C (big-endian PCM, 'sowt', u-law / a-law) and Sun AU (PCM 8/16/24/32-bit, u-law) via the
+    standard library's aifc / sunau.  Compressed formats (FLAC, MP3, Ogg) need a decoder this image does not have -- librosa
+    would hand them to libsndfile / audioread (utils/audio.py:3-20)."""
+    with open(file, "rb") as f:
+        magic = f.read(12)
+    if magic[:4] == b"FORM" and magic[8:12] in (b"AIFF", b"AIFC"):
+        import aifc
+        with aifc.open(file, "rb") as a:
+            nch, width, sr, n = a.getnchannels(), a.getsampwidth(), a.getframerate(), a.getnframes()
+            raw = a.readframes(n)                       # aifc hands PCM back big-endian ('sowt' and the companded types already converted)
+        return _pcm_to_float(raw, width, nch, big_endian=True), int(sr)
+    if magic[:4] == b".snd":
+        import sunau
+        with sunau.open(file, "rb") as a:
+            nch, width, sr, n = a.getnchannels(), a.getsampwidth(), a.getframerate(), a.getnframes()
+            raw = a.readframes(n)                       # u-law arrives as 16-bit linear in native byte order, PCM as stored (big-endian)
+            ulaw = a.getcomptype() == "ULAW"
+        import sys
+        return _pcm_to_float(raw, width, nch, big_endian=(sys.byteorder == "big") if ulaw else True), int(sr)
+    if magic[:4] not in (b"RIFF", b"RIFX", b"RF64"):
+        raise ValueError(f"{file}: not a WAV / AIFF / AU file (magic {magic[:4]!r}); compressed formats need a decoder that is not in this build")
     from scipy.io import wavfile
     sr, data = wavfile.read(file)
     if data.ndim == 1:

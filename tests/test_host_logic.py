@@ -548,3 +548,38 @@ def test_whisper_tokenizer_stand_in(tmp_path, monkeypatch):
     with pytest.raises(ValueError):                                                        # a rank file of the wrong size is refused
         _write_tiktoken(str(tmp_path / "gpt2.tiktoken"), ranks, pad_to=50257)
         get_tokenizer(False)
+
+
+def test_audio_decode_wav_aiff_au(tmp_path):
+    """utils.audio._decode (the host half of load_audio_file, utils/audio.py:3-20): the same two-channel signal stored as 16-bit
+    WAV, 16- and 24-bit AIFF and 16-bit / u-law Sun AU decodes to the same float32 [channels, N] (u-law to its own precision);
+    anything else is refused by name."""
+    import aifc
+    import sunau
+    import audioop
+    from scipy.io import wavfile
+    from lyricalignment_amd.utils.audio import _decode
+    rs = np.random.RandomState(0)
+    pcm = (rs.uniform(-0.9, 0.9, size=(1000, 2)) * 32767).astype(np.int16)
+    want = pcm.T.astype(np.float32) / 32768.0
+    wavfile.write(str(tmp_path / "a.wav"), 22050, pcm)
+    with aifc.open(str(tmp_path / "a.aiff"), "wb") as f:
+        f.setnchannels(2); f.setsampwidth(2); f.setframerate(22050); f.writeframes(pcm.astype(">i2").tobytes())
+    with aifc.open(str(tmp_path / "b.aiff"), "wb") as f:
+        f.setnchannels(2); f.setsampwidth(3); f.setframerate(22050)
+        f.writeframes(audioop.byteswap(audioop.lin2lin(pcm.astype("<i2").tobytes(), 2, 3), 3))
+    with sunau.open(str(tmp_path / "a.au"), "wb") as f:
+        f.setnchannels(2); f.setsampwidth(2); f.setframerate(22050); f.setcomptype("NONE", "not compressed")   # (the module's default is u-law)
+        f.writeframes(pcm.astype(">i2").tobytes())
+    with sunau.open(str(tmp_path / "u.au"), "wb") as f:
+        f.setnchannels(2); f.setsampwidth(2); f.setframerate(8000); f.setcomptype("ULAW", "ulaw")
+        f.writeframes(pcm.tobytes())                                                       # native 16-bit in, the module compands
+    for name in ("a.wav", "a.aiff", "b.aiff", "a.au"):
+        x, sr = _decode(str(tmp_path / name))
+        assert sr == 22050 and x.dtype == np.float32 and x.shape == (2, 1000), name
+        np.testing.assert_array_equal(x, want, err_msg=name)
+    x, sr = _decode(str(tmp_path / "u.au"))
+    assert sr == 8000 and x.shape == (2, 1000) and np.abs(x - want).max() < 0.04          # 8-bit companding
+    (tmp_path / "x.flac").write_bytes(b"fLaC" + bytes(64))
+    with pytest.raises(ValueError, match="not a WAV / AIFF / AU"):
+        _decode(str(tmp_path / "x.flac"))
