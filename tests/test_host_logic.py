@@ -583,3 +583,30 @@ def test_audio_decode_wav_aiff_au(tmp_path):
     (tmp_path / "x.flac").write_bytes(b"fLaC" + bytes(64))
     with pytest.raises(ValueError, match="not a WAV / AIFF / AU"):
         _decode(str(tmp_path / "x.flac"))
+
+
+def test_resolve_tokenizer_forms(tmp_path, monkeypatch):
+    """transcribe.resolve_tokenizer: None -> the stand-in for the model's vocabulary (multilingual from dims.n_vocab >= 51865, like
+    whisper's is_multilingual); a stand-in / foreign tokenizer object -> wrapped; a TokenizerSpec -> itself."""
+    from types import SimpleNamespace
+    from lyricalignment_amd.tokenizer import get_tokenizer
+    from lyricalignment_amd.transcribe import TokenizerSpec, resolve_tokenizer
+    monkeypatch.delenv("LA_WHISPER_ASSETS", raising=False)
+    multi, english = SimpleNamespace(dims=SimpleNamespace(n_vocab=51865)), SimpleNamespace(dims=SimpleNamespace(n_vocab=51864))
+    s = resolve_tokenizer(multi, None, "zh", "transcribe")
+    assert s.multilingual and s.codec is None and s.eot == 50257 and s.non_speech_ids == ()
+    assert not resolve_tokenizer(english).multilingual and resolve_tokenizer(english).eot == 50256
+    spec = TokenizerSpec(non_speech_ids=(1, 2))
+    assert resolve_tokenizer(multi, spec) is spec
+
+    class Foreign:                                   # the surface of an openai-whisper Tokenizer that is used
+        non_speech_tokens = (5, 7)
+        def encode(self, text): return [220] if text == " " else [1, 2, 3]
+        def decode(self, ids): return "x" * len(ids)
+    f = resolve_tokenizer(multi, Foreign())
+    assert f.multilingual and f.non_speech_ids == (5, 7) and f.blank_id == 220 and f.decode([1, 2, 60000]) == "xx"
+    ranks, _ = _train_synthetic_ranks()
+    _write_tiktoken(str(tmp_path / "multilingual.tiktoken"), ranks, pad_to=50257)
+    tok = get_tokenizer(True, language="zh", vocab_path=str(tmp_path))
+    w = resolve_tokenizer(multi, tok)
+    assert w.codec is tok and w.non_speech_ids == tok.non_speech_tokens and w.decode(tok.encode("la la") + [tok.eot]) == "la la"
