@@ -198,6 +198,67 @@ def fit_head(model, device, fit_seed_offset: int = 100, ridge: float = 1e-3) -> 
     return {"fit_frame_accuracy": acc, "fit_clips": BATCH, "probe_weight_absmax": float(W[:-1].abs().max())}
 
 
+class PowerSampler:
+    """Socket power and shader clock of one GPU read from its hwmon nodes (power1_input in microwatts, freq1_input in hertz;
+    plain sysfs reads, nothing is set) every 50 ms by a thread while the timed region runs -- the roofline's `peak` is the
+    datasheet rate at the nominal 2.4 GHz, and this says what clock the package actually held under its power cap.
+    Silent when the nodes are not there (-> None in the JSON)."""
+
+    def __init__(self, device_index: int):
+        self.samples, self.cap_w, self._stop, self._thread, self._dir = [], None, False, None, None
+        try:
+            import glob
+            want = None
+            try:
+                pr = torch.cuda.get_device_properties(device_index)
+                want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}"
+            except Exception:
+                pass
+            cands = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
+            cands = [c for c in cands if os.path.exists(os.path.join(c, "power1_input")) and os.path.exists(os.path.join(c, "freq1_input"))]
+            if want is not None:
+                hit = [c for c in cands if want in os.path.realpath(os.path.dirname(os.path.dirname(c)))]
+                cands = hit or (cands if len(cands) == 1 else [])
+            if cands:
+                self._dir = cands[0]
+                with open(os.path.join(self._dir, "power1_cap")) as f:
+                    self.cap_w = int(f.read()) / 1e6
+        except Exception:
+            self._dir = None
+
+    def _read(self):
+        with open(os.path.join(self._dir, "power1_input")) as f:
+            w = int(f.read()) / 1e6
+        with open(os.path.join(self._dir, "freq1_input")) as f:
+            mhz = int(f.read()) / 1e6
+        return w, mhz
+
+    def _run(self):
+        while not self._stop:
+            try:
+                self.samples.append(self._read())
+            except Exception:
+                return
+            time.sleep(0.05)
+
+    def start(self):
+        if self._dir is not None:
+            import threading
+            self._thread = threading.Thread(target=self._run, daemon=True)
+            self._thread.start()
+
+    def stop(self):
+        self._stop = True
+        if self._thread is not None:
+            self._thread.join(timeout=1.0)
+        if not self.samples:
+            return None
+        w = sorted(s[0] for s in self.samples)
+        f = sorted(s[1] for s in self.samples)
+        return {"socket_w_median": w[len(w) // 2], "socket_w_max": w[-1], "cap_w": self.cap_w, "sclk_mhz_median": f[len(f) // 2],
+                "sclk_mhz_min": f[0], "samples": len(w), "source": "hwmon power1_input / freq1_input every 50 ms through the timed region"}
+
+
 def usable_cores() -> int:
     """Cores this process may actually use: scheduler affinity capped by the cgroup CPU quota (a container on a
     256-thread host often owns only a few cores; oversubscribing torch's intra-op pool makes it crawl)."""
@@ -584,8 +645,11 @@ def main():
     L.la_timer_reset()
     L.la_timer_sample(args.timer_period)
     L.la_timer_enable(os.environ.get("LA_BENCH_TIMER", "gemm_bf16").encode())
+    power = PowerSampler(local_rank) if rank == 0 else None
     barrier()
     torch.cuda.synchronize()
+    if power is not None:
+        power.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -594,6 +658,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    power_reading = power.stop() if power is not None else None
     L.la_timer_disable()
     log(f"timed region: {args.steps} steps in {elapsed:.3f} s")
     eng.check_gru()
@@ -645,6 +710,7 @@ def main():
                          "launches_per_step": seen.value / max(args.steps, 1),
                          "avg_launch_ms": total_ms.value / max(launches.value, 1),
                          "timed_launches": launches.value,
+                         "power": power_reading,
                          "timing": f"HIP events around every {args.timer_period}. launch of the family on its own stream (an event record "
                                    "is a barrier packet: ~6.6 us of stream idle time each; bracketing every launch costs 0.66 ms per step)"},
         }

@@ -610,3 +610,22 @@ def test_resolve_tokenizer_forms(tmp_path, monkeypatch):
     tok = get_tokenizer(True, language="zh", vocab_path=str(tmp_path))
     w = resolve_tokenizer(multi, tok)
     assert w.codec is tok and w.non_speech_ids == tok.non_speech_tokens and w.decode(tok.encode("la la") + [tok.eot]) == "la la"
+
+
+def test_bench_power_sampler_is_silent_without_hwmon_nodes(tmp_path):
+    """bench.PowerSampler: no readable hwmon node (this container) -> no thread, None in the JSON; with a directory holding the
+    three nodes it reports medians in watts / MHz."""
+    import time
+    import bench
+    p = bench.PowerSampler(0)
+    if p._dir is None:
+        p.start()
+        assert p.stop() is None
+    (tmp_path / "power1_input").write_text("1340000000\n")
+    (tmp_path / "freq1_input").write_text("1920000000\n")
+    q = bench.PowerSampler.__new__(bench.PowerSampler)
+    q.samples, q.cap_w, q._stop, q._thread, q._dir = [], 1400.0, False, None, str(tmp_path)
+    q.start()
+    time.sleep(0.12)
+    r = q.stop()
+    assert r["socket_w_median"] == 1340.0 and r["sclk_mhz_median"] == 1920.0 and r["cap_w"] == 1400.0 and r["samples"] >= 2
