@@ -543,6 +543,24 @@ def other_config_mode(args, rank, world, local_rank, device, dist):
         dist.destroy_process_group()
 
 
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` outside a launcher: start N ranks (one per GPU) as a CHILD `torch.distributed.run`
+    with the same arguments and return its exit code.  This parent has made no HIP call (importing torch makes none) and
+    makes none: the ranks' stdout is inherited, so rank 0's JSON line is this command's JSON line."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"--gpus {n} without a launcher: starting {n} ranks: {' '.join(cmd)}")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -570,11 +588,16 @@ def main():
                     help="align mode: the roofline leg brackets every n-th launch of the GEMM family with HIP events (1 = every launch; odd and not a divisor of the 199 launches per pair of batches, so every shape is sampled alike)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process becomes the launcher of N ranks and never touches the GPU
+        raise SystemExit(launch_ranks(args.gpus))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start one rank per GPU "
+                         f"(plain `python bench.py --gpus {args.gpus}` does that by itself)")
     # host threads: the box reports every core of the node, the cgroup quota is what this job may use, and with one rank
     # per GPU the ranks share it (random-init weight generation runs on the host)
     torch.set_num_threads(max(1, usable_cores() // max(world, 1)))
@@ -593,6 +616,9 @@ def main():
             dist.init_process_group(backend="nccl", device_id=device)
         else:
             dist.init_process_group(backend=backend)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but the process group has {dist.get_world_size()} ranks")
+        world = dist.get_world_size()
 
     if args.mode == "finetune":
         return finetune_mode(args, rank, world, local_rank, device, dist)

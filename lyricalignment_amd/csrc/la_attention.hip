@@ -639,11 +639,11 @@ static int attention_launch(int dtype_arg, AttnParams p, int batch, hipStream_t 
         } else if (dtype == LA_F16) hipLaunchKernelGGL((attention_bf16_kernel<la::f16_t, 4, false, 0, true>), grid, block, 0, stream, p);
         else hipLaunchKernelGGL((attention_bf16_kernel<bf16_t, 4, false, 0, true>), grid, block, 0, stream, p);
     } else {
-        static bool attr_done = false;
-        if (!attr_done) {
+        static la::DeviceOnce attr_once;
+        if (attr_once.pending()) {
             LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_f32_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 4 * KT * 256));
-            attr_done = true;
+            attr_once.mark();
         }
         la::TimerScope ts("attention_f32", stream);
         hipLaunchKernelGGL(attention_f32_kernel, grid, block, 4 * KT * 256, stream, p);

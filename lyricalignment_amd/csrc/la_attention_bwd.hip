@@ -336,6 +336,7 @@ extern "C" int la_attention_bwd_f32(const float *q, int64_t ld_q, const float *k
     if (batch == 0 || q_len == 0 || kv_len == 0) return LA_OK;
     LA_CHECK_ARG(q && k && v && o && dout && dq && dk && dv && workspace, "attention_bwd: null pointer");
     LA_CHECK_ARG(batch > 0 && q_len > 0 && kv_len > 0 && n_head > 0, "attention_bwd: bad sizes");
+    LA_CHECK_ARG(!causal || q_len == kv_len, "attention_bwd: the causal mask needs q_len == kv_len (as la_attention_ex / la_attention_lse_f32)");
     LA_CHECK_ARG(ld_q % 4 == 0 && ld_kv % 4 == 0 && ld_o % 4 == 0 && ld_do % 4 == 0 && ld_dq % 4 == 0 && ld_dkv % 4 == 0 &&
                      ld_q >= 64 * n_head && ld_kv >= 64 * n_head && ld_o >= 64 * n_head && ld_do >= 64 * n_head && ld_dq >= 64 * n_head && ld_dkv >= 64 * n_head,
                  "attention_bwd: row pitches must be multiples of 4 floats and cover 64 x heads columns");
@@ -348,11 +349,11 @@ extern "C" int la_attention_bwd_f32(const float *q, int64_t ld_q, const float *k
     float *lse = static_cast<float *>(workspace);
     BwdParams p{q, k, v, o, dout, dq, dk, dv, ld_q, ld_kv, ld_o, ld_do, ld_dq, ld_dkv, batch, q_len, kv_len, n_head, causal ? 1 : 0,
                 lse_in ? const_cast<float *>(lse_in) : lse, lse + (size_t)batch * n_head * q_len, lse_in ? 1 : 0};
-    static bool attr_done = false;
-    if (!attr_done) {
+    static la::DeviceOnce attr_once;
+    if (attr_once.pending()) {
         LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_kv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * TILE * 4));
         LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_q_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * TILE * 4));
-        attr_done = true;
+        attr_once.mark();
     }
     la::TimerScope ts("attention_bwd_f32", stream);
     const dim3 gq(la::cdiv(q_len, BT), n_head, batch), gk(la::cdiv(kv_len, BT), n_head, batch);

@@ -43,6 +43,26 @@ void *stream_scratch(hipStream_t stream, int purpose, size_t bytes);
         }                                                                               \
     } while (0)
 
+// ---- a function attribute (dynamic-LDS ceiling) set once per DEVICE, not once per process ----
+// hipFuncSetAttribute applies to the current device's code object: a process driving two devices must set it on both.
+// Bit d of `done` = set on device d; concurrent first callers both set it (idempotent).
+struct DeviceOnce {
+    unsigned long long done[4] = {0, 0, 0, 0};
+    static int current() {
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess) d = 0;
+        return d & 255;
+    }
+    bool pending() const {
+        const int d = current();
+        return !((__atomic_load_n(&done[d >> 6], __ATOMIC_ACQUIRE) >> (d & 63)) & 1ull);
+    }
+    void mark() {
+        const int d = current();
+        __atomic_fetch_or(&done[d >> 6], 1ull << (d & 63), __ATOMIC_RELEASE);
+    }
+};
+
 // ---- optional per-kernel-family event timer (bench.py roofline leg) ---------
 struct TimerScope {
     bool active;

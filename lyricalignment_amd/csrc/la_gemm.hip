@@ -621,10 +621,10 @@ __global__ __launch_bounds__(MONO::THREADS, 1) void gemm_mono_kernel(GemmParams 
 template <bool OUT_F32, typename T16, int LNM = 0>
 int launch_mono(GemmParams p, int batch, hipStream_t stream) {
     auto kern = gemm_mono_kernel<OUT_F32, T16, LNM>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static la::DeviceOnce attr_once;
+    if (attr_once.pending()) {
         LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, MONO::LDS));
-        attr_done = true;
+        attr_once.mark();
     }
     p.tiles_m = la::cdiv(p.M, 256);
     p.tiles_n = la::cdiv(p.N, 256);
@@ -648,10 +648,10 @@ int launch_mono_modes(GemmParams p, int batch, hipStream_t stream) {
 template <bool OUT_F32, bool DUO, typename T16, int LNM = 0>
 int launch_pp_loop(GemmParams p, int batch, hipStream_t stream) {
     auto kern = gemm_pp_kernel<OUT_F32, DUO, T16, LNM>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static la::DeviceOnce attr_once;
+    if (attr_once.pending()) {
         LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, PP::LDS));
-        attr_done = true;
+        attr_once.mark();
     }
     p.tiles_m = la::cdiv(p.M, PP::TM);
     p.tiles_n = la::cdiv(p.N, PP::TN);
@@ -689,10 +689,10 @@ int launch_pp(GemmParams p, int batch, hipStream_t stream) {
 template <typename T, bool OUT_F32, typename CF, bool TA = false, bool TW = false>
 int launch(GemmParams p, int batch, hipStream_t stream, const char *family) {
     auto kern = gemm_kernel<T, OUT_F32, CF, TA, TW>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static la::DeviceOnce attr_once;
+    if (attr_once.pending()) {
         LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS));
-        attr_done = true;
+        attr_once.mark();
     }
     p.tiles_m = la::cdiv(p.M, CF::TM);
     if (const char *g = getenv("LA_GELU_PK")) p.epilogue |= atoi(g) == 2 ? 8192 : 4096;

@@ -504,14 +504,14 @@ static int gru_forward(int32_t dtype, const float *gi, const void *w_hh, const f
 #undef LA_GRU_LAUNCH16_
     } else {
         const size_t lds_bytes = 16 + (size_t)2 * 3 * 16 * hidden * 4;
-        static bool attr_done = false;
-        if (!attr_done) {
+        static la::DeviceOnce attr_once;
+        if (attr_once.pending()) {
             const int max_lds = 16 + 2 * 3 * 16 * 384 * 4;
             LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gru_kernel<float, 24, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
             LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gru_kernel<float, 24, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
             LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gru_kernel<float, 24, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
             LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gru_kernel<float, 24, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
-            attr_done = true;
+            attr_once.mark();
         }
         la::TimerScope ts("gru_f32", stream);
         if (batch <= 16 || GROUP == 16) {
@@ -753,13 +753,13 @@ extern "C" int la_gru_layer_bwd(const float *gates, const float *out, const floa
                    reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(workspace) + 16),
                    reinterpret_cast<int *>(workspace), timeout_flag, nsplit};
     const size_t lds_bytes = 16 + (size_t)2 * 16 * 3 * hidden * 4;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static la::DeviceOnce attr_once;
+    if (attr_once.pending()) {
         LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gru_bwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    16 + 2 * 16 * 3 * 384 * 4));
         LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gru_bwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    16 + 2 * 16 * 3 * 384 * 4));
-        attr_done = true;
+        attr_once.mark();
     }
     la::TimerScope ts("gru_bwd_f32", stream);
     if (batch <= 16 || GROUP == 16) hipLaunchKernelGGL(gru_bwd_kernel<1>, dim3(nsplit, 2, groups), dim3(128), lds_bytes, stream, p);

@@ -364,10 +364,10 @@ bool plan_viterbi(int batch, int max_frames, int max_labels, VitPlan *pl) {
 template <int NW, bool DPP>
 int launch_viterbi(const VitParams &p, const VitPlan &pl, int batch, hipStream_t stream) {
     auto kern = viterbi_kernel<NW, DPP>;
-    static bool attr_done = false;            // once per instantiation, to the planner's budget (pl.lds_bytes never exceeds it)
-    if (pl.lds_bytes > 48 * 1024 && !attr_done) {
+    static la::DeviceOnce attr_once;            // once per instantiation, to the planner's budget (pl.lds_bytes never exceeds it)
+    if (pl.lds_bytes > 48 * 1024 && attr_once.pending()) {
         LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
-        attr_done = true;
+        attr_once.mark();
     }
     la::TimerScope ts("viterbi", stream);
     hipLaunchKernelGGL(kern, dim3(batch), dim3(NW * 64), pl.lds_bytes, stream, p);
@@ -416,11 +416,11 @@ extern "C" int la_viterbi_batch(const float *em, int64_t em_batch_stride, int64_
         la::TimerScope ts("viterbi", stream);
 #define LA_STRIP_CASE(RV)                                                                                                  \
     case RV: {                                                                                                             \
-        static bool attr_done = false;                                                                                     \
-        if (!attr_done) {                                                                                                  \
+        static la::DeviceOnce attr_once;                                                                                     \
+        if (attr_once.pending()) {                                                                                                  \
             LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(viterbi_strip_kernel<RV>),                           \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));                      \
-            attr_done = true;                                                                                              \
+            attr_once.mark();                                                                                              \
         }                                                                                                                  \
         hipLaunchKernelGGL(viterbi_strip_kernel<RV>, dim3(batch), dim3(1024), pl.lds_bytes, stream, p);                    \
         break;                                                                                                             \

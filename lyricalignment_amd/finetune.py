@@ -262,7 +262,11 @@ class FineTuner:
         accum = int(accum_grad_steps or len(micro_batches))
         m = self.model
         mel = None
-        if fused and len(micro_batches) > 1 and not get_orig_len and not m._encoder_frozen():
+        # the fused form takes one loss set for all micro-batches: it needs them homogeneous (all with or all without the decoder
+        # pair) and free of the extra transcript batch micro_step accepts; anything else takes the loop, which trains each as given
+        has_dec = [mb.get("decoder_input") is not None and mb.get("decoder_output") is not None for mb in micro_batches]
+        homogeneous = (all(has_dec) or not any(has_dec)) and not any(mb.get("transcript_batch") is not None for mb in micro_batches)
+        if fused and homogeneous and len(micro_batches) > 1 and not get_orig_len and not m._encoder_frozen():
             # the log-mel of every micro-batch on its own (zero-padding to ITS longest clip, clamp at ITS maximum - 8: the reference
             # computes one log-mel per batch, module/align_model.py:78-84), then one batch of 30 s windows
             from .whisper_compat import N_FRAMES, pad_or_trim

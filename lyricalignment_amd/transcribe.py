@@ -287,7 +287,8 @@ class _Decoder:
                     saved = 0
                     for key in sorted(scores, key=scores.get, reverse=True):
                         if key[-1] == tok.eot:
-                            finished[i][key] = scores[key]
+                            if len(finished[i]) < max_cand:          # whisper's BeamSearchDecoder.update: first in stays, never evicted
+                                finished[i][key] = scores[key]
                         else:
                             new_seqs.append(list(key)); new_lp.append(scores[key]); src.append(sources[key])
                             saved += 1
@@ -297,9 +298,6 @@ class _Decoder:
                         new_seqs.append(list(new_seqs[-1]) if saved else seqs[i * beam] + [tok.eot])
                         new_lp.append(new_lp[-1] if saved else NEG_INF); src.append(src[-1] if saved else i * beam)
                         saved += 1
-                    if len(finished[i]) > max_cand:
-                        keep = sorted(finished[i], key=finished[i].get, reverse=True)[:max_cand]
-                        finished[i] = {k_: finished[i][k_] for k_ in keep}
                 seqs, sum_lp = new_seqs, new_lp
                 src_dev = torch.tensor(src, dtype=torch.int64, device=dev)
                 for li in range(len(caches)):
@@ -476,12 +474,13 @@ def transcribe(model, audio, *, task: str = "transcribe", language: Optional[str
                 duration = (stamps[-1] - tok.timestamp_begin) * TIME_PRECISION
             current.append(new_segment(time_offset, time_offset + duration, tokens, result))
             seek += segment_size
-        if not condition_on_previous_text or result.temperature > 0.5:
-            prompt_reset_since = len(all_tokens)                      # do not feed a probably wrong window forward as a prompt
         for seg in current:                                           # drop segments that are empty or of zero length
             if seg["start"] == seg["end"] or not [t for t in seg["tokens"] if t < tok.eot]:
                 seg["tokens"], seg["text"] = [], ("" if tok.codec is not None else None)
         segments += [s for s in current if s["tokens"]]
         all_tokens += [t for s in current for t in s["tokens"]]
+        if not condition_on_previous_text or result.temperature > 0.5:
+            prompt_reset_since = len(all_tokens)                      # AFTER this window's tokens went in: do not feed a
+                                                                      # probably wrong window forward as a prompt
     body = all_tokens[len(initial_prompt or []):]
     return {"text": tok.decode([t for t in body if t < tok.eot]), "tokens": body, "segments": segments, "language": language}

@@ -78,8 +78,10 @@ def _decode(file: str):
         import aifc
         with aifc.open(file, "rb") as a:
             nch, width, sr, n = a.getnchannels(), a.getsampwidth(), a.getframerate(), a.getnframes()
-            raw = a.readframes(n)                       # aifc hands PCM back big-endian ('sowt' and the companded types already converted)
-        return _pcm_to_float(raw, width, nch, big_endian=True), int(sr)
+            raw = a.readframes(n)                       # PCM and 'sowt' come back big-endian; u-law / a-law are expanded by
+            companded = a.getcomptype() in (b"ulaw", b"ULAW", b"alaw", b"ALAW")   # audioop to NATIVE-endian 16-bit samples
+        import sys
+        return _pcm_to_float(raw, width, nch, big_endian=(sys.byteorder == "big") if companded else True), int(sr)
     if magic[:4] == b".snd":
         import sunau
         with sunau.open(file, "rb") as a:

@@ -268,3 +268,96 @@ def pad_or_trim(array, length: int = N_FRAMES, *, axis: int = -1):
         pad[axis] = (0, length - array.shape[axis])
         array = np.pad(array, pad)
     return array
+
+
+# ----------------------------------------------------------------------------------------------- Hugging Face <-> upstream names
+# The reference stores upstream openai-whisper key names under `whisper_model.` (train_multitask.py:461-465 saves
+# AlignModel.state_dict(); inference_alignment.py:86-124 loads it back).  Whisper weights that exist on disk without the network
+# are usually the Hugging Face export of the same tensors under other names.  The two tables below are the
+# whole difference; tensors are identical (HF stores the sinusoid table of the encoder as an Embedding weight, upstream as a buffer).
+_HF_LAYER = (("self_attn.q_proj", "attn.query"), ("self_attn.k_proj", "attn.key"), ("self_attn.v_proj", "attn.value"),
+             ("self_attn.out_proj", "attn.out"), ("self_attn_layer_norm", "attn_ln"),
+             ("encoder_attn.q_proj", "cross_attn.query"), ("encoder_attn.k_proj", "cross_attn.key"),
+             ("encoder_attn.v_proj", "cross_attn.value"), ("encoder_attn.out_proj", "cross_attn.out"),
+             ("encoder_attn_layer_norm", "cross_attn_ln"), ("fc1", "mlp.0"), ("fc2", "mlp.2"), ("final_layer_norm", "mlp_ln"))
+_HF_TOP = (("encoder.embed_positions.weight", "encoder.positional_embedding"), ("encoder.layer_norm.", "encoder.ln_post."),
+           ("decoder.embed_tokens.weight", "decoder.token_embedding.weight"),
+           ("decoder.embed_positions.weight", "decoder.positional_embedding"), ("decoder.layer_norm.", "decoder.ln."))
+
+
+def hf_to_upstream_key(key: str) -> Optional[str]:
+    """`model.encoder.layers.3.self_attn.q_proj.weight` (transformers WhisperModel / WhisperForConditionalGeneration) ->
+    `encoder.blocks.3.attn.query.weight` (openai-whisper); None for `proj_out.weight` (tied to the token embedding: upstream
+    has no such tensor)."""
+    if key == "proj_out.weight":
+        return None
+    k = key[len("model."):] if key.startswith("model.") else key
+    for hf, up in _HF_TOP:
+        if k.startswith(hf):
+            return up + k[len(hf):]
+    side, _, rest = k.partition(".layers.")
+    if rest:
+        idx, _, tail = rest.partition(".")
+        for hf, up in _HF_LAYER:
+            if tail.startswith(hf + "."):
+                return f"{side}.blocks.{idx}.{up}{tail[len(hf):]}"
+        raise KeyError(f"unknown Hugging Face whisper layer key {key!r}")
+    if k.split(".")[0] in ("encoder", "decoder") and k.split(".")[1] in ("conv1", "conv2"):
+        return k
+    raise KeyError(f"unknown Hugging Face whisper key {key!r}")
+
+
+def upstream_to_hf_key(key: str) -> str:
+    """Inverse of hf_to_upstream_key (keys of WhisperForConditionalGeneration: `model.` prefix)."""
+    for hf, up in _HF_TOP:
+        if key.startswith(up):
+            return "model." + hf + key[len(up):]
+    side, _, rest = key.partition(".blocks.")
+    if rest:
+        idx, _, tail = rest.partition(".")
+        for hf, up in sorted(_HF_LAYER, key=lambda t: -len(t[1])):       # `cross_attn_ln` before `cross_attn`, `attn_ln` before `attn`
+            if tail.startswith(up + "."):
+                return f"model.{side}.layers.{idx}.{hf}{tail[len(up):]}"
+        raise KeyError(f"unknown whisper block key {key!r}")
+    return "model." + key
+
+
+def hf_state_dict_to_upstream(sd: dict, prefix: str = "") -> dict:
+    """A transformers Whisper state_dict under upstream names (tensors shared, not copied); prefix='whisper_model.' gives the
+    keys AlignModel.state_dict() uses for the backbone."""
+    out = {}
+    for k, v in sd.items():
+        u = hf_to_upstream_key(k)
+        if u is not None:
+            out[prefix + u] = v
+    return out
+
+
+def upstream_key_shapes(dims: ModelDimensions, with_decoder: bool = True) -> dict:
+    """{upstream key: shape} of a whisper checkpoint of these dimensions, written out from SURVEY.md Appendix B / C (NOT read off
+    this package's modules: tests hold both the modules and a transformers model of the same size to this table)."""
+    d, dt = dims.n_audio_state, dims.n_text_state
+    s = {"encoder.conv1.weight": (d, dims.n_mels, 3), "encoder.conv1.bias": (d,), "encoder.conv2.weight": (d, d, 3),
+         "encoder.conv2.bias": (d,), "encoder.positional_embedding": (dims.n_audio_ctx, d),
+         "encoder.ln_post.weight": (d,), "encoder.ln_post.bias": (d,)}
+
+    def block(p: str, w: int, cross: bool):
+        for a in ("attn", "cross_attn") if cross else ("attn",):
+            for n in ("query", "key", "value", "out"):
+                s[f"{p}.{a}.{n}.weight"] = (w, w)
+                if n != "key":                                   # whisper's key projection has no bias
+                    s[f"{p}.{a}.{n}.bias"] = (w,)
+            s[f"{p}.{a}_ln.weight"] = s[f"{p}.{a}_ln.bias"] = (w,)
+        s[f"{p}.mlp.0.weight"], s[f"{p}.mlp.0.bias"] = (4 * w, w), (4 * w,)
+        s[f"{p}.mlp.2.weight"], s[f"{p}.mlp.2.bias"] = (w, 4 * w), (w,)
+        s[f"{p}.mlp_ln.weight"] = s[f"{p}.mlp_ln.bias"] = (w,)
+
+    for i in range(dims.n_audio_layer):
+        block(f"encoder.blocks.{i}", d, False)
+    if with_decoder:
+        s["decoder.token_embedding.weight"] = (dims.n_vocab, dt)
+        s["decoder.positional_embedding"] = (dims.n_text_ctx, dt)
+        s["decoder.ln.weight"] = s["decoder.ln.bias"] = (dt,)
+        for i in range(dims.n_text_layer):
+            block(f"decoder.blocks.{i}", dt, True)
+    return s

@@ -300,6 +300,24 @@ def test_finetune_bench_two_ranks_run_the_gradient_allreduce():
     assert out["allreduce_GBps"] is None or out["allreduce_GBps"] > 0        # bus bandwidth of the one exchange step
 
 
+@pytest.mark.parametrize("extra", [[], ["--mode", "finetune", "--model", "tiny", "--accum", "2"]], ids=["align", "finetune"])
+def test_plain_bench_gpus_2_starts_its_own_two_ranks(extra):
+    """`python3 bench.py --gpus 2 ...` with NO launcher around it (how the driver's scaling run may call it): the parent makes
+    no GPU call, starts torch.distributed.run as a child with the same arguments and exits with its code; the ranks assert
+    world size == --gpus and rank 0 prints the one JSON line with n_gpus = 2."""
+    env = dict(os.environ, LA_BENCH_SAME_DEVICE="1", LA_BENCH_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", *extra]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["value"] > 0
+    assert "starting 2 ranks" in r.stderr and "rank 1/2" in r.stderr and "rank 0/2" in r.stderr
+
+
 @pytest.mark.parametrize("mode_args", [["--mode", "longform", "--songs", "4"], ["--mode", "largev2", "--clips", "64"]])
 def test_other_config_bench_modes_two_ranks(mode_args):
     """BASELINE configs[4] (long form) and configs[3] (large-v2 float16) through bench.py with 2 ranks over gloo on one device:

@@ -580,6 +580,11 @@ def test_audio_decode_wav_aiff_au(tmp_path):
         np.testing.assert_array_equal(x, want, err_msg=name)
     x, sr = _decode(str(tmp_path / "u.au"))
     assert sr == 8000 and x.shape == (2, 1000) and np.abs(x - want).max() < 0.04          # 8-bit companding
+    with aifc.open(str(tmp_path / "u.aifc"), "wb") as f:                                   # AIFF-C u-law: audioop expands it to NATIVE-endian
+        f.setnchannels(2); f.setsampwidth(2); f.setframerate(8000); f.setcomptype(b"ULAW", b"ulaw")   # samples (round-3 advisor finding)
+        f.writeframes(pcm.tobytes())
+    x, sr = _decode(str(tmp_path / "u.aifc"))
+    assert sr == 8000 and x.shape == (2, 1000) and np.abs(x - want).max() < 0.04
     (tmp_path / "x.flac").write_bytes(b"fLaC" + bytes(64))
     with pytest.raises(ValueError, match="not a WAV / AIFF / AU"):
         _decode(str(tmp_path / "x.flac"))
@@ -629,3 +634,147 @@ def test_bench_power_sampler_is_silent_without_hwmon_nodes(tmp_path):
     time.sleep(0.12)
     r = q.stop()
     assert r["socket_w_median"] == 1340.0 and r["sclk_mhz_median"] == 1920.0 and r["cap_w"] == 1400.0 and r["samples"] >= 2
+
+
+def test_bench_gpus_n_without_launcher_becomes_a_launcher_and_touches_no_gpu(monkeypatch):
+    """`python bench.py --gpus 4 --mode finetune` with no WORLD_SIZE in the environment: main() must hand the same arguments
+    to a CHILD torch.distributed.run with 4 ranks on 127.0.0.1, exit with the child's code and never initialise the device
+    itself (a process that has touched the GPU must not start other programs in its place on this pool)."""
+    import subprocess
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--mode", "finetune", "--steps", "3"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "4", "--mode", "finetune", "--steps", "3"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert not torch.cuda.is_initialized()
+    # inside a launcher with the wrong rank count the run refuses instead of reporting a wrong n_gpus
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "WORLD_SIZE=2" in str(e.value.code)
+
+
+def _hf_whisper(dims, meta: bool):
+    from transformers import WhisperConfig, WhisperForConditionalGeneration
+    cfg = WhisperConfig(vocab_size=dims.n_vocab, num_mel_bins=dims.n_mels, d_model=dims.n_audio_state, encoder_layers=dims.n_audio_layer,
+                        decoder_layers=dims.n_text_layer, encoder_attention_heads=dims.n_audio_head, decoder_attention_heads=dims.n_text_head,
+                        encoder_ffn_dim=4 * dims.n_audio_state, decoder_ffn_dim=4 * dims.n_text_state,
+                        max_source_positions=dims.n_audio_ctx, max_target_positions=dims.n_text_ctx)
+    if meta:
+        with torch.device("meta"):
+            return WhisperForConditionalGeneration(cfg)
+    torch.manual_seed(11)
+    return WhisperForConditionalGeneration(cfg)
+
+
+@pytest.mark.parametrize("name", ["tiny", "medium", "large-v2"])
+def test_whisper_key_names_and_shapes_against_transformers(name):
+    """f2 pin (no real checkpoint is reachable): every key and shape of a transformers WhisperForConditionalGeneration of the
+    named size, mapped through SURVEY.md Appendix C's Hugging Face <-> upstream name table (whisper_compat.hf_to_upstream_key),
+    must be exactly (a) the table of upstream keys / shapes written out from Appendix B/C (whisper_compat.upstream_key_shapes) and
+    (b) the state_dict of this package's Whisper container -- so a drift of a key name or shape in whisper_compat.py fails here
+    against an independent implementation of the same architecture.  The inverse map reproduces HF's key set."""
+    from lyricalignment_amd import whisper_compat as wc
+    dims = wc.dims_for(name)
+    dims.n_text_layer = dims.n_audio_layer
+    hf = _hf_whisper(dims, meta=True).state_dict()
+    up = wc.hf_state_dict_to_upstream(hf)
+    table = wc.upstream_key_shapes(dims)
+    assert {k: tuple(v.shape) for k, v in up.items()} == table
+    with torch.device("meta"):
+        ours = wc.Whisper(dims, with_decoder=True)
+    mine = {k: tuple(v.shape) for k, v in ours.state_dict().items() if "mask" not in k and "alignment_heads" not in k}
+    assert mine == table
+    assert {wc.upstream_to_hf_key(k) for k in up} == set(hf) - {"proj_out.weight"}
+    assert wc.hf_to_upstream_key("proj_out.weight") is None
+    assert wc.hf_to_upstream_key("model.encoder.layers.3.self_attn.k_proj.weight") == "encoder.blocks.3.attn.key.weight"
+    assert wc.hf_to_upstream_key("model.decoder.layers.0.encoder_attn_layer_norm.bias") == "decoder.blocks.0.cross_attn_ln.bias"
+    with pytest.raises(KeyError):
+        wc.hf_to_upstream_key("model.encoder.layers.0.self_attn.rotary.weight")
+
+
+def test_checkpoint_made_from_a_transformers_state_dict_loads_into_align_model(tmp_path):
+    """f2: a best_model.pt whose backbone tensors come from an INDEPENDENT implementation (random-init transformers whisper-tiny,
+    renamed by the Appendix C table, `whisper_model.` prefix as AlignModel.state_dict() has it) plus head tensors under the
+    reference's head keys (fixture head_state_dict_keys.json, made from the reference's RNN class) loads through
+    data.load_align_model -- dims inferred from the tensors -- with every tensor bit-equal, and saves back to the same keys."""
+    from lyricalignment_amd import data, whisper_compat as wc
+    dims = wc.dims_for("tiny")
+    dims.n_text_layer = dims.n_audio_layer
+    hf = _hf_whisper(dims, meta=False).state_dict()
+    sd = wc.hf_state_dict_to_upstream(hf, prefix="whisper_model.")
+    H, V = 48, 91
+    head_shapes = {"rnn.weight_ih_l0": (3 * H, dims.n_audio_state), "rnn.weight_ih_l1": (3 * H, 2 * H), "fc.weight": (V, 2 * H), "fc.bias": (V,)}
+    g = torch.Generator().manual_seed(3)
+    for k in load_json("head_state_dict_keys.json"):
+        base = k.replace("_reverse", "")
+        shape = head_shapes.get(base) or ((3 * H, H) if "weight_hh" in k else (3 * H,))
+        sd["align_rnn." + k] = torch.randn(shape, generator=g) * 0.1
+    torch.save(sd, tmp_path / "best_model.pt")
+    m = data.load_align_model(str(tmp_path), "best", device="cpu")
+    got = m.state_dict()
+    assert set(got) - {k for k in got if "mask" in k} == set(sd)
+    for k, v in sd.items():
+        assert got[k].shape == v.shape and torch.equal(got[k].float(), v.float()), k
+    assert (m.whisper_model.dims.n_audio_layer, m.whisper_model.dims.n_audio_state, m.whisper_model.dims.n_vocab) == (4, 384, 51865)
+    assert m.align_rnn.rnn.hidden_size == H and m.align_rnn.fc.out_features == V
+    data.save_align_model(m, str(tmp_path / "again"), "last")
+    assert set(torch.load(tmp_path / "again" / "last_model.pt")) - {k for k in got if "mask" in k} == set(sd)
+
+
+@pytest.mark.parametrize("condition,temps,expect_reset", [(False, (0.0,), True), (True, (0.0,), False), (True, (0.8,), True)])
+def test_transcribe_prompt_reset_drops_the_window_it_is_meant_to_drop(monkeypatch, condition, temps, expect_reset):
+    """whisper/transcribe.py extends all_tokens with the window's tokens FIRST and only then moves prompt_reset_since: with
+    condition_on_previous_text=False, or after a window decoded at temperature > 0.5, the next window's prompt is EMPTY (round-3
+    advisor finding: the reset ran before the extend, so exactly the window that should be dropped was fed forward).  The decoder
+    and the engine are stubs: this is the host-side window loop only."""
+    from lyricalignment_amd import transcribe as tr
+    from lyricalignment_amd.module import align_model as am
+    tok = tr.TokenizerSpec(multilingual=True)
+    ts = tok.timestamp_begin
+
+    class Eng:
+        device = torch.device("cpu")
+
+        def encode(self, mel, out_dtype=None):
+            return torch.zeros(1, 4, 8)
+
+    prompts = []
+
+    class StubDecoder:
+        def __init__(self, eng, tok_, options, n_ctx, rng):
+            self.o = options
+
+        def run(self, xa, n_audio):
+            prompts.append(list(self.o.prompt or []))
+            w = len(prompts)
+            # one closed segment [0 s, 30 s] of two text tokens: a single timestamp at the end -> seek advances one whole window
+            return [tr.DecodingResult(tokens=[ts, 100 + w, 200 + w, ts + 1500], avg_logprob=-0.1, no_speech_prob=0.0,
+                                      temperature=self.o.temperature, compression_ratio=1.0)]
+
+    class Model:
+        dims = type("D", (), {"n_text_ctx": 448, "n_vocab": 51865})()
+
+    monkeypatch.setattr(am, "decoder_engine_of", lambda m: Eng())
+    monkeypatch.setattr(tr, "_Decoder", StubDecoder)
+    mel = torch.zeros(80, 2 * tr.N_FRAMES)                                  # two full windows
+    out = tr.transcribe(Model(), None, mel=mel, tokenizer=tok, temperature=temps, condition_on_previous_text=condition,
+                        compression_ratio_threshold=None, logprob_threshold=None, no_speech_threshold=None)
+    assert len(prompts) == 2 and prompts[0] == []
+    assert prompts[1] == ([] if expect_reset else [ts, 101, 201, ts + 1500])
+    assert [t for t in out["tokens"] if t < tok.eot] == [101, 201, 102, 202]

@@ -88,6 +88,30 @@ def bench_gemm(iters):
         print(f"gemm {name:14s} M={M} N={N} K={K}: median {med*1e3:8.1f} us  min {mn*1e3:8.1f} us  {fl/med/1e9:7.1f} TF/s (min {fl/mn/1e9:7.1f})", flush=True)
 
 
+def bench_gemm_calib(iters):
+    """Calibration against the guide's verified 256x256 8-phase template (cdna_hip_programming.md section 5: ~1320-1340 TF/s at
+    4096^3 and ~1470 at 8192^3 on uniform random [-1, 1) operands): the shipped kernel on exactly those problems -- square,
+    plain bf16 out, no bias -- next to torch.matmul (hipBLASLt) on the same operands, interleaved rounds in one process; and
+    the K = 1024 / 4096 encoder shapes with the same plain epilogue, to separate "the shape" from "the main loop"."""
+    shapes = [(4096, 4096, 4096), (8192, 8192, 8192), (48000, 3072, 1024), (48000, 4096, 1024), (48000, 1024, 1024), (48000, 1024, 4096),
+              (8192, 8192, 1024)]
+    for M, N, K in shapes:
+        a = (torch.rand(M, K, device="cuda") * 2 - 1).to(torch.bfloat16)
+        w = (torch.rand(N, K, device="cuda") * 2 - 1).to(torch.bfloat16)
+        out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        ref = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        wt = w.t()
+        fl = 2.0 * M * N * K
+        ours, blas = [], []
+        for rd in range(3):
+            ours.append(timeit(lambda: ops.gemm(a, w, out), iters)[0])
+            blas.append(timeit(lambda: torch.matmul(a, wt, out=ref), iters)[0])
+        err = float((out.float() - ref.float()).abs().max()) / max(1e-9, float(ref.float().abs().max()))
+        o, b = sorted(ours)[1], sorted(blas)[1]
+        print(f"calib M={M} N={N} K={K}: this kernel {o*1e3:8.1f} us = {fl/o/1e9:7.1f} TF/s | torch.matmul {b*1e3:8.1f} us = {fl/b/1e9:7.1f} TF/s "
+              f"| max rel diff {err:.2e}", flush=True)
+
+
 def bench_attn(iters):
     B, T, H = 32, 1500, 16
     qkv = rnd(B * T, 3 * H * 64)
@@ -181,6 +205,9 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     if a.what == "gemm" and a.variants:
         bench_gemm_variants(a.iters, [int(v) for v in a.variants.split(",")])
+        sys.exit(0)
+    if a.what == "calib":
+        bench_gemm_calib(a.iters)
         sys.exit(0)
     if a.what in ("gemm", "all"): bench_gemm(a.iters)
     if a.what in ("attn", "all"): bench_attn(a.iters)
