@@ -138,14 +138,41 @@ def synthetic_mel(plans, n_frames: int = 3000, seed: int = 2) -> np.ndarray:
     return np.clip(mel, -1.0, 1.0)
 
 
-def build_inputs(device, seed_offset: int = 0):
-    """-> (mel [32,80,3000] f32, labels [32,Lmax] i32, n_labels [32] i32 on the device, Ls host, plans).
+def synthetic_waveform(plans, device, n_frames: int = 3000, seed: int = 2) -> torch.Tensor:
+    """--from-waveform: the same songs as synthetic_mel, as 16 kHz audio [len(plans), n_frames * 160] float32 on the device: every
+    note is a chord of 80 partials at the mel channels' centre frequencies whose amplitudes follow the note's timbre envelope over
+    40 dB (10^(2 env - 2), loudness 0.8 .. 1.0, random phases) plus -60 dB noise, so its log-mel -- computed by the device kernel
+    INSIDE the timed step -- has the note structure the transcript names.  Setup only (torch on the device, outside the timing)."""
+    from lyricalignment_amd.audio_frontend import _slaney_hz_to_mel, _slaney_mel_to_hz
+    rs = np.random.RandomState(seed + 5000)
+    env, _ = timbre_bank()
+    edges_hz = _slaney_mel_to_hz(np.linspace(_slaney_hz_to_mel(0.0), _slaney_hz_to_mel(8000.0), 82))
+    omega = torch.from_numpy(2.0 * np.pi * edges_hz[1:-1] / 16000.0).to(device=device, dtype=torch.float32)[:, None]      # [80, 1]
+    wave = torch.empty((len(plans), n_frames * 160), dtype=torch.float32, device=device)
+    for b, (edges, timbre) in enumerate(plans):
+        for t0, t1, k in zip(edges[:-1], edges[1:], timbre):
+            n = int(t1 - t0) * 160
+            amp = torch.from_numpy(10.0 ** (2.0 * env[k] - 2.0) * rs.uniform(0.8, 1.0) / 8.0).to(device=device, dtype=torch.float32)[:, None]
+            ph = torch.from_numpy(rs.uniform(0.0, 2.0 * np.pi, size=(80, 1))).to(device=device, dtype=torch.float32)
+            t = torch.arange(n, device=device, dtype=torch.float32)[None, :]
+            wave[b, int(t0) * 160: int(t1) * 160] = (amp * torch.sin(omega * t + ph)).sum(dim=0)
+    g = torch.Generator(device="cpu").manual_seed(seed + 6000)
+    wave += (torch.rand(wave.shape, generator=g) * 2e-3 - 1e-3).to(device)
+    return wave
+
+
+def build_inputs(device, seed_offset: int = 0, from_waveform: bool = False):
+    """-> (mel [32,80,3000] f32, labels [32,Lmax] i32, n_labels [32] i32 on the device, Ls host, plans)
+    (from_waveform: mel is the WAVEFORM [32, 480000] f32 of the same songs instead -- the step then starts at the log-mel).
     Every clip is a line of L = 5..26 sung notes (note_plan) and its transcript is the class id of each note's timbre: what
     was sung, as the reference's datasets give it.  (Rounds 1-2 used random ids unrelated to the audio: near-tied lattices
     whose boundaries no two precisions agree on -- profiles/r3_selfcheck_diagnosis.md.)"""
     Ls = np.random.RandomState(3 + seed_offset).randint(5, 27, size=BATCH)
     plans = note_plan(Ls, 3000, 2 + seed_offset)
-    mel = torch.from_numpy(synthetic_mel(plans, 3000, 2 + seed_offset)).to(device)
+    if from_waveform:
+        mel = synthetic_waveform(plans, device, 3000, 2 + seed_offset)
+    else:
+        mel = torch.from_numpy(synthetic_mel(plans, 3000, 2 + seed_offset)).to(device)
     _, ids = timbre_bank()
     labels = np.zeros((BATCH, int(Ls.max())), dtype=np.int32)
     for b, (_, timbre) in enumerate(plans):
@@ -153,7 +180,7 @@ def build_inputs(device, seed_offset: int = 0):
     return mel, torch.from_numpy(labels).to(device), torch.from_numpy(Ls.astype(np.int32)).to(device), Ls, plans
 
 
-def fit_head(model, device, fit_seed_offset: int = 100, ridge: float = 1e-3) -> dict:
+def fit_head(model, device, fit_seed_offset: int = 100, ridge: float = 1e-3, from_waveform: bool = False) -> dict:
     """Give the synthetic AlignModel a head that has "learnt" the synthetic songs, the way a fine-tuned checkpoint has learnt
     its corpus: a linear probe.  A batch of OTHER songs (seed fit_seed_offset; same timbres, other melodies and noise) goes
     through the random-init encoder and BiGRU on the device; the output Linear's rows of the N_TIMBRES syllable classes are the
@@ -174,7 +201,10 @@ def fit_head(model, device, fit_seed_offset: int = 100, ridge: float = 1e-3) -> 
         fc.weight[-1].zero_()
         fc.bias[-1] = HEAD_SILENCE_BIAS
         eng = model.engine()
-        mel, _, _, Ls, plans = build_inputs(device, seed_offset=fit_seed_offset)
+        mel, _, _, Ls, plans = build_inputs(device, seed_offset=fit_seed_offset, from_waveform=from_waveform)
+        if from_waveform:
+            from lyricalignment_amd.audio_frontend import log_mel_spectrogram
+            mel = log_mel_spectrogram(mel, device=device)
         X = eng.head_hidden(eng.encode(mel), BATCH, T_FRAMES, T_FRAMES).double()          # [32*1500, 2H]
         sung = np.empty((BATCH, T_FRAMES), dtype=np.int64)
         for b, (edges, timbre) in enumerate(plans):
@@ -584,6 +614,9 @@ def main():
     ap.add_argument("--accum", type=int, default=8, help="finetune mode: micro-steps per optimizer step (reference default 8)")
     ap.add_argument("--accum-mode", choices=["fused", "loop"], default="fused",
                     help="finetune mode: the accum micro-batches as one fused forward / backward (per-micro-batch losses) or as a loop")
+    ap.add_argument("--from-waveform", action="store_true",
+                    help="align mode: the step starts one stage earlier, at the resident 16 kHz waveform [32, 480000] f32 -- the device "
+                         "log-mel (la_logmel_f32_prepared) runs inside the timed step and feeds the encoder; adds logmel_ms_per_step")
     ap.add_argument("--timer-period", type=int, default=7,
                     help="align mode: the roofline leg brackets every n-th launch of the GEMM family with HIP events (1 = every launch; odd and not a divisor of the 199 launches per pair of batches, so every shape is sampled alike)")
     args = ap.parse_args()
@@ -633,12 +666,17 @@ def main():
     wm = wc.build_model(MODEL, seed=0)
     model = AlignModel(wm, embed_dim=dims.n_audio_state, hidden_dim=HIDDEN, output_dim=VOCAB, device=f"cuda:{local_rank}",
                        compute_dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float16).eval()
-    fit = fit_head(model, device)                                  # a head that has learnt the synthetic songs (linear probe)
+    fit = fit_head(model, device, from_waveform=args.from_waveform)   # a head that has learnt the synthetic songs (linear probe)
     log(f"head fitted: {fit}")
     with torch.no_grad():
         eng = model.engine()
     log("weights packed on the device")
-    mel, labels, n_labels, Ls, plans = build_inputs(device, seed_offset=0)      # same synthetic batch on every rank (weak scaling)
+    mel, labels, n_labels, Ls, plans = build_inputs(device, seed_offset=0, from_waveform=args.from_waveform)   # same batch on every rank
+    wave = None
+    if args.from_waveform:
+        from lyricalignment_amd.audio_frontend import log_mel_spectrogram
+        wave = mel                                                 # [32, 480000] f32, resident
+        mel = log_mel_spectrogram(wave, device=device)             # (what the timed steps recompute; kept for the host self-check)
     pinned = [torch.empty((BATCH, labels.shape[1]), dtype=torch.int32).pin_memory() for _ in range(2)]
     pinned_status = torch.empty((BATCH,), dtype=torch.int32).pin_memory()
 
@@ -647,10 +685,11 @@ def main():
 
     def step():
         with torch.no_grad():
+            mel_in = mel if wave is None else log_mel_spectrogram(wave, device=device)     # 2 launches on the encoder's stream
             if pipe is not None:   # encoder of this batch overlaps the head (GRU/FC/DP) of the previous one
-                pipe.submit(mel, labels, n_labels, n_frames=T_FRAMES, use_ctc=True, host_out=(pinned[0], pinned[1], pinned_status))
+                pipe.submit(mel_in, labels, n_labels, n_frames=T_FRAMES, use_ctc=True, host_out=(pinned[0], pinned[1], pinned_status))
                 return
-            onset, offset, score, status = eng.align_mel(mel, labels, n_labels, n_frames=T_FRAMES, use_ctc=True)
+            onset, offset, score, status = eng.align_mel(mel_in, labels, n_labels, n_frames=T_FRAMES, use_ctc=True)
         pinned[0].copy_(onset, non_blocking=True)
         pinned[1].copy_(offset, non_blocking=True)
         pinned_status.copy_(status, non_blocking=True)
@@ -706,6 +745,14 @@ def main():
     launched = alg + 2.0 * 3000 * (128 - 80) * 3 * d_
     achieved_tf = work.value * (alg / launched) / (total_ms.value * 1e-3) / 1e12 if total_ms.value > 0 else 0.0
 
+    logmel_ms = None
+    if wave is not None:                      # the log-mel alone on the chip (it overlaps the previous batch's encoder inside the step)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+        for a_, b_ in evs:
+            a_.record(); log_mel_spectrogram(wave, device=device); b_.record()
+        torch.cuda.synchronize()
+        logmel_ms = sorted(a_.elapsed_time(b_) for a_, b_ in evs)[5]
+
     selfcheck_failed = False
     if rank == 0:
         audio_sec = world * BATCH * CLIP_SECONDS * args.steps
@@ -740,6 +787,11 @@ def main():
                          "timing": f"HIP events around every {args.timer_period}. launch of the family on its own stream (an event record "
                                    "is a barrier packet: ~6.6 us of stream idle time each; bracketing every launch costs 0.66 ms per step)"},
         }
+        if wave is not None:
+            out["config"]["input"] = "16 kHz waveform [32, 480000] f32 resident in HBM; device log-mel inside the timed step"
+            out["logmel_ms_per_step"] = logmel_ms
+            out["logmel_launches_per_step"] = 2
+            out["logmel_algorithmic_bytes"] = BATCH * (480000 * 4 + 80 * 3000 * 4)
         if world > 1:
             out["cpu_baseline"] = None          # the host baseline is timed on rank 0 of the N = 1 run only
         elif not args.no_cpu_baseline:

@@ -178,6 +178,20 @@ int la_logmel_f32(const float *audio, int32_t batch, int32_t n_samples,
                   const float *mel_filters, const float *window,
                   float *mel, int64_t mel_batch_stride, int64_t mel_row_stride,
                   void *workspace, size_t workspace_bytes, void *stream);
+/*
+ * The same with the constants (windowed DFT matrix in MFMA fragment order, padded
+ * filter bank) built once per (mel_filters, window) pair into a caller-owned
+ * device buffer of la_logmel_constants_bytes(): 2 launches per call instead of 3.
+ * whisper builds its window and loads its filter asset once per process the same
+ * way (whisper.audio.mel_filters is lru-cached).
+ */
+int la_logmel_constants_bytes(size_t *bytes);
+int la_logmel_constants(const float *mel_filters, const float *window,
+                        void *consts, size_t consts_bytes, void *stream);
+int la_logmel_f32_prepared(const float *audio, int32_t batch, int32_t n_samples,
+                           const void *consts,
+                           float *mel, int64_t mel_batch_stride, int64_t mel_row_stride,
+                           void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------- */
 /* building blocks of embed_audio / align_rnn                                 */

@@ -41,6 +41,9 @@ SYMBOLS = {
     "la_emissions_from_logits": (c_int32, [_P, _I64, _I64, _I32, _I32, _I32, _I32, _P, _I32, _P, _I32, _P, _I64, _I64, _P]),
     "la_logmel_workspace_bytes": (c_int32, [_I32, _I32, POINTER(_SZ)]),
     "la_logmel_f32": (c_int32, [_P, _I32, _I32, _P, _P, _P, _I64, _I64, _P, _SZ, _P]),
+    "la_logmel_constants_bytes": (c_int32, [POINTER(_SZ)]),
+    "la_logmel_constants": (c_int32, [_P, _P, _P, _SZ, _P]),
+    "la_logmel_f32_prepared": (c_int32, [_P, _I32, _I32, _P, _P, _I64, _I64, _P, _SZ, _P]),
     "la_gemm": (c_int32, [_I32, _I32, _I32, _I32, _I32, _P, _I64, _I64, _P, _P, _I64, _I64, _P, _P, _I64, _I64, _I32, _P]),
     "la_layernorm": (c_int32, [_P, _I64, _I32, _I32, _P, _P, _P, _I64, _I32, _P]),
     "la_attention": (c_int32, [_I32, _P, _I64, _P, _I64, _I32, _I32, _I32, _P]),

@@ -51,6 +51,21 @@ def _device_tables(device_index: int):
     return filt, win
 
 
+@functools.lru_cache(maxsize=2)
+def _device_constants(device_index: int) -> torch.Tensor:
+    """The log-mel kernel's constants (windowed DFT matrix in fragment order + padded filter bank), built once per device
+    from the two tables above (la_logmel_constants) -- whisper caches its filter asset per process the same way."""
+    dev = torch.device("cuda", device_index)
+    filt, win = _device_tables(device_index)
+    need = ctypes.c_size_t(0)
+    check(lib().la_logmel_constants_bytes(ctypes.byref(need)), "logmel_constants_bytes")
+    consts = torch.empty((need.value,), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        check(lib().la_logmel_constants(ptr(filt), ptr(win), ptr(consts), need.value, stream_ptr()), "logmel_constants")
+        torch.cuda.current_stream().synchronize()      # other streams may use the buffer from now on
+    return consts
+
+
 def log_mel_spectrogram(audio: Union[np.ndarray, torch.Tensor], device="cuda") -> torch.Tensor:
     """[.., N] float waveform(s) -> [.., 80, N // 160] float32 on `device` (device log-mel kernel).
     Same contract as whisper.audio.log_mel_spectrogram incl. the whole-tensor max for the -8 floor."""
@@ -64,11 +79,11 @@ def log_mel_spectrogram(audio: Union[np.ndarray, torch.Tensor], device="cuda") -
     a = audio.reshape(-1, audio.shape[-1]).to(device=dev, dtype=torch.float32).contiguous()
     B, N = a.shape
     frames = N // HOP_LENGTH
-    filt, win = _device_tables(dev.index if dev.index is not None else torch.cuda.current_device())
+    consts = _device_constants(dev.index if dev.index is not None else torch.cuda.current_device())
     mel = torch.empty((B, N_MELS, frames), dtype=torch.float32, device=dev)
     need = ctypes.c_size_t(0)
     check(lib().la_logmel_workspace_bytes(B, N, ctypes.byref(need)), "logmel_workspace_bytes")
     ws = torch.empty((need.value,), dtype=torch.uint8, device=dev)
-    check(lib().la_logmel_f32(ptr(a), B, N, ptr(filt), ptr(win), ptr(mel), mel.stride(0), mel.stride(1), ptr(ws), need.value,
-                              stream_ptr()), "logmel_f32")
+    check(lib().la_logmel_f32_prepared(ptr(a), B, N, ptr(consts), ptr(mel), mel.stride(0), mel.stride(1), ptr(ws), need.value,
+                                       stream_ptr()), "logmel_f32_prepared")
     return mel[0] if squeeze else mel.reshape(*audio.shape[:-1], N_MELS, frames)

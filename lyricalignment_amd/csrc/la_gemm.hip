@@ -312,8 +312,13 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams &p, int z, f32x4 
                 float4 t[8];
                 float2 st[8];
                 if constexpr (RES) {
+                    if (epi & (1 << 16)) {                 // developer probe (LA_EPI_PROBE & 1): no residual loads
 #pragma unroll
-                    for (int it = 0; it < 8; ++it) t[it] = *reinterpret_cast<const float4 *>(rw + (int64_t)(h * 32 + it * 4 + q) * p.ldr);
+                        for (int it = 0; it < 8; ++it) t[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    } else {
+#pragma unroll
+                        for (int it = 0; it < 8; ++it) t[it] = *reinterpret_cast<const float4 *>(rw + (int64_t)(h * 32 + it * 4 + q) * p.ldr);
+                    }
                 }
                 if constexpr (LNM == 2) {
 #pragma unroll
@@ -333,10 +338,12 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams &p, int z, f32x4 
                     const int64_t off = (int64_t)(h * 32 + rl) * p.ldc;
                     TC *c = cw + off;
                     if constexpr (sizeof(TC) == 4) {
-                        *reinterpret_cast<float4 *>(c) = make_float4(v[0], v[1], v[2], v[3]);
+                        if (!(epi & (2 << 16)) || v[0] == 12345.678f)      // developer probe (LA_EPI_PROBE & 2): no f32 store
+                            *reinterpret_cast<float4 *>(c) = make_float4(v[0], v[1], v[2], v[3]);
                         if constexpr (LNM == 1) {
                             const ushort4 pk = la::Pack4<T16>::run(v[0], v[1], v[2], v[3]);
-                            *reinterpret_cast<ushort4 *>(c2w + off) = pk;
+                            if (!(epi & (4 << 16)) || v[1] == 12345.678f)  // developer probe (LA_EPI_PROBE & 4): no 16-bit copy
+                                *reinterpret_cast<ushort4 *>(c2w + off) = pk;
                             if (part) {
                                 const float2 sg = segment_stats<T16>(pk);
                                 if (r == 0) part[h * 32 + rl] = sg;
@@ -660,6 +667,7 @@ int launch_pp_loop(GemmParams p, int batch, hipStream_t stream) {
     // (in-pipeline sweep: 1 -> 46.1 ms/step, 4 -> 45.7, 8 -> 45.9, 16 -> 46.4).
     p.group = getenv("LA_GEMM_GROUP") ? std::min(p.group, p.tiles_n) : std::min(p.tiles_n, std::max(4, p.group / 2));
     if (const char *g = getenv("LA_GELU_PK")) p.epilogue |= atoi(g) == 2 ? 8192 : 4096;
+    if (const char *g = getenv("LA_EPI_PROBE")) p.epilogue |= (atoi(g) & 7) << 16;     // developer probes of the epilogue's memory legs
     la::TimerScope ts("gemm_bf16", stream, 2.0 * p.M * p.N * p.K * batch);
     hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, batch), dim3(PP::THREADS), PP::LDS, stream, p);
     LA_LAUNCH_CHECK();

@@ -48,6 +48,33 @@ def test_log_mel_matches_oracle():
     np.testing.assert_allclose(one.numpy(), mo.log_mel_spectrogram(_wave(480000, 3)).numpy(), rtol=0, atol=2e-4)
 
 
+def test_log_mel_ragged_lengths_and_the_one_call_entry_point():
+    """The fused tile kernel at lengths that are not multiples of the 64-frame tile or of the hop (partial last tile, the reflect
+    padding at both ends inside ONE tile, a 3-clip batch whose whole-tensor maximum sits in another clip's tile), and
+    la_logmel_f32 (constants built inside the call, 3 launches) against la_logmel_f32_prepared (cached constants): same bits."""
+    import ctypes
+    from lyricalignment_amd import _lib
+    from lyricalignment_amd.audio_frontend import _device_tables, log_mel_spectrogram
+    from oracle import model_oracle as mo
+    for n in (201, 333, 10241, 12345, 64 * 160, 65 * 160 + 159):
+        batch = np.stack([_wave(n, 4) * 1e-3, _wave(n, 5), _wave(n, 6) * 0.1])
+        ours = log_mel_spectrogram(batch)
+        ref = mo.log_mel_spectrogram(batch)
+        assert ours.shape == ref.shape == (3, 80, n // 160)
+        np.testing.assert_allclose(ours.cpu().numpy(), ref.numpy(), rtol=0, atol=2e-4, err_msg=str(n))
+        a = torch.from_numpy(batch).cuda()
+        filt, win = _device_tables(torch.cuda.current_device())
+        mel = torch.full((3, 80, n // 160 + 5), 7.0, device="cuda")                    # row pitch > frames: the slack stays untouched
+        need = ctypes.c_size_t(0)
+        _lib.check(_lib.lib().la_logmel_workspace_bytes(3, n, ctypes.byref(need)), "ws")
+        ws = torch.empty((need.value,), dtype=torch.uint8, device="cuda")
+        _lib.check(_lib.lib().la_logmel_f32(_lib.ptr(a), 3, n, _lib.ptr(filt), _lib.ptr(win), _lib.ptr(mel), mel.stride(0), mel.stride(1),
+                                            _lib.ptr(ws), need.value, _lib.stream_ptr()), "logmel_f32")
+        assert torch.equal(mel[:, :, : n // 160], ours) and bool((mel[:, :, n // 160:] == 7.0).all())
+    with pytest.raises(ValueError):
+        log_mel_spectrogram(_wave(200, 1))                                                # torch.stft refuses the reflect pad there too
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 6e-2), (torch.float16, 8e-3)])
 def test_encoder_matches_oracle(dtype, tol):
     from oracle import model_oracle as mo

@@ -112,6 +112,35 @@ def bench_gemm_calib(iters):
               f"| max rel diff {err:.2e}", flush=True)
 
 
+def bench_epi_probe(iters):
+    """What bounds the residual GEMMs' epilogue (out-proj / MLP-down with the f32 residual stream and its 16-bit copy): the same
+    launch with legs of the epilogue's memory traffic left out (LA_EPI_PROBE bits: 1 no residual loads, 2 no f32 store, 4 no 16-bit
+    copy), interleaved rounds in one process.  Results of the probe launches are garbage."""
+    M = 48000
+    for name, N, K in (("out_proj", 1024, 1024), ("mlp_down", 1024, 4096)):
+        a, w = rnd(M, K), rnd(N, K, scale=K ** -0.5)
+        bias = torch.randn(N, device="cuda")
+        x = torch.randn(M, N, device="cuda")
+        h = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        plain = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        res = {}
+        for rd in range(3):
+            for probe in (0, 1, 2, 4, 6, 7, -1):
+                if probe >= 0:
+                    os.environ["LA_EPI_PROBE"] = str(probe)
+                    fn = lambda: ops.gemm(a, w, x, bias=bias, residual=x, out_f32=True, out16=h)
+                else:
+                    os.environ.pop("LA_EPI_PROBE", None)
+                    fn = lambda: ops.gemm(a, w, plain, bias=bias)
+                res.setdefault(probe, []).append(timeit(fn, iters)[0])
+        os.environ.pop("LA_EPI_PROBE", None)
+        names = {0: "full (f32 residual in place + 16-bit copy)", 1: "no residual loads", 2: "no f32 store", 4: "no 16-bit copy",
+                 6: "no stores at all", 7: "no residual loads, no stores", -1: "plain 16-bit out, bias only"}
+        for probe, ts in res.items():
+            t = sorted(ts)[1]
+            print(f"epi-probe {name} N={N} K={K} {names[probe]:45s}: {t*1e3:7.1f} us", flush=True)
+
+
 def bench_attn(iters):
     B, T, H = 32, 1500, 16
     qkv = rnd(B * T, 3 * H * 64)
@@ -205,6 +234,9 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     if a.what == "gemm" and a.variants:
         bench_gemm_variants(a.iters, [int(v) for v in a.variants.split(",")])
+        sys.exit(0)
+    if a.what == "epi":
+        bench_epi_probe(a.iters)
         sys.exit(0)
     if a.what == "calib":
         bench_gemm_calib(a.iters)
