@@ -392,6 +392,22 @@ int la_gemm_fused_ln(int32_t dtype, int32_t M, int32_t N, int32_t K, int32_t bat
                      const void *W, void *C, int64_t ldc, int64_t strideC, const float *bias, const float *residual, int64_t ldr,
                      int64_t strideR, int32_t epilogue, void *C2, int64_t ldc2, int64_t strideC2, const float *ln_stats,
                      const float *ln_csum, float *ln_part, void *stream);
+/*
+ * The residual stream of the 16-bit encoder kept SPLIT (the default of la_encoder_forward wherever the LayerNorm fold applies):
+ *   hi [M][ld] `dtype` = x rounded to the operand type -- at the same time the raw A operand of the next folded GEMM,
+ *   lo [M][ld] uint8   = the remainder x - hi in units of ulp(hi) / 256, offset by 128
+ * (x to 8 bits below the operand type's last place; 3 + 3 bytes per element through HBM per read-modify-write instead of the
+ * 4 + 4 + 2 of an f32 stream with a 16-bit copy).  la_gemm_split: (hi, lo) <- epi(A W^T) + residual, epilogue = LA_EPI_BIAS |
+ * LA_EPI_GELU | LA_EPI_RESIDUAL; with LA_EPI_RESIDUAL the residual is `residual` (f32 rows, as la_gemm takes them: the stem's
+ * positional embedding) or, when that pointer is NULL, the stream itself, updated in place (x += out-proj, x += mlp:
+ * whisper/model.py ResidualAttentionBlock.forward).  ln_part as la_gemm_fused_ln.  LA_EUNSUPPORTED for f32 and for shapes the
+ * 256x256 kernel does not take.  la_layernorm_split: la_layernorm over rows of such a stream (ln_post).
+ */
+int la_gemm_split(int32_t dtype, int32_t M, int32_t N, int32_t K, int32_t batch, const void *A, int64_t lda, int64_t strideA,
+                  const void *W, void *hi, void *lo, int64_t ld, int64_t stride, const float *bias, const float *residual,
+                  int64_t ldr, int64_t strideR, int32_t epilogue, float *ln_part, void *stream);
+int la_layernorm_split(int32_t dtype, const void *hi, const void *lo, int64_t ldx, int32_t M, int32_t d, const float *gamma,
+                       const float *beta, void *y, int64_t ldy, int32_t out_dtype, void *stream);
 /* producer with ln_part != NULL (N % 64 == 0): also stores, per row and 64-column segment of the 16-bit copy, (mean, sum of
  * squared deviations) into ln_part [N/64][M][2]; la_ln_stats_finalize combines them into stats [M][2] = (mean, rstd) --
  * the same numbers la_row_stats16 computes, without reading the copy back. */

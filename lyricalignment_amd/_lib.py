@@ -71,6 +71,8 @@ SYMBOLS = {
     "la_gemm_fused_ln": (c_int32, [_I32, _I32, _I32, _I32, _I32, _P, _I64, _I64, _P, _P, _I64, _I64, _P, _P, _I64, _I64, _I32, _P, _I64, _I64,
                                    _P, _P, _P, _P]),
     "la_ln_stats_finalize": (c_int32, [_P, _I32, _I32, ctypes.c_float, _P, _P]),
+    "la_gemm_split": (c_int32, [_I32, _I32, _I32, _I32, _I32, _P, _I64, _I64, _P, _P, _P, _I64, _I64, _P, _P, _I64, _I64, _I32, _P, _P]),
+    "la_layernorm_split": (c_int32, [_I32, _P, _P, _I64, _I32, _I32, _P, _P, _P, _I64, _I32, _P]),
     "la_row_stats16": (c_int32, [_I32, _P, _I64, _I32, _I32, ctypes.c_float, _P, _P]),
     "la_gemm_ex": (c_int32, [_I32, _I32, _I32, _I32, _I32, _P, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _P, _I32, _P]),
     "la_transpose_pad_batched_f32": (c_int32, [_P, _I64, _I64, _I32, _I32, _P, _I64, _I64, _I32, _I32, _I32, _P]),

@@ -111,6 +111,46 @@ template <> struct Pack4<_Float16> {
     }
 };
 
+// ---- the "split" residual stream of the 16-bit modes -------------------------------------------------------------------
+// The encoder's residual stream x is f32 in the reference (whisper/model.py ResidualAttentionBlock: x = x + attn(..); x = x + mlp(..)).
+// In the 16-bit modes it lives as TWO arrays of the same [M][d] shape:
+//   hi = x rounded to the operand type (bf16 / f16) -- at the same time the RAW A operand of the next LayerNorm-folded GEMM,
+//        which LDS-DMA can only read as stored bytes;
+//   lo = one byte per element: the remainder x - hi in units of ulp(hi) / 256, offset by 128 (|x - hi| <= ulp / 2 -> 0 .. 255).
+// x is reproduced to 8 bits below the operand type's last place (bf16: 16 significant bits, f16: 19), far inside the rounding the
+// 16-bit GEMM operands add every layer, and a read-modify-write of the stream moves 3 + 3 bytes per element instead of the
+// 4 + 4 + 2 of an f32 stream with a 16-bit copy beside it: the residual GEMMs' epilogue is bound by exactly those bytes
+// (tools/kbench.py epi).  frexp / ldexp keep the scaling exact for every exponent; hi = 0 decodes to exactly 0 + (lo - 128) 2^-SH.
+template <typename T16> struct SplitRes;
+template <> struct SplitRes<bf16_t> {
+    static constexpr int SH = 16;                                    // unit = 2^(E - 7 - 8), frexp exponent e = E + 1
+    __device__ static __forceinline__ float hi_f32(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
+    __device__ static __forceinline__ unsigned short round16(float x) { return f32_to_bf16(x); }
+};
+template <> struct SplitRes<_Float16> {
+    static constexpr int SH = 19;                                    // unit = 2^(E - 10 - 8)
+    __device__ static __forceinline__ float hi_f32(unsigned short b) { return (float)__builtin_bit_cast(_Float16, b); }
+    __device__ static __forceinline__ unsigned short round16(float x) { return __builtin_bit_cast(unsigned short, (_Float16)x); }
+};
+// x from (hi bits, lo byte as a float 0 .. 255)
+template <typename T16> __device__ __forceinline__ float split_decode(unsigned short hb, float q) {
+    const float hf = SplitRes<T16>::hi_f32(hb);
+    return hf + __builtin_amdgcn_ldexpf(q - 128.0f, __builtin_amdgcn_frexp_expf(hf) - SplitRes<T16>::SH);
+}
+// x -> hi bits; q = the lo byte before rounding / saturation (v_cvt_pk_u8_f32 rounds and clamps to 0 .. 255)
+template <typename T16> __device__ __forceinline__ unsigned short split_encode(float x, float &q) {
+    const unsigned short hb = SplitRes<T16>::round16(x);
+    const float hf = SplitRes<T16>::hi_f32(hb);
+    q = __builtin_amdgcn_ldexpf(x - hf, SplitRes<T16>::SH - __builtin_amdgcn_frexp_expf(hf)) + 128.0f;
+    return hb;
+}
+__device__ __forceinline__ unsigned pack_u8x4(float a, float b, float c, float d) {
+    unsigned w = __builtin_amdgcn_cvt_pk_u8_f32(a, 0, 0u);
+    w = __builtin_amdgcn_cvt_pk_u8_f32(b, 1, w);
+    w = __builtin_amdgcn_cvt_pk_u8_f32(c, 2, w);
+    return __builtin_amdgcn_cvt_pk_u8_f32(d, 3, w);
+}
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
     static constexpr int kDtype = LA_F32;

@@ -128,6 +128,63 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *x, int64_t 
     }
 }
 
+// The same LayerNorm over rows of the SPLIT residual stream (la_common.h SplitRes: hi 16-bit + lo byte per element), decoded on
+// the way in; everything after the load is layernorm_kernel's arithmetic in the same order.
+template <typename T16, typename TOut, int MAXV>
+__global__ __launch_bounds__(256) void layernorm_split_kernel(const unsigned short *hi, const unsigned char *lo, int64_t ldx, int M, int d,
+                                                              const float *gamma, const float *beta, TOut *y, int64_t ldy) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const unsigned short *hr = hi + (int64_t)row * ldx;
+    const unsigned char *lr = lo + (int64_t)row * ldx;
+    float4 v[MAXV];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < d) {
+            const ushort4 h4 = *reinterpret_cast<const ushort4 *>(hr + c);
+            const unsigned w = *reinterpret_cast<const unsigned *>(lr + c);
+            v[i] = make_float4(la::split_decode<T16>(h4.x, (float)(w & 0xffu)), la::split_decode<T16>(h4.y, (float)((w >> 8) & 0xffu)),
+                               la::split_decode<T16>(h4.z, (float)((w >> 16) & 0xffu)), la::split_decode<T16>(h4.w, (float)(w >> 24)));
+            sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        } else {
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    const float mean = wave_sum(sum) / (float)d;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < d) {
+            const float a = v[i].x - mean, b2 = v[i].y - mean, c2 = v[i].z - mean, d2 = v[i].w - mean;
+            sq += (a * a + b2 * b2) + (c2 * c2 + d2 * d2);
+        }
+    }
+    const float var = wave_sum(sq) / (float)d;
+    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+    TOut *yr = y + (int64_t)row * ldy;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < d) {
+            const float4 g = *reinterpret_cast<const float4 *>(gamma + c);
+            const float4 bt = *reinterpret_cast<const float4 *>(beta + c);
+            float o0 = (v[i].x - mean) * rstd * g.x + bt.x;
+            float o1 = (v[i].y - mean) * rstd * g.y + bt.y;
+            float o2 = (v[i].z - mean) * rstd * g.z + bt.z;
+            float o3 = (v[i].w - mean) * rstd * g.w + bt.w;
+            if constexpr (sizeof(TOut) == 4) {
+                *reinterpret_cast<float4 *>(yr + c) = make_float4(o0, o1, o2, o3);
+            } else {
+                *reinterpret_cast<ushort4 *>(yr + c) = la::Pack4<TOut>::run(o0, o1, o2, o3);
+            }
+        }
+    }
+}
+
 // Row statistics of 16-bit rows (the raw copy of the residual stream that the LayerNorm-folded GEMMs consume):
 // stats[row] = (mean, 1 / sqrt(var + eps)), two-pass on the row held in registers.  One wave per row, d <= 64*8*MAXV.
 template <typename T16, int MAXV>
@@ -275,6 +332,37 @@ extern "C" int la_layernorm(const float *x, int64_t ldx, int32_t M, int32_t d, c
         hipLaunchKernelGGL((layernorm_kernel<bf16_t, 8>), grid, block, 0, stream, x, ldx, M, d, gamma, beta, (bf16_t *)y, ldy);
     LA_LAUNCH_CHECK();
     return LA_OK;
+}
+
+template <typename T16>
+static int layernorm_split_launch(const void *hi, const void *lo, int64_t ldx, int M, int d, const float *gamma, const float *beta, void *y,
+                                  int64_t ldy, int out_dtype, hipStream_t stream) {
+    const dim3 grid(la::cdiv(M, 4)), block(256);
+    const unsigned short *h = reinterpret_cast<const unsigned short *>(hi);
+    const unsigned char *l = reinterpret_cast<const unsigned char *>(lo);
+    if (out_dtype == LA_F32)
+        hipLaunchKernelGGL((layernorm_split_kernel<T16, float, 8>), grid, block, 0, stream, h, l, ldx, M, d, gamma, beta, (float *)y, ldy);
+    else if (out_dtype == LA_F16)
+        hipLaunchKernelGGL((layernorm_split_kernel<T16, la::f16_t, 8>), grid, block, 0, stream, h, l, ldx, M, d, gamma, beta, (la::f16_t *)y, ldy);
+    else
+        hipLaunchKernelGGL((layernorm_split_kernel<T16, bf16_t, 8>), grid, block, 0, stream, h, l, ldx, M, d, gamma, beta, (bf16_t *)y, ldy);
+    LA_LAUNCH_CHECK();
+    return LA_OK;
+}
+
+// LayerNorm of the split residual stream (hi `dtype` [M][ldx] + lo uint8 [M][ldx]); ln_post of the 16-bit encoder.
+extern "C" int la_layernorm_split(int32_t dtype, const void *hi, const void *lo, int64_t ldx, int32_t M, int32_t d, const float *gamma,
+                                  const float *beta, void *y, int64_t ldy, int32_t out_dtype, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (M == 0) return LA_OK;
+    LA_CHECK_ARG(hi && lo && gamma && beta && y, "layernorm_split: null pointer");
+    LA_CHECK_ARG(dtype == LA_BF16 || dtype == LA_F16, "layernorm_split: the stream's hi part is bf16 or f16");
+    LA_CHECK_ARG(d > 0 && d % 4 == 0 && d <= 64 * 4 * 8 && ldx % 4 == 0 && ldy % 4 == 0 && (uintptr_t)hi % 8 == 0 && (uintptr_t)lo % 4 == 0,
+                 "layernorm_split: d=%d unsupported or misaligned rows", d);
+    LA_CHECK_ARG(out_dtype == LA_F32 || out_dtype == LA_BF16 || out_dtype == LA_F16, "layernorm_split: bad dtype");
+    la::TimerScope ts("layernorm", stream);
+    return dtype == LA_F16 ? layernorm_split_launch<la::f16_t>(hi, lo, ldx, M, d, gamma, beta, y, ldy, out_dtype, stream)
+                           : layernorm_split_launch<bf16_t>(hi, lo, ldx, M, d, gamma, beta, y, ldy, out_dtype, stream);
 }
 
 extern "C" int la_row_stats16(int32_t dtype, const void *x, int64_t ldx, int32_t M, int32_t d, float eps, float *stats, void *stream_) {

@@ -26,6 +26,7 @@ struct GemmParams {
     int64_t ldr, strideR;
     int epilogue;
     int tiles_m, tiles_n, group;
+    int mblock = 0;                    // ping-pong kernel: row tiles per M block of the tile order (tile_coord_mb; 0 = column groups over all of M)
     // LayerNorm folded into the GEMMs around it (ping-pong kernel only; la_gemm_fused_ln):
     void *C2 = nullptr;                // producer: second, 16-bit copy of the f32 result rows (the next GEMM's raw A operand)
     int64_t ldc2 = 0, strideC2 = 0;
@@ -408,12 +409,138 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams &p, int z, f32x4 
     }
 }
 
+// Epilogue of the producers of the SPLIT residual stream (LNM = 3; la_gemm_split, la_common.h SplitRes): the wave's 128x64 tile
+//   x = epi(acc) (+ an f32 residual: the stem's positional embedding | + the stream's own rows (hi, lo), updated in place)
+// leaves as hi = x rounded to T16 (p.C2: the next GEMM's raw A operand) and lo = one byte per element (p.C) -- 3 + 3 bytes per
+// element through HBM instead of the 4 + 4 + 2 of wave_epilogue's f32 stream with a 16-bit copy.  Same staging (through the
+// wave's LDS region, row-major quads), same order of operations on the f32 values as wave_epilogue<true, T16, 1>.
+constexpr int LA_EPI_SPLIT_INPLACE = 1 << 20;    // internal: the residual is the split stream itself
+template <typename T16>
+__device__ __forceinline__ void wave_epilogue_split(const GemmParams &p, int z, f32x4 (&acc)[8][4], int wrow0, int wcol0, bool has_bias,
+                                                    float bias_l, unsigned char *reg) {
+    const int lane = threadIdx.x & 63;
+    const int r = lane & 15, q = lane >> 4;
+    unsigned char *LO = reinterpret_cast<unsigned char *>(p.C) + (int64_t)z * p.strideC;
+    T16 *HI = reinterpret_cast<T16 *>(p.C2) + (int64_t)z * p.strideC;
+    const float *R = p.residual ? p.residual + (int64_t)z * p.strideR : nullptr;
+    const bool do_gelu = p.epilogue & LA_EPI_GELU;
+    const bool res_f32 = (p.epilogue & LA_EPI_RESIDUAL) && R;
+    const bool res_split = p.epilogue & LA_EPI_SPLIT_INPLACE;
+    const int epi = p.epilogue;
+    float b4[4];
+    const float cs4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b4[j] = __int_as_float(__builtin_amdgcn_ds_bpermute((r * 4 + j) * 4, __float_as_int(bias_l)));
+    constexpr int PITCH = EPI_PITCH;
+    const bool fast_c = (p.ldc % 4 == 0) && ((uintptr_t)LO % 4 == 0) && ((uintptr_t)HI % 8 == 0) && (p.strideC % 4 == 0);
+    const bool fast_r = res_f32 && (p.ldr % 4 == 0) && ((uintptr_t)R % 16 == 0);
+    if (wrow0 + 128 <= p.M && wcol0 + 64 <= p.N && fast_c && (!res_f32 || fast_r)) {
+        const int64_t base = (int64_t)wrow0 * p.ldc + wcol0 + r * 4;
+        unsigned char *low = LO + base;
+        T16 *hiw = HI + base;
+        const float *rw = res_f32 ? R + (int64_t)wrow0 * p.ldr + wcol0 + r * 4 : nullptr;
+        float2 *part = p.ln_part ? reinterpret_cast<float2 *>(p.ln_part) + (int64_t)(wcol0 >> 6) * p.M + wrow0 : nullptr;
+        auto fast = [&](auto rkc) {
+            constexpr int RK = decltype(rkc)::value;             // 0: no residual, 1: f32 rows, 2: the split stream in place
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                float4 t[8];
+                ushort4 th[8];
+                unsigned tl[8];
+                if constexpr (RK == 1) {
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) t[it] = *reinterpret_cast<const float4 *>(rw + (int64_t)(h * 32 + it * 4 + q) * p.ldr);
+                }
+                if constexpr (RK == 2) {
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) {
+                        const int64_t off = (int64_t)(h * 32 + it * 4 + q) * p.ldc;
+                        th[it] = *reinterpret_cast<const ushort4 *>(hiw + off);
+                        tl[it] = *reinterpret_cast<const unsigned *>(low + off);
+                    }
+                }
+#pragma unroll
+                for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni)
+                        *reinterpret_cast<f32x4 *>(reg + (mm * 16 + r) * PITCH + (ni * 16 + q * 4) * 4) = acc[2 * h + mm][ni];
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int rl = it * 4 + q;
+                    f32x4 v = *reinterpret_cast<const f32x4 *>(reg + rl * PITCH + r * 16);
+                    epi_quad<true, 0>(v, b4, cs4, make_float2(0.f, 0.f), has_bias, do_gelu, epi);
+                    if constexpr (RK == 1) { v[0] += t[it].x; v[1] += t[it].y; v[2] += t[it].z; v[3] += t[it].w; }
+                    if constexpr (RK == 2) {
+                        const unsigned w = tl[it];
+                        v[0] += la::split_decode<T16>(th[it].x, (float)(w & 0xffu));
+                        v[1] += la::split_decode<T16>(th[it].y, (float)((w >> 8) & 0xffu));
+                        v[2] += la::split_decode<T16>(th[it].z, (float)((w >> 16) & 0xffu));
+                        v[3] += la::split_decode<T16>(th[it].w, (float)(w >> 24));
+                    }
+                    float q0, q1, q2, q3;
+                    ushort4 pk;
+                    pk.x = la::split_encode<T16>(v[0], q0); pk.y = la::split_encode<T16>(v[1], q1);
+                    pk.z = la::split_encode<T16>(v[2], q2); pk.w = la::split_encode<T16>(v[3], q3);
+                    const int64_t off = (int64_t)(h * 32 + rl) * p.ldc;
+                    *reinterpret_cast<ushort4 *>(hiw + off) = pk;
+                    *reinterpret_cast<unsigned *>(low + off) = la::pack_u8x4(q0, q1, q2, q3);
+                    if (part) {
+                        const float2 sg = segment_stats<T16>(pk);
+                        if (r == 0) part[h * 32 + rl] = sg;
+                    }
+                }
+            }
+        };
+        if (res_split) fast(std::integral_constant<int, 2>{});
+        else if (res_f32) fast(std::integral_constant<int, 1>{});
+        else fast(std::integral_constant<int, 0>{});
+        return;
+    }
+    // edge wave tiles (the last row of tiles of M = 48000 = 187.5 x 256, any unaligned call): element by element
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                *reinterpret_cast<f32x4 *>(reg + (mm * 16 + r) * PITCH + (ni * 16 + q * 4) * 4) = acc[2 * h + mm][ni];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int rl = it * 4 + q;
+            const int m = wrow0 + h * 32 + rl;
+            const int n = wcol0 + r * 4;
+            f32x4 v = *reinterpret_cast<const f32x4 *>(reg + rl * PITCH + r * 16);
+            epi_quad<true, 0>(v, b4, cs4, make_float2(0.f, 0.f), has_bias, do_gelu, epi);
+            if (m >= p.M || n >= p.N) continue;
+            const int nv = min(4, p.N - n);
+            const int64_t off = (int64_t)m * p.ldc + n;
+            for (int j = 0; j < nv; ++j) {
+                float x = v[j];
+                if (res_f32) x += R[(int64_t)m * p.ldr + n + j];
+                if (res_split) x += la::split_decode<T16>(reinterpret_cast<const unsigned short *>(HI)[off + j], (float)LO[off + j]);
+                float qf;
+                reinterpret_cast<unsigned short *>(HI)[off + j] = la::split_encode<T16>(x, qf);
+                LO[off + j] = (unsigned char)(la::pack_u8x4(qf, 0.f, 0.f, 0.f) & 0xffu);
+                v[j] = x;
+            }
+            if (p.ln_part) {                                     // N % 64 == 0 (host check): the 16 lanes of the row are all here
+                float qd;
+                ushort4 pk;
+                pk.x = la::split_encode<T16>(v[0], qd); pk.y = la::split_encode<T16>(v[1], qd);
+                pk.z = la::split_encode<T16>(v[2], qd); pk.w = la::split_encode<T16>(v[3], qd);
+                const float2 sg = segment_stats<T16>(pk);
+                if (r == 0) reinterpret_cast<float2 *>(p.ln_part)[(int64_t)(wcol0 >> 6) * p.M + m] = sg;
+            }
+        }
+    }
+}
+
 template <bool OUT_F32, bool DUO, typename T16, int LNM = 0>
 __global__ __launch_bounds__(PP::THREADS, 2) void gemm_pp_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int nwg = p.tiles_m * p.tiles_n;
     const int tile = xcd_remap(blockIdx.x, nwg);
-    const TileCoord tc = tile_coord(tile, p.tiles_m, p.tiles_n, p.group);
+    const TileCoord tc = tile_coord_mb(tile, p.tiles_m, p.tiles_n, p.group, p.mblock);
     const int m0 = tc.tm * PP::TM, n0 = tc.tn * PP::TN;
     const int z = blockIdx.y;
     const T16 *A = reinterpret_cast<const T16 *>(p.A) + (int64_t)z * p.strideA;
@@ -436,7 +563,8 @@ __global__ __launch_bounds__(PP::THREADS, 2) void gemm_pp_kernel(GemmParams p) {
     else mainloop_pp<T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
 
     __syncthreads();
-    wave_epilogue<OUT_F32, T16, LNM>(p, z, acc, m0 + wr * 128, n0 + wc * 64, has_bias, bias_l, csum_l, lds + wave * (32 * EPI_PITCH));
+    if constexpr (LNM == 3) wave_epilogue_split<T16>(p, z, acc, m0 + wr * 128, n0 + wc * 64, has_bias, bias_l, lds + wave * (32 * EPI_PITCH));
+    else wave_epilogue<OUT_F32, T16, LNM>(p, z, acc, m0 + wr * 128, n0 + wc * 64, has_bias, bias_l, csum_l, lds + wave * (32 * EPI_PITCH));
 }
 
 // Epilogue of the one-wave-per-SIMD kernel: one wave's 128x128 tile, accumulators in the AGPRs.  Per pass of 32 rows the wave
@@ -666,6 +794,12 @@ int launch_pp_loop(GemmParams p, int batch, hipStream_t stream) {
     // At least 4: with fewer, the K=4096 GEMM (N = 4 tiles) re-reads its 2 MB-per-row-block A panel once per column tile
     // (in-pipeline sweep: 1 -> 46.1 ms/step, 4 -> 45.7, 8 -> 45.9, 16 -> 46.4).
     p.group = getenv("LA_GEMM_GROUP") ? std::min(p.group, p.tiles_n) : std::min(p.tiles_n, std::max(4, p.group / 2));
+    // More than one column group: the groups follow each other inside blocks of 32 row tiles (tile_coord_mb), so a block's A panels
+    // (16 MB at K = 1024) are re-read per group out of the Infinity Cache instead of once per sweep over all of M.  Alone on the chip
+    // with cold A the MLP-up shape runs 438 -> 352 us (tools/kbench.py order); inside the pipeline, where A was just written, 0.6 %
+    // of the step (profiles/r4_ab_mblock.txt).
+    p.mblock = p.tiles_n > p.group ? 32 : 0;
+    if (const char *g = getenv("LA_GEMM_MBLOCK")) p.mblock = atoi(g);                  // developer sweep (read per launch)
     if (const char *g = getenv("LA_GELU_PK")) p.epilogue |= atoi(g) == 2 ? 8192 : 4096;
     if (const char *g = getenv("LA_EPI_PROBE")) p.epilogue |= (atoi(g) & 7) << 16;     // developer probes of the epilogue's memory legs
     la::TimerScope ts("gemm_bf16", stream, 2.0 * p.M * p.N * p.K * batch);
@@ -885,6 +1019,41 @@ extern "C" int la_gemm_fused_ln(int32_t dtype, int32_t M, int32_t N, int32_t K, 
     const LnFuse ln{C2, ldc2, strideC2, ln_stats, ln_csum, ln_part};
     return gemm_run_ldw(dtype, M, N, K, batch, A, lda, strideA, W, 0, 0, C, ldc, strideC, bias, 0, residual, ldr, strideR, epilogue,
                         (hipStream_t)stream_, &ln);
+}
+
+// The residual GEMMs of the 16-bit encoder on the SPLIT stream (SplitRes in la_common.h): (hi, lo) <- epi(A W^T) + residual, where
+// the residual is an f32 array (the stem: conv2 + positional embedding writes the stream) or the stream itself (in place:
+// x += out-proj / x += mlp).  hi [M][ld] `dtype` is at the same time the raw A operand of the next LayerNorm-folded GEMM.
+extern "C" int la_gemm_split(int32_t dtype, int32_t M, int32_t N, int32_t K, int32_t batch, const void *A, int64_t lda, int64_t strideA,
+                             const void *W, void *hi, void *lo, int64_t ld, int64_t stride, const float *bias, const float *residual,
+                             int64_t ldr, int64_t strideR, int32_t epilogue, float *ln_part, void *stream_) {
+    if (M == 0 || N == 0 || batch == 0) return LA_OK;
+    if (dtype != LA_BF16 && dtype != LA_F16) {
+        la::set_error("gemm_split: 16-bit compute dtypes only");
+        return LA_EUNSUPPORTED;
+    }
+    LA_CHECK_ARG(A && W && hi && lo, "gemm_split: null pointer");
+    LA_CHECK_ARG(M > 0 && N > 0 && K > 0 && batch > 0, "gemm_split: bad sizes");
+    if (N <= 128 || (int64_t)la::cdiv(M, 256) * la::cdiv(N, 256) * batch < 192 || K % 64 != 0) {
+        la::set_error("gemm_split: shape M=%d N=%d K=%d batch=%d does not run on the 256x256 kernel the split epilogue is built into", M, N, K, batch);
+        return LA_EUNSUPPORTED;
+    }
+    LA_CHECK_ARG((epilogue & ~(LA_EPI_BIAS | LA_EPI_GELU | LA_EPI_RESIDUAL)) == 0, "gemm_split: epilogue takes BIAS, GELU, RESIDUAL only");
+    LA_CHECK_ARG((lda * 2) % 16 == 0 && (strideA * 2) % 16 == 0 && ((uintptr_t)A % 16 == 0) && ((uintptr_t)W % 16 == 0),
+                 "gemm_split: A/W rows must be 16-byte aligned");
+    LA_CHECK_ARG(!(epilogue & LA_EPI_BIAS) || bias, "gemm_split: bias epilogue without pointer");
+    LA_CHECK_ARG(ld >= N && ((uintptr_t)hi % 2 == 0), "gemm_split: row pitch below N");
+    LA_CHECK_ARG(!ln_part || (N % 64 == 0 && batch == 1 && (uintptr_t)ln_part % 8 == 0), "gemm_split: partial statistics need N %% 64 == 0, batch 1");
+    int epi = epilogue & (LA_EPI_BIAS | LA_EPI_GELU);
+    if (epilogue & LA_EPI_RESIDUAL) epi |= residual ? LA_EPI_RESIDUAL : LA_EPI_SPLIT_INPLACE;
+    GemmParams p{M, N, K, A, lda, strideA, W, (int64_t)K, 0, lo, ld, stride, bias, 0, residual, ldr, strideR, epi,
+                 0, la::cdiv(N, BN), pick_group(K, 2, la::cdiv(N, BN))};
+    p.C2 = hi; p.ldc2 = ld; p.strideC2 = stride; p.ln_part = ln_part;
+    hipStream_t stream = (hipStream_t)stream_;
+    const char *dbg_env = getenv("LA_PP_DBG");
+    const bool duo = K % 128 == 0 && K >= 256 && !(dbg_env && atoi(dbg_env) == 99);
+    if (dtype == LA_F16) return duo ? launch_pp_loop<true, true, la::f16_t, 3>(p, batch, stream) : launch_pp_loop<true, false, la::f16_t, 3>(p, batch, stream);
+    return duo ? launch_pp_loop<true, true, bf16_t, 3>(p, batch, stream) : launch_pp_loop<true, false, bf16_t, 3>(p, batch, stream);
 }
 
 extern "C" int la_ln_stats_finalize(const float *part, int32_t slots, int32_t M, float eps, float *stats, void *stream_) {

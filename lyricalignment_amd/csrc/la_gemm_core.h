@@ -262,8 +262,26 @@ __device__ __forceinline__ TileCoord tile_coord(int tile, int tiles_m, int tiles
     const int rem = tile - g * per_group;
     return TileCoord{rem / gw, base_n + rem % gw};
 }
+// The same with the M dimension cut into blocks of `mblock` row tiles first (0 = the order above): inside a block the column
+// groups follow each other, so a block's A panels (mblock x 256 rows x K) are re-read once per group while they are still in the
+// XCD's L2 / the Infinity Cache instead of once per sweep over ALL of M; with mblock x group = the 32 workgroups an XCD runs at a
+// time, the resident set is an mblock x group supertile walked in step along K.
+__device__ __forceinline__ TileCoord tile_coord_mb(int tile, int tiles_m, int tiles_n, int group, int mblock) {
+    if (mblock <= 0) return tile_coord(tile, tiles_m, tiles_n, group);
+    const int per_block = mblock * tiles_n;
+    int b = tile / per_block;
+    const int nb = tiles_m / mblock;
+    int rows = mblock;
+    if (b >= nb) { b = nb; rows = tiles_m - nb * mblock; }
+    const int off = tile - b * per_block;
+    const int g = off / (rows * group);
+    const int base_n = g * group;
+    const int gw = min(group, tiles_n - base_n);
+    const int rem = off - g * rows * group;
+    return TileCoord{b * mblock + rem / gw, base_n + rem % gw};
+}
 inline int pick_group(int K, int elem_bytes, int tiles_n) {
-    static const char *force = getenv("LA_GEMM_GROUP");   // developer sweep
+    const char *force = getenv("LA_GEMM_GROUP");   // developer sweep (read per launch: tools/kbench.py flips it between rounds)
     if (force) { const int g = atoi(force); return g < 1 ? 1 : (g > tiles_n ? tiles_n : g); }
     const int64_t tile_bytes = (int64_t)BN * K * elem_bytes;
     int g = (int)((2 << 20) / tile_bytes);

@@ -100,7 +100,17 @@ extern "C" int la_encoder_forward(const la_encoder_weights *w, const float *mel,
                    LA_EPI_BIAS | LA_EPI_GELU, stream));
     const bool fused = encoder_fused_ln(w, batch);
     const int epi2 = LA_EPI_BIAS | LA_EPI_GELU | LA_EPI_RESIDUAL | out_f32;
-    if (fused) {
+    // With the LayerNorm fold the residual stream is kept SPLIT (la_gemm_split: hi = b.h, the next GEMM's raw operand, + one lo byte
+    // per element in the first quarter of b.x) instead of f32 with a 16-bit copy beside it: the residual GEMMs' epilogues are bound
+    // by the stream's bytes.  LA_RESID_SPLIT=0 (read per call) keeps the f32 stream: the A/B partner.
+    const char *split_env = getenv("LA_RESID_SPLIT");
+    const bool split = fused && !(split_env && split_env[0] == '0');
+    unsigned char *lo = reinterpret_cast<unsigned char *>(b.x);
+    if (split) {
+        LA_TRY(la_gemm_split(dt, N_CTX, d, 3 * d, batch, b.y1, 2 * d, (int64_t)(N_FRAMES + 2) * d, w->conv2_w, b.h, lo, d, (int64_t)N_CTX * d,
+                             w->conv2_b, w->pos, d, 0, LA_EPI_BIAS | LA_EPI_GELU | LA_EPI_RESIDUAL, nullptr, stream));
+        LA_TRY(la_row_stats16(dt, b.h, d, M, d, 1e-5f, b.stats, stream));
+    } else if (fused) {
         LA_TRY(la_gemm_fused_ln(dt, N_CTX, d, 3 * d, batch, b.y1, 2 * d, (int64_t)(N_FRAMES + 2) * d, w->conv2_w, b.x, d, (int64_t)N_CTX * d,
                                 w->conv2_b, w->pos, d, 0, epi2, b.h, d, (int64_t)N_CTX * d, nullptr, nullptr, nullptr, stream));
         LA_TRY(la_row_stats16(dt, b.h, d, M, d, 1e-5f, b.stats, stream));
@@ -116,11 +126,13 @@ extern "C" int la_encoder_forward(const la_encoder_weights *w, const float *mel,
             LA_TRY(la_gemm_fused_ln(dt, M, 3 * d, d, 1, b.h, d, 0, k.wqkv_ln, b.qkv, 3 * d, 0, k.bqkv_ln, nullptr, 0, 0, LA_EPI_BIAS, nullptr, 0, 0,
                                     b.stats, k.cqkv, nullptr, stream));
             LA_TRY(la_attention(dt_attn, b.qkv, 3 * d, b.att, d, batch, N_CTX, w->n_head, stream));
-            LA_TRY(la_gemm_fused_ln(dt, M, d, d, 1, b.att, d, 0, k.wo, b.x, d, 0, k.bo, b.x, d, 0, epi_res, b.h, d, 0, nullptr, nullptr, nullptr, stream));
+            if (split) LA_TRY(la_gemm_split(dt, M, d, d, 1, b.att, d, 0, k.wo, b.h, lo, d, 0, k.bo, nullptr, 0, 0, LA_EPI_BIAS | LA_EPI_RESIDUAL, nullptr, stream));
+            else LA_TRY(la_gemm_fused_ln(dt, M, d, d, 1, b.att, d, 0, k.wo, b.x, d, 0, k.bo, b.x, d, 0, epi_res, b.h, d, 0, nullptr, nullptr, nullptr, stream));
             LA_TRY(la_row_stats16(dt, b.h, d, M, d, 1e-5f, b.stats, stream));
             LA_TRY(la_gemm_fused_ln(dt, M, 4 * d, d, 1, b.h, d, 0, k.w1_ln, b.u, 4 * d, 0, k.b1_ln, nullptr, 0, 0, LA_EPI_BIAS | LA_EPI_GELU, nullptr, 0, 0,
                                     b.stats, k.c1, nullptr, stream));
-            LA_TRY(la_gemm_fused_ln(dt, M, d, 4 * d, 1, b.u, 4 * d, 0, k.w2, b.x, d, 0, k.b2, b.x, d, 0, epi_res, b.h, d, 0, nullptr, nullptr, nullptr, stream));
+            if (split) LA_TRY(la_gemm_split(dt, M, d, 4 * d, 1, b.u, 4 * d, 0, k.w2, b.h, lo, d, 0, k.b2, nullptr, 0, 0, LA_EPI_BIAS | LA_EPI_RESIDUAL, nullptr, stream));
+            else LA_TRY(la_gemm_fused_ln(dt, M, d, 4 * d, 1, b.u, 4 * d, 0, k.w2, b.x, d, 0, k.b2, b.x, d, 0, epi_res, b.h, d, 0, nullptr, nullptr, nullptr, stream));
             LA_TRY(la_row_stats16(dt, b.h, d, M, d, 1e-5f, b.stats, stream));
         } else {
             LA_TRY(la_layernorm(b.x, d, M, d, k.ln1_g, k.ln1_b, b.h, d, dt, stream));
@@ -132,6 +144,7 @@ extern "C" int la_encoder_forward(const la_encoder_weights *w, const float *mel,
             LA_TRY(la_gemm(dt, M, d, 4 * d, 1, b.u, 4 * d, 0, k.w2, b.x, d, 0, k.b2, b.x, d, 0, epi_res, stream));
         }
     }
+    if (split) return la_layernorm_split(dt, b.h, lo, d, M, d, w->lnp_g, w->lnp_b, out, ld_out, out_dtype, stream);
     return la_layernorm(b.x, d, M, d, w->lnp_g, w->lnp_b, out, ld_out, out_dtype, stream);
 }
 

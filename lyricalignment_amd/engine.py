@@ -36,6 +36,9 @@ LN_FUSION = os.environ.get("LA_LN_FUSION", "1") != "0"   # developer switch: 0 =
 # "epilogue" = the producer GEMM takes them per 64-column segment while the rows pass through its registers + a finalize
 # kernel.  Measured in the pipeline: the epilogue form costs the residual GEMMs more (+0.7 ms) than the pass it removes.
 LN_STATS_IN_EPILOGUE = os.environ.get("LA_LN_STATS", "pass") == "epilogue"
+# With the LayerNorm fold the residual stream is kept SPLIT (ops.gemm_split: hi 16-bit = the next GEMM's raw operand, + one lo byte
+# per element) instead of f32 with a 16-bit copy beside it; 0 = the f32 stream (the A/B partner; la_model.cpp reads the same switch).
+RESID_SPLIT = os.environ.get("LA_RESID_SPLIT", "1") != "0"
 # The kernel sequences of encode() and of the head + DP exist twice: as ONE C call each (csrc/la_model.cpp: la_encoder_forward,
 # la_align_head_forward -- the default) and spelled out below in Python over the op-level calls (LA_ENGINE_PY=1; also what the
 # training path and the developer switches above use).  Same kernels, same order, same results.
@@ -306,8 +309,14 @@ class AlignEngine:
         # below 65504, as it must for whisper's own fp16 inference); otherwise the separate LayerNorm pass.
         fused = (LN_FUSION and dt in (torch.bfloat16, torch.float16) and e.blocks and e.blocks[0].wqkv_ln is not None and d > 128
                  and -(-M // 256) * -(-d // 256) >= 192 and -(-N_CTX // 256) * -(-d // 256) * B >= 192)
-        ops.gemm(y1, e.conv2_w, x, bias=e.conv2_b, gelu=True, residual=e.pos, out_f32=True, M=N_CTX, lda=2 * d, batch=B,
-                 stride_a=(N_FRAMES + 2) * d, stride_c=N_CTX * d, ldc=d, ldr=d, stride_r=0, out16=h if fused else None)
+        split = fused and RESID_SPLIT
+        if split:
+            lo = x.view(torch.uint8).view(-1)[: M * d].view(M, d)         # the stream's lo bytes live in the first quarter of x
+            ops.gemm_split(y1, e.conv2_w, h, lo, bias=e.conv2_b, gelu=True, residual=e.pos, M=N_CTX, lda=2 * d, batch=B,
+                           stride_a=(N_FRAMES + 2) * d, stride_c=N_CTX * d, ld=d, ldr=d, stride_r=0)
+        else:
+            ops.gemm(y1, e.conv2_w, x, bias=e.conv2_b, gelu=True, residual=e.pos, out_f32=True, M=N_CTX, lda=2 * d, batch=B,
+                     stride_a=(N_FRAMES + 2) * d, stride_c=N_CTX * d, ldc=d, ldr=d, stride_r=0, out16=h if fused else None)
         if fused:
             stats = self._get("ln_stats", (M, 2), torch.float32)
             part = self._get("ln_part", (d // 64, M, 2), torch.float32) if (LN_STATS_IN_EPILOGUE and d % 64 == 0) else None
@@ -322,10 +331,16 @@ class AlignEngine:
             for blk in e.blocks:
                 ops.gemm(h, blk.wqkv_ln, qkv, bias=blk.bqkv_ln, ln_stats=stats, ln_csum=blk.cqkv)
                 ops.attention(qkv, B, N_CTX, e.n_head, out=att, q_log2=e.q_log2)
-                ops.gemm(att, blk.wo, x, bias=blk.bo, residual=x, out_f32=True, out16=h, ln_part=part)   # x += out-proj; h = bf16(x)
+                if split:
+                    ops.gemm_split(att, blk.wo, h, lo, bias=blk.bo, in_place=True, ln_part=part)         # (h, lo) += out-proj
+                else:
+                    ops.gemm(att, blk.wo, x, bias=blk.bo, residual=x, out_f32=True, out16=h, ln_part=part)   # x += out-proj; h = bf16(x)
                 row_stats()
                 ops.gemm(h, blk.w1_ln, u, bias=blk.b1_ln, gelu=True, ln_stats=stats, ln_csum=blk.c1)
-                ops.gemm(u, blk.w2, x, bias=blk.b2, residual=x, out_f32=True, out16=h, ln_part=part)     # x += mlp; h = bf16(x)
+                if split:
+                    ops.gemm_split(u, blk.w2, h, lo, bias=blk.b2, in_place=True, ln_part=part)           # (h, lo) += mlp
+                else:
+                    ops.gemm(u, blk.w2, x, bias=blk.b2, residual=x, out_f32=True, out16=h, ln_part=part)     # x += mlp; h = bf16(x)
                 row_stats()
         else:
             for blk in e.blocks:
@@ -338,7 +353,10 @@ class AlignEngine:
                 ops.gemm(u, blk.w2, x, bias=blk.b2, residual=x, out_f32=True)            # x += mlp (in place)
         out_dtype = out_dtype or dt
         y = out if out is not None else self._get(f"enc_out{slot}", (M, d), out_dtype)
-        ops.layernorm(x, e.lnp_g, e.lnp_b, out_dtype, out=y)
+        if split:
+            ops.layernorm_split(h, lo, e.lnp_g, e.lnp_b, out_dtype, out=y)
+        else:
+            ops.layernorm(x, e.lnp_g, e.lnp_b, out_dtype, out=y)
         return y
 
     # ---- text decoder: Whisper.logits(tokens, audio_features) --------------------------------

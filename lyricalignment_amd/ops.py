@@ -195,6 +195,81 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out_dtyp
     return out
 
 
+def gemm_split(a: torch.Tensor, w: torch.Tensor, hi: torch.Tensor, lo: torch.Tensor, *, bias: Optional[torch.Tensor] = None,
+               residual: Optional[torch.Tensor] = None, in_place: bool = False, gelu: bool = False, M: Optional[int] = None,
+               lda: Optional[int] = None, batch: int = 1, stride_a: int = 0, stride_c: int = 0, ld: Optional[int] = None,
+               ldr: Optional[int] = None, stride_r: int = 0, ln_part: Optional[torch.Tensor] = None) -> None:
+    """(hi, lo) <- epi(a w^T) + residual on the SPLIT residual stream of the 16-bit encoder (la_gemm_split): hi = x rounded to the
+    operand dtype [M, N] (the next LayerNorm-folded GEMM's raw operand), lo uint8 [M, N] = the remainder in units of ulp(hi) / 256.
+    residual: f32 rows (the stem's positional embedding), or in_place=True: the stream's own rows (x += ...)."""
+    _dev(a, "a"); _dev(w, "w"); _dev(hi, "hi", w.dtype); _dev(lo, "lo", torch.uint8)
+    if a.dtype != w.dtype or w.dtype not in (torch.bfloat16, torch.float16):
+        raise ValueError("gemm_split: 16-bit operands of one dtype")
+    if w.dim() != 2 or not w.is_contiguous():
+        raise ValueError("gemm_split: w must be contiguous [N,K]")
+    if residual is not None and in_place:
+        raise ValueError("gemm_split: residual is either an f32 array or the stream itself")
+    N, K = w.shape
+    if M is None:
+        if a.dim() != 2 or a.stride(1) != 1 or a.shape[1] != K:
+            raise ValueError("gemm_split: a must be [M,K] with unit inner stride (or pass M/lda)")
+        M, lda = a.shape[0], a.stride(0)
+    if _capacity(a) < (batch - 1) * stride_a + (M - 1) * lda + K:
+        raise ValueError("gemm_split: a buffer smaller than the addressed view")
+    ld = hi.stride(-2) if ld is None else ld
+    need = (batch - 1) * stride_c + (M - 1) * ld + N
+    if _capacity(hi) < need or _capacity(lo) < need:
+        raise ValueError("gemm_split: hi / lo smaller than the addressed view")
+    epi = 0
+    if bias is not None:
+        _dev(bias, "bias", torch.float32)
+        if bias.numel() < N:
+            raise ValueError("gemm_split: bias shorter than N")
+        epi |= EPI_BIAS
+    if residual is not None:
+        _dev(residual, "residual", torch.float32)
+        ldr = residual.stride(-2) if ldr is None else ldr
+        if _capacity(residual) < (batch - 1) * stride_r + (M - 1) * ldr + N:
+            raise ValueError("gemm_split: residual buffer smaller than the addressed view")
+    if residual is not None or in_place:
+        epi |= EPI_RESIDUAL
+    if gelu:
+        epi |= EPI_GELU
+    if ln_part is not None:
+        _dev(ln_part, "ln_part", torch.float32)
+        if N % 64 or ln_part.numel() < (N // 64) * M * 2 or not ln_part.is_contiguous():
+            raise ValueError("gemm_split: ln_part [N/64, M, 2], N % 64 == 0")
+    check(lib().la_gemm_split(dtype_code(w.dtype), M, N, K, batch, ptr(a), lda, stride_a, ptr(w), ptr(hi), ptr(lo), ld, stride_c, ptr(bias),
+                              ptr(residual), ldr or 0, stride_r, epi, ptr(ln_part), stream_ptr()), "gemm_split")
+
+
+def split_decode(hi: torch.Tensor, lo: torch.Tensor) -> torch.Tensor:
+    """The f32 values a split residual stream (hi 16-bit, lo uint8) stands for -- plain torch, for tests and inspection; the
+    kernels decode in registers (la_common.h SplitRes): x = hi + (lo - 128) * 2^(e - SH), e the frexp exponent of hi."""
+    hf = hi.float()
+    _, e = torch.frexp(hf)
+    sh = 16 if hi.dtype == torch.bfloat16 else 19
+    return hf + torch.ldexp(lo.float() - 128.0, e.to(torch.int32) - sh)
+
+
+def layernorm_split(hi: torch.Tensor, lo: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out_dtype: torch.dtype,
+                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """LayerNorm over rows of a split residual stream (la_layernorm_split)."""
+    _dev(hi, "hi"); _dev(lo, "lo", torch.uint8); _dev(gamma, "gamma", torch.float32); _dev(beta, "beta", torch.float32)
+    if hi.dtype not in (torch.bfloat16, torch.float16) or hi.dim() != 2 or hi.stride(1) != 1 or lo.shape != hi.shape or lo.stride() != hi.stride():
+        raise ValueError("layernorm_split: hi [M,d] 16-bit and lo [M,d] uint8 of one layout expected")
+    M, d = hi.shape
+    if gamma.numel() != d or beta.numel() != d:
+        raise ValueError("layernorm_split: gamma/beta size mismatch")
+    if out is None:
+        out = torch.empty((M, d), dtype=out_dtype, device=hi.device)
+    if out.dtype != out_dtype or out.shape != (M, d) or out.stride(1) != 1:
+        raise ValueError("layernorm_split: bad out buffer")
+    check(lib().la_layernorm_split(dtype_code(hi.dtype), ptr(hi), ptr(lo), hi.stride(0), M, d, ptr(gamma), ptr(beta), ptr(out), out.stride(0),
+                                   dtype_code(out_dtype), stream_ptr()), "layernorm_split")
+    return out
+
+
 def mel_to_rows(mel: torch.Tensor, c_pad: int, dtype: torch.dtype) -> torch.Tensor:
     """mel [B,n_mels,frames] f32 -> [B, frames+2, c_pad] channels-last, zero border rows / pad channels."""
     _dev(mel, "mel", torch.float32)

@@ -487,3 +487,83 @@ def test_kernel_timer_sampling_and_work_accounting():
     assert work.value == 3 * 2.0 * 512 * 384 * 256
     L.la_timer_reset()
     L.la_timer_sample(1)
+
+
+# ------------------------------------------------------------------------------------------------ split residual stream
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_gemm_split_stream_matches_the_f32_stream(dtype):
+    """la_gemm_split (the residual GEMMs of the 16-bit encoder on the SPLIT stream: hi 16-bit + lo byte) against the f32-stream
+    form of the same kernel (la_gemm_fused_ln with a 16-bit copy), same operands: hi is bit-for-bit the 16-bit copy, the decoded
+    stream is within half a lo unit (ulp(hi) / 512) of the f32 row, for the stem form (GELU + f32 residual, batched), the in-place
+    form (x += ...), and partial last tiles (M = 6000 = 23.4 row tiles: the element-wise edge path)."""
+    from lyricalignment_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(3)
+    M, N, K = 6000, 2048, 256
+    sh = 16 if dtype == torch.bfloat16 else 19
+
+    def unit(hi):
+        _, e = torch.frexp(hi.float())
+        return torch.ldexp(torch.ones_like(hi, dtype=torch.float32), e.to(torch.int32) - sh)
+
+    a = (torch.randn(M, K, device="cuda", generator=g)).to(dtype)
+    w = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(dtype)
+    bias = torch.randn(N, device="cuda", generator=g)
+    res = torch.randn(M, N, device="cuda", generator=g) * 3.0
+    res[5, 7] = 0.0
+    # stem form: f32 residual in, split stream out
+    x = torch.empty(M, N, device="cuda")
+    h = torch.empty(M, N, device="cuda", dtype=dtype)
+    ops.gemm(a, w, x, bias=bias, residual=res, gelu=True, out_f32=True, out16=h)
+    hi = torch.empty(M, N, device="cuda", dtype=dtype)
+    lo = torch.zeros(M, N, device="cuda", dtype=torch.uint8)
+    ops.gemm_split(a, w, hi, lo, bias=bias, residual=res, gelu=True)
+    assert torch.equal(hi.view(torch.int16), h.view(torch.int16))
+    dec = ops.split_decode(hi, lo)
+    assert bool(((dec - x).abs() <= 0.5001 * unit(hi)).all())
+    assert float((dec - x).abs().max()) < float((h.float() - x).abs().max()) / 100          # 8 more bits than the 16-bit copy alone
+    # in-place form: the stream is its own residual
+    a2 = (torch.randn(M, K, device="cuda", generator=g)).to(dtype)
+    w2 = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(dtype)
+    x0 = ops.split_decode(hi, lo)
+    x1 = x0.clone()
+    h1 = torch.empty_like(h)
+    ops.gemm(a2, w2, x1, bias=bias, residual=x1, out_f32=True, out16=h1)
+    ops.gemm_split(a2, w2, hi, lo, bias=bias, in_place=True)
+    assert torch.equal(hi.view(torch.int16), h1.view(torch.int16))
+    assert bool(((ops.split_decode(hi, lo) - x1).abs() <= 0.5001 * unit(hi)).all())
+    # ln_part (statistics of the hi rows from inside the epilogue) and LayerNorm over the decoded rows
+    part = torch.empty(N // 64, M, 2, device="cuda")
+    hi2, lo2 = hi.clone(), lo.clone()
+    ops.gemm_split(a, w, hi2, lo2, bias=bias, in_place=True, ln_part=part)
+    st = ops.ln_stats_finalize(part)
+    ref = ops.row_stats16(hi2)
+    assert torch.allclose(st, ref, rtol=2e-5, atol=2e-6)
+    gam, bet = torch.randn(N, device="cuda", generator=g), torch.randn(N, device="cuda", generator=g)
+    y = ops.layernorm_split(hi2, lo2, gam, bet, torch.float32)
+    y_ref = ops.layernorm(ops.split_decode(hi2, lo2), gam, bet, torch.float32)
+    assert torch.equal(y, y_ref)
+    with pytest.raises(NotImplementedError):
+        ops.gemm_split(a[:256], w[:128], hi[:256, :128].contiguous(), lo[:256, :128].contiguous())      # not a 256x256-kernel shape
+
+
+def test_gemm_split_batched_stem_layout_and_zero_rows():
+    """The stem's call shape: batch of clips, overlapping-row A view, residual rows shared by every clip (stride_r = 0), hi / lo
+    with a batch stride; an all-zero product row decodes to exactly the residual it was given."""
+    from lyricalignment_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(4)
+    B, T, d = 12, 1500, 1024
+    y1 = torch.zeros(B, 2 * T + 2, d, device="cuda", dtype=torch.bfloat16)
+    y1[1:] = (torch.randn(B - 1, 2 * T + 2, d, device="cuda", generator=g) * 0.5).to(torch.bfloat16)     # clip 0: zero activations
+    w = (torch.randn(d, 3 * d, device="cuda", generator=g) * (3 * d) ** -0.5).to(torch.bfloat16)
+    pos = torch.randn(T, d, device="cuda", generator=g)
+    x = torch.empty(B * T, d, device="cuda")
+    h = torch.empty(B * T, d, device="cuda", dtype=torch.bfloat16)
+    kw = dict(M=T, lda=2 * d, batch=B, stride_a=(2 * T + 2) * d, stride_c=T * d, ldr=d, stride_r=0)
+    ops.gemm(y1, w, x, residual=pos, out_f32=True, ldc=d, out16=h, **kw)
+    hi = torch.empty_like(h)
+    lo = torch.empty(B * T, d, device="cuda", dtype=torch.uint8)
+    ops.gemm_split(y1, w, hi, lo, residual=pos, ld=d, **kw)
+    assert torch.equal(hi.view(torch.int16), h.view(torch.int16))
+    dec = ops.split_decode(hi, lo)
+    assert float((dec - x).abs().max()) <= float(x.abs().max()) * 2.0 ** -16
+    assert float((dec[:T] - pos).abs().max()) <= float(pos.abs().max()) * 2.0 ** -16

@@ -141,6 +141,32 @@ def bench_epi_probe(iters):
             print(f"epi-probe {name} N={N} K={K} {names[probe]:45s}: {t*1e3:7.1f} us", flush=True)
 
 
+def bench_tile_order(iters):
+    """Tile order sweep of the 256x256 kernel (LA_GEMM_GROUP = column tiles per group, LA_GEMM_MBLOCK = row tiles per M block, 0 =
+    groups sweep all of M), plain 16-bit epilogue, uniform random operands, interleaved rounds; torch.matmul beside it."""
+    shapes = [(48000, 4096, 1024), (48000, 3072, 1024), (48000, 1024, 4096), (8192, 8192, 8192), (4096, 4096, 4096)]
+    orders = [(None, None), (4, 8), (4, 4), (8, 4), (2, 16), (4, 16), (8, 8), (16, 2), (4, 32)]
+    for M, N, K in shapes:
+        a = (torch.rand(M, K, device="cuda") * 2 - 1).to(torch.bfloat16)
+        w = (torch.rand(N, K, device="cuda") * 2 - 1).to(torch.bfloat16)
+        out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        ref = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        wt = w.t()
+        fl = 2.0 * M * N * K
+        res = {}
+        for rd in range(3):
+            for g, mb in orders:
+                for k_, v_ in (("LA_GEMM_GROUP", g), ("LA_GEMM_MBLOCK", mb)):
+                    if v_ is None: os.environ.pop(k_, None)
+                    else: os.environ[k_] = str(v_)
+                res.setdefault((g, mb), []).append(timeit(lambda: ops.gemm(a, w, out), iters)[0])
+            os.environ.pop("LA_GEMM_GROUP", None); os.environ.pop("LA_GEMM_MBLOCK", None)
+            res.setdefault("blas", []).append(timeit(lambda: torch.matmul(a, wt, out=ref), iters)[0])
+        for key, ts in res.items():
+            t = sorted(ts)[1]
+            print(f"order M={M} N={N} K={K} (group, mblock)={key}: {t*1e3:8.1f} us = {fl/t/1e9:7.1f} TF/s", flush=True)
+
+
 def bench_attn(iters):
     B, T, H = 32, 1500, 16
     qkv = rnd(B * T, 3 * H * 64)
@@ -234,6 +260,9 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     if a.what == "gemm" and a.variants:
         bench_gemm_variants(a.iters, [int(v) for v in a.variants.split(",")])
+        sys.exit(0)
+    if a.what == "order":
+        bench_tile_order(a.iters)
         sys.exit(0)
     if a.what == "epi":
         bench_epi_probe(a.iters)
