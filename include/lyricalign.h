@@ -395,7 +395,7 @@ int la_gemm_fused_ln(int32_t dtype, int32_t M, int32_t N, int32_t K, int32_t bat
 /*
  * The residual stream of the 16-bit encoder kept SPLIT (the default of la_encoder_forward wherever the LayerNorm fold applies):
  *   hi [M][ld] `dtype` = x rounded to the operand type -- at the same time the raw A operand of the next folded GEMM,
- *   lo [M][ld] uint8   = the remainder x - hi in units of ulp(hi) / 256, offset by 128
+ *   lo [M][ld] uint8   = the remainder x - hi in steps of ulp(hi) / 254, offset by 128
  * (x to 8 bits below the operand type's last place; 3 + 3 bytes per element through HBM per read-modify-write instead of the
  * 4 + 4 + 2 of an f32 stream with a 16-bit copy).  la_gemm_split: (hi, lo) <- epi(A W^T) + residual, epilogue = LA_EPI_BIAS |
  * LA_EPI_GELU | LA_EPI_RESIDUAL; with LA_EPI_RESIDUAL the residual is `residual` (f32 rows, as la_gemm takes them: the stem's

@@ -116,7 +116,8 @@ template <> struct Pack4<_Float16> {
 // In the 16-bit modes it lives as TWO arrays of the same [M][d] shape:
 //   hi = x rounded to the operand type (bf16 / f16) -- at the same time the RAW A operand of the next LayerNorm-folded GEMM,
 //        which LDS-DMA can only read as stored bytes;
-//   lo = one byte per element: the remainder x - hi in units of ulp(hi) / 256, offset by 128 (|x - hi| <= ulp / 2 -> 0 .. 255).
+//   lo = one byte per element: the remainder x - hi in units of ulp(hi) / 254, offset by 128 (|x - hi| <= ulp / 2 -> 1 .. 255,
+//        symmetric, 128 = no remainder: an x that is exactly representable -- zero included -- comes back exactly).
 // x is reproduced to 8 bits below the operand type's last place (bf16: 16 significant bits, f16: 19), far inside the rounding the
 // 16-bit GEMM operands add every layer, and a read-modify-write of the stream moves 3 + 3 bytes per element instead of the
 // 4 + 4 + 2 of an f32 stream with a 16-bit copy beside it: the residual GEMMs' epilogue is bound by exactly those bytes
@@ -132,16 +133,17 @@ template <> struct SplitRes<_Float16> {
     __device__ static __forceinline__ float hi_f32(unsigned short b) { return (float)__builtin_bit_cast(_Float16, b); }
     __device__ static __forceinline__ unsigned short round16(float x) { return __builtin_bit_cast(unsigned short, (_Float16)x); }
 };
-// x from (hi bits, lo byte as a float 0 .. 255)
+// x from (hi bits, lo byte as a float 0 .. 255): hi + (q - 128) (128 / 127) 2^(e - SH), e = frexp exponent of hi
+constexpr float kSplitStep = 128.0f / 127.0f;
 template <typename T16> __device__ __forceinline__ float split_decode(unsigned short hb, float q) {
     const float hf = SplitRes<T16>::hi_f32(hb);
-    return hf + __builtin_amdgcn_ldexpf(q - 128.0f, __builtin_amdgcn_frexp_expf(hf) - SplitRes<T16>::SH);
+    return hf + __builtin_amdgcn_ldexpf(fmaf(q, kSplitStep, -128.0f * kSplitStep), __builtin_amdgcn_frexp_expf(hf) - SplitRes<T16>::SH);
 }
-// x -> hi bits; q = the lo byte before rounding / saturation (v_cvt_pk_u8_f32 rounds and clamps to 0 .. 255)
+// x -> hi bits; q = the lo byte before rounding (1 .. 255 for |x - hi| <= ulp / 2; v_cvt_pk_u8_f32 rounds to nearest and saturates)
 template <typename T16> __device__ __forceinline__ unsigned short split_encode(float x, float &q) {
     const unsigned short hb = SplitRes<T16>::round16(x);
     const float hf = SplitRes<T16>::hi_f32(hb);
-    q = __builtin_amdgcn_ldexpf(x - hf, SplitRes<T16>::SH - __builtin_amdgcn_frexp_expf(hf)) + 128.0f;
+    q = fmaf(__builtin_amdgcn_ldexpf(x - hf, SplitRes<T16>::SH - __builtin_amdgcn_frexp_expf(hf)), 127.0f / 128.0f, 128.0f);
     return hb;
 }
 __device__ __forceinline__ unsigned pack_u8x4(float a, float b, float c, float d) {

@@ -271,9 +271,13 @@ __device__ __forceinline__ void epi_quad(f32x4 &v, const float (&b4)[4], const f
 // requested together before the staging.  Round 2 applied the LayerNorm fold and the GELU in the accumulator layout, before the
 // staging: 16 row statistics + 32 broadcast column operands live beside the 128 accumulators -- the LayerNorm-consumer
 // instantiations (QKV, MLP-up) sat at 256 VGPRs with 107-127 spilled registers and 112 B of scratch per lane.
+// LNM = 4: as 2, with the row statistics taken by the main loop itself (mainloop_duo_asm STAT_WC) and left in LDS: stats_tab[row
+// of the tile] = (mean, rstd), tile_m0 = the tile's first row.
 template <bool OUT_F32, typename T16, int LNM>
 __device__ __forceinline__ void wave_epilogue(const GemmParams &p, int z, f32x4 (&acc)[8][4], int wrow0, int wcol0, bool has_bias,
-                                              float bias_l, float csum_l, unsigned char *reg) {
+                                              float bias_l, float csum_l, unsigned char *reg, const float2 *stats_tab = nullptr,
+                                              int tile_m0 = 0) {
+    constexpr bool LNC = LNM == 2 || LNM == 4;               // LayerNorm consumer
     const int lane = threadIdx.x & 63;
     const int r = lane & 15, q = lane >> 4;
     typedef typename std::conditional<OUT_F32, float, T16>::type TC;
@@ -287,9 +291,9 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams &p, int z, f32x4 
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         b4[j] = __int_as_float(__builtin_amdgcn_ds_bpermute((r * 4 + j) * 4, __float_as_int(bias_l)));
-        cs4[j] = LNM == 2 ? __int_as_float(__builtin_amdgcn_ds_bpermute((r * 4 + j) * 4, __float_as_int(csum_l))) : 0.f;
+        cs4[j] = LNC ? __int_as_float(__builtin_amdgcn_ds_bpermute((r * 4 + j) * 4, __float_as_int(csum_l))) : 0.f;
     }
-    const float2 *stats = reinterpret_cast<const float2 *>(p.ln_stats);
+    const float2 *stats = reinterpret_cast<const float2 *>(p.ln_stats);      // LNM == 2: [M] rows in memory
     constexpr int PITCH = EPI_PITCH;
     const bool fast_c = ((p.ldc * (int64_t)sizeof(TC)) % 16 == 0) && ((uintptr_t)C % 16 == 0);
     const bool fast_r = do_res && (p.ldr % 4 == 0) && ((uintptr_t)R % 16 == 0);
@@ -325,6 +329,10 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams &p, int z, f32x4 
 #pragma unroll
                     for (int it = 0; it < 8; ++it) st[it] = stats[wrow0 + h * 32 + it * 4 + q];
                 }
+                if constexpr (LNM == 4) {
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) st[it] = stats_tab[wrow0 - tile_m0 + h * 32 + it * 4 + q];
+                }
 #pragma unroll
                 for (int mm = 0; mm < 2; ++mm)
 #pragma unroll
@@ -334,7 +342,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams &p, int z, f32x4 
                 for (int it = 0; it < 8; ++it) {
                     const int rl = it * 4 + q;
                     f32x4 v = *reinterpret_cast<const f32x4 *>(reg + rl * PITCH + r * 16);
-                    epi_quad<OUT_F32, LNM>(v, b4, cs4, LNM == 2 ? st[it] : make_float2(0.f, 0.f), has_bias, do_gelu, epi);
+                    epi_quad<OUT_F32, LNC ? 2 : LNM>(v, b4, cs4, LNC ? st[it] : make_float2(0.f, 0.f), has_bias, do_gelu, epi);
                     if constexpr (RES) { v[0] += t[it].x; v[1] += t[it].y; v[2] += t[it].z; v[3] += t[it].w; }
                     const int64_t off = (int64_t)(h * 32 + rl) * p.ldc;
                     TC *c = cw + off;
@@ -376,7 +384,8 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams &p, int z, f32x4 
             f32x4 v = *reinterpret_cast<const f32x4 *>(reg + rl * PITCH + r * 16);
             float2 st = make_float2(0.f, 0.f);
             if constexpr (LNM == 2) st = stats[min(m, p.M - 1)];
-            epi_quad<OUT_F32, LNM>(v, b4, cs4, st, has_bias, do_gelu, epi);
+            if constexpr (LNM == 4) st = stats_tab[wrow0 - tile_m0 + h * 32 + rl];
+            epi_quad<OUT_F32, LNC ? 2 : LNM>(v, b4, cs4, st, has_bias, do_gelu, epi);
             if (m >= p.M || n >= p.N) continue;
             const int nv = min(4, p.N - n);
             if (do_res) {
@@ -535,9 +544,23 @@ __device__ __forceinline__ void wave_epilogue_split(const GemmParams &p, int z, 
     }
 }
 
+#ifdef LA_TILE_STAMPS
+// Diagnostic build only (tools/tile_timeline.py): per workgroup (wall clock at entry, after the prologue, after the main loop, at
+// the end; HW_ID) into a buffer that nothing else reads -- where a tile's lifetime goes and how long a CU waits for its next one.
+__device__ unsigned long long *g_tile_stamps = nullptr;
+extern "C" int la_debug_set_tile_stamps(void *buf) {
+    unsigned long long *b = static_cast<unsigned long long *>(buf);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_tile_stamps), &b, sizeof(b)) == hipSuccess ? LA_OK : LA_EHIP;
+}
+#endif
+
 template <bool OUT_F32, bool DUO, typename T16, int LNM = 0>
 __global__ __launch_bounds__(PP::THREADS, 2) void gemm_pp_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+#ifdef LA_TILE_STAMPS
+    const unsigned long long stamp_t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long stamp_t1 = stamp_t0;
+#endif
     const int nwg = p.tiles_m * p.tiles_n;
     const int tile = xcd_remap(blockIdx.x, nwg);
     const TileCoord tc = tile_coord_mb(tile, p.tiles_m, p.tiles_n, p.group, p.mblock);
@@ -556,15 +579,59 @@ __global__ __launch_bounds__(PP::THREADS, 2) void gemm_pp_kernel(GemmParams p) {
     const int ncol = min(n0 + wc * 64 + lane, p.N - 1);
     const float bias_l = has_bias ? bias[ncol] : 0.f;
     float csum_l = 0.f;
-    if constexpr (LNM == 2) csum_l = p.ln_csum[ncol];
+    if constexpr (LNM == 2 || LNM == 4) csum_l = p.ln_csum[ncol];
 
     f32x4 acc[8][4];
-    if constexpr (DUO) mainloop_duo_asm<T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
-    else mainloop_pp<T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
+#ifdef LA_TILE_STAMPS
+#define LA_STAMP_ARG , stamp_t1
+#else
+#define LA_STAMP_ARG
+#endif
+    float sacc[4] = {0.f, 0.f, 0.f, 0.f};
+    float2 *stats_tab = reinterpret_cast<float2 *>(lds + 120 * 1024);        // LNM == 4: inside ring slot 3, clear of the epilogue staging
+    if constexpr (LNM == 4) {
+        static_assert(DUO || LNM != 4, "the main loop takes the row statistics only in its hand-placed form");
+        const int wc_u = __builtin_amdgcn_readfirstlane(wc);
+        switch (wc_u) {                                                       // (the fragment registers are named at compile time)
+            case 0: mainloop_duo_asm<T16, 0>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc LA_STAMP_ARG, sacc); break;
+            case 1: mainloop_duo_asm<T16, 1>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc LA_STAMP_ARG, sacc); break;
+            case 2: mainloop_duo_asm<T16, 2>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc LA_STAMP_ARG, sacc); break;
+            default: mainloop_duo_asm<T16, 3>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc LA_STAMP_ARG, sacc); break;
+        }
+        // sum over the four lanes that hold one row's four k chunks, then (mean, rstd) of rows wr * 128 + (2 wc + i) * 16 + r
+        const float inv_k = 1.0f / (float)p.K;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float s1 = sacc[2 * i], s2 = sacc[2 * i + 1];
+            s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+            s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+            const float mean = s1 * inv_k;
+            const float var = fmaxf(fmaf(-mean, mean, s2 * inv_k), 0.f);
+            if (lane < 16) stats_tab[wr * 128 + (2 * wc + i) * 16 + lane] = make_float2(mean, 1.0f / sqrtf(var + 1e-5f));
+        }
+    } else if constexpr (DUO) {
+        mainloop_duo_asm<T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc LA_STAMP_ARG);
+    } else {
+        mainloop_pp<T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
+    }
+#ifdef LA_TILE_STAMPS
+    const unsigned long long stamp_t2 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     __syncthreads();
     if constexpr (LNM == 3) wave_epilogue_split<T16>(p, z, acc, m0 + wr * 128, n0 + wc * 64, has_bias, bias_l, lds + wave * (32 * EPI_PITCH));
-    else wave_epilogue<OUT_F32, T16, LNM>(p, z, acc, m0 + wr * 128, n0 + wc * 64, has_bias, bias_l, csum_l, lds + wave * (32 * EPI_PITCH));
+    else wave_epilogue<OUT_F32, T16, LNM>(p, z, acc, m0 + wr * 128, n0 + wc * 64, has_bias, bias_l, csum_l, lds + wave * (32 * EPI_PITCH), stats_tab, m0);
+#ifdef LA_TILE_STAMPS
+    if (threadIdx.x == 0 && g_tile_stamps) {
+        unsigned long long *o = g_tile_stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+        o[0] = stamp_t0; o[1] = stamp_t1; o[2] = stamp_t2; o[3] = __builtin_amdgcn_s_memrealtime();
+        unsigned hw_id, xcc_id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+        o[4] = hw_id; o[5] = xcc_id;
+        o[6] = tile;
+    }
+#endif
 }
 
 // Epilogue of the one-wave-per-SIMD kernel: one wave's 128x128 tile, accumulators in the AGPRs.  Per pass of 32 rows the wave
@@ -821,6 +888,13 @@ int launch_pp(GemmParams p, int batch, hipStream_t stream) {
         if (dbg == 73 && fits) return launch_mono_modes<OUT_F32, T16>(p, batch, stream);
     }
     const bool duo = fits && dbg != 99;
+    if (p.ln_csum && !p.ln_stats) {                   // LayerNorm consumer whose main loop takes the row statistics itself
+        if (!duo) {
+            la::set_error("gemm_fused_ln: in-loop row statistics need the hand-placed main loop (K %% 128 == 0, K >= 256; K = %d)", p.K);
+            return LA_EUNSUPPORTED;
+        }
+        return launch_pp_loop<OUT_F32, true, T16, 4>(p, batch, stream);
+    }
     if (p.ln_stats) return duo ? launch_pp_loop<OUT_F32, true, T16, 2>(p, batch, stream) : launch_pp_loop<OUT_F32, false, T16, 2>(p, batch, stream);
     if constexpr (OUT_F32) {
         if (p.C2) return duo ? launch_pp_loop<OUT_F32, true, T16, 1>(p, batch, stream) : launch_pp_loop<OUT_F32, false, T16, 1>(p, batch, stream);
@@ -947,8 +1021,9 @@ static int gemm_run_ldw(int dtype, int M, int N, int K, int batch, const void *A
             LA_CHECK_ARG(!ln->C2 || (out_f32 && ln->ldc2 == ldc && ln->strideC2 == strideC && ldc % 4 == 0 && (uintptr_t)ln->C2 % 8 == 0),
                          "gemm_fused_ln: the 16-bit copy accompanies an f32 result and shares its row pitch / batch stride");
             LA_CHECK_ARG(!(ln->C2 && ln->stats), "gemm_fused_ln: a GEMM is the producer or the consumer of a folded LayerNorm, not both");
-            LA_CHECK_ARG((ln->stats == nullptr) == (ln->csum == nullptr), "gemm_fused_ln: stats and csum go together");
-            LA_CHECK_ARG(!ln->stats || batch == 1, "gemm_fused_ln: the LayerNorm epilogue takes batch 1");
+            LA_CHECK_ARG(!ln->stats || ln->csum, "gemm_fused_ln: row statistics without the column sums of the folded weights");
+            LA_CHECK_ARG(!ln->csum || batch == 1, "gemm_fused_ln: the LayerNorm epilogue takes batch 1");
+            LA_CHECK_ARG(!(ln->C2 && ln->csum), "gemm_fused_ln: a GEMM is the producer or the consumer of a folded LayerNorm, not both");
             LA_CHECK_ARG(!ln->part || (ln->C2 && N % 64 == 0 && batch == 1 && (uintptr_t)ln->part % 8 == 0),
                          "gemm_fused_ln: partial statistics go with the 16-bit copy, N % 64 == 0, batch 1");
             p.C2 = ln->C2; p.ldc2 = ln->ldc2; p.strideC2 = ln->strideC2; p.ln_stats = ln->stats; p.ln_csum = ln->csum; p.ln_part = ln->part;
@@ -1015,7 +1090,7 @@ extern "C" int la_gemm_fused_ln(int32_t dtype, int32_t M, int32_t N, int32_t K, 
         la::set_error("gemm_fused_ln: 16-bit compute dtypes only");
         return LA_EUNSUPPORTED;
     }
-    LA_CHECK_ARG(C2 || ln_stats, "gemm_fused_ln: neither a second output nor row statistics given");
+    LA_CHECK_ARG(C2 || ln_csum, "gemm_fused_ln: neither a second output nor the consumer's column sums given");
     const LnFuse ln{C2, ldc2, strideC2, ln_stats, ln_csum, ln_part};
     return gemm_run_ldw(dtype, M, N, K, batch, A, lda, strideA, W, 0, 0, C, ldc, strideC, bias, 0, residual, ldr, strideR, epilogue,
                         (hipStream_t)stream_, &ln);

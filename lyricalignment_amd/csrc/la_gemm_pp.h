@@ -390,9 +390,41 @@ template <> struct MmaAsmV<_Float16> {
 // DMA as an early burst, wait / barrier at the very end, the two waves of a SIMD in different gaps): all within +-1 % on the
 // encoder's shapes, one 2.5 % slower -- the loop is LDS-bandwidth-bound (96 KiB of fragment reads + 32 KiB of DMA writes per
 // k-step = the 128 B per clock of a 1024-cycle k-step), not placement-bound.  This is the placement that was kept.
-template <typename T16 = bf16_t>
+// Diagnostic build (LA_EXTRA_CXXFLAGS=-DLA_TILE_STAMPS, tools/tile_timeline.py): the 100 MHz wall clock at the end of the prologue
+#ifdef LA_TILE_STAMPS
+#define LA_STAMP_PARAM , unsigned long long &stamp_t1
+#define LA_STAMP_T1() stamp_t1 = __builtin_amdgcn_s_memrealtime()
+#else
+#define LA_STAMP_PARAM
+#define LA_STAMP_T1()
+#endif
+// STAT_WC >= 0 (the LayerNorm-consumer GEMMs, round 4): the wave also takes the row statistics of the A rows it multiplies -- the
+// RAW rows of the residual stream whose LayerNorm is folded into this GEMM -- from the fragments it already holds: per k-step
+// v_dot2c_f32_{bf16,f16} of each fragment dword with (1, 1) and with itself, i.e. 16 two-term dot products into sacc = (sum, sum of
+// squares) of row blocks mi = 2 STAT_WC and 2 STAT_WC + 1 (the four waves of a row group hold the same A fragments: wave column
+// wc = STAT_WC takes a quarter of them, so every row is summed once per tile; STAT_WC is a template parameter because the
+// fragment registers are named at compile time -- the kernel switches on its wave column around the whole main loop).  Two per slot
+// in eight MFMA gaps that carry nothing else.  Replaces the separate statistics pass over the stream (la_row_stats16: 98 MB and a
+// launch per LayerNorm) and the epilogue's statistics loads.
+template <typename T> struct Dot2cAsm;
+template <> struct Dot2cAsm<bf16_t> {
+    static constexpr unsigned ONES = 0x3F803F80u;
+    __device__ static __forceinline__ void run(float &s1, float &s2, unsigned v, unsigned ones) {
+        asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(s1) : "v"(v), "v"(ones));
+        asm volatile("v_dot2c_f32_bf16 %0, %1, %1" : "+v"(s2) : "v"(v));
+    }
+};
+template <> struct Dot2cAsm<_Float16> {
+    static constexpr unsigned ONES = 0x3C003C00u;
+    __device__ static __forceinline__ void run(float &s1, float &s2, unsigned v, unsigned ones) {
+        asm volatile("v_dot2c_f32_f16 %0, %1, %2" : "+v"(s1) : "v"(v), "v"(ones));
+        asm volatile("v_dot2c_f32_f16 %0, %1, %1" : "+v"(s2) : "v"(v));
+    }
+};
+template <typename T16 = bf16_t, int STAT_WC = -1>
 __device__ __forceinline__ void mainloop_duo_asm(const T16 *A, int64_t lda, int M, const T16 *W, int64_t ldw, int N, int K,
-                                                 int m0, int n0, unsigned char *lds, f32x4 (&acc)[8][4]) {
+                                                 int m0, int n0, unsigned char *lds, f32x4 (&acc)[8][4] LA_STAMP_PARAM,
+                                                 float *sacc = nullptr) {
     constexpr int STAGE = 32768, OPS = 16384, SB = 64;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -434,6 +466,7 @@ __device__ __forceinline__ void mainloop_duo_asm(const T16 *A, int64_t lda, int 
     }
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // stages 0 and 1 landed; the 8 pieces of stages 2 and 3 may stay in flight
     LA_PP_BARRIER();
+    LA_STAMP_T1();
     u32x4 fa[2][8], fw[2][4];
     ds_read128_asm<0 * 1024>(fw[0][0], fw_lo); ds_read128_asm<1 * 1024>(fw[0][1], fw_lo); ds_read128_asm<2 * 1024>(fw[0][2], fw_lo);
     ds_read128_asm<3 * 1024>(fw[0][3], fw_lo);
@@ -447,6 +480,8 @@ __device__ __forceinline__ void mainloop_duo_asm(const T16 *A, int64_t lda, int 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     LA_PP_BARRIER();
 
+    unsigned stat_ones = Dot2cAsm<T16>::ONES;
+    if constexpr (STAT_WC >= 0) asm volatile("" : "+v"(stat_ones));          // one VGPR for the loop, not a literal per instruction
     auto kstep = [&](int s, auto nxc, auto pfc, auto vmc, auto curc, auto slotc) __attribute__((always_inline)) {
         constexpr bool NX = decltype(nxc)::value, PF = decltype(pfc)::value;
         constexpr int VM = decltype(vmc)::value;
@@ -458,6 +493,13 @@ __device__ __forceinline__ void mainloop_duo_asm(const T16 *A, int64_t lda, int 
         static_for<0, 32>([&](auto jc) __attribute__((always_inline)) {
             constexpr int j = decltype(jc)::value, mi = j >> 2, ni = j & 3;
             MmaAsmV<T16>::run(fw[CUR][ni], fa[CUR][mi], acc[mi][ni]);
+            if constexpr (STAT_WC >= 0) {
+                constexpr int slot = j == 4 ? 0 : j == 6 ? 1 : j == 12 ? 2 : j == 14 ? 3 : j == 20 ? 4 : j == 22 ? 5 : j == 25 ? 6 : j == 27 ? 7 : -1;
+                if constexpr (slot >= 0) {
+                    constexpr int fi = slot >> 2, dw = slot & 3;         // slots 0-3: the dwords of fragment 0, slots 4-7: of fragment 1
+                    Dot2cAsm<T16>::run(sacc[2 * fi], sacc[2 * fi + 1], fa[CUR][2 * STAT_WC + fi][dw], stat_ones);
+                }
+            }
             if constexpr (NX && (j & 1) == 1 && j / 2 < 12) {
                 constexpr int i = j / 2;                        // fragments of the next k-step: W 0..3, then A 0..7
                 if constexpr (i < 4) ds_read128_asm<OFFN + i * 1024>(fw[CUR ^ 1][i], fwn);

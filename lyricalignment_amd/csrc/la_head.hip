@@ -85,7 +85,12 @@ __global__ __launch_bounds__(PP::THREADS, 2) void fc_lse_pp_kernel(LseParams p) 
     const int tn = tc.tn;
     const int m0 = tc.tm * PP::TM, n0 = tn * PP::TN;
     f32x4 acc[8][4];
+#ifdef LA_TILE_STAMPS
+    unsigned long long stamp_unused = 0;
+    if constexpr (DUO) mainloop_duo_asm<T16>(reinterpret_cast<const T16 *>(p.A), p.lda, p.M, reinterpret_cast<const T16 *>(p.W), p.K, p.N, p.K, m0, n0, lds, acc, stamp_unused);
+#else
     if constexpr (DUO) mainloop_duo_asm<T16>(reinterpret_cast<const T16 *>(p.A), p.lda, p.M, reinterpret_cast<const T16 *>(p.W), p.K, p.N, p.K, m0, n0, lds, acc);
+#endif
     else mainloop_pp<T16>(reinterpret_cast<const T16 *>(p.A), p.lda, p.M, reinterpret_cast<const T16 *>(p.W), p.K, p.N, p.K, m0, n0, lds, acc);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -106,14 +106,22 @@ extern "C" int la_encoder_forward(const la_encoder_weights *w, const float *mel,
     const char *split_env = getenv("LA_RESID_SPLIT");
     const bool split = fused && !(split_env && split_env[0] == '0');
     unsigned char *lo = reinterpret_cast<unsigned char *>(b.x);
+    // Row statistics of the folded LayerNorms: taken by the consumer GEMM's own main loop from the A fragments it multiplies
+    // (la_gemm_fused_ln with ln_stats = NULL: K = d a multiple of 128) -- no la_row_stats16 pass over the stream.
+    // LA_LN_STATS=pass (read per call) keeps the separate pass: the A/B partner.
+    const char *stats_env = getenv("LA_LN_STATS");
+    const char *dbg_env = getenv("LA_PP_DBG");
+    const bool stats_in_loop = fused && d % 128 == 0 && d >= 256 && !(stats_env && strcmp(stats_env, "loop") != 0) &&
+                               !(dbg_env && (atoi(dbg_env) == 99 || atoi(dbg_env) == 73));
+    const float *ln_stats = stats_in_loop ? nullptr : b.stats;
     if (split) {
         LA_TRY(la_gemm_split(dt, N_CTX, d, 3 * d, batch, b.y1, 2 * d, (int64_t)(N_FRAMES + 2) * d, w->conv2_w, b.h, lo, d, (int64_t)N_CTX * d,
                              w->conv2_b, w->pos, d, 0, LA_EPI_BIAS | LA_EPI_GELU | LA_EPI_RESIDUAL, nullptr, stream));
-        LA_TRY(la_row_stats16(dt, b.h, d, M, d, 1e-5f, b.stats, stream));
+        if (!stats_in_loop) LA_TRY(la_row_stats16(dt, b.h, d, M, d, 1e-5f, b.stats, stream));
     } else if (fused) {
         LA_TRY(la_gemm_fused_ln(dt, N_CTX, d, 3 * d, batch, b.y1, 2 * d, (int64_t)(N_FRAMES + 2) * d, w->conv2_w, b.x, d, (int64_t)N_CTX * d,
                                 w->conv2_b, w->pos, d, 0, epi2, b.h, d, (int64_t)N_CTX * d, nullptr, nullptr, nullptr, stream));
-        LA_TRY(la_row_stats16(dt, b.h, d, M, d, 1e-5f, b.stats, stream));
+        if (!stats_in_loop) LA_TRY(la_row_stats16(dt, b.h, d, M, d, 1e-5f, b.stats, stream));
     } else {
         LA_TRY(la_gemm(dt, N_CTX, d, 3 * d, batch, b.y1, 2 * d, (int64_t)(N_FRAMES + 2) * d, w->conv2_w, b.x, d, (int64_t)N_CTX * d,
                        w->conv2_b, w->pos, d, 0, epi2, stream));
@@ -124,16 +132,16 @@ extern "C" int la_encoder_forward(const la_encoder_weights *w, const float *mel,
         if (fused) {
             LA_CHECK_ARG(k.wqkv_ln && k.cqkv && k.bqkv_ln && k.w1_ln && k.c1 && k.b1_ln, "encoder_forward: block %d lacks the LayerNorm-folded weights", l);
             LA_TRY(la_gemm_fused_ln(dt, M, 3 * d, d, 1, b.h, d, 0, k.wqkv_ln, b.qkv, 3 * d, 0, k.bqkv_ln, nullptr, 0, 0, LA_EPI_BIAS, nullptr, 0, 0,
-                                    b.stats, k.cqkv, nullptr, stream));
+                                    ln_stats, k.cqkv, nullptr, stream));
             LA_TRY(la_attention(dt_attn, b.qkv, 3 * d, b.att, d, batch, N_CTX, w->n_head, stream));
             if (split) LA_TRY(la_gemm_split(dt, M, d, d, 1, b.att, d, 0, k.wo, b.h, lo, d, 0, k.bo, nullptr, 0, 0, LA_EPI_BIAS | LA_EPI_RESIDUAL, nullptr, stream));
             else LA_TRY(la_gemm_fused_ln(dt, M, d, d, 1, b.att, d, 0, k.wo, b.x, d, 0, k.bo, b.x, d, 0, epi_res, b.h, d, 0, nullptr, nullptr, nullptr, stream));
-            LA_TRY(la_row_stats16(dt, b.h, d, M, d, 1e-5f, b.stats, stream));
+            if (!stats_in_loop) LA_TRY(la_row_stats16(dt, b.h, d, M, d, 1e-5f, b.stats, stream));
             LA_TRY(la_gemm_fused_ln(dt, M, 4 * d, d, 1, b.h, d, 0, k.w1_ln, b.u, 4 * d, 0, k.b1_ln, nullptr, 0, 0, LA_EPI_BIAS | LA_EPI_GELU, nullptr, 0, 0,
-                                    b.stats, k.c1, nullptr, stream));
+                                    ln_stats, k.c1, nullptr, stream));
             if (split) LA_TRY(la_gemm_split(dt, M, d, 4 * d, 1, b.u, 4 * d, 0, k.w2, b.h, lo, d, 0, k.b2, nullptr, 0, 0, LA_EPI_BIAS | LA_EPI_RESIDUAL, nullptr, stream));
             else LA_TRY(la_gemm_fused_ln(dt, M, d, 4 * d, 1, b.u, 4 * d, 0, k.w2, b.x, d, 0, k.b2, b.x, d, 0, epi_res, b.h, d, 0, nullptr, nullptr, nullptr, stream));
-            LA_TRY(la_row_stats16(dt, b.h, d, M, d, 1e-5f, b.stats, stream));
+            if (!stats_in_loop) LA_TRY(la_row_stats16(dt, b.h, d, M, d, 1e-5f, b.stats, stream));
         } else {
             LA_TRY(la_layernorm(b.x, d, M, d, k.ln1_g, k.ln1_b, b.h, d, dt, stream));
             LA_TRY(la_gemm(dt, M, 3 * d, d, 1, b.h, d, 0, k.wqkv, b.qkv, 3 * d, 0, k.bqkv, nullptr, 0, 0, LA_EPI_BIAS, stream));

@@ -32,10 +32,12 @@ N_FRAMES = 3000   # whisper.audio.N_FRAMES
 N_CTX = 1500      # encoder positions
 C_PAD = 128       # mel channels padded so 3*C is a multiple of the GEMM K tile
 LN_FUSION = os.environ.get("LA_LN_FUSION", "1") != "0"   # developer switch: 0 = always the separate LayerNorm pass
-# Row statistics of the folded LayerNorm: "pass" (default) = row_stats16 reads the bf16 copy back (98 MB, 21 us);
-# "epilogue" = the producer GEMM takes them per 64-column segment while the rows pass through its registers + a finalize
-# kernel.  Measured in the pipeline: the epilogue form costs the residual GEMMs more (+0.7 ms) than the pass it removes.
-LN_STATS_IN_EPILOGUE = os.environ.get("LA_LN_STATS", "pass") == "epilogue"
+# Row statistics of the folded LayerNorm: "loop" (default since round 4) = the CONSUMER GEMM's main loop takes them from the A
+# fragments it multiplies (v_dot2c in MFMA gaps: no pass over the stream, no statistics loads in its epilogue); "pass" =
+# row_stats16 reads the 16-bit rows back (98 MB, 21 us per LayerNorm); "epilogue" = the producer GEMM takes them per 64-column
+# segment while the rows pass through its registers + a finalize kernel (costs the residual GEMMs more than the pass it removes).
+LN_STATS = os.environ.get("LA_LN_STATS", "loop")
+LN_STATS_IN_EPILOGUE = LN_STATS == "epilogue"
 # With the LayerNorm fold the residual stream is kept SPLIT (ops.gemm_split: hi 16-bit = the next GEMM's raw operand, + one lo byte
 # per element) instead of f32 with a 16-bit copy beside it; 0 = the f32 stream (the A/B partner; la_model.cpp reads the same switch).
 RESID_SPLIT = os.environ.get("LA_RESID_SPLIT", "1") != "0"
@@ -321,13 +323,20 @@ class AlignEngine:
             stats = self._get("ln_stats", (M, 2), torch.float32)
             part = self._get("ln_part", (d // 64, M, 2), torch.float32) if (LN_STATS_IN_EPILOGUE and d % 64 == 0) else None
 
+            in_loop = LN_STATS == "loop" and d % 128 == 0 and d >= 256 and os.environ.get("LA_PP_DBG") not in ("99", "73")
+            if in_loop:
+                stats = None                                                                  # ln_csum alone: the main loop takes them
+
             def row_stats():
+                if in_loop:
+                    return
                 if part is not None:
                     ops.ln_stats_finalize(part, out=stats)
                 else:
                     ops.row_stats16(h, out=stats)
 
-            ops.row_stats16(h, out=stats)                                                     # of the stem's output (batched GEMM)
+            if not in_loop:
+                ops.row_stats16(h, out=stats)                                                 # of the stem's output (batched GEMM)
             for blk in e.blocks:
                 ops.gemm(h, blk.wqkv_ln, qkv, bias=blk.bqkv_ln, ln_stats=stats, ln_csum=blk.cqkv)
                 ops.attention(qkv, B, N_CTX, e.n_head, out=att, q_log2=e.q_log2)

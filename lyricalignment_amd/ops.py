@@ -84,7 +84,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None, *
     (M, lda, stride_a): that is how the conv-as-GEMM views (overlapping rows) are expressed.
     LayerNorm folded into the neighbouring GEMMs (la_gemm_fused_ln): `out16` = a second, 16-bit copy of the f32 result rows
     (same row pitch / batch stride as out), `ln_part` [N/64, M, 2] = also its per-segment partial row statistics
-    (ln_stats_finalize turns them into [M,2]); `ln_stats` [M,2] + `ln_csum` [N] = apply rstd (acc - mean c) before the bias."""
+    (ln_stats_finalize turns them into [M,2]); `ln_stats` [M,2] + `ln_csum` [N] = apply rstd (acc - mean c) before the bias;
+    `ln_csum` alone = the same with the row statistics of `a` taken inside the main loop (K % 128 == 0, K >= 256)."""
     _dev(a, "a"); _dev(w, "w")
     dt = dtype_code(w.dtype)
     if a.dtype != w.dtype:
@@ -128,7 +129,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None, *
         epi |= EPI_MISH
     if c_dtype == torch.float32 and dt != LA_F32:
         epi |= EPI_OUT_F32
-    if out16 is not None or ln_stats is not None:
+    if out16 is not None or ln_stats is not None or ln_csum is not None:
         if out16 is not None:
             _dev(out16, "out16", w.dtype)
             if c_dtype != torch.float32 or _capacity(out16) < (batch - 1) * stride_c + (M - 1) * ldc + N:
@@ -137,10 +138,14 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None, *
             _dev(ln_part, "ln_part", torch.float32)
             if out16 is None or N % 64 or ln_part.numel() < (N // 64) * M * 2 or not ln_part.is_contiguous():
                 raise ValueError("gemm: ln_part [N/64, M, 2] goes with out16, N % 64 == 0")
+        if ln_stats is not None or ln_csum is not None:      # ln_csum alone: the main loop takes the row statistics itself
+            _dev(ln_csum, "ln_csum", torch.float32)
+            if ln_csum.numel() < N or batch != 1:
+                raise ValueError("gemm: ln_csum [N] expected (batch 1)")
         if ln_stats is not None:
-            _dev(ln_stats, "ln_stats", torch.float32); _dev(ln_csum, "ln_csum", torch.float32)
-            if ln_stats.numel() < 2 * M or ln_csum.numel() < N or batch != 1 or not ln_stats.is_contiguous():
-                raise ValueError("gemm: ln_stats [M,2] / ln_csum [N] expected (batch 1)")
+            _dev(ln_stats, "ln_stats", torch.float32)
+            if ln_stats.numel() < 2 * M or not ln_stats.is_contiguous():
+                raise ValueError("gemm: ln_stats [M,2] expected")
         check(lib().la_gemm_fused_ln(dt, M, N, K, batch, ptr(a), lda, stride_a, ptr(w), ptr(out), ldc, stride_c, ptr(bias),
                                      ptr(residual), ldr or 0, stride_r, epi, ptr(out16), ldc, stride_c, ptr(ln_stats), ptr(ln_csum),
                                      ptr(ln_part), stream_ptr()), "gemm_fused_ln")
@@ -200,7 +205,7 @@ def gemm_split(a: torch.Tensor, w: torch.Tensor, hi: torch.Tensor, lo: torch.Ten
                lda: Optional[int] = None, batch: int = 1, stride_a: int = 0, stride_c: int = 0, ld: Optional[int] = None,
                ldr: Optional[int] = None, stride_r: int = 0, ln_part: Optional[torch.Tensor] = None) -> None:
     """(hi, lo) <- epi(a w^T) + residual on the SPLIT residual stream of the 16-bit encoder (la_gemm_split): hi = x rounded to the
-    operand dtype [M, N] (the next LayerNorm-folded GEMM's raw operand), lo uint8 [M, N] = the remainder in units of ulp(hi) / 256.
+    operand dtype [M, N] (the next LayerNorm-folded GEMM's raw operand), lo uint8 [M, N] = the remainder in steps of ulp(hi) / 254.
     residual: f32 rows (the stem's positional embedding), or in_place=True: the stream's own rows (x += ...)."""
     _dev(a, "a"); _dev(w, "w"); _dev(hi, "hi", w.dtype); _dev(lo, "lo", torch.uint8)
     if a.dtype != w.dtype or w.dtype not in (torch.bfloat16, torch.float16):
@@ -245,11 +250,12 @@ def gemm_split(a: torch.Tensor, w: torch.Tensor, hi: torch.Tensor, lo: torch.Ten
 
 def split_decode(hi: torch.Tensor, lo: torch.Tensor) -> torch.Tensor:
     """The f32 values a split residual stream (hi 16-bit, lo uint8) stands for -- plain torch, for tests and inspection; the
-    kernels decode in registers (la_common.h SplitRes): x = hi + (lo - 128) * 2^(e - SH), e the frexp exponent of hi."""
+    kernels decode in registers (la_common.h SplitRes): x = hi + (lo - 128) (128 / 127) 2^(e - SH), e the frexp exponent of hi."""
     hf = hi.float()
     _, e = torch.frexp(hf)
     sh = 16 if hi.dtype == torch.bfloat16 else 19
-    return hf + torch.ldexp(lo.float() - 128.0, e.to(torch.int32) - sh)
+    step = torch.tensor(128.0 / 127.0, dtype=torch.float32, device=hi.device)
+    return hf + torch.ldexp(torch.addcmul(-128.0 * step, lo.float(), step), e.to(torch.int32) - sh)
 
 
 def layernorm_split(hi: torch.Tensor, lo: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out_dtype: torch.dtype,
