@@ -106,12 +106,12 @@ extern "C" int la_encoder_forward(const la_encoder_weights *w, const float *mel,
     const char *split_env = getenv("LA_RESID_SPLIT");
     const bool split = fused && !(split_env && split_env[0] == '0');
     unsigned char *lo = reinterpret_cast<unsigned char *>(b.x);
-    // Row statistics of the folded LayerNorms: taken by the consumer GEMM's own main loop from the A fragments it multiplies
-    // (la_gemm_fused_ln with ln_stats = NULL: K = d a multiple of 128) -- no la_row_stats16 pass over the stream.
-    // LA_LN_STATS=pass (read per call) keeps the separate pass: the A/B partner.
+    // Row statistics of the folded LayerNorms: la_row_stats16 over the stream's hi rows.  LA_LN_STATS=loop (read per call) lets the
+    // consumer GEMM's own main loop take them from the A fragments it multiplies instead (la_gemm_fused_ln with ln_stats = NULL; K = d
+    // a multiple of 128): measured slower -- the extra vector instructions cost the loop more than the pass they remove.
     const char *stats_env = getenv("LA_LN_STATS");
     const char *dbg_env = getenv("LA_PP_DBG");
-    const bool stats_in_loop = fused && d % 128 == 0 && d >= 256 && !(stats_env && strcmp(stats_env, "loop") != 0) &&
+    const bool stats_in_loop = fused && d % 128 == 0 && d >= 256 && stats_env && strcmp(stats_env, "loop") == 0 &&
                                !(dbg_env && (atoi(dbg_env) == 99 || atoi(dbg_env) == 73));
     const float *ln_stats = stats_in_loop ? nullptr : b.stats;
     if (split) {

@@ -32,11 +32,13 @@ N_FRAMES = 3000   # whisper.audio.N_FRAMES
 N_CTX = 1500      # encoder positions
 C_PAD = 128       # mel channels padded so 3*C is a multiple of the GEMM K tile
 LN_FUSION = os.environ.get("LA_LN_FUSION", "1") != "0"   # developer switch: 0 = always the separate LayerNorm pass
-# Row statistics of the folded LayerNorm: "loop" (default since round 4) = the CONSUMER GEMM's main loop takes them from the A
-# fragments it multiplies (v_dot2c in MFMA gaps: no pass over the stream, no statistics loads in its epilogue); "pass" =
-# row_stats16 reads the 16-bit rows back (98 MB, 21 us per LayerNorm); "epilogue" = the producer GEMM takes them per 64-column
-# segment while the rows pass through its registers + a finalize kernel (costs the residual GEMMs more than the pass it removes).
-LN_STATS = os.environ.get("LA_LN_STATS", "loop")
+# Row statistics of the folded LayerNorm: "pass" (default) = row_stats16 reads the 16-bit rows back (98 MB, 21 us per LayerNorm);
+# "loop" = the CONSUMER GEMM's main loop takes them from the A fragments it multiplies (v_dot2c in MFMA gaps: no pass over the
+# stream, no statistics loads in its epilogue -- but 16 more vector instructions per k-step in a loop that is issue- and
+# power-bound: the QKV / MLP-up launches run ~7 % slower, 42.7 against 42.2 ms per step, profiles/r4_ab_ln_stats_in_loop.txt);
+# "epilogue" = the producer GEMM takes them per 64-column segment while the rows pass through its registers + a finalize kernel
+# (costs the residual GEMMs more than the pass it removes).
+LN_STATS = os.environ.get("LA_LN_STATS", "pass")
 LN_STATS_IN_EPILOGUE = LN_STATS == "epilogue"
 # With the LayerNorm fold the residual stream is kept SPLIT (ops.gemm_split: hi 16-bit = the next GEMM's raw operand, + one lo byte
 # per element) instead of f32 with a 16-bit copy beside it; 0 = the f32 stream (the A/B partner; la_model.cpp reads the same switch).

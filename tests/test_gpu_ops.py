@@ -570,7 +570,9 @@ def test_gemm_split_stream_matches_the_f32_stream(dtype):
     ops.gemm(a2, w2, x1, bias=bias, residual=x1, out_f32=True, out16=h1)
     ops.gemm_split(a2, w2, hi, lo, bias=bias, in_place=True)
     assert torch.equal(hi.view(torch.int16), h1.view(torch.int16))
-    assert bool(((ops.split_decode(hi, lo) - x1).abs() <= 0.505 * unit(hi) + 2.4e-7 * x1.abs()).all())
+    # (+ an f32 ulp of the LARGER of old and new value: the kernel decodes the old stream with one fused multiply-add where torch
+    #  rounds twice, and x0 + delta may cancel to something whose lo step is smaller than that ulp)
+    assert bool(((ops.split_decode(hi, lo) - x1).abs() <= 0.505 * unit(hi) + 2.4e-7 * torch.maximum(x1.abs(), x0.abs())).all())
     # ln_part (statistics of the hi rows from inside the epilogue) and LayerNorm over the decoded rows
     part = torch.empty(N // 64, M, 2, device="cuda")
     hi2, lo2 = hi.clone(), lo.clone()
