@@ -580,6 +580,12 @@ __global__ __launch_bounds__(PP::THREADS, 2) void gemm_pp_kernel(GemmParams p) {
     const float bias_l = has_bias ? bias[ncol] : 0.f;
     float csum_l = 0.f;
     if constexpr (LNM == 2 || LNM == 4) csum_l = p.ln_csum[ncol];
+    // LNM == 2: the tile's 256 row statistics are requested here too (32 rows per wave) and handed to the epilogue through LDS after
+    // the main loop: loaded inside the epilogue they were one exposed L2 round trip per pass of 32 rows, four per tile.
+    float2 st_pre = make_float2(0.f, 1.f);
+    if constexpr (LNM == 2) {
+        if (lane < 32) st_pre = reinterpret_cast<const float2 *>(p.ln_stats)[min(m0 + wr * 128 + wc * 32 + lane, p.M - 1)];
+    }
 
     f32x4 acc[8][4];
 #ifdef LA_TILE_STAMPS
@@ -614,13 +620,16 @@ __global__ __launch_bounds__(PP::THREADS, 2) void gemm_pp_kernel(GemmParams p) {
     } else {
         mainloop_pp<T16>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc);
     }
+    if constexpr (LNM == 2) {
+        if (lane < 32) stats_tab[wr * 128 + wc * 32 + lane] = st_pre;       // (both main loops end behind a barrier: slot 3 is free)
+    }
 #ifdef LA_TILE_STAMPS
     const unsigned long long stamp_t2 = __builtin_amdgcn_s_memrealtime();
 #endif
 
     __syncthreads();
     if constexpr (LNM == 3) wave_epilogue_split<T16>(p, z, acc, m0 + wr * 128, n0 + wc * 64, has_bias, bias_l, lds + wave * (32 * EPI_PITCH));
-    else wave_epilogue<OUT_F32, T16, LNM>(p, z, acc, m0 + wr * 128, n0 + wc * 64, has_bias, bias_l, csum_l, lds + wave * (32 * EPI_PITCH), stats_tab, m0);
+    else wave_epilogue<OUT_F32, T16, LNM == 2 ? 4 : LNM>(p, z, acc, m0 + wr * 128, n0 + wc * 64, has_bias, bias_l, csum_l, lds + wave * (32 * EPI_PITCH), stats_tab, m0);
 #ifdef LA_TILE_STAMPS
     if (threadIdx.x == 0 && g_tile_stamps) {
         unsigned long long *o = g_tile_stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
