@@ -387,7 +387,7 @@ def finetune_mode(args, rank, world, local_rank, device, dist):
     torch.manual_seed(0)                       # the head's torch-default initialisation: identical on every rank
     model = AlignModel(wm, embed_dim=dims.n_audio_state, hidden_dim=HIDDEN, output_dim=VOCAB, dropout=0.15, train_transcript=True,
                        device=f"cuda:{local_rank}").to(device)
-    tuner = ft.FineTuner(model, warmup_steps=1, train_steps=10000)
+    tuner = ft.FineTuner(model, warmup_steps=1, train_steps=10000, allreduce_chunks=args.allreduce_chunks)
     B, n_tok = 2, 32
     rs = np.random.RandomState(114514 + rank)   # reference seed (train_multitask.py:136-139) + rank: every rank its own clips
     audios = [(rs.randn(480000) * 0.1).astype(np.float32) for _ in range(B)]
@@ -405,14 +405,21 @@ def finetune_mode(args, rank, world, local_rank, device, dist):
     def step(timed):
         # the accumulation loop of train_step: fused = ONE forward / backward over the accum x 2 clips, per-micro-batch losses
         # (FineTuner.accumulate; --accum-mode loop = accum separate micro-steps, the round-1/2 form)
+        # the exchange step of the data-parallel path rides on the last backward (finetune.OverlappedAllReduce: chunks of the flat
+        # buckets are all-reduced as autograd completes them); step() waits for it -- what is left exposed is bracketed there
         tuner.accumulate([micro] * args.accum, accum_grad_steps=args.accum, fused=args.accum_mode == "fused")
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        ft.allreduce_mean_(tuner.grad, tuner.world)          # the one exchange step of the data-parallel path
-        e1.record()
-        if timed:
-            ar_events.append((e0, e1))
-        tuner.step(allreduced=True)
+        if tuner.overlap is None:               # --allreduce-chunks 0: one blocking all-reduce per bucket, bracketed here
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            ft.allreduce_mean_(tuner.grad, tuner.world)
+            e1.record()
+            if timed:
+                ar_events.append((e0, e1))
+            tuner.step(allreduced=True)
+            return
+        tuner.step()
+        if timed and getattr(tuner.overlap, "_events", None) is not None:
+            ar_events.append(tuner.overlap._events)
 
     for _ in range(args.warmup):
         step(False)
@@ -460,11 +467,13 @@ def finetune_mode(args, rank, world, local_rank, device, dist):
             "config": {"workload": f"whisper-{args.model} multitask fine-tune step, per-GPU micro-batch {B} x 30 s x accum {args.accum} "
                                    "(BASELINE.json configs[2])", "mode": "finetune", "micro_batch": B, "accum": args.accum, "accum_mode": args.accum_mode,
                        "decoder_tokens": n_tok, "grad_bytes_per_step": grad_bytes,
-                       "sharding": "clips over ranks; one all-reduce (sum) per flat gradient bucket per optimizer step"},
+                       "sharding": f"clips over ranks; the flat gradient buckets all-reduced (sum) once per optimizer step in >= {args.allreduce_chunks} "
+                                   "chunks, each as soon as the last backward has completed it (overlapped with the rest of that backward)"},
             "micro_step_ms": (elapsed / args.steps * 1e3 - ar_ms) / args.accum,
             "allreduce_ms_per_step": ar_ms,
-            # bus bandwidth of the ring all-reduce: 2 (N - 1) / N x the gradient bytes cross every rank's links per step
-            "allreduce_GBps": (2.0 * (world - 1) / world * grad_bytes / (ar_ms * 1e-3) / 1e9) if (world > 1 and ar_ms > 0) else None,
+            "allreduce_exposed_ms": ar_ms,      # what the exchange costs on the compute stream after the overlap (0 at N = 1)
+            # bus bandwidth of the ring all-reduce (only meaningful for the blocking form, --allreduce-chunks 0)
+            "allreduce_GBps": (2.0 * (world - 1) / world * grad_bytes / (ar_ms * 1e-3) / 1e9) if (world > 1 and ar_ms > 0 and args.allreduce_chunks == 0) else None,
             "roofline": {"bound": "mfma", "kernel": "gemm_kernel<float> (v_mfma_f32_16x16x4_f32; every Linear forward + both backward products)",
                          "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s", "frac": achieved / 157.3, "traffic": None,
                          "launches_per_step": seen.value / max(args.steps, 1), "avg_launch_ms": total_ms.value / max(launches.value, 1),
@@ -612,6 +621,9 @@ def main():
     ap.add_argument("--songs", type=int, default=16, help="longform mode: 180 s songs per GPU and step")
     ap.add_argument("--model", default=MODEL, help="finetune mode only: whisper architecture (medium = configs[2])")
     ap.add_argument("--accum", type=int, default=8, help="finetune mode: micro-steps per optimizer step (reference default 8)")
+    ap.add_argument("--allreduce-chunks", type=int, default=4,
+                    help="finetune mode: chunks the backbone gradient bucket is all-reduced in, each launched as the last backward completes it "
+                         "(0 = one blocking all-reduce per bucket after the backward)")
     ap.add_argument("--accum-mode", choices=["fused", "loop"], default="fused",
                     help="finetune mode: the accum micro-batches as one fused forward / backward (per-micro-batch losses) or as a loop")
     ap.add_argument("--from-waveform", action="store_true",

@@ -274,6 +274,74 @@ def test_gradient_allreduce_world_size_2_gloo(tmp_path):
         np.testing.assert_allclose([o["hs"], o["bs"]], [float(h.sum()), float(b.sum())], rtol=1e-5)
 
 
+_WORKER_OVERLAP = r'''
+import os, sys, json
+sys.path.insert(0, %(root)r)
+import torch, torch.distributed as dist
+from lyricalignment_amd.finetune import OverlappedAllReduce, allreduce_mean_
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group(backend="gloo", init_method="tcp://127.0.0.1:%(port)d", rank=rank, world_size=world)
+torch.manual_seed(7)
+net = torch.nn.Sequential(*[torch.nn.Linear(96, 96) for _ in range(8)], torch.nn.Linear(96, 4))        # 18 parameters, ~75 k elements
+unused = torch.nn.Parameter(torch.zeros(5000))               # a parameter the backward never reaches (a frozen branch)
+groups = [[net[-1].weight, net[-1].bias], [p for m in net[:-1] for p in m.parameters()] + [unused]]
+flat, grad = [], []
+for params in groups:                                        # FineTuner's bucket construction: .data / .grad are views
+    n = sum(p.numel() for p in params)
+    f, g = torch.empty(n), torch.zeros(n)
+    off = 0
+    for p in params:
+        f[off: off + p.numel()].copy_(p.detach().reshape(-1)); p.data = f[off: off + p.numel()].view_as(p); p.grad = g[off: off + p.numel()].view_as(p)
+        off += p.numel()
+    flat.append(f); grad.append(g)
+ov = OverlappedAllReduce(groups, grad, world, min_chunks=4)
+x = torch.randn(16, 96, generator=torch.Generator().manual_seed(50 + rank))
+launched_during = []
+for step in range(2):                                        # second step: hooks disarm and re-arm
+    for g in grad: g.zero_()
+    net(x).square().sum().backward()                         # an earlier micro-step: accumulates, nothing may be sent
+    assert not ov.launched_any()
+    ov.arm()
+    net(x * 0.5).square().sum().backward()                   # the last micro-step: chunks leave as they complete
+    launched_during.append(sum(ov._launched))
+    ov.finish()
+    mine = [g.clone() for g in grad]
+    ref = []
+    for g in grad: g.zero_()
+    net(x).square().sum().backward(); net(x * 0.5).square().sum().backward()
+    allreduce_mean_(grad, world)                             # the single blocking all-reduce per bucket
+    same = all(torch.equal(a, b) for a, b in zip(mine, grad))
+print(json.dumps({"rank": rank, "chunks": len(ov.chunks), "launched_during": launched_during, "same": same,
+                  "sum": float(sum(float(g.double().sum()) for g in mine))}))
+dist.destroy_process_group()
+'''
+
+
+def test_overlapped_gradient_allreduce_world_size_2_gloo(tmp_path):
+    """finetune.OverlappedAllReduce on CPU / gloo, 2 ranks: the flat buckets are cut at parameter boundaries into >= 4 chunks for
+    the large bucket, every chunk whose parameters all received their gradient in the ARMED backward is all-reduced from the
+    post-accumulate hook (during that backward), the chunk holding a parameter the backward never reaches is reduced by
+    finish(); nothing is sent during an un-armed (earlier micro-step's) backward; the result is bit-equal to one blocking
+    all-reduce per bucket, on both ranks, two optimizer steps in a row."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "worker_ov.py"
+    script.write_text(_WORKER_OVERLAP % {"root": ROOT, "port": port})
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=180)
+        assert p.returncode == 0, e[-2000:]
+        outs.append(json.loads(o.strip().splitlines()[-1]))
+    for o in outs:
+        assert o["same"] and o["chunks"] >= 5                           # head bucket 1 chunk + backbone >= 4
+        assert all(0 < n < o["chunks"] for n in o["launched_during"])   # some during the backward, the unreached one at finish()
+    assert outs[0]["sum"] == outs[1]["sum"]
+
+
 def test_frame_labels_and_records_match_reference(tmp_path):
     from lyricalignment_amd import data
     for c in load_json("frame_labels.json")["cases"]:
