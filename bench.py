@@ -51,7 +51,7 @@ def total_flops_per_clip(d: int, n_layer: int, H: int = HIDDEN, V: int = VOCAB) 
     return float(enc + gru + 2 * T * 2 * H * V)
 
 
-PMC_SUMMARY = "r3f_pmc_gemm_pp.csv"   # FETCH_SIZE / WRITE_SIZE passes over bench.py itself (end of round 3)
+PMC_SUMMARY = "r4_pmc_gemm_pp.csv"   # FETCH_SIZE / WRITE_SIZE passes over bench.py itself (round 4: split residual stream)
 
 
 def measured_gemm_traffic_per_launch():
