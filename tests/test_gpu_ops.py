@@ -558,8 +558,9 @@ def test_gemm_split_stream_matches_the_f32_stream(dtype):
     ops.gemm_split(a, w, hi, lo, bias=bias, residual=res, gelu=True)
     assert torch.equal(hi.view(torch.int16), h.view(torch.int16))
     dec = ops.split_decode(hi, lo)
-    # (half a lo unit + an f32 ulp or two: the two instantiations may contract GELU's last multiply with the residual add differently)
-    assert bool(((dec - x).abs() <= 0.505 * unit(hi) + 2.4e-7 * x.abs()).all())
+    # (half a lo step + a few f32 ulps: the two instantiations may contract GELU's last multiply with the residual add differently,
+    #  and with f16 the lo step is only 32 f32 ulps)
+    assert bool(((dec - x).abs() <= 0.505 * unit(hi) + 1e-6 * x.abs()).all())
     assert float((dec - x).abs().max()) < float((h.float() - x).abs().max()) / 100          # 8 more bits than the 16-bit copy alone
     # in-place form: the stream is its own residual
     a2 = (torch.randn(M, K, device="cuda", generator=g)).to(dtype)
@@ -572,7 +573,7 @@ def test_gemm_split_stream_matches_the_f32_stream(dtype):
     assert torch.equal(hi.view(torch.int16), h1.view(torch.int16))
     # (+ an f32 ulp of the LARGER of old and new value: the kernel decodes the old stream with one fused multiply-add where torch
     #  rounds twice, and x0 + delta may cancel to something whose lo step is smaller than that ulp)
-    assert bool(((ops.split_decode(hi, lo) - x1).abs() <= 0.505 * unit(hi) + 2.4e-7 * torch.maximum(x1.abs(), x0.abs())).all())
+    assert bool(((ops.split_decode(hi, lo) - x1).abs() <= 0.505 * unit(hi) + 1e-6 * torch.maximum(x1.abs(), x0.abs())).all())
     # ln_part (statistics of the hi rows from inside the epilogue) and LayerNorm over the decoded rows
     part = torch.empty(N // 64, M, 2, device="cuda")
     hi2, lo2 = hi.clone(), lo.clone()
