@@ -125,11 +125,13 @@ template <> struct Pack4<_Float16> {
 template <typename T16> struct SplitRes;
 template <> struct SplitRes<bf16_t> {
     static constexpr int SH = 16;                                    // unit = 2^(E - 7 - 8), frexp exponent e = E + 1
+    static constexpr int EMIN = -200;                                // (bf16 subnormals start at 2^-126: never a residual value)
     __device__ static __forceinline__ float hi_f32(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
     __device__ static __forceinline__ unsigned short round16(float x) { return f32_to_bf16(x); }
 };
 template <> struct SplitRes<_Float16> {
     static constexpr int SH = 19;                                    // unit = 2^(E - 10 - 8)
+    static constexpr int EMIN = -13;                                 // f16 subnormals (|hi| < 2^-14) all have the ulp of E = -14
     __device__ static __forceinline__ float hi_f32(unsigned short b) { return (float)__builtin_bit_cast(_Float16, b); }
     __device__ static __forceinline__ unsigned short round16(float x) { return __builtin_bit_cast(unsigned short, (_Float16)x); }
 };
@@ -137,13 +139,15 @@ template <> struct SplitRes<_Float16> {
 constexpr float kSplitStep = 128.0f / 127.0f;
 template <typename T16> __device__ __forceinline__ float split_decode(unsigned short hb, float q) {
     const float hf = SplitRes<T16>::hi_f32(hb);
-    return hf + __builtin_amdgcn_ldexpf(fmaf(q, kSplitStep, -128.0f * kSplitStep), __builtin_amdgcn_frexp_expf(hf) - SplitRes<T16>::SH);
+    const int e = SplitRes<T16>::EMIN > -100 ? max(__builtin_amdgcn_frexp_expf(hf), SplitRes<T16>::EMIN) : __builtin_amdgcn_frexp_expf(hf);
+    return hf + __builtin_amdgcn_ldexpf(fmaf(q, kSplitStep, -128.0f * kSplitStep), e - SplitRes<T16>::SH);
 }
 // x -> hi bits; q = the lo byte before rounding (1 .. 255 for |x - hi| <= ulp / 2; v_cvt_pk_u8_f32 rounds to nearest and saturates)
 template <typename T16> __device__ __forceinline__ unsigned short split_encode(float x, float &q) {
     const unsigned short hb = SplitRes<T16>::round16(x);
     const float hf = SplitRes<T16>::hi_f32(hb);
-    q = fmaf(__builtin_amdgcn_ldexpf(x - hf, SplitRes<T16>::SH - __builtin_amdgcn_frexp_expf(hf)), 127.0f / 128.0f, 128.0f);
+    const int e = SplitRes<T16>::EMIN > -100 ? max(__builtin_amdgcn_frexp_expf(hf), SplitRes<T16>::EMIN) : __builtin_amdgcn_frexp_expf(hf);
+    q = fmaf(__builtin_amdgcn_ldexpf(x - hf, SplitRes<T16>::SH - e), 127.0f / 128.0f, 128.0f);
     return hb;
 }
 __device__ __forceinline__ unsigned pack_u8x4(float a, float b, float c, float d) {

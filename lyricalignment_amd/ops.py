@@ -254,6 +254,8 @@ def split_decode(hi: torch.Tensor, lo: torch.Tensor) -> torch.Tensor:
     hf = hi.float()
     _, e = torch.frexp(hf)
     sh = 16 if hi.dtype == torch.bfloat16 else 19
+    if hi.dtype == torch.float16:
+        e = e.clamp(min=-13)                       # f16 subnormals share the ulp of the smallest normal binade
     step = torch.tensor(128.0 / 127.0, dtype=torch.float32, device=hi.device)
     return hf + torch.ldexp(torch.addcmul(-128.0 * step, lo.float(), step), e.to(torch.int32) - sh)
 
