@@ -2,7 +2,10 @@
 // the GRU input projections (whisper.model.AudioEncoder; module/align_model.py:23-33).
 // Main loop: la_gemm_core.h.  bf16 operands use v_mfma_f32_16x16x32_bf16, f32 operands
 // v_mfma_f32_16x16x4_f32 (exact fmaf chains: the parity mode).
+#include <algorithm>
+#include <mutex>
 #include <type_traits>
+#include <vector>
 
 #include "la_gemm_core.h"
 #include "la_gemm_pp.h"
@@ -273,12 +276,23 @@ __device__ __forceinline__ void epi_quad(f32x4 &v, const float (&b4)[4], const f
 // instantiations (QKV, MLP-up) sat at 256 VGPRs with 107-127 spilled registers and 112 B of scratch per lane.
 // LNM = 4: as 2, with the row statistics taken by the main loop itself (mainloop_duo_asm STAT_WC) and left in LDS: stats_tab[row
 // of the tile] = (mean, rstd), tile_m0 = the tile's first row.
-template <bool OUT_F32, typename T16, int LNM>
+// STG: how an interior wave tile is staged through LDS on its way to the row-major layout.  0 = passes of 32 rows, row pitch 272 B
+// (8.5 KiB per wave at `reg`); 1 = passes of 16 rows in 4 KiB per wave, 256-byte rows with the 16-byte chunks XOR-swizzled by the row
+// (chunk c of row r at c ^ r: conflict-free for the transposing b128 writes and the row-major b128 reads) -- the persistent kernel's
+// form: 8 x 4 KiB = 32 KiB beside the four ring slots, so the NEXT tile's first stages can land in the ring under this epilogue.
+// Edge wave tiles always take the element-wise path below with the 32-row staging.
+template <bool OUT_F32, typename T16, int LNM, int STG = 0>
 __device__ __forceinline__ void wave_epilogue(const GemmParams &p, int z, f32x4 (&acc)[8][4], int wrow0, int wcol0, bool has_bias,
                                               float bias_l, float csum_l, unsigned char *reg, const float2 *stats_tab = nullptr,
-                                              int tile_m0 = 0) {
-    constexpr bool LNC = LNM == 2 || LNM == 4;               // LayerNorm consumer
-    const int lane = threadIdx.x & 63;
+                                              int tile_m0 = 0, unsigned char *reg_edge = nullptr, float2 sr0 = float2{0.f, 1.f},
+                                              float2 sr1 = float2{0.f, 1.f}, int lane_in = -1) {
+    // LNM = 5 (persistent kernel: no LDS left for a statistics table): the statistics of the wave's 128 rows sit in the wave's own
+    // registers -- sr0 = (mean, rstd) of row `lane`, sr1 of row 64 + lane -- and reach the lane that needs them by ds_bpermute.
+    constexpr bool LNC = LNM == 2 || LNM == 4 || LNM == 5;   // LayerNorm consumer
+    constexpr int NPASS = STG ? 8 : 4, NIT = STG ? 4 : 8, RP = STG ? 16 : 32;    // passes per wave tile, row quads and rows per pass
+    // (lane_in: the persistent kernel hands in a lane id it has made opaque per tile, so that hipcc does not hoist this function's
+    //  lane arithmetic out of the tile loop and keep it alive across the main loop, where every register is spoken for)
+    const int lane = lane_in >= 0 ? lane_in : (int)(threadIdx.x & 63);
     const int r = lane & 15, q = lane >> 4;
     typedef typename std::conditional<OUT_F32, float, T16>::type TC;
     TC *C = reinterpret_cast<TC *>(p.C) + (int64_t)z * p.strideC;
@@ -313,38 +327,54 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams &p, int z, f32x4 
         auto fast = [&](auto resc) {
             constexpr bool RES = decltype(resc)::value;
 #pragma unroll
-            for (int h = 0; h < 4; ++h) {
-                float4 t[8];
-                float2 st[8];
+            for (int h = 0; h < NPASS; ++h) {
+                float4 t[NIT];
+                float2 st[NIT];
                 if constexpr (RES) {
                     if (epi & (1 << 16)) {                 // developer probe (LA_EPI_PROBE & 1): no residual loads
 #pragma unroll
-                        for (int it = 0; it < 8; ++it) t[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        for (int it = 0; it < NIT; ++it) t[it] = make_float4(0.f, 0.f, 0.f, 0.f);
                     } else {
 #pragma unroll
-                        for (int it = 0; it < 8; ++it) t[it] = *reinterpret_cast<const float4 *>(rw + (int64_t)(h * 32 + it * 4 + q) * p.ldr);
+                        for (int it = 0; it < NIT; ++it) t[it] = *reinterpret_cast<const float4 *>(rw + (int64_t)(h * RP + it * 4 + q) * p.ldr);
                     }
                 }
                 if constexpr (LNM == 2) {
 #pragma unroll
-                    for (int it = 0; it < 8; ++it) st[it] = stats[wrow0 + h * 32 + it * 4 + q];
+                    for (int it = 0; it < NIT; ++it) st[it] = stats[wrow0 + h * RP + it * 4 + q];
                 }
                 if constexpr (LNM == 4) {
 #pragma unroll
-                    for (int it = 0; it < 8; ++it) st[it] = stats_tab[wrow0 - tile_m0 + h * 32 + it * 4 + q];
+                    for (int it = 0; it < NIT; ++it) st[it] = stats_tab[wrow0 - tile_m0 + h * RP + it * 4 + q];
                 }
+                if constexpr (LNM == 5) {
 #pragma unroll
-                for (int mm = 0; mm < 2; ++mm)
+                    for (int it = 0; it < NIT; ++it) {
+                        const int src = (((h * RP + it * 4) & 63) + q) * 4;
+                        const float2 sr = h * RP >= 64 ? sr1 : sr0;
+                        st[it] = make_float2(__int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(sr.x))),
+                                             __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(sr.y))));
+                    }
+                }
+                if constexpr (STG == 0) {
+#pragma unroll
+                    for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                        for (int ni = 0; ni < 4; ++ni)
+                            *reinterpret_cast<f32x4 *>(reg + (mm * 16 + r) * PITCH + (ni * 16 + q * 4) * 4) = acc[2 * h + mm][ni];
+                } else {
 #pragma unroll
                     for (int ni = 0; ni < 4; ++ni)
-                        *reinterpret_cast<f32x4 *>(reg + (mm * 16 + r) * PITCH + (ni * 16 + q * 4) * 4) = acc[2 * h + mm][ni];
+                        *reinterpret_cast<f32x4 *>(reg + r * 256 + (((ni * 4 + q) ^ r) << 4)) = acc[h][ni];
+                }
 #pragma unroll
-                for (int it = 0; it < 8; ++it) {
+                for (int it = 0; it < NIT; ++it) {
                     const int rl = it * 4 + q;
-                    f32x4 v = *reinterpret_cast<const f32x4 *>(reg + rl * PITCH + r * 16);
+                    f32x4 v = STG == 0 ? *reinterpret_cast<const f32x4 *>(reg + rl * PITCH + r * 16)
+                                       : *reinterpret_cast<const f32x4 *>(reg + rl * 256 + ((r ^ rl) << 4));
                     epi_quad<OUT_F32, LNC ? 2 : LNM>(v, b4, cs4, LNC ? st[it] : make_float2(0.f, 0.f), has_bias, do_gelu, epi);
                     if constexpr (RES) { v[0] += t[it].x; v[1] += t[it].y; v[2] += t[it].z; v[3] += t[it].w; }
-                    const int64_t off = (int64_t)(h * 32 + rl) * p.ldc;
+                    const int64_t off = (int64_t)(h * RP + rl) * p.ldc;
                     TC *c = cw + off;
                     if constexpr (sizeof(TC) == 4) {
                         if (!(epi & (2 << 16)) || v[0] == 12345.678f)      // developer probe (LA_EPI_PROBE & 2): no f32 store
@@ -355,7 +385,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams &p, int z, f32x4 
                                 *reinterpret_cast<ushort4 *>(c2w + off) = pk;
                             if (part) {
                                 const float2 sg = segment_stats<T16>(pk);
-                                if (r == 0) part[h * 32 + rl] = sg;
+                                if (r == 0) part[h * RP + rl] = sg;
                             }
                         }
                     } else {
@@ -369,6 +399,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams &p, int z, f32x4 
     }
     T16 *C2 = nullptr;
     if constexpr (LNM == 1 && OUT_F32) C2 = reinterpret_cast<T16 *>(p.C2) + (int64_t)z * p.strideC;
+    if (reg_edge) reg = reg_edge;                            // (STG 1 callers: the 32-row staging lives elsewhere)
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
 #pragma unroll
@@ -385,6 +416,12 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams &p, int z, f32x4 
             float2 st = make_float2(0.f, 0.f);
             if constexpr (LNM == 2) st = stats[min(m, p.M - 1)];
             if constexpr (LNM == 4) st = stats_tab[wrow0 - tile_m0 + h * 32 + rl];
+            if constexpr (LNM == 5) {
+                const int src = (((h * 32 + it * 4) & 63) + q) * 4;
+                const float2 sr = h * 32 >= 64 ? sr1 : sr0;
+                st = make_float2(__int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(sr.x))),
+                                 __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(sr.y))));
+            }
             epi_quad<OUT_F32, LNC ? 2 : LNM>(v, b4, cs4, st, has_bias, do_gelu, epi);
             if (m >= p.M || n >= p.N) continue;
             const int nv = min(4, p.N - n);
@@ -424,10 +461,11 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams &p, int z, f32x4 
 // element through HBM instead of the 4 + 4 + 2 of wave_epilogue's f32 stream with a 16-bit copy.  Same staging (through the
 // wave's LDS region, row-major quads), same order of operations on the f32 values as wave_epilogue<true, T16, 1>.
 constexpr int LA_EPI_SPLIT_INPLACE = 1 << 20;    // internal: the residual is the split stream itself
-template <typename T16>
+template <typename T16, int STG = 0>
 __device__ __forceinline__ void wave_epilogue_split(const GemmParams &p, int z, f32x4 (&acc)[8][4], int wrow0, int wcol0, bool has_bias,
-                                                    float bias_l, unsigned char *reg) {
-    const int lane = threadIdx.x & 63;
+                                                    float bias_l, unsigned char *reg, unsigned char *reg_edge = nullptr, int lane_in = -1) {
+    constexpr int NPASS = STG ? 8 : 4, NIT = STG ? 4 : 8, RP = STG ? 16 : 32;    // as wave_epilogue
+    const int lane = lane_in >= 0 ? lane_in : (int)(threadIdx.x & 63);
     const int r = lane & 15, q = lane >> 4;
     unsigned char *LO = reinterpret_cast<unsigned char *>(p.C) + (int64_t)z * p.strideC;
     T16 *HI = reinterpret_cast<T16 *>(p.C2) + (int64_t)z * p.strideC;
@@ -452,31 +490,38 @@ __device__ __forceinline__ void wave_epilogue_split(const GemmParams &p, int z, 
         auto fast = [&](auto rkc) {
             constexpr int RK = decltype(rkc)::value;             // 0: no residual, 1: f32 rows, 2: the split stream in place
 #pragma unroll
-            for (int h = 0; h < 4; ++h) {
-                float4 t[8];
-                ushort4 th[8];
-                unsigned tl[8];
+            for (int h = 0; h < NPASS; ++h) {
+                float4 t[NIT];
+                ushort4 th[NIT];
+                unsigned tl[NIT];
                 if constexpr (RK == 1) {
 #pragma unroll
-                    for (int it = 0; it < 8; ++it) t[it] = *reinterpret_cast<const float4 *>(rw + (int64_t)(h * 32 + it * 4 + q) * p.ldr);
+                    for (int it = 0; it < NIT; ++it) t[it] = *reinterpret_cast<const float4 *>(rw + (int64_t)(h * RP + it * 4 + q) * p.ldr);
                 }
                 if constexpr (RK == 2) {
 #pragma unroll
-                    for (int it = 0; it < 8; ++it) {
-                        const int64_t off = (int64_t)(h * 32 + it * 4 + q) * p.ldc;
+                    for (int it = 0; it < NIT; ++it) {
+                        const int64_t off = (int64_t)(h * RP + it * 4 + q) * p.ldc;
                         th[it] = *reinterpret_cast<const ushort4 *>(hiw + off);
                         tl[it] = *reinterpret_cast<const unsigned *>(low + off);
                     }
                 }
+                if constexpr (STG == 0) {
 #pragma unroll
-                for (int mm = 0; mm < 2; ++mm)
+                    for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                        for (int ni = 0; ni < 4; ++ni)
+                            *reinterpret_cast<f32x4 *>(reg + (mm * 16 + r) * PITCH + (ni * 16 + q * 4) * 4) = acc[2 * h + mm][ni];
+                } else {
 #pragma unroll
                     for (int ni = 0; ni < 4; ++ni)
-                        *reinterpret_cast<f32x4 *>(reg + (mm * 16 + r) * PITCH + (ni * 16 + q * 4) * 4) = acc[2 * h + mm][ni];
+                        *reinterpret_cast<f32x4 *>(reg + r * 256 + (((ni * 4 + q) ^ r) << 4)) = acc[h][ni];
+                }
 #pragma unroll
-                for (int it = 0; it < 8; ++it) {
+                for (int it = 0; it < NIT; ++it) {
                     const int rl = it * 4 + q;
-                    f32x4 v = *reinterpret_cast<const f32x4 *>(reg + rl * PITCH + r * 16);
+                    f32x4 v = STG == 0 ? *reinterpret_cast<const f32x4 *>(reg + rl * PITCH + r * 16)
+                                       : *reinterpret_cast<const f32x4 *>(reg + rl * 256 + ((r ^ rl) << 4));
                     epi_quad<true, 0>(v, b4, cs4, make_float2(0.f, 0.f), has_bias, do_gelu, epi);
                     if constexpr (RK == 1) { v[0] += t[it].x; v[1] += t[it].y; v[2] += t[it].z; v[3] += t[it].w; }
                     if constexpr (RK == 2) {
@@ -490,12 +535,12 @@ __device__ __forceinline__ void wave_epilogue_split(const GemmParams &p, int z, 
                     ushort4 pk;
                     pk.x = la::split_encode<T16>(v[0], q0); pk.y = la::split_encode<T16>(v[1], q1);
                     pk.z = la::split_encode<T16>(v[2], q2); pk.w = la::split_encode<T16>(v[3], q3);
-                    const int64_t off = (int64_t)(h * 32 + rl) * p.ldc;
+                    const int64_t off = (int64_t)(h * RP + rl) * p.ldc;
                     *reinterpret_cast<ushort4 *>(hiw + off) = pk;
                     *reinterpret_cast<unsigned *>(low + off) = la::pack_u8x4(q0, q1, q2, q3);
                     if (part) {
                         const float2 sg = segment_stats<T16>(pk);
-                        if (r == 0) part[h * 32 + rl] = sg;
+                        if (r == 0) part[h * RP + rl] = sg;
                     }
                 }
             }
@@ -506,6 +551,7 @@ __device__ __forceinline__ void wave_epilogue_split(const GemmParams &p, int z, 
         return;
     }
     // edge wave tiles (the last row of tiles of M = 48000 = 187.5 x 256, any unaligned call): element by element
+    if (reg_edge) reg = reg_edge;
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
 #pragma unroll
@@ -641,6 +687,168 @@ __global__ __launch_bounds__(PP::THREADS, 2) void gemm_pp_kernel(GemmParams p) {
         o[6] = tile;
     }
 #endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// PERSISTENT form of the 256x256 kernel (round 4; hand-placed main loop, batch 1, 16-bit operands).
+// tools/tile_timeline.py: 26-43 % of a K = 1024 tile's time on its CU is not the main loop -- 2.4-3.0 us of prologue (waiting for its
+// first two stages), the epilogue, and 1.1-4.0 us until the next workgroup enters (a wave retires only when its stores are
+// acknowledged).  Here a workgroup stays: it DRAWS tiles from a ticket counter (one per XCD, so an XCD keeps walking its own
+// contiguous run of tile ids -- the L2 sharing of the hardware-dispatched form -- and steals from the next XCD's run when its own
+// is empty), and before it starts a tile's epilogue it has already issued the NEXT tile's stages 0 .. 3 into the ring: they land
+// under the epilogue, the epilogue's stores drain under the next main loop (duo_run PREFETCHED: its first waits are counted
+// so that no store is forced), and nothing waits for a dispatch.  Dynamic tickets keep what the dispatcher gives for free: a
+// workgroup that starts late (CUs held by the head stream's resident recurrence) simply draws fewer tiles.
+//   * Ticket: wave 0 issues a returning atomic at the TOP of a tile's main loop and reads it at the end (in flight ~1 us, the loop
+//     takes 25-100).  The result lands asynchronously, so it is parked in a register hipcc does not manage across that span: the
+//     physical v255, named in both asm statements and as their clobber (the kernel's other values sit in v0 .. ~v240; the build
+//     checks the assembly: v255 may not be written between the two).  An AGPR would be the natural home, but any AGPR use makes
+//     hipcc split the 256-register budget 128 / 128 and spill ~550 registers.  Broadcast through one LDS word, two barriers.
+//   * LDS: all 160 KiB -- ring slots [0, 128 K) and 8 x 4 KiB of epilogue staging behind them (wave_epilogue STG = 1); the LayerNorm
+//     statistics travel in registers (LNM = 5).  A partial (edge) tile takes the element-wise epilogue with its 32-row staging at the
+//     ring's front, so nothing is prefetched before it.
+//   * Exit: the last workgroup to leave (a second counter) zeroes the tickets for the next launch on the stream.
+struct PersistTickets { unsigned head[8]; unsigned done; unsigned pad[7]; };
+
+template <bool OUT_F32, typename T16, int LNM>
+__global__ __launch_bounds__(PP::THREADS, 2) void gemm_pp_persist_kernel(GemmParams p, PersistTickets *tk) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int EM = LNM == 2 ? 5 : LNM;                   // epilogue form: LayerNorm statistics from the wave's registers
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(la::lds_addr_u32(lds));
+    const int nt = p.tiles_m * p.tiles_n;
+    const int q8 = nt >> 3, r8 = nt & 7;
+    unsigned xcc_raw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_raw));
+    int cur_x = (int)(xcc_raw & 7u);                         // the XCD whose run of tile ids this workgroup currently draws from
+    int tried = 0;                                           // runs found empty so far
+    int *tslot = reinterpret_cast<int *>(lds);               // ticket broadcast word (ring slot 0; free whenever it is used)
+    const T16 *A = reinterpret_cast<const T16 *>(p.A);
+    const T16 *W = reinterpret_cast<const T16 *>(p.W);
+    const bool has_bias = (p.epilogue & LA_EPI_BIAS) && p.bias;
+
+    // ticket k of run x -> tile id, or -1 and move on to the next run (wave 0 only; all values wave-uniform)
+    auto resolve = [&](unsigned k) -> int {
+        while (true) {
+            const int len = q8 + (cur_x < r8 ? 1 : 0);
+            if ((int)k < len) return (cur_x < r8 ? cur_x * (q8 + 1) : r8 * (q8 + 1) + (cur_x - r8) * q8) + (int)k;
+            if (++tried >= 8) return -1;
+            cur_x = (cur_x + 1) & 7;
+            unsigned kk = 0;
+            if ((tid & 63) == 0) kk = __hip_atomic_fetch_add(&tk->head[cur_x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            k = __builtin_amdgcn_readfirstlane(kk);
+        }
+    };
+    auto broadcast = [&](int v) -> int {                     // wave 0's value to every wave (the ring is free at both call sites)
+        if (tid == 0) *tslot = v;
+        __syncthreads();
+        const int r = __builtin_amdgcn_readfirstlane(*tslot);
+        __syncthreads();
+        return r;
+    };
+
+    int t = 0;
+    if (wave == 0) {
+        unsigned kk = 0;
+        if ((tid & 63) == 0) kk = __hip_atomic_fetch_add(&tk->head[cur_x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t = resolve(__builtin_amdgcn_readfirstlane(kk));
+    }
+    t = broadcast(t);
+
+    la::gemm::DuoCtx c;
+    float bias_l = 0.f, csum_l = 0.f;
+    float2 sr0 = make_float2(0.f, 1.f), sr1 = make_float2(0.f, 1.f);
+    int m0 = 0, n0 = 0;
+    // everything a tile needs before its main loop: coordinates, DMA addresses, the stages 0 .. 3, the epilogue's per-column /
+    // per-row operands (requested here, used after the loop)
+    auto open_tile = [&](int tile, la::gemm::DuoCtx &cc, int &mm0, int &nn0, float &b_l, float &cs_l, float2 &s0, float2 &s1) {
+        int lane = tid & 63;
+        asm volatile("" : "+v"(lane));                       // (keeps hipcc from hoisting a tile's lane arithmetic across the other tile's loop)
+        const TileCoord tc = tile_coord_mb(tile, p.tiles_m, p.tiles_n, p.group, p.mblock);
+        mm0 = tc.tm * PP::TM; nn0 = tc.tn * PP::TN;
+        la::gemm::duo_setup<T16>(cc, A, p.lda, p.M, W, p.ldw, p.N, mm0, nn0, lds0, wave, lane);
+        la::gemm::duo_issue_prologue(cc);
+        const int ncol = min(nn0 + wc * 64 + lane, p.N - 1);
+        b_l = has_bias ? p.bias[ncol] : 0.f;
+        if constexpr (LNM == 2) {
+            cs_l = p.ln_csum[ncol];
+            const float2 *st = reinterpret_cast<const float2 *>(p.ln_stats);
+            s0 = st[min(mm0 + wr * 128 + lane, p.M - 1)];
+            s1 = st[min(mm0 + wr * 128 + 64 + lane, p.M - 1)];
+        }
+    };
+    if (t >= 0) open_tile(t, c, m0, n0, bias_l, csum_l, sr0, sr1);
+    bool prefetched = false;
+    for (int guard = 0; t >= 0 && guard <= nt; ++guard) {
+        if (wave == 0 && tried < 8) {                        // the next ticket: in flight during the main loop, parked in v255
+            unsigned one = 1;
+            unsigned *hp = &tk->head[cur_x];
+            if ((tid & 63) == 0)
+                asm volatile("global_atomic_add v255, %0, %1, off sc0" ::"v"(hp), "v"(one) : "memory", "v255");
+        }
+        f32x4 acc[8][4];
+#ifdef LA_TILE_STAMPS
+        const unsigned long long ps0 = __builtin_amdgcn_s_memrealtime();
+        unsigned long long ps1 = ps0;
+        if (prefetched) la::gemm::duo_run<T16, -1, true>(c, p.K, acc, ps1);
+        else la::gemm::duo_run<T16, -1, false>(c, p.K, acc, ps1);
+        const unsigned long long ps2 = __builtin_amdgcn_s_memrealtime();
+#else
+        if (prefetched) la::gemm::duo_run<T16, -1, true>(c, p.K, acc);
+        else la::gemm::duo_run<T16, -1, false>(c, p.K, acc);
+#endif
+        int tn = -1;
+        if (wave == 0 && tried < 8) {
+            unsigned kk = 0;
+            asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, v255" : "=v"(kk)::"memory", "v255");
+            tn = resolve(__builtin_amdgcn_readfirstlane(kk));
+        }
+        tn = broadcast(tn);
+        const bool interior = m0 + PP::TM <= p.M && n0 + PP::TN <= p.N;
+        const bool chain = tn >= 0 && interior;
+        la::gemm::DuoCtx cn;
+        float bias_n = 0.f, csum_n = 0.f;
+        float2 sn0 = make_float2(0.f, 1.f), sn1 = make_float2(0.f, 1.f);
+        int mn0 = 0, nn0 = 0;
+        if (chain) open_tile(tn, cn, mn0, nn0, bias_n, csum_n, sn0, sn1);      // its stages land under this tile's epilogue
+        unsigned char *stg = lds + 4 * 32768 + wave * 4096, *stg_edge = lds + wave * (32 * EPI_PITCH);
+#ifdef LA_TILE_STAMPS
+        const unsigned long long ps3 = __builtin_amdgcn_s_memrealtime();
+#endif
+        int lane_e = tid & 63;
+        asm volatile("" : "+v"(lane_e));
+        if constexpr (LNM == 3) wave_epilogue_split<T16, 1>(p, 0, acc, m0 + wr * 128, n0 + wc * 64, has_bias, bias_l, stg, stg_edge, lane_e);
+        else wave_epilogue<OUT_F32, T16, EM, 1>(p, 0, acc, m0 + wr * 128, n0 + wc * 64, has_bias, bias_l, csum_l, stg, nullptr, m0, stg_edge, sr0, sr1, lane_e);
+#ifdef LA_TILE_STAMPS
+        if (tid == 0 && g_tile_stamps) {       // per tile: top of the iteration, first fragments in, main loop done, epilogue begins / ends
+            unsigned long long *o = g_tile_stamps + (size_t)t * 8;
+            unsigned hw_id, xcc_id;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+            o[0] = ps0; o[1] = ps1; o[2] = ps2; o[3] = __builtin_amdgcn_s_memrealtime(); o[4] = hw_id; o[5] = xcc_id; o[6] = ps3; o[7] = prefetched ? 1 : 0;
+        }
+#endif
+        if (tn < 0) break;
+        if (chain) {
+            c = cn; m0 = mn0; n0 = nn0; bias_l = bias_n; csum_l = csum_n; sr0 = sn0; sr1 = sn1;
+        } else {
+            __syncthreads();                                 // an edge tile staged at the ring's front: everyone is done with it
+            open_tile(tn, c, m0, n0, bias_l, csum_l, sr0, sr1);
+        }
+        prefetched = chain;
+        t = tn;
+    }
+    // the last workgroup out re-arms the counters for the next launch on this stream
+    if (tid == 0) {
+        const unsigned prev = __hip_atomic_fetch_add(&tk->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev == gridDim.x - 1) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) __hip_atomic_store(&tk->head[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&tk->done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // Epilogue of the one-wave-per-SIMD kernel: one wave's 128x128 tile, accumulators in the AGPRs.  Per pass of 32 rows the wave
@@ -884,6 +1092,86 @@ int launch_pp_loop(GemmParams p, int batch, hipStream_t stream) {
     return LA_OK;
 }
 
+// Ticket words of the persistent kernel: one block per (device, stream), zeroed when created (on that stream) and left zeroed by
+// every launch's last workgroup.  Launches on one stream are ordered, so a block is never shared by two running kernels.
+PersistTickets *persist_tickets(hipStream_t stream) {
+    struct Slot { int dev; hipStream_t stream; PersistTickets *ptr; };
+    static std::mutex mu;
+    static std::vector<Slot> slots;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    for (const Slot &sl : slots)
+        if (sl.dev == dev && sl.stream == stream) return sl.ptr;
+    PersistTickets *ptr = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&ptr), sizeof(PersistTickets)) != hipSuccess) return nullptr;
+    if (hipMemsetAsync(ptr, 0, sizeof(PersistTickets), stream) != hipSuccess) { (void)hipFree(ptr); return nullptr; }
+    slots.push_back(Slot{dev, stream, ptr});
+    return ptr;
+}
+
+int device_cu_count() {
+    static int n[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    dev &= 63;
+    if (n[dev] == 0) {
+        int v = 0;
+        n[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+    }
+    return n[dev];
+}
+
+// The persistent form takes a launch when its tiles outnumber the CUs (there is a next tile to prefetch), the hand-placed main
+// loop fits, and every interior wave tile will take the wide epilogue path (row pitches / pointers aligned: checked HERE, because
+// the persistent kernel prefetches into the LDS the element-wise path would stage through).  LA_GEMM_PERSIST=0 (read per launch)
+// keeps one workgroup per tile: the A/B partner.
+template <bool OUT_F32, typename T16, int LNM>
+bool persist_eligible(const GemmParams &p, int batch, bool duo) {
+    // MEASURED SLOWER than one workgroup per tile (profiles/r4_kbench_persistent_ab.txt, r4_persistent_kernel_timeline.txt; DESIGN.md
+    // "GEMM, round 4"): opt-in with LA_GEMM_PERSIST=1 (read per launch), bf16 only.
+    const char *e = getenv("LA_GEMM_PERSIST");
+    if (!(e && e[0] == '1')) return false;
+    if (!std::is_same<T16, bf16_t>::value) return false;
+    if (!duo || batch != 1) return false;
+    const int nt = la::cdiv(p.M, PP::TM) * la::cdiv(p.N, PP::TN);
+    if (nt <= device_cu_count()) return false;
+    if (p.N % PP::TN != 0) return false;                                   // (column edges would need the element-wise path too)
+    if constexpr (LNM == 3) {
+        if (!(p.ldc % 4 == 0 && (uintptr_t)p.C % 4 == 0 && (uintptr_t)p.C2 % 8 == 0)) return false;
+        if ((p.epilogue & LA_EPI_RESIDUAL) && p.residual && !(p.ldr % 4 == 0 && (uintptr_t)p.residual % 16 == 0)) return false;
+    } else {
+        const int64_t es = OUT_F32 ? 4 : 2;
+        if (!((p.ldc * es) % 16 == 0 && (uintptr_t)p.C % 16 == 0)) return false;
+        if ((p.epilogue & LA_EPI_RESIDUAL) && p.residual && !(p.ldr % 4 == 0 && (uintptr_t)p.residual % 16 == 0)) return false;
+    }
+    return true;
+}
+
+template <bool OUT_F32, typename T16, int LNM>
+int launch_pp_persist(GemmParams p, hipStream_t stream) {
+    auto kern = gemm_pp_persist_kernel<OUT_F32, T16, LNM>;
+    constexpr int LDS_BYTES = 160 * 1024;
+    static la::DeviceOnce attr_once;
+    if (attr_once.pending()) {
+        LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        attr_once.mark();
+    }
+    PersistTickets *tk = persist_tickets(stream);
+    if (!tk) { la::set_error("gemm: ticket block allocation failed"); return LA_EHIP; }
+    p.tiles_m = la::cdiv(p.M, PP::TM);
+    p.tiles_n = la::cdiv(p.N, PP::TN);
+    p.group = getenv("LA_GEMM_GROUP") ? std::min(p.group, p.tiles_n) : std::min(p.tiles_n, std::max(4, p.group / 2));
+    p.mblock = p.tiles_n > p.group ? 32 : 0;
+    if (const char *g = getenv("LA_GEMM_MBLOCK")) p.mblock = atoi(g);
+    if (const char *g = getenv("LA_GELU_PK")) p.epilogue |= atoi(g) == 2 ? 8192 : 4096;
+    const int grid = std::min(p.tiles_m * p.tiles_n, device_cu_count());
+    la::TimerScope ts("gemm_bf16", stream, 2.0 * p.M * p.N * p.K);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(PP::THREADS), LDS_BYTES, stream, p, tk);
+    LA_LAUNCH_CHECK();
+    return LA_OK;
+}
+
 // Main loop: the hand-placed flat stream (mainloop_duo_asm) where its k-step structure fits -- K a multiple of 128 (four k-steps
 // of 32 per ring turn), at least 256 -- else the quadrant ping-pong; LA_PP_DBG=99 forces the ping-pong, 73 selects the
 // one-wave-per-SIMD kernel (read per launch: tools/kbench.py flips it between rounds of one process).  Same tile, same
@@ -904,9 +1192,17 @@ int launch_pp(GemmParams p, int batch, hipStream_t stream) {
         }
         return launch_pp_loop<OUT_F32, true, T16, 4>(p, batch, stream);
     }
-    if (p.ln_stats) return duo ? launch_pp_loop<OUT_F32, true, T16, 2>(p, batch, stream) : launch_pp_loop<OUT_F32, false, T16, 2>(p, batch, stream);
+    if (p.ln_stats) {
+        if constexpr (std::is_same<T16, bf16_t>::value) {
+            if (persist_eligible<OUT_F32, T16, 2>(p, batch, duo)) return launch_pp_persist<OUT_F32, T16, 2>(p, stream);
+        }
+        return duo ? launch_pp_loop<OUT_F32, true, T16, 2>(p, batch, stream) : launch_pp_loop<OUT_F32, false, T16, 2>(p, batch, stream);
+    }
     if constexpr (OUT_F32) {
         if (p.C2) return duo ? launch_pp_loop<OUT_F32, true, T16, 1>(p, batch, stream) : launch_pp_loop<OUT_F32, false, T16, 1>(p, batch, stream);
+    }
+    if constexpr (std::is_same<T16, bf16_t>::value) {
+        if (persist_eligible<OUT_F32, T16, 0>(p, batch, duo)) return launch_pp_persist<OUT_F32, T16, 0>(p, stream);
     }
     return duo ? launch_pp_loop<OUT_F32, true, T16>(p, batch, stream) : launch_pp_loop<OUT_F32, false, T16>(p, batch, stream);
 }
@@ -1136,7 +1432,10 @@ extern "C" int la_gemm_split(int32_t dtype, int32_t M, int32_t N, int32_t K, int
     hipStream_t stream = (hipStream_t)stream_;
     const char *dbg_env = getenv("LA_PP_DBG");
     const bool duo = K % 128 == 0 && K >= 256 && !(dbg_env && atoi(dbg_env) == 99);
-    if (dtype == LA_F16) return duo ? launch_pp_loop<true, true, la::f16_t, 3>(p, batch, stream) : launch_pp_loop<true, false, la::f16_t, 3>(p, batch, stream);
+    if (dtype == LA_F16) {
+        return duo ? launch_pp_loop<true, true, la::f16_t, 3>(p, batch, stream) : launch_pp_loop<true, false, la::f16_t, 3>(p, batch, stream);
+    }
+    if (persist_eligible<true, bf16_t, 3>(p, batch, duo)) return launch_pp_persist<true, bf16_t, 3>(p, stream);
     return duo ? launch_pp_loop<true, true, bf16_t, 3>(p, batch, stream) : launch_pp_loop<true, false, bf16_t, 3>(p, batch, stream);
 }
 

@@ -421,25 +421,25 @@ template <> struct Dot2cAsm<_Float16> {
         asm volatile("v_dot2c_f32_f16 %0, %1, %1" : "+v"(s2) : "v"(v));
     }
 };
-template <typename T16 = bf16_t, int STAT_WC = -1>
-__device__ __forceinline__ void mainloop_duo_asm(const T16 *A, int64_t lda, int M, const T16 *W, int64_t ldw, int N, int K,
-                                                 int m0, int n0, unsigned char *lds, f32x4 (&acc)[8][4] LA_STAMP_PARAM,
-                                                 float *sacc = nullptr) {
+// The loop in three pieces, so that a PERSISTENT workgroup (gemm_pp_persist_kernel) can issue the next tile's first stages before the
+// current tile's epilogue: duo_setup (per-tile addresses), duo_issue_prologue (the DMA of stages 0 .. 3), duo_run (entry wait, first
+// fragments, the k-steps).  mainloop_duo_asm = the three in a row.
+struct DuoCtx {
+    unsigned voff[4];              // this wave's four DMA pieces of a stage: per-lane byte offsets (row clamp + source-side swizzle)
+    const unsigned char *src0;     // the wave's operand panel (W rows n0 .. for waves 0-3, A rows m0 .. for waves 4-7), K offset 0
+    unsigned piece0;               // LDS address of the wave's first piece in ring slot 0
+    unsigned fa_lo, fa_hi, fw_lo, fw_hi;   // fragment read bases (slots 0-1 / 2-3)
+};
+template <typename T16>
+__device__ __forceinline__ void duo_setup(DuoCtx &c, const T16 *A, int64_t lda, int M, const T16 *W, int64_t ldw, int N, int m0, int n0,
+                                          unsigned lds0, int wave, int lane) {
     constexpr int STAGE = 32768, OPS = 16384, SB = 64;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int r = lane & 15, q = lane >> 4;
-    const int ns = K / 32;
     const int64_t lda_b = lda * 2, ldw_b = ldw * 2;
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
     // this wave's 4 pieces of every stage: waves 0..3 carry the W image (rows 64 wave .. + 63), waves 4..7 the A image
     const bool is_w = wave < 4;
     const int pw = wave & 3;
-    unsigned voff[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int rt = (4 * pw + i) * 16 + (lane >> 2);
@@ -447,24 +447,45 @@ __device__ __forceinline__ void mainloop_duo_asm(const T16 *A, int64_t lda, int 
         int rg = (is_w ? n0 : m0) + rt;
         const int lim = (is_w ? N : M) - 1;
         rg = rg > lim ? lim : rg;
-        voff[i] = (unsigned)((int64_t)(rg - (is_w ? n0 : m0)) * (is_w ? ldw_b : lda_b)) + sw;
+        c.voff[i] = (unsigned)((int64_t)(rg - (is_w ? n0 : m0)) * (is_w ? ldw_b : lda_b)) + sw;
     }
-    const unsigned char *src0 = is_w ? reinterpret_cast<const unsigned char *>(W) + (int64_t)n0 * ldw_b
-                                     : reinterpret_cast<const unsigned char *>(A) + (int64_t)m0 * lda_b;
-    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_u32(lds));
-    const unsigned piece0 = lds0 + (is_w ? OPS : 0) + (4 * pw) * 1024;
-    auto issue1 = [&](const unsigned char *src, int slot, int i) __attribute__((always_inline)) {
-        glds16_so(voff[i], src, piece0 + slot * STAGE + i * 1024);
-    };
-    const unsigned fa_lo = lds0 + (unsigned)((wr * 128 + r) * SB + ((q ^ swz2(r)) << 4)), fa_hi = fa_lo + 2 * STAGE;
-    const unsigned fw_lo = lds0 + OPS + (unsigned)((wc * 64 + r) * SB + ((q ^ swz2(r)) << 4)), fw_hi = fw_lo + 2 * STAGE;
-
+    c.src0 = is_w ? reinterpret_cast<const unsigned char *>(W) + (int64_t)n0 * ldw_b
+                  : reinterpret_cast<const unsigned char *>(A) + (int64_t)m0 * lda_b;
+    c.piece0 = lds0 + (is_w ? OPS : 0) + (4 * pw) * 1024;
+    c.fa_lo = lds0 + (unsigned)((wr * 128 + r) * SB + ((q ^ swz2(r)) << 4));
+    c.fa_hi = c.fa_lo + 2 * STAGE;
+    c.fw_lo = lds0 + OPS + (unsigned)((wc * 64 + r) * SB + ((q ^ swz2(r)) << 4));
+    c.fw_hi = c.fw_lo + 2 * STAGE;
+}
+__device__ __forceinline__ void duo_issue_prologue(const DuoCtx &c) {
+    constexpr int STAGE = 32768, SB = 64;
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) issue1(src0 + st * SB, st, i);
+        for (int i = 0; i < 4; ++i) glds16_so(c.voff[i], c.src0 + st * SB, c.piece0 + st * STAGE + i * 1024);
     }
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // stages 0 and 1 landed; the 8 pieces of stages 2 and 3 may stay in flight
+}
+// PREFETCHED: stages 0 .. 3 were issued BEFORE the previous tile's epilogue (whose >= 24 vector-memory operations -- its stores --
+// are younger than them in this wave's queue): one wait retires all four without forcing a single store, k-steps 0 and 1 (which
+// would retire stages 2 and 3) wait for their fragment reads only, and from k-step 2 on -- whose wait needs stage 4, issued
+// after those stores -- the stream is the ordinary one: by then (>= 2 k-steps, ~2 us) the stores have drained.
+template <typename T16 = bf16_t, int STAT_WC = -1, bool PREFETCHED = false>
+__device__ __forceinline__ void duo_run(const DuoCtx &c, int K, f32x4 (&acc)[8][4] LA_STAMP_PARAM, float *sacc = nullptr) {
+    constexpr int STAGE = 32768, SB = 64;
+    const int ns = K / 32;
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const unsigned fa_lo = c.fa_lo, fa_hi = c.fa_hi, fw_lo = c.fw_lo, fw_hi = c.fw_hi;
+    const unsigned char *src0 = c.src0;
+    const unsigned piece0 = c.piece0;
+    unsigned voff[4] = {c.voff[0], c.voff[1], c.voff[2], c.voff[3]};
+    auto issue1 = [&](const unsigned char *src, int slot, int i) __attribute__((always_inline)) {
+        glds16_so(voff[i], src, piece0 + slot * STAGE + i * 1024);
+    };
+    if constexpr (PREFETCHED) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // stages 0 and 1 landed; the 8 pieces of stages 2 and 3 may stay in flight
     LA_PP_BARRIER();
     LA_STAMP_T1();
     u32x4 fa[2][8], fw[2][4];
@@ -507,7 +528,8 @@ __device__ __forceinline__ void mainloop_duo_asm(const T16 *A, int64_t lda, int 
             }
             if constexpr (PF && (j & 7) == 2) issue1(src, SW, j >> 3);
             if constexpr (j == 28) {
-                if constexpr (VM == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+                if constexpr (VM == 63) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (PREFETCHED: its stage landed long ago)
+                else if constexpr (VM == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
                 else if constexpr (VM == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             }
@@ -522,7 +544,15 @@ __device__ __forceinline__ void mainloop_duo_asm(const T16 *A, int64_t lda, int 
     typedef std::integral_constant<int, 3> I3;
     typedef std::integral_constant<int, 4> V4;
     typedef std::integral_constant<int, 8> V8;
+    typedef std::integral_constant<int, 63> V63;
     int s = 0;                              // ns is a multiple of 4, >= 8 (host check)
+    if constexpr (PREFETCHED) {             // the first ring turn with the two wait-free k-steps (s + 4 < ns holds: ns >= 8)
+        kstep(0, TT{}, TT{}, V63{}, I0{}, I0{});
+        kstep(1, TT{}, TT{}, V63{}, I1{}, I1{});
+        kstep(2, TT{}, TT{}, V8{}, I0{}, I2{});
+        kstep(3, TT{}, TT{}, V8{}, I1{}, I3{});
+        s = 4;
+    }
     for (; s + 4 < ns; s += 4) {
         kstep(s, TT{}, TT{}, V8{}, I0{}, I0{});
         kstep(s + 1, TT{}, TT{}, V8{}, I1{}, I1{});
@@ -535,6 +565,22 @@ __device__ __forceinline__ void mainloop_duo_asm(const T16 *A, int64_t lda, int 
     kstep(s + 3, F{}, F{}, I0{}, I1{}, I3{});
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     LA_PP_BARRIER();
+}
+template <typename T16 = bf16_t, int STAT_WC = -1>
+__device__ __forceinline__ void mainloop_duo_asm(const T16 *A, int64_t lda, int M, const T16 *W, int64_t ldw, int N, int K,
+                                                 int m0, int n0, unsigned char *lds, f32x4 (&acc)[8][4] LA_STAMP_PARAM,
+                                                 float *sacc = nullptr) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_u32(lds));
+    DuoCtx c;
+    duo_setup<T16>(c, A, lda, M, W, ldw, N, m0, n0, lds0, wave, lane);
+    duo_issue_prologue(c);
+#ifdef LA_TILE_STAMPS
+    duo_run<T16, STAT_WC, false>(c, K, acc, stamp_t1, sacc);
+#else
+    duo_run<T16, STAT_WC, false>(c, K, acc, sacc);
+#endif
 }
 
 }  // namespace gemm

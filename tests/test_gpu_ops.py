@@ -1,5 +1,7 @@
 """GPU numerics of the encoder / head building blocks through the C ABI, against plain
 torch fp32 references of the same op (floating-point kernels: tolerance stated per test)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -612,3 +614,58 @@ def test_gemm_split_batched_stem_layout_and_zero_rows():
     dec = ops.split_decode(hi, lo)
     assert float((dec - x).abs().max()) <= float(x.abs().max()) * 1.6e-5
     assert float((dec[:T] - pos).abs().max()) <= float(pos.abs().max()) * 1.6e-5
+
+
+# ------------------------------------------------------------------------------------------------ persistent 256x256 kernel
+@pytest.mark.parametrize("dtype", [torch.bfloat16])
+def test_gemm_persistent_kernel_is_bit_identical_to_one_workgroup_per_tile(dtype):
+    """gemm_pp_persist_kernel (opt-in, LA_GEMM_PERSIST=1 read per launch, bf16: workgroups draw tiles from per-XCD ticket counters and
+    issue the next tile's first stages before the current tile's epilogue) against the one-workgroup-per-tile kernel: the same main loop, the
+    same epilogue arithmetic, so the same bits -- for the plain, LayerNorm-consumer (+ GELU), f32-out + residual and split-stream
+    forms, with a partial last row of tiles (M = 48000 = 187.5 x 256: edge tiles break the prefetch chain), five launches each (a
+    race in the ticket / prefetch choreography would show as a differing run), while another stream keeps CUs busy so that some
+    persistent workgroups start late and the tickets have to balance."""
+    from lyricalignment_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(11)
+    M = 48000
+    side = torch.cuda.Stream()
+    sa = torch.randn(8192, 1024, device="cuda", generator=g).to(dtype)
+    sw = torch.randn(4096, 1024, device="cuda", generator=g).to(dtype)
+
+    def both(fn):
+        os.environ.pop("LA_GEMM_PERSIST", None)
+        ref = [t.clone() for t in fn()]
+        for it in range(5):
+            with torch.cuda.stream(side):
+                for _ in range(1 + it % 3):
+                    ops.gemm(sa[: 2048 * (1 + it % 4)], sw)
+            os.environ["LA_GEMM_PERSIST"] = "1"
+            try:
+                out = fn()
+            finally:
+                os.environ.pop("LA_GEMM_PERSIST", None)
+            torch.cuda.synchronize()
+            for a_, b_ in zip(out, ref):
+                assert torch.equal(a_.view(torch.int16) if a_.dtype != torch.float32 and a_.dtype != torch.uint8 else a_,
+                                   b_.view(torch.int16) if b_.dtype != torch.float32 and b_.dtype != torch.uint8 else b_), f"run {it}"
+
+    for N, K in ((3072, 1024), (1024, 4096)):
+        a = torch.randn(M, K, device="cuda", generator=g).to(dtype)
+        w = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(dtype)
+        bias = torch.randn(N, device="cuda", generator=g)
+        csum = torch.randn(N, device="cuda", generator=g)
+        stats = torch.stack([torch.randn(M, device="cuda", generator=g) * 0.1, 1.0 + 0.1 * torch.rand(M, device="cuda", generator=g)], dim=1).contiguous()
+        out16 = torch.empty(M, N, device="cuda", dtype=dtype)
+        both(lambda: [ops.gemm(a, w, out16, bias=bias)])                                                    # plain
+        both(lambda: [ops.gemm(a, w, out16, bias=bias, gelu=True, ln_stats=stats, ln_csum=csum)])          # LayerNorm consumer + GELU
+        res = torch.randn(M, N, device="cuda", generator=g)
+        outf = torch.empty(M, N, device="cuda")
+        both(lambda: [ops.gemm(a, w, outf, bias=bias, residual=res, out_f32=True)])                         # f32 out + f32 residual
+        hi0 = torch.randn(M, N, device="cuda", generator=g).to(dtype)
+        lo0 = torch.randint(1, 256, (M, N), device="cuda", generator=g, dtype=torch.uint8)
+
+        def split():
+            hi, lo = hi0.clone(), lo0.clone()
+            ops.gemm_split(a, w, hi, lo, bias=bias, in_place=True)
+            return [hi, lo]
+        both(split)                                                                                         # split stream in place

@@ -167,6 +167,38 @@ def bench_tile_order(iters):
             print(f"order M={M} N={N} K={K} (group, mblock)={key}: {t*1e3:8.1f} us = {fl/t/1e9:7.1f} TF/s", flush=True)
 
 
+def bench_persist(iters):
+    """The persistent 256x256 kernel (opt-in LA_GEMM_PERSIST=1: tickets + next tile's stages prefetched under the epilogue) against one
+    workgroup per tile on the encoder's four GEMMs WITH their epilogues, interleaved rounds in one process."""
+    M = 48000
+    cases = [("qkv (LN consumer)", 3072, 1024, "ln"), ("mlp_up (LN consumer + GELU)", 4096, 1024, "ln_gelu"), ("out_proj (split stream)", 1024, 1024, "split"),
+             ("mlp_down (split stream)", 1024, 4096, "split"), ("plain 16-bit", 3072, 1024, "plain")]
+    for name, N, K, kind in cases:
+        a, w = rnd(M, K), rnd(N, K, scale=K ** -0.5)
+        bias = torch.randn(N, device="cuda")
+        if kind == "split":
+            hi = torch.randn(M, N, device="cuda").bfloat16()
+            lo = torch.full((M, N), 128, dtype=torch.uint8, device="cuda")
+            fn = lambda: ops.gemm_split(a, w, hi, lo, bias=bias, in_place=True)
+        elif kind == "plain":
+            out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+            fn = lambda: ops.gemm(a, w, out, bias=bias)
+        else:
+            out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+            stats = torch.stack([torch.zeros(M, device="cuda"), torch.ones(M, device="cuda")], dim=1).contiguous()
+            csum = torch.randn(N, device="cuda")
+            fn = lambda: ops.gemm(a, w, out, bias=bias, gelu=kind == "ln_gelu", ln_stats=stats, ln_csum=csum)
+        res = {"1": [], "0": []}
+        for rd in range(3):
+            for flag in ("1", "0"):
+                os.environ["LA_GEMM_PERSIST"] = flag
+                res[flag].append(timeit(fn, iters)[0])
+        os.environ.pop("LA_GEMM_PERSIST", None)
+        fl = 2.0 * M * N * K
+        p_, o_ = sorted(res["1"])[1], sorted(res["0"])[1]
+        print(f"persist {name:30s} N={N} K={K}: persistent {p_*1e3:7.1f} us ({fl/p_/1e9:6.1f} TF/s) | one workgroup per tile {o_*1e3:7.1f} us ({fl/o_/1e9:6.1f} TF/s) | {100*(o_/p_-1):+.1f} %", flush=True)
+
+
 def bench_attn(iters):
     B, T, H = 32, 1500, 16
     qkv = rnd(B * T, 3 * H * 64)
@@ -260,6 +292,9 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     if a.what == "gemm" and a.variants:
         bench_gemm_variants(a.iters, [int(v) for v in a.variants.split(",")])
+        sys.exit(0)
+    if a.what == "persist":
+        bench_persist(a.iters)
         sys.exit(0)
     if a.what == "order":
         bench_tile_order(a.iters)

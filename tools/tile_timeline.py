@@ -41,6 +41,31 @@ for name in (sys.argv[1:] or ["qkv", "mlp_up", "out_proj", "mlp_down"]):
     torch.cuda.synchronize()
     _lib.lib().la_debug_set_tile_stamps(0)
     s = buf.cpu().numpy().reshape(tiles, 8)
+    if os.environ.get("LA_GEMM_PERSIST") == "1":
+        # persistent kernel: one record per TILE: iteration top, first fragments in, main loop done, epilogue end, HW_ID, XCC_ID,
+        # epilogue begin, prefetched flag
+        tt = s[:, [0, 1, 2, 6, 3]].astype(np.float64) * 0.01
+        tt -= tt[:, 0].min()
+        cu = (s[:, 5] & 0xF) * 65536 + ((s[:, 4] >> 8) & 0xFF)
+        pf = s[:, 7] == 1
+        gaps = []
+        for c in np.unique(cu):
+            idx = np.where(cu == c)[0]
+            idx = idx[np.argsort(tt[idx, 0])]
+            gaps += list(tt[idx[1:], 0] - tt[idx[:-1], 4])
+        q = lambda x: f"median {np.median(x):6.2f}  p10 {np.percentile(x, 10):6.2f}  p90 {np.percentile(x, 90):6.2f}"
+        print(f"{name} (persistent): N={N} K={K} {kind}: launch {ev0.elapsed_time(ev1) * 1e3:.1f} us, {tiles} tiles on {len(np.unique(cu))} CUs, "
+              f"{int(pf.sum())} tiles with prefetched stages, last ends at {tt[:, 4].max():.1f} us")
+        for sel, lab in ((pf, "prefetched"), (~pf, "not prefetched")):
+            if sel.sum() == 0:
+                continue
+            print(f"   [{lab}] entry (top -> first fragments)      {q(tt[sel, 1] - tt[sel, 0])} us")
+            print(f"   [{lab}] main loop                          {q(tt[sel, 2] - tt[sel, 1])} us")
+            print(f"   [{lab}] ticket + next tile's stages issued {q(tt[sel, 3] - tt[sel, 2])} us")
+            print(f"   [{lab}] epilogue                           {q(tt[sel, 4] - tt[sel, 3])} us")
+        print(f"   epilogue end -> next iteration top        {q(np.array(gaps))} us (n = {len(gaps)})")
+        print(f"   tile period                               {np.median(tt[:, 4] - tt[:, 0]) + np.median(gaps):6.2f} us", flush=True)
+        continue
     t = s[:, :4].astype(np.float64) * 0.01                      # 100 MHz ticks -> us
     t -= t[:, 0].min()
     cu = (s[:, 5] & 0xF) * 65536 + ((s[:, 4] >> 8) & 0xFF)    # (XCC, SE / SH / CU bits of HW_ID)
