@@ -520,6 +520,41 @@ def test_fused_gradient_accumulation_equals_the_loop_of_micro_steps():
         np.testing.assert_allclose(g_fused.numpy(), g_loop.numpy(), rtol=0, atol=3e-4 * scale)
 
 
+def test_fused_accumulation_with_heterogeneous_micro_batches_takes_the_loop():
+    """Round-3 advisor finding: accumulate(fused=True) used to drop the decoder loss for ALL micro-batches as soon as one of them came
+    without a decoder pair (and ignored transcript_batch).  Heterogeneous micro-batches now take the loop of micro_step() calls: the
+    decoder CE of the micro-batch that has a pair is in the loss vector and in the gradients, exactly as accumulate(fused=False)."""
+    from lyricalignment_amd import finetune as ft
+    audios, labels, frame_labels, dec_in, dec_out = _tiny_batch()
+    mbs = [dict(audios=audios, ctc_labels=labels, frame_labels=frame_labels, decoder_input=dec_in, decoder_output=dec_out),
+           dict(audios=audios[::-1], ctc_labels=labels.flip(0), frame_labels=frame_labels.flip(0))]           # no decoder pair
+    out = []
+    for fused in (False, True):
+        model = _tiny_full_model(dropout=0.0)
+        torch.manual_seed(3)
+        with torch.no_grad():
+            for p_ in model.align_rnn.parameters():
+                p_.copy_(torch.randn(p_.shape) * 0.1)
+        tuner = ft.FineTuner(model, vocab_size=40, world=1)
+        l = tuner.accumulate(mbs, fused=fused).cpu()
+        out.append((l, [g.clone().cpu() for g in tuner.grad]))
+    assert float(out[0][0][3]) > 0                                   # the decoder CE of the first micro-batch is there
+    assert torch.equal(out[0][0], out[1][0])                         # same path -> same bits
+    for a, b in zip(out[0][1], out[1][1]):
+        assert torch.equal(a, b)
+
+
+def test_attention_backward_refuses_a_causal_mask_with_unequal_lengths():
+    """Round-3 advisor finding: la_attention_bwd_f32 accepted causal != 0 with q_len != kv_len although its mask has no kv_len - q_len
+    offset (the forward entry points reject that combination): now LA_EINVAL."""
+    from lyricalignment_amd import encoder_train as et
+    B, Tq, Tk, H = 1, 8, 12, 1
+    q = torch.randn(B * Tq, 64, device="cuda"); kv = torch.randn(B * Tk, 128, device="cuda"); do = torch.randn(B * Tq, 64, device="cuda")
+    dq = torch.empty_like(q); dkv = torch.empty_like(kv)
+    with pytest.raises(ValueError):
+        et.attention_bwd_ex(q, kv[:, :64], kv[:, 64:], do, dq, dkv[:, :64], dkv[:, 64:], B, Tq, Tk, H, causal=True, o=torch.randn_like(q))
+
+
 def test_out_of_vocabulary_token_ids_are_clamped_not_faulted():
     """A decoder prompt with ids outside [0, n_vocab) (bad user data; the reference would raise from nn.Embedding) must not become
     an out-of-bounds gather / atomic on the device: la_embed_tokens and la_embed_tokens_bwd_f32 clamp the id the same way."""
