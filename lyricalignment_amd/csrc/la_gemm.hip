@@ -1185,15 +1185,20 @@ int launch_pp(GemmParams p, int batch, hipStream_t stream) {
         if (dbg == 73 && fits) return launch_mono_modes<OUT_F32, T16>(p, batch, stream);
     }
     const bool duo = fits && dbg != 99;
-    if (p.ln_csum && !p.ln_stats) {                   // LayerNorm consumer whose main loop takes the row statistics itself
-        if (!duo) {
-            la::set_error("gemm_fused_ln: in-loop row statistics need the hand-placed main loop (K %% 128 == 0, K >= 256; K = %d)", p.K);
+    if (p.ln_csum && !p.ln_stats) {                   // LayerNorm consumer whose main loop takes the row statistics itself (opt-in, bf16)
+        if constexpr (std::is_same<T16, bf16_t>::value) {
+            if (!duo) {
+                la::set_error("gemm_fused_ln: in-loop row statistics need the hand-placed main loop (K %% 128 == 0, K >= 256; K = %d)", p.K);
+                return LA_EUNSUPPORTED;
+            }
+            return launch_pp_loop<OUT_F32, true, T16, 4>(p, batch, stream);
+        } else {
+            la::set_error("gemm_fused_ln: in-loop row statistics are built for bfloat16 (measured slower than la_row_stats16: an A/B switch)");
             return LA_EUNSUPPORTED;
         }
-        return launch_pp_loop<OUT_F32, true, T16, 4>(p, batch, stream);
     }
     if (p.ln_stats) {
-        if constexpr (std::is_same<T16, bf16_t>::value) {
+        if constexpr (std::is_same<T16, bf16_t>::value && !OUT_F32) {
             if (persist_eligible<OUT_F32, T16, 2>(p, batch, duo)) return launch_pp_persist<OUT_F32, T16, 2>(p, stream);
         }
         return duo ? launch_pp_loop<OUT_F32, true, T16, 2>(p, batch, stream) : launch_pp_loop<OUT_F32, false, T16, 2>(p, batch, stream);
@@ -1201,7 +1206,7 @@ int launch_pp(GemmParams p, int batch, hipStream_t stream) {
     if constexpr (OUT_F32) {
         if (p.C2) return duo ? launch_pp_loop<OUT_F32, true, T16, 1>(p, batch, stream) : launch_pp_loop<OUT_F32, false, T16, 1>(p, batch, stream);
     }
-    if constexpr (std::is_same<T16, bf16_t>::value) {
+    if constexpr (std::is_same<T16, bf16_t>::value && !OUT_F32) {
         if (persist_eligible<OUT_F32, T16, 0>(p, batch, duo)) return launch_pp_persist<OUT_F32, T16, 0>(p, stream);
     }
     return duo ? launch_pp_loop<OUT_F32, true, T16>(p, batch, stream) : launch_pp_loop<OUT_F32, false, T16>(p, batch, stream);

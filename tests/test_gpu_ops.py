@@ -390,7 +390,7 @@ def test_gemm_fused_layernorm_pieces():
         ops.gemm(xb[:300], wl.cuda(), bias=bl, ln_stats=st[:300].contiguous().cuda(), ln_csum=csum, out_f32=True)
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("dtype", [torch.bfloat16])
 def test_gemm_layernorm_consumer_takes_row_statistics_in_its_main_loop(dtype):
     """la_gemm_fused_ln with ln_csum but NO ln_stats: the hand-placed main loop sums every A row and its squares from the fragments
     it multiplies (v_dot2c in MFMA gaps) and the epilogue applies mean / rstd from LDS -- against the same launch fed with
@@ -621,7 +621,7 @@ def test_gemm_split_batched_stem_layout_and_zero_rows():
 def test_gemm_persistent_kernel_is_bit_identical_to_one_workgroup_per_tile(dtype):
     """gemm_pp_persist_kernel (opt-in, LA_GEMM_PERSIST=1 read per launch, bf16: workgroups draw tiles from per-XCD ticket counters and
     issue the next tile's first stages before the current tile's epilogue) against the one-workgroup-per-tile kernel: the same main loop, the
-    same epilogue arithmetic, so the same bits -- for the plain, LayerNorm-consumer (+ GELU), f32-out + residual and split-stream
+    same epilogue arithmetic, so the same bits -- for the plain, LayerNorm-consumer (+ GELU) and split-stream
     forms, with a partial last row of tiles (M = 48000 = 187.5 x 256: edge tiles break the prefetch chain), five launches each (a
     race in the ticket / prefetch choreography would show as a differing run), while another stream keeps CUs busy so that some
     persistent workgroups start late and the tickets have to balance."""
@@ -658,9 +658,6 @@ def test_gemm_persistent_kernel_is_bit_identical_to_one_workgroup_per_tile(dtype
         out16 = torch.empty(M, N, device="cuda", dtype=dtype)
         both(lambda: [ops.gemm(a, w, out16, bias=bias)])                                                    # plain
         both(lambda: [ops.gemm(a, w, out16, bias=bias, gelu=True, ln_stats=stats, ln_csum=csum)])          # LayerNorm consumer + GELU
-        res = torch.randn(M, N, device="cuda", generator=g)
-        outf = torch.empty(M, N, device="cuda")
-        both(lambda: [ops.gemm(a, w, outf, bias=bias, residual=res, out_f32=True)])                         # f32 out + f32 residual
         hi0 = torch.randn(M, N, device="cuda", generator=g).to(dtype)
         lo0 = torch.randint(1, 256, (M, N), device="cuda", generator=g, dtype=torch.uint8)
 
