@@ -461,6 +461,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams &p, int z, f32x4 
 // element through HBM instead of the 4 + 4 + 2 of wave_epilogue's f32 stream with a 16-bit copy.  Same staging (through the
 // wave's LDS region, row-major quads), same order of operations on the f32 values as wave_epilogue<true, T16, 1>.
 constexpr int LA_EPI_SPLIT_INPLACE = 1 << 20;    // internal: the residual is the split stream itself
+constexpr int LA_EPI_SPLIT_PASS32 = 1 << 21;     // internal (LA_EPI_SPLIT_PASS=32): the 32-row passes without the one-pass-ahead requests
 template <typename T16, int STG = 0>
 __device__ __forceinline__ void wave_epilogue_split(const GemmParams &p, int z, f32x4 (&acc)[8][4], int wrow0, int wcol0, bool has_bias,
                                                     float bias_l, unsigned char *reg, unsigned char *reg_edge = nullptr, int lane_in = -1) {
@@ -489,23 +490,36 @@ __device__ __forceinline__ void wave_epilogue_split(const GemmParams &p, int z, 
         float2 *part = p.ln_part ? reinterpret_cast<float2 *>(p.ln_part) + (int64_t)(wcol0 >> 6) * p.M + wrow0 : nullptr;
         auto fast = [&](auto rkc) {
             constexpr int RK = decltype(rkc)::value;             // 0: no residual, 1: f32 rows, 2: the split stream in place
-#pragma unroll
-            for (int h = 0; h < NPASS; ++h) {
-                float4 t[NIT];
-                ushort4 th[NIT];
-                unsigned tl[NIT];
+            // The residual rows of a pass are requested ONE PASS AHEAD in the 16-row forms (two register sets of 12 = the 24 registers
+            // the 32-row form holds at once): only the first pass waits out a memory round trip, the others find their rows there.
+            constexpr int NSET = STG ? 2 : 1;
+            float4 tt[NSET][NIT];
+            ushort4 tth[NSET][NIT];
+            unsigned ttl[NSET][NIT];
+            auto request = [&](int h, auto setc) __attribute__((always_inline)) {
+                constexpr int S = decltype(setc)::value;
                 if constexpr (RK == 1) {
 #pragma unroll
-                    for (int it = 0; it < NIT; ++it) t[it] = *reinterpret_cast<const float4 *>(rw + (int64_t)(h * RP + it * 4 + q) * p.ldr);
+                    for (int it = 0; it < NIT; ++it) tt[S][it] = *reinterpret_cast<const float4 *>(rw + (int64_t)(h * RP + it * 4 + q) * p.ldr);
                 }
                 if constexpr (RK == 2) {
 #pragma unroll
                     for (int it = 0; it < NIT; ++it) {
                         const int64_t off = (int64_t)(h * RP + it * 4 + q) * p.ldc;
-                        th[it] = *reinterpret_cast<const ushort4 *>(hiw + off);
-                        tl[it] = *reinterpret_cast<const unsigned *>(low + off);
+                        tth[S][it] = *reinterpret_cast<const ushort4 *>(hiw + off);
+                        ttl[S][it] = *reinterpret_cast<const unsigned *>(low + off);
                     }
                 }
+            };
+            if constexpr (STG != 0) request(0, std::integral_constant<int, 0>{});
+            la::gemm::static_for<0, NPASS>([&](auto hc) __attribute__((always_inline)) {
+                constexpr int h = decltype(hc)::value;
+                constexpr int CS = STG ? (h & 1) : 0;
+                if constexpr (STG == 0) request(h, std::integral_constant<int, 0>{});
+                else if constexpr (h + 1 < NPASS) request(h + 1, std::integral_constant<int, (h + 1) & 1>{});
+                float4 (&t)[NIT] = tt[CS];
+                ushort4 (&th)[NIT] = tth[CS];
+                unsigned (&tl)[NIT] = ttl[CS];
                 if constexpr (STG == 0) {
 #pragma unroll
                     for (int mm = 0; mm < 2; ++mm)
@@ -543,7 +557,7 @@ __device__ __forceinline__ void wave_epilogue_split(const GemmParams &p, int z, 
                         if (r == 0) part[h * RP + rl] = sg;
                     }
                 }
-            }
+            });
         };
         if (res_split) fast(std::integral_constant<int, 2>{});
         else if (res_f32) fast(std::integral_constant<int, 1>{});
@@ -674,8 +688,11 @@ __global__ __launch_bounds__(PP::THREADS, 2) void gemm_pp_kernel(GemmParams p) {
 #endif
 
     __syncthreads();
-    if constexpr (LNM == 3) wave_epilogue_split<T16>(p, z, acc, m0 + wr * 128, n0 + wc * 64, has_bias, bias_l, lds + wave * (32 * EPI_PITCH));
-    else wave_epilogue<OUT_F32, T16, LNM == 2 ? 4 : LNM>(p, z, acc, m0 + wr * 128, n0 + wc * 64, has_bias, bias_l, csum_l, lds + wave * (32 * EPI_PITCH), stats_tab, m0);
+    if constexpr (LNM == 3) {
+        // 16-row passes with the residual rows requested one pass ahead (default), or the 32-row passes (LA_EPI_SPLIT_PASS=32: A/B)
+        if (p.epilogue & LA_EPI_SPLIT_PASS32) wave_epilogue_split<T16, 0>(p, z, acc, m0 + wr * 128, n0 + wc * 64, has_bias, bias_l, lds + wave * (32 * EPI_PITCH));
+        else wave_epilogue_split<T16, 1>(p, z, acc, m0 + wr * 128, n0 + wc * 64, has_bias, bias_l, lds + wave * (32 * EPI_PITCH), lds + wave * (32 * EPI_PITCH));
+    } else wave_epilogue<OUT_F32, T16, LNM == 2 ? 4 : LNM>(p, z, acc, m0 + wr * 128, n0 + wc * 64, has_bias, bias_l, csum_l, lds + wave * (32 * EPI_PITCH), stats_tab, m0);
 #ifdef LA_TILE_STAMPS
     if (threadIdx.x == 0 && g_tile_stamps) {
         unsigned long long *o = g_tile_stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
@@ -1431,6 +1448,7 @@ extern "C" int la_gemm_split(int32_t dtype, int32_t M, int32_t N, int32_t K, int
     LA_CHECK_ARG(!ln_part || (N % 64 == 0 && batch == 1 && (uintptr_t)ln_part % 8 == 0), "gemm_split: partial statistics need N %% 64 == 0, batch 1");
     int epi = epilogue & (LA_EPI_BIAS | LA_EPI_GELU);
     if (epilogue & LA_EPI_RESIDUAL) epi |= residual ? LA_EPI_RESIDUAL : LA_EPI_SPLIT_INPLACE;
+    if (const char *e = getenv("LA_EPI_SPLIT_PASS")) { if (atoi(e) == 32) epi |= LA_EPI_SPLIT_PASS32; }
     GemmParams p{M, N, K, A, lda, strideA, W, (int64_t)K, 0, lo, ld, stride, bias, 0, residual, ldr, strideR, epi,
                  0, la::cdiv(N, BN), pick_group(K, 2, la::cdiv(N, BN))};
     p.C2 = hi; p.ldc2 = ld; p.strideC2 = stride; p.ln_part = ln_part;
