@@ -461,6 +461,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams &p, int z, f32x4 
 // element through HBM instead of the 4 + 4 + 2 of wave_epilogue's f32 stream with a 16-bit copy.  Same staging (through the
 // wave's LDS region, row-major quads), same order of operations on the f32 values as wave_epilogue<true, T16, 1>.
 constexpr int LA_EPI_SPLIT_INPLACE = 1 << 20;    // internal: the residual is the split stream itself
+constexpr int LA_EPI_Q4_PRIO = 1 << 23;          // internal (LA_GEMM_Q4_PRIO=1): gemm_q4_kernel's prologue / epilogue at wave priority 3
 constexpr int LA_EPI_SPLIT_PASS32 = 1 << 21;     // internal (LA_EPI_SPLIT_PASS=32): the 32-row passes without the one-pass-ahead requests
 template <typename T16, int STG = 0>
 __device__ __forceinline__ void wave_epilogue_split(const GemmParams &p, int z, f32x4 (&acc)[8][4], int wrow0, int wcol0, bool has_bias,
@@ -692,6 +693,70 @@ __global__ __launch_bounds__(PP::THREADS, 2) void gemm_pp_kernel(GemmParams p) {
         // 16-row passes with the residual rows requested one pass ahead (default), or the 32-row passes (LA_EPI_SPLIT_PASS=32: A/B)
         if (p.epilogue & LA_EPI_SPLIT_PASS32) wave_epilogue_split<T16, 0>(p, z, acc, m0 + wr * 128, n0 + wc * 64, has_bias, bias_l, lds + wave * (32 * EPI_PITCH));
         else wave_epilogue_split<T16, 1>(p, z, acc, m0 + wr * 128, n0 + wc * 64, has_bias, bias_l, lds + wave * (32 * EPI_PITCH), lds + wave * (32 * EPI_PITCH));
+    } else wave_epilogue<OUT_F32, T16, LNM == 2 ? 4 : LNM>(p, z, acc, m0 + wr * 128, n0 + wc * 64, has_bias, bias_l, csum_l, lds + wave * (32 * EPI_PITCH), stats_tab, m0);
+#ifdef LA_TILE_STAMPS
+    if (threadIdx.x == 0 && g_tile_stamps) {
+        unsigned long long *o = g_tile_stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+        o[0] = stamp_t0; o[1] = stamp_t1; o[2] = stamp_t2; o[3] = __builtin_amdgcn_s_memrealtime();
+        unsigned hw_id, xcc_id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+        o[4] = hw_id; o[5] = xcc_id;
+        o[6] = tile;
+    }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Four-wave workgroups, two resident per CU (mainloop_q4_asm, la_gemm_pp.h; LA_GEMM_Q4=1): 256 x 128 tiles, the 8-wave kernel's wave
+// tiles and epilogues.  One workgroup's prologue / epilogue / dispatch gap runs under the other's main loop.
+template <bool OUT_F32, typename T16, int LNM = 0, int REM = 8, bool WIDE = false>
+__global__ __launch_bounds__(Q4::THREADS, 2) void gemm_q4_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+#ifdef LA_TILE_STAMPS
+    const unsigned long long stamp_t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long stamp_t1 = stamp_t0;
+#endif
+    // LA_GEMM_Q4_PRIO=1: prologue and epilogue at raised wave priority -- they are short, latency-bound phases that share the SIMDs
+    // with the OTHER workgroup's main loop; at equal priority the timeline shows them stretched 2-4 x (tools/tile_timeline.py).
+    const bool prio = p.epilogue & LA_EPI_Q4_PRIO;
+    if (prio) __builtin_amdgcn_s_setprio(3);
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int tile = xcd_remap(blockIdx.x, nwg);
+    const TileCoord tc = tile_coord_mb(tile, p.tiles_m, p.tiles_n, p.group, p.mblock);
+    constexpr int TM = WIDE ? Q4::TN : Q4::TM, TN = WIDE ? Q4::TM : Q4::TN;      // 256 x 128, or 128 x 256 (WIDE)
+    const int m0 = tc.tm * TM, n0 = tc.tn * TN;
+    const int z = blockIdx.y;
+    const T16 *A = reinterpret_cast<const T16 *>(p.A) + (int64_t)z * p.strideA;
+    const T16 *W = reinterpret_cast<const T16 *>(p.W) + (int64_t)z * p.strideW;
+    const float *bias = p.bias ? p.bias + (int64_t)z * p.strideBias : nullptr;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = WIDE ? 0 : wave >> 1, wc = WIDE ? wave : wave & 1;
+    const bool has_bias = (p.epilogue & LA_EPI_BIAS) && bias;
+    const int ncol = min(n0 + wc * 64 + lane, p.N - 1);          // per-column operands before the main loop (as gemm_pp_kernel)
+    const float bias_l = has_bias ? bias[ncol] : 0.f;
+    float csum_l = 0.f;
+    if constexpr (LNM == 2) csum_l = p.ln_csum[ncol];
+    float2 st_pre = make_float2(0.f, 1.f);
+    constexpr int SROWS = TM / 4;                               // rows of the tile whose statistics this wave fetches
+    if constexpr (LNM == 2) {
+        if (lane < SROWS) st_pre = reinterpret_cast<const float2 *>(p.ln_stats)[min(m0 + wave * SROWS + lane, p.M - 1)];
+    }
+
+    f32x4 acc[8][4];
+    mainloop_q4_asm<T16, REM, WIDE>(A, p.lda, p.M, W, p.ldw, p.N, p.K, m0, n0, lds, acc LA_STAMP_ARG);
+    if (prio) __builtin_amdgcn_s_setprio(3);
+    float2 *stats_tab = reinterpret_cast<float2 *>(lds + Q4::STATS);         // behind the ring: clear of the epilogue staging
+    if constexpr (LNM == 2) {
+        if (lane < SROWS) stats_tab[wave * SROWS + lane] = st_pre;
+    }
+#ifdef LA_TILE_STAMPS
+    const unsigned long long stamp_t2 = __builtin_amdgcn_s_memrealtime();
+#endif
+    __syncthreads();
+    if constexpr (LNM == 3) {
+        wave_epilogue_split<T16, 1>(p, z, acc, m0 + wr * 128, n0 + wc * 64, has_bias, bias_l, lds + wave * (32 * EPI_PITCH), lds + wave * (32 * EPI_PITCH));
     } else wave_epilogue<OUT_F32, T16, LNM == 2 ? 4 : LNM>(p, z, acc, m0 + wr * 128, n0 + wc * 64, has_bias, bias_l, csum_l, lds + wave * (32 * EPI_PITCH), stats_tab, m0);
 #ifdef LA_TILE_STAMPS
     if (threadIdx.x == 0 && g_tile_stamps) {
@@ -1081,8 +1146,39 @@ int launch_mono_modes(GemmParams p, int batch, hipStream_t stream) {
     return launch_mono<OUT_F32, T16, 0>(p, batch, stream);
 }
 
+// LA_GEMM_Q4=1 (read per launch): the four-wave, two-workgroups-per-CU form for the shapes the hand-placed loop takes (bf16).
+template <bool OUT_F32, typename T16, int LNM, bool WIDE>
+int launch_q4(GemmParams p, int batch, hipStream_t stream) {
+    auto kern = gemm_q4_kernel<OUT_F32, T16, LNM, 8, WIDE>;
+    static la::DeviceOnce attr_once;
+    if (attr_once.pending()) {
+        LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Q4::LDS));
+        attr_once.mark();
+    }
+    p.tiles_m = la::cdiv(p.M, WIDE ? Q4::TN : Q4::TM);
+    p.tiles_n = la::cdiv(p.N, WIDE ? Q4::TM : Q4::TN);
+    // column groups of the same WIDTH and row blocks of the same HEIGHT as the 8-wave kernel's (which counts 256 x 256 tiles)
+    const int gw = WIDE ? 1 : 2, mh = WIDE ? 2 : 1;
+    p.group = getenv("LA_GEMM_GROUP") ? std::min(gw * p.group, p.tiles_n) : std::min(p.tiles_n, gw * std::max(4, p.group / 2));
+    p.mblock = p.tiles_n > p.group ? 32 * mh : 0;
+    if (const char *g = getenv("LA_GEMM_MBLOCK")) p.mblock = atoi(g);
+    if (const char *g = getenv("LA_GELU_PK")) p.epilogue |= atoi(g) == 2 ? 8192 : 4096;
+    if (const char *g = getenv("LA_GEMM_Q4_PRIO")) { if (atoi(g) == 1) p.epilogue |= LA_EPI_Q4_PRIO; }
+    la::TimerScope ts("gemm_bf16", stream, 2.0 * p.M * p.N * p.K * batch);
+    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, batch), dim3(Q4::THREADS), Q4::LDS, stream, p);
+    LA_LAUNCH_CHECK();
+    return LA_OK;
+}
+
 template <bool OUT_F32, bool DUO, typename T16, int LNM = 0>
 int launch_pp_loop(GemmParams p, int batch, hipStream_t stream) {
+    if constexpr (DUO && std::is_same<T16, bf16_t>::value && ((LNM == 3 && OUT_F32) || ((LNM == 0 || LNM == 2) && !OUT_F32))) {
+        const char *q4 = getenv("LA_GEMM_Q4");
+        if (q4 && Q4::rem_of(p.K / 32) == 8) {                     // (K = 256, 1024, 4096, ..); 1 = 256 x 128 tiles, 2 = 128 x 256
+            if (atoi(q4) == 1) return launch_q4<OUT_F32, T16, LNM, false>(p, batch, stream);
+            if (atoi(q4) == 2) return launch_q4<OUT_F32, T16, LNM, true>(p, batch, stream);
+        }
+    }
     auto kern = gemm_pp_kernel<OUT_F32, DUO, T16, LNM>;
     static la::DeviceOnce attr_once;
     if (attr_once.pending()) {

@@ -666,3 +666,49 @@ def test_gemm_persistent_kernel_is_bit_identical_to_one_workgroup_per_tile(dtype
             ops.gemm_split(a, w, hi, lo, bias=bias, in_place=True)
             return [hi, lo]
         both(split)                                                                                         # split stream in place
+
+
+# ------------------------------------------------------------------------------------------------ four-wave workgroups, two per CU
+@pytest.mark.parametrize("form", ["1", "2"])
+def test_gemm_four_wave_two_workgroups_per_cu_is_bit_identical(form):
+    """gemm_q4_kernel (opt-in, LA_GEMM_Q4 read per launch, bf16: 256 x 128 tiles (1) or 128 x 256 tiles (2), four waves, a ring of
+    three stages, two workgroups resident per CU) against the 8-wave kernel: the same wave tiles, accumulation order and epilogues, so
+    the same bits -- plain, LayerNorm consumer (+ GELU) and the split stream in place; M with a partial last row of tiles, N with a
+    partial last column tile in the plain form (edge epilogue), K = 256 (loop body never runs), 1024 and 4096."""
+    from lyricalignment_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(12)
+    dtype = torch.bfloat16
+
+    def both(fn):
+        os.environ.pop("LA_GEMM_Q4", None)
+        ref = [t.clone() for t in fn()]
+        os.environ["LA_GEMM_Q4"] = form
+        try:
+            out = fn()
+        finally:
+            os.environ.pop("LA_GEMM_Q4", None)
+        torch.cuda.synchronize()
+        for a_, b_ in zip(out, ref):
+            assert torch.equal(a_.view(torch.int16) if a_.dtype == dtype else a_, b_.view(torch.int16) if b_.dtype == dtype else b_)
+
+    for M, N, K in ((12500, 1024, 256), (6100, 3072, 1024), (12500, 1024, 4096)):       # (>= 192 tiles: the 256x256 kernel's launches)
+        a = torch.randn(M, K, device="cuda", generator=g).to(dtype)
+        w = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(dtype)
+        bias = torch.randn(N, device="cuda", generator=g)
+        csum = torch.randn(N, device="cuda", generator=g)
+        stats = torch.stack([torch.randn(M, device="cuda", generator=g) * 0.1, 1.0 + 0.1 * torch.rand(M, device="cuda", generator=g)], dim=1).contiguous()
+        out16 = torch.empty(M, N, device="cuda", dtype=dtype)
+        both(lambda: [ops.gemm(a, w, out16, bias=bias)])
+        both(lambda: [ops.gemm(a, w, out16, bias=bias, gelu=True, ln_stats=stats, ln_csum=csum)])
+        hi0 = torch.randn(M, N, device="cuda", generator=g).to(dtype)
+        lo0 = torch.randint(1, 256, (M, N), device="cuda", generator=g, dtype=torch.uint8)
+
+        def split():
+            hi, lo = hi0.clone(), lo0.clone()
+            ops.gemm_split(a, w, hi, lo, bias=bias, in_place=True)
+            return [hi, lo]
+        both(split)
+    a = torch.randn(12500, 1024, device="cuda", generator=g).to(dtype)                # partial last column tile (N = 1000)
+    w = (torch.randn(1000, 1024, device="cuda", generator=g) / 32).to(dtype)
+    out16 = torch.empty(12500, 1000, device="cuda", dtype=dtype)
+    both(lambda: [ops.gemm(a, w, out16)])

@@ -167,9 +167,10 @@ def bench_tile_order(iters):
             print(f"order M={M} N={N} K={K} (group, mblock)={key}: {t*1e3:8.1f} us = {fl/t/1e9:7.1f} TF/s", flush=True)
 
 
-def bench_persist(iters):
+def bench_persist(iters, flag_name="LA_GEMM_PERSIST", label="persistent", on="1"):
     """The persistent 256x256 kernel (opt-in LA_GEMM_PERSIST=1: tickets + next tile's stages prefetched under the epilogue) against one
-    workgroup per tile on the encoder's four GEMMs WITH their epilogues, interleaved rounds in one process."""
+    workgroup per tile on the encoder's four GEMMs WITH their epilogues, interleaved rounds in one process.  `q4`: the same
+    comparison for the four-wave / two-workgroups-per-CU form (LA_GEMM_Q4=1), with a bit-identity check of every case first."""
     M = 48000
     cases = [("qkv (LN consumer)", 3072, 1024, "ln"), ("mlp_up (LN consumer + GELU)", 4096, 1024, "ln_gelu"), ("out_proj (split stream)", 1024, 1024, "split"),
              ("mlp_down (split stream)", 1024, 4096, "split"), ("plain 16-bit", 3072, 1024, "plain")]
@@ -188,15 +189,23 @@ def bench_persist(iters):
             stats = torch.stack([torch.zeros(M, device="cuda"), torch.ones(M, device="cuda")], dim=1).contiguous()
             csum = torch.randn(N, device="cuda")
             fn = lambda: ops.gemm(a, w, out, bias=bias, gelu=kind == "ln_gelu", ln_stats=stats, ln_csum=csum)
-        res = {"1": [], "0": []}
+        same = None
+        if kind != "split":                       # (the in-place split update is checked by tests/test_gpu_ops.py)
+            outs = []
+            for flag in (on, "0"):
+                os.environ[flag_name] = flag
+                out.zero_(); fn(); torch.cuda.synchronize()
+                outs.append(out.clone())
+            same = bool(torch.equal(outs[0], outs[1]))
+        res = {on: [], "0": []}
         for rd in range(3):
-            for flag in ("1", "0"):
-                os.environ["LA_GEMM_PERSIST"] = flag
+            for flag in (on, "0"):
+                os.environ[flag_name] = flag
                 res[flag].append(timeit(fn, iters)[0])
-        os.environ.pop("LA_GEMM_PERSIST", None)
+        os.environ.pop(flag_name, None)
         fl = 2.0 * M * N * K
-        p_, o_ = sorted(res["1"])[1], sorted(res["0"])[1]
-        print(f"persist {name:30s} N={N} K={K}: persistent {p_*1e3:7.1f} us ({fl/p_/1e9:6.1f} TF/s) | one workgroup per tile {o_*1e3:7.1f} us ({fl/o_/1e9:6.1f} TF/s) | {100*(o_/p_-1):+.1f} %", flush=True)
+        p_, o_ = sorted(res[on])[1], sorted(res["0"])[1]
+        print(f"{label} {name:30s} N={N} K={K}: {label} {p_*1e3:7.1f} us ({fl/p_/1e9:6.1f} TF/s) | one 8-wave workgroup per tile {o_*1e3:7.1f} us ({fl/o_/1e9:6.1f} TF/s) | {100*(o_/p_-1):+.1f} % | identical bits: {same}", flush=True)
 
 
 def bench_attn(iters):
@@ -295,6 +304,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if a.what == "persist":
         bench_persist(a.iters)
+        sys.exit(0)
+    if a.what in ("q4", "q4w"):                                   # 256 x 128 tiles / 128 x 256 tiles
+        bench_persist(a.iters, "LA_GEMM_Q4", a.what, "1" if a.what == "q4" else "2")
         sys.exit(0)
     if a.what == "order":
         bench_tile_order(a.iters)

@@ -17,7 +17,8 @@ for name in (sys.argv[1:] or ["qkv", "mlp_up", "out_proj", "mlp_down"]):
     a = torch.randn(M, K, device="cuda").bfloat16()
     w = (torch.randn(N, K, device="cuda") * K ** -0.5).bfloat16()
     bias = torch.randn(N, device="cuda")
-    tiles = -(-M // 256) * -(-N // 256)
+    q4 = os.environ.get("LA_GEMM_Q4", "0")                   # four-wave workgroups, two per CU: 256 x 128 (1) or 128 x 256 (2) tiles
+    tiles = -(-M // 256) * -(-N // 256) if q4 not in ("1", "2") else (-(-M // 256) * -(-N // 128) if q4 == "1" else -(-M // 128) * -(-N // 256))
     buf = torch.zeros(tiles * 8, dtype=torch.int64, device="cuda")
     _lib.lib().la_debug_set_tile_stamps.argtypes = [ctypes.c_void_p]
     if kind == "split":
@@ -70,6 +71,26 @@ for name in (sys.argv[1:] or ["qkv", "mlp_up", "out_proj", "mlp_down"]):
     t -= t[:, 0].min()
     cu = (s[:, 5] & 0xF) * 65536 + ((s[:, 4] >> 8) & 0xFF)    # (XCC, SE / SH / CU bits of HW_ID)
     pro, loop, epi = t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2]
+    if q4 in ("1", "2"):
+        # two workgroups share a CU: per CU, the share of its busy span with 0 / 1 / 2 workgroups inside their main loops
+        q = lambda x: f"median {np.median(x):6.2f}  p10 {np.percentile(x, 10):6.2f}  p90 {np.percentile(x, 90):6.2f}"
+        share = np.zeros(3)
+        for c in np.unique(cu):
+            idx = np.where(cu == c)[0]
+            ev = sorted([(t[i, 1], 1) for i in idx] + [(t[i, 2], -1) for i in idx])
+            lo, hi, n, last = t[idx, 0].min(), t[idx, 3].max(), 0, None
+            last = lo
+            for when, d in ev:
+                share[min(n, 2)] += when - last
+                last, n = when, n + d
+            share[0] += hi - last
+        share /= share.sum()
+        print(f"{name} (q4={q4}): N={N} K={K} {kind}: launch {ev0.elapsed_time(ev1) * 1e3:.1f} us, {tiles} tiles on {len(np.unique(cu))} CUs, last workgroup ends at {t[:, 3].max():.1f} us")
+        print(f"   prologue (entry -> stages 0, 1 in)  {q(pro)} us")
+        print(f"   main loop                           {q(loop)} us")
+        print(f"   epilogue                            {q(epi)} us")
+        print(f"   CU time with 0 / 1 / 2 workgroups in their main loops: {share[0]:.2f} / {share[1]:.2f} / {share[2]:.2f}", flush=True)
+        continue
     gaps, first = [], []
     for c in np.unique(cu):
         idx = np.where(cu == c)[0]
