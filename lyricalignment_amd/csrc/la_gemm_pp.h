@@ -457,10 +457,15 @@ __device__ __forceinline__ void duo_setup(DuoCtx &c, const T16 *A, int64_t lda, 
     c.fw_lo = lds0 + OPS + (unsigned)((wc * 64 + r) * SB + ((q ^ swz2(r)) << 4));
     c.fw_hi = c.fw_lo + 2 * STAGE;
 }
+// Prefetch distance of the hand-placed loop in stages (ring of 4): 4 = stage s + 4 goes into the slot k-step s has just freed;
+// 3 (a library built with -DLA_DUO_DIST=3: one stage less in flight per wave) is the A/B partner, same results.
+#ifndef LA_DUO_DIST
+#define LA_DUO_DIST 4
+#endif
 __device__ __forceinline__ void duo_issue_prologue(const DuoCtx &c) {
     constexpr int STAGE = 32768, SB = 64;
 #pragma unroll
-    for (int st = 0; st < 4; ++st) {
+    for (int st = 0; st < LA_DUO_DIST; ++st) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) glds16_so(c.voff[i], c.src0 + st * SB, c.piece0 + st * STAGE + i * 1024);
     }
@@ -469,6 +474,11 @@ __device__ __forceinline__ void duo_issue_prologue(const DuoCtx &c) {
 // are younger than them in this wave's queue): one wait retires all four without forcing a single store, k-steps 0 and 1 (which
 // would retire stages 2 and 3) wait for their fragment reads only, and from k-step 2 on -- whose wait needs stage 4, issued
 // after those stores -- the stream is the ordinary one: by then (>= 2 k-steps, ~2 us) the stores have drained.
+// Timing-only knock-outs of the hand-placed k-step (a library built with LA_EXTRA_CXXFLAGS=-DLA_DUO_PROBE=<bits>; results are garbage):
+// 1 = no barrier, 2 = no counted vmcnt wait, 4 = no LDS-DMA issue, 8 = no fragment reads.  What each leg costs the loop.
+#ifndef LA_DUO_PROBE
+#define LA_DUO_PROBE 0
+#endif
 template <typename T16 = bf16_t, int STAT_WC = -1, bool PREFETCHED = false>
 __device__ __forceinline__ void duo_run(const DuoCtx &c, int K, f32x4 (&acc)[8][4] LA_STAMP_PARAM, float *sacc = nullptr) {
     constexpr int STAGE = 32768, SB = 64;
@@ -484,7 +494,9 @@ __device__ __forceinline__ void duo_run(const DuoCtx &c, int K, f32x4 (&acc)[8][
     auto issue1 = [&](const unsigned char *src, int slot, int i) __attribute__((always_inline)) {
         glds16_so(voff[i], src, piece0 + slot * STAGE + i * 1024);
     };
+    // (PREFETCHED -- the persistent kernel -- has its entry waits counted for distance 4: not to be run from a -DLA_DUO_DIST=3 build)
     if constexpr (PREFETCHED) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else if constexpr (LA_DUO_DIST == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // stages 0 and 1 landed; the 8 pieces of stages 2 and 3 may stay in flight
     LA_PP_BARRIER();
     LA_STAMP_T1();
@@ -507,10 +519,10 @@ __device__ __forceinline__ void duo_run(const DuoCtx &c, int K, f32x4 (&acc)[8][
         constexpr bool NX = decltype(nxc)::value, PF = decltype(pfc)::value;
         constexpr int VM = decltype(vmc)::value;
         constexpr int CUR = decltype(curc)::value, SLOT = decltype(slotc)::value;
-        constexpr int SN = (SLOT + 1) & 3, SW = SLOT;
+        constexpr int SN = (SLOT + 1) & 3, SW = (SLOT + LA_DUO_DIST) & 3;
         constexpr int OFFN = (SN & 1) * STAGE;
         const unsigned fan = SN >= 2 ? fa_hi : fa_lo, fwn = SN >= 2 ? fw_hi : fw_lo;
-        const unsigned char *src = src0 + (int64_t)(s + 4) * SB;
+        const unsigned char *src = src0 + (int64_t)(s + LA_DUO_DIST) * SB;
         static_for<0, 32>([&](auto jc) __attribute__((always_inline)) {
             constexpr int j = decltype(jc)::value, mi = j >> 2, ni = j & 3;
             MmaAsmV<T16>::run(fw[CUR][ni], fa[CUR][mi], acc[mi][ni]);
@@ -521,19 +533,19 @@ __device__ __forceinline__ void duo_run(const DuoCtx &c, int K, f32x4 (&acc)[8][
                     Dot2cAsm<T16>::run(sacc[2 * fi], sacc[2 * fi + 1], fa[CUR][2 * STAT_WC + fi][dw], stat_ones);
                 }
             }
-            if constexpr (NX && (j & 1) == 1 && j / 2 < 12) {
+            if constexpr (NX && (j & 1) == 1 && j / 2 < 12 && !(LA_DUO_PROBE & 8)) {
                 constexpr int i = j / 2;                        // fragments of the next k-step: W 0..3, then A 0..7
                 if constexpr (i < 4) ds_read128_asm<OFFN + i * 1024>(fw[CUR ^ 1][i], fwn);
                 else ds_read128_asm<OFFN + (i - 4) * 1024>(fa[CUR ^ 1][i - 4], fan);
             }
-            if constexpr (PF && (j & 7) == 2) issue1(src, SW, j >> 3);
+            if constexpr (PF && (j & 7) == 2 && !(LA_DUO_PROBE & 4)) issue1(src, SW, j >> 3);
             if constexpr (j == 28) {
-                if constexpr (VM == 63) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (PREFETCHED: its stage landed long ago)
-                else if constexpr (VM == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-                else if constexpr (VM == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+                if constexpr (VM == 63 || (LA_DUO_PROBE & 2)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (PREFETCHED: its stage landed long ago)
+                else if constexpr (VM == 8 && LA_DUO_DIST == 4) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+                else if constexpr (VM == 8 || VM == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             }
-            if constexpr (j == 29) asm volatile("s_barrier" ::: "memory");
+            if constexpr (j == 29 && !(LA_DUO_PROBE & 1)) asm volatile("s_barrier" ::: "memory");
         });
     };
     typedef std::false_type F;
@@ -559,7 +571,8 @@ __device__ __forceinline__ void duo_run(const DuoCtx &c, int K, f32x4 (&acc)[8][
         kstep(s + 2, TT{}, TT{}, V8{}, I0{}, I2{});
         kstep(s + 3, TT{}, TT{}, V8{}, I1{}, I3{});
     }
-    kstep(s, TT{}, F{}, V4{}, I0{}, I0{});
+    if constexpr (LA_DUO_DIST == 3) kstep(s, TT{}, TT{}, V4{}, I0{}, I0{});       // (stage ns - 1 is still to be issued)
+    else kstep(s, TT{}, F{}, V4{}, I0{}, I0{});
     kstep(s + 1, TT{}, F{}, I0{}, I1{}, I1{});
     kstep(s + 2, TT{}, F{}, I0{}, I0{}, I2{});
     kstep(s + 3, F{}, F{}, I0{}, I1{}, I3{});
