@@ -654,7 +654,9 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # LA_BENCH_FORCE_DIST=1 (test knob): form the process group at world size 1 too, so that a one-GPU box exercises the RCCL
+    # code path of the N > 1 runs (init with device_id, barrier, all_reduce MAX) -- needs RANK / WORLD_SIZE / MASTER_* from a launcher
+    if world > 1 or os.environ.get("LA_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":

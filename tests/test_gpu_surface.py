@@ -318,6 +318,26 @@ def test_plain_bench_gpus_2_starts_its_own_two_ranks(extra):
     assert "starting 2 ranks" in r.stderr and "rank 1/2" in r.stderr and "rank 0/2" in r.stderr
 
 
+@pytest.mark.parametrize("extra", [[], ["--mode", "finetune", "--model", "tiny", "--accum", "2"]], ids=["align", "finetune"])
+def test_bench_process_group_over_rccl_at_world_size_one(extra):
+    """The N > 1 runs form their process group over RCCL (backend "nccl", device_id = the rank's GPU) and call barrier() and
+    all_reduce(MAX) around the timed region; a one-GPU box cannot hold two RCCL ranks, so this drives exactly those calls
+    with ONE rank under the launcher (LA_BENCH_FORCE_DIST=1): a wrong keyword, a CPU tensor handed to RCCL or a missing
+    HSA_ENABLE_IPC_MODE_LEGACY would fail here instead of in the first 8-GPU run."""
+    env = dict(os.environ, LA_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LA_BENCH_SAME_DEVICE", "LA_BENCH_DIST_BACKEND"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", *extra]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["steps"] == 2 and out["value"] > 0
+
+
 @pytest.mark.parametrize("mode_args", [["--mode", "longform", "--songs", "4"], ["--mode", "largev2", "--clips", "64"]])
 def test_other_config_bench_modes_two_ranks(mode_args):
     """BASELINE configs[4] (long form) and configs[3] (large-v2 float16) through bench.py with 2 ranks over gloo on one device:
