@@ -601,14 +601,21 @@ static int attention_launch(int dtype_arg, AttnParams p, int batch, hipStream_t 
     const dim3 grid(la::cdiv(p.q_len, QT) * p.n_head * batch), block(256);
     if (dtype == LA_BF16 || dtype == LA_F16) {
         la::TimerScope ts("attention_bf16", stream);
-        const char *nw_env = getenv("LA_ATTN_NW");        // developer A/B (read per launch): 8 = 256-query workgroups
-        if (nw_env && atoi(nw_env) == 8 && p.q_len >= 256) {
+        // 256-query workgroups of 8 waves where a sequence has at least four of them (the encoder: T = 1500): every K / V tile is
+        // staged once for twice the queries -- two LDS-DMA pieces per wave and tile instead of four, and the GEMM knock-outs of
+        // round 4 price a piece at 60-185 cycles of issue -- same results, 325 against 333 us per layer alone, -0.25 ms per step
+        // same-box (profiles/r4_ab_attention_8_waves.txt).  LA_ATTN_NW=4 | 8 (read per launch) forces either form.
+        const char *nw_env = getenv("LA_ATTN_NW");
+        const int nw = nw_env ? atoi(nw_env) : (p.q_len >= 1024 ? 8 : 4);
+        if (nw == 8 && p.q_len >= 256) {
             const dim3 grid8(la::cdiv(p.q_len, 256) * p.n_head * batch), block8(512);
             const char *opt8 = getenv("LA_ATTN_OPT");
             if (opt8 && atoi(opt8) == 0) {
                 if (dtype == LA_F16) hipLaunchKernelGGL((attention_bf16_kernel<la::f16_t, 8>), grid8, block8, 0, stream, p);
                 else hipLaunchKernelGGL((attention_bf16_kernel<bf16_t, 8>), grid8, block8, 0, stream, p);
             } else if (dtype == LA_F16) hipLaunchKernelGGL((attention_bf16_kernel<la::f16_t, 8, false, 0, true>), grid8, block8, 0, stream, p);
+            else if (qlog2 && !(getenv("LA_ATTN_FOLD") && atoi(getenv("LA_ATTN_FOLD")) == 0))
+                hipLaunchKernelGGL((attention_bf16_kernel<bf16_t, 8, false, 0, true, 0, true>), grid8, block8, 0, stream, p);
             else hipLaunchKernelGGL((attention_bf16_kernel<bf16_t, 8, false, 0, true>), grid8, block8, 0, stream, p);
 #ifdef LA_ATTN_KNOCKOUT
         } else if (const char *ko = getenv("LA_ATTN_KO")) {  // diagnostic build: parts of the tile loop left out (bf16 only)

@@ -146,9 +146,12 @@ def test_attention(B, T, H, dtype):
     np.testing.assert_allclose(out.double().numpy(), ref.numpy(), rtol=0, atol=tol)
 
 
-def test_attention_online_rescale_spike():
-    """Force the running-max update: one key late in the sequence dominates one query (cdna guide rule 26)."""
+@pytest.mark.parametrize("nw", ["4", "8"])
+def test_attention_online_rescale_spike(nw, monkeypatch):
+    """Force the running-max update: one key late in the sequence dominates one query (cdna guide rule 26).  Both workgroup forms
+    of the 16-bit kernels (LA_ATTN_NW: 128-query / 256-query workgroups; the second is the default from 1024 positions on)."""
     from lyricalignment_amd import ops
+    monkeypatch.setenv("LA_ATTN_NW", nw)
     T, H = 300, 1
     qkv = _rand(T, 192, seed=31, scale=0.3)
     qkv[7, :64] = 0.0; qkv[7, 0] = 4.0           # query 7 looks at feature 0
@@ -184,11 +187,14 @@ def test_attention_q_log2(B, T, H, dtype):
     np.testing.assert_allclose(out.double().numpy(), ref.numpy(), rtol=0, atol=2e-2)
 
 
-def test_attention_q_log2_extreme_scores():
+@pytest.mark.parametrize("nw", ["4", "8"])
+def test_attention_q_log2_extreme_scores(nw, monkeypatch):
     """The exp2-domain kernel's two exits from its no-maximum fast path: scores above 2^30 (the redo path installs a maximum and
     the wave subtracts it from then on) and queries whose scores ALL lie below 2^-100 (the sum underflows: the block repeats its
-    sweep the textbook way) -- next to ordinary queries in the same block, in the first / a middle / the last tile."""
+    sweep the textbook way) -- next to ordinary queries in the same block, in the first / a middle / the last tile.  Both
+    workgroup forms (LA_ATTN_NW)."""
     from lyricalignment_amd import ops
+    monkeypatch.setenv("LA_ATTN_NW", nw)
     T, H = 300, 1
     qkv = _rand(T, 192, seed=33, scale=0.3)
     qkv[:, 64] = 0.0
@@ -216,6 +222,28 @@ def test_attention_q_log2_extreme_scores():
         yd = yb.double()
         ref = torch.softmax((yd[:, :64] / 1.4426950408889634) @ yd[:, 64:128].T, dim=-1) @ yd[:, 128:]
         np.testing.assert_allclose(out.double().numpy(), ref.numpy(), rtol=0, atol=2e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("q_log2", [False, True])
+def test_attention_256_query_workgroups_give_the_same_bits(dtype, q_log2, monkeypatch):
+    """The 8-wave / 256-query workgroup form (default from 1024 positions on: a K / V tile is staged once for twice the queries)
+    against the 4-wave / 128-query form (LA_ATTN_NW=4): every query's sweep over the keys is the same arithmetic in the same
+    order, so the outputs are identical -- T = 1500 (the encoder; a partial last query block in both forms) and 1100, peaked scores."""
+    from lyricalignment_amd import ops
+    for B, T, H in ((2, 1500, 3), (1, 1100, 2)):
+        d = H * 64
+        qkv = _rand(B * T, 3 * d, seed=40 + T, scale=1.0)
+        qkv[:, :d] *= 0.125 * 3.0 * (1.4426950408889634 if q_log2 else 1.0)
+        x = qkv.to(dtype).cuda()
+        monkeypatch.setenv("LA_ATTN_NW", "4")
+        ref = ops.attention(x, B, T, H, q_log2=q_log2).clone()
+        monkeypatch.setenv("LA_ATTN_NW", "8")
+        out8 = ops.attention(x, B, T, H, q_log2=q_log2).clone()
+        monkeypatch.delenv("LA_ATTN_NW")
+        out = ops.attention(x, B, T, H, q_log2=q_log2)
+        assert torch.equal(out8.view(torch.int16), ref.view(torch.int16))
+        assert torch.equal(out.view(torch.int16), ref.view(torch.int16))
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
