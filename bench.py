@@ -610,8 +610,9 @@ def main():
     ap.add_argument("--dtype", choices=["bf16", "f16"], default="bf16",
                     help="16-bit operand type of the throughput kernels (BASELINE configs[1] is quoted on bf16)")
     ap.add_argument("--encoder-streams", type=int, default=1, help="HIP streams the encoders of consecutive batches alternate between")
-    ap.add_argument("--head-group", type=int, default=2,
-                    help="batches whose head (GRU / FC / DP) runs as one launch set in the two-stream pipeline")
+    ap.add_argument("--head-group", type=int, default=4,
+                    help="batches whose head (GRU / FC / DP) runs as one launch set in the two-stream pipeline "
+                         "(same-box sweep, profiles/r4_sweep_pipeline_shape.txt: 2 -> 42.47, 4 -> 42.27, 5 -> 42.23, 10 -> 42.69 ms per step)")
     ap.add_argument("--mode", choices=["align", "finetune", "largev2", "longform"], default="align",
                     help="align = BASELINE configs[1] (the headline metric); finetune = configs[2], the data-parallel multitask "
                          "fine-tune step (float32, per-GPU micro-batch 2 x 30 s, --accum micro-steps, ONE gradient all-reduce per step); "
