@@ -666,7 +666,8 @@ class PipelinedAligner:
         self._enc_events = [torch.cuda.Event() for _ in range(self.n_enc)]
         self._enc_i = 0
         self.stream_e = self._enc_streams[0]
-        self.stream_h = torch.cuda.Stream(device=dev, priority=-1)   # the GRU's few workgroups should dispatch promptly
+        # the GRU's few workgroups should dispatch promptly (LA_HEAD_PRIO: developer A/B of the head stream's priority, -1 | 0)
+        self.stream_h = torch.cuda.Stream(device=dev, priority=int(os.environ.get("LA_HEAD_PRIO", "-1")))
         self.enc_done = [torch.cuda.Event(), torch.cuda.Event()]
         self.head_done = [torch.cuda.Event(), torch.cuda.Event()]
         self._head_used = [False, False]
