@@ -448,6 +448,33 @@ def test_attention_ex_causal_and_cross():
         np.testing.assert_allclose(out.double().numpy(), ref.numpy(), rtol=0, atol=tol)
 
 
+def test_attention_ex_causal_and_cross_on_long_sequences():
+    """From 1024 query positions on the 16-bit kernels run 256-query / 8-wave workgroups (la_attention.hip); the text decoder never
+    gets there, but la_attention_ex is a public entry point: causal self-attention over 1100 positions (block diagonal clipping with
+    256-query blocks, a partial last block) and cross-attention of 1100 queries over 1300 keys, bf16 and f16, against float64."""
+    from lyricalignment_amd import ops
+    g = torch.Generator().manual_seed(61)
+    B, n, m, H = 1, 1100, 1300, 2
+    d = H * 64
+    for dtype, tol in ((torch.bfloat16, 2e-2), (torch.float16, 4e-3)):
+        qkv = (torch.randn(B * n, 3 * d, generator=g)).to(dtype)
+        qkv[:, :d] *= 0.3
+        x = qkv.cuda()
+        out = ops.attention_ex(x[:, :d], x[:, d:2 * d], x[:, 2 * d:], B, n, n, H, causal=True).float().cpu()
+        xd = qkv.double().reshape(B, n, 3, H, 64)
+        q, k, v = xd[:, :, 0].transpose(1, 2), xd[:, :, 1].transpose(1, 2), xd[:, :, 2].transpose(1, 2)
+        mask = torch.full((n, n), float("-inf"), dtype=torch.float64).triu_(1)
+        ref = (torch.softmax(q @ k.transpose(-1, -2) + mask, dim=-1) @ v).transpose(1, 2).reshape(B * n, d)
+        np.testing.assert_allclose(out.double().numpy(), ref.numpy(), rtol=0, atol=tol)
+        kv = torch.randn(B * m, 2 * d, generator=g).to(dtype)
+        y = kv.cuda()
+        out = ops.attention_ex(x[:, :d], y[:, :d], y[:, d:], B, n, m, H, causal=False).float().cpu()
+        kd = kv.double().reshape(B, m, 2, H, 64)
+        k2, v2 = kd[:, :, 0].transpose(1, 2), kd[:, :, 1].transpose(1, 2)
+        ref = (torch.softmax(q @ k2.transpose(-1, -2), dim=-1) @ v2).transpose(1, 2).reshape(B * n, d)
+        np.testing.assert_allclose(out.double().numpy(), ref.numpy(), rtol=0, atol=tol)
+
+
 @pytest.mark.parametrize("B,n0,steps", [(2, 3, 12), (1, 1, 20)])
 def test_greedy_decode_with_kv_cache_matches_full_recompute(B, n0, steps):
     """Whisper.decode_greedy (cross K/V projected once, self K/V cache, one-token attention, device argmax) against the
