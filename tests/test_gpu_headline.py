@@ -55,11 +55,11 @@ def headline():
                 ref=[t.cpu().numpy().copy() for t in ref[:2]])
 
 
-def _run_pipeline(h, submits, head_group=2):
+def _run_pipeline(h, submits, head_group=2, encoder_streams=1):
     """submits: list of batch counts, one drain() after each -> list of (onset, offset) numpy arrays, one per submitted batch."""
     from lyricalignment_amd.engine import PipelinedAligner
     bench = h["bench"]
-    pipe = PipelinedAligner(h["eng"], head_group=head_group)
+    pipe = PipelinedAligner(h["eng"], head_group=head_group, encoder_streams=encoder_streams)
     got = []
     with torch.no_grad():
         for n in submits:
@@ -70,16 +70,63 @@ def _run_pipeline(h, submits, head_group=2):
     return got
 
 
-def test_pipeline_with_partial_flush_is_bit_identical_to_single_stream(headline):
-    """5 + 4 submits through PipelinedAligner(head_group=2): head launch sets of 64, 64, 32 (partial flush at the drain), 64, 64
-    clips on stream H beside the next encoders on stream E.  Every batch's frames == the single-stream align_mel result: the
-    pipeline changes which kernels are in flight together, never a result (the driver's --warmup 5 --steps 20 shape)."""
+def _bench_shapes():
+    """(head_group, encoder_streams, submits) of the pipeline: bench.py's OWN defaults with the driver's --warmup / --steps (read from
+    bench.py at collection time, so a change of a default there changes what is held to the oracle here), and the earlier shapes."""
+    import bench
+    return [pytest.param(bench.DEFAULT_HEAD_GROUP, bench.DEFAULT_ENCODER_STREAMS, [bench.DRIVER_WARMUP, bench.DRIVER_STEPS], id="bench-defaults-driver-run"),
+            pytest.param(bench.DEFAULT_HEAD_GROUP, bench.DEFAULT_ENCODER_STREAMS, [bench.DEFAULT_WARMUP, 5], id="bench-defaults-partial-flush"),
+            pytest.param(bench.DEFAULT_HEAD_GROUP, 1, [bench.DEFAULT_HEAD_GROUP, 6], id="roofline-pass-shape"),
+            pytest.param(2, 1, [5, 4], id="head-group-2")]
+
+
+@pytest.mark.parametrize("head_group,encoder_streams,submits", _bench_shapes())
+def test_pipeline_with_partial_flush_is_bit_identical_to_single_stream(headline, head_group, encoder_streams, submits):
+    """The pipeline shapes bench.py runs -- its defaults (head over DEFAULT_HEAD_GROUP batches = 128 clips per launch set,
+    DEFAULT_ENCODER_STREAMS encoder streams) under the driver's `--warmup 5 --steps 20` (a partial flush of 1 batch at the first drain,
+    five full groups after it), the one-encoder-stream pass its roofline leg is measured on, and the round-2 shape (head groups of 2:
+    64, 64, 32, 64, 64 clips).  Every batch's frames == the single-stream align_mel result: the pipeline changes which kernels are in
+    flight together, never a result; and the LAST batch -- what bench.py's self-check reads -- against the fp32 oracle's own
+    end-to-end boundaries on the first clips, to bench.py's tolerance (inference_alignment.py:159-177)."""
+    bench = headline["bench"]
     mask = np.arange(headline["labels"].shape[1])[None, :] < headline["Ls"][:, None]
-    got = _run_pipeline(headline, [5, 4])
-    assert len(got) == 9
+    got = _run_pipeline(headline, submits, head_group=head_group, encoder_streams=encoder_streams)
+    assert len(got) == sum(submits)
     for i, (on, off, st) in enumerate(got):
         assert (st == 0).all()
         assert (on[mask] == headline["ref"][0][mask]).all() and (off[mask] == headline["ref"][1][mask]).all(), f"batch {i} differs"
+    on, off, _ = got[-1]
+    on_err = np.concatenate([np.abs(on[b, :o["L"]] * 0.02 - o["on"]) for b, o in enumerate(headline["oracle"])])
+    off_err = np.concatenate([np.abs(off[b, :o["L"]] * 0.02 - o["off"]) for b, o in enumerate(headline["oracle"])])
+    assert on_err.mean() <= bench.SELFCHECK_TOL_S and off_err.mean() <= bench.SELFCHECK_TOL_S
+    assert max(on_err.max(), off_err.max()) <= 0.2
+
+
+def test_head_over_the_bench_group_of_128_clips_emissions_against_oracle(headline):
+    """The head launch set of the bench's default pipeline -- DEFAULT_HEAD_GROUP batches = 128 clips through ONE GRU / FC launch set
+    (8 workgroup groups of the persistent recurrence) -- emission log-probs of the LAST batch's first clips against the fp32 oracle
+    (the 32-clip launch set is held to it below), and every batch's emissions bit-identical to the first batch's (same clips)."""
+    from lyricalignment_amd import _lib
+    bench, eng = headline["bench"], headline["eng"]
+    G, B, T = bench.DEFAULT_HEAD_GROUP, bench.BATCH, bench.T_FRAMES
+    with torch.no_grad():
+        feats = torch.empty((G * B * T, eng.enc.d), dtype=eng.enc.dtype, device=eng.device)
+        for j in range(G):
+            eng.encode(headline["mel"], out=feats[j * B * T:(j + 1) * B * T])
+        labels, n_labels = torch.cat([headline["labels"]] * G, dim=0), torch.cat([headline["n_labels"]] * G, dim=0)
+        em = eng.emissions(feats, G * B, T, T, labels, n_labels, _lib.LA_VARIANT_CTC).view(G, B, T, -1)
+        valid = (torch.arange(em.shape[-1], device=em.device)[None, :] <= headline["n_labels"][:, None].long())[:, None, :]   # [B, 1, Lmax+1]
+        for j in range(1, G):       # (columns past a clip's own labels are not written: compared where they are)
+            assert torch.equal(em[j][valid.expand_as(em[j])], em[0][valid.expand_as(em[0])]), f"batch {j} of the 128-clip head launch set differs from batch 0"
+        em = em[G - 1, :N_ORACLE_CLIPS].cpu()
+    errs = []
+    for b, o in enumerate(headline["oracle"]):
+        L = o["L"]
+        idx = headline["labels"][b, :L].cpu().long() - 1
+        errs.append(torch.cat([(em[b, :, 1:1 + L] - o["lp"][:, idx]).abs().flatten(), (em[b, :, 0] - o["ls"][:, 0]).abs()]))
+    errs = torch.cat(errs)
+    assert float(errs.mean()) < 0.06 and float(errs.max()) < 0.6
+    eng.check_gru()
 
 
 def test_headline_batch_boundaries_and_emissions_against_oracle(headline):
