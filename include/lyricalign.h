@@ -104,6 +104,28 @@ int la_timer_reset(void);
 int la_timer_sample(int32_t period);
 int la_timer_read_work(double *total_ms, int64_t *timed_launches, double *timed_work, int64_t *all_launches);
 
+/* Library options: the few choices between SHIPPED kernel forms that a caller (or a test) may want to pin.  Each is resolved ONCE per
+ * process -- on first use, from the environment variable named below -- into a plain struct that the launch paths read; no launch
+ * calls getenv.  la_set_option overrides a value at run time (between launches; not synchronised with launches in flight on other
+ * threads), la_get_option reads it back.  Unknown name -> LA_EINVAL.
+ *   name              env                 values
+ *   "gemm_tile"       LA_GEMM_TILE        0 = by shape (default) | 128 | 256 (the 256 x 128 three-stage tile) | 512 (force the 256 x 256 kernel)
+ *   "gemm_loop"       LA_PP_DBG           0 = hand-placed main loop where K % 128 == 0 (default) | 99 = quadrant ping-pong loop
+ *                                         everywhere (the loop of the other K; identical bits)
+ *   "gemm_splitk"     LA_GEMM_NO_SPLITK   1 = float32 GEMMs with few tiles cut K over batch slots (default) | 0 = never (no library scratch)
+ *   "attn_nw"         LA_ATTN_NW          0 = 256-query workgroups from 1024 positions on (default) | 4 = 128-query | 8 = 256-query
+ *   "gru_nw"          LA_GRU_NW           0 = 8-wave workgroups (default) | 4 = 4-wave workgroups of the persistent recurrence
+ *   "gru_fence"       LA_GRU_FENCE        0 = write-through hand-off (default) | 1 = release / acquire fences
+ *   "viterbi_dpp"     LA_VITERBI_NO_DPP   1 = DPP wave shifts (default) | 0 = the LDS-exchange form
+ *   "head_clip_cap"   LA_HEAD_CLIP_CAP    0 = by residency (default) | n = clips per head launch set of la_align_head_forward
+ *   "ln_fusion"       LA_LN_FUSION        1 = LayerNorm folded into the 16-bit encoder GEMMs where they run on the 256 x 256 kernel | 0 = never
+ *   "resid_split"     LA_RESID_SPLIT      1 = the 16-bit encoder keeps its residual stream split (hi 16-bit + lo byte) | 0 = f32 stream
+ * A library built with -DLA_EXPERIMENTS (tools/build_variant.sh; la_has_experiments() == 1) additionally carries the measured-slower
+ * kernel structures of rounds 2-4 and their per-launch developer switches; the shipped library has neither. */
+int la_set_option(const char *name, int64_t value);
+int la_get_option(const char *name, int64_t *value);
+int la_has_experiments(void);
+
 /* ------------------------------------------------------------------------- */
 /* forced-alignment DP   (replaces utils/alignment.py:73-119 + :141-185)      */
 /* ------------------------------------------------------------------------- */
@@ -413,6 +435,27 @@ int la_layernorm_split(int32_t dtype, const void *hi, const void *lo, int64_t ld
  * the same numbers la_row_stats16 computes, without reading the copy back. */
 int la_ln_stats_finalize(const float *part, int32_t slots, int32_t M, float eps, float *stats, void *stream);
 int la_row_stats16(int32_t dtype, const void *x, int64_t ldx, int32_t M, int32_t d, float eps, float *stats, void *stream);
+
+/* float32 Linear products on the f16 matrix pipe at float32 accuracy ("f16x2"; the fine-tune step's nn.Linear forward and both
+ * backward products, train_multitask.py:325-326).  gfx950 multiplies float32 operands at 1/16 of its 16-bit MFMA rate.  A float32
+ * matrix, its rows scaled by powers of two (largest magnitude of a row in [2^13, 2^14)), splits exactly into two IEEE-half PLANES
+ * (hi = f16(x s), lo = f16(x s - hi): 22 bits), and  A W^T = (sa sw^T) o (A_lo W_hi^T + A_hi W_lo^T + A_hi W_hi^T) + O(2^-22)
+ * -- three f16 products accumulated in f32 inside ONE pass of the 256 x 256 kernel over segmented K, the scales applied in its
+ * epilogue.  Measured (profiles/r5_kbench_f32emu.txt): 2.5-3.2 x faster than float32 la_gemm on the fine-tune shapes, error against
+ * a float64 product SMALLER than float32 la_gemm's own.
+ *   la_split_f16x2:    x [rows][cols] f32 (pitch ldx) -> planes [rows][2][kp] f16 (kp >= cols, % 8 == 0; tail columns zero) and
+ *                      inv_scale [rows] f32 (1 / s, a power of two).
+ *   la_split_f16x2_t:  the same of x^T -- planes_t [cols][2][mp] (mp >= rows, % 16 == 0), inv_scale_t [cols]: the operands of a
+ *                      weight gradient dW = dY^T X, whose contraction runs over the rows of dY and X.  Uses library scratch (4 B per column).
+ *   la_gemm_f16x2:     C [M][N] f32 (pitch ldc) = epi((A W^T) o sa sw^T); A = planes [M][2][K], W = planes [N][2][K] (K = the padded
+ *                      plane length both were split to), epilogue = LA_EPI_BIAS | LA_EPI_GELU (erf) | LA_EPI_RESIDUAL (f32 rows, pitch
+ *                      ldr).  slots > 1 cuts K into `slots` equal chunks run as batch slots into library scratch and summed in slot
+ *                      order (few tiles, long K: the weight gradients).  Domain: K / slots a multiple of 128 and >= 256, N > 128,
+ *                      ceil(M/256) ceil(N/256) slots >= 192 -- else LA_EUNSUPPORTED (the caller keeps float32 la_gemm for small shapes). */
+int la_split_f16x2(const float *x, int64_t ldx, int32_t rows, int32_t cols, void *planes, int64_t kp, float *inv_scale, void *stream);
+int la_split_f16x2_t(const float *x, int64_t ldx, int32_t rows, int32_t cols, void *planes_t, int64_t mp, float *inv_scale_t, void *stream);
+int la_gemm_f16x2(int32_t M, int32_t N, int32_t K, int32_t slots, const void *A, const float *sa, const void *W, const float *sw,
+                  float *C, int64_t ldc, const float *bias, const float *residual, int64_t ldr, int32_t epilogue, void *stream);
 
 /* Backward-pass building blocks of the Whisper encoder (float32): la_gemm with a row pitch for W and per-batch strides
  * (attention gradients batch over heads inside the packed [T][3d] projections), batched zero-padded transposes, exact-erf

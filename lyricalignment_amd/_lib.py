@@ -35,6 +35,12 @@ SYMBOLS = {
     "la_timer_reset": (c_int32, []),
     "la_timer_sample": (c_int32, [c_int32]),
     "la_timer_read_work": (c_int32, [POINTER(c_double), POINTER(c_int64), POINTER(c_double), POINTER(c_int64)]),
+    "la_split_f16x2": (c_int32, [_P, _I64, _I32, _I32, _P, _I64, _P, _P]),
+    "la_split_f16x2_t": (c_int32, [_P, _I64, _I32, _I32, _P, _I64, _P, _P]),
+    "la_gemm_f16x2": (c_int32, [_I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _I64, _P, _P, _I64, _I32, _P]),
+    "la_set_option": (c_int32, [c_char_p, c_int64]),
+    "la_get_option": (c_int32, [c_char_p, POINTER(c_int64)]),
+    "la_has_experiments": (c_int32, []),
     "la_viterbi_workspace_bytes": (c_int32, [_I32, _I32, _I32, POINTER(_SZ)]),
     "la_viterbi_batch": (c_int32, [_P, _I64, _I64, _P, _I32, _P, _P, _I32, _I32, _I32, _P, _P, _I32, _P, _P, _P, _SZ, _P]),
     "la_viterbi_core": (c_int32, [_P, _I64, _P, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
@@ -162,6 +168,39 @@ def check(rc: int, what: str = "") -> None:
     if rc == LA_ETIMEOUT:
         raise TimeoutError(f"liblyricalign_hip in-kernel wait timed out: {detail}")
     raise LyricAlignHipError(f"liblyricalign_hip status {rc}: {detail}")
+
+
+def set_option(name: str, value: int) -> None:
+    """include/lyricalign.h la_set_option: pin one of the library's choices between shipped kernel forms (takes effect on the next launch)."""
+    check(lib().la_set_option(name.encode(), int(value)), "set_option")
+
+
+def get_option(name: str) -> int:
+    v = c_int64(0)
+    check(lib().la_get_option(name.encode(), ctypes.byref(v)), "get_option")
+    return int(v.value)
+
+
+class option:
+    """with option("gemm_loop", 99): ...  -- the option set for the block, its previous value restored afterwards (tests)."""
+
+    def __init__(self, name: str, value: int):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        self.prev = get_option(self.name)
+        set_option(self.name, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        set_option(self.name, self.prev)
+        return False
+
+
+def has_experiments() -> bool:
+    """True for a library built with -DLA_EXPERIMENTS (tools/build_variant.sh): the measured-slower kernel structures and their
+    per-launch developer switches are present.  The shipped library returns False."""
+    return bool(lib().la_has_experiments())
 
 
 def ptr(t) -> int:

@@ -19,8 +19,12 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(CSRC, "_obj")
-LIB = os.path.join(HERE, "liblyricalign_hip.so")
+# LA_BUILD_VARIANT=<name> (tools/build_variant.sh): a second library ab/<name>/liblyricalign_hip.so with its own object directory,
+# compiled with LA_EXTRA_CXXFLAGS; with -DLA_EXPERIMENTS among them the sources under csrc/lab/ (the measured-slower kernel
+# structures of rounds 2-4 and their developer switches) are built in.  The default build never compiles csrc/lab/.
+VARIANT = os.environ.get("LA_BUILD_VARIANT", "")
+OBJ = os.path.join(CSRC, "_obj" + ("_" + VARIANT if VARIANT else ""))
+LIB = (os.path.join(HERE, "..", "ab", VARIANT, "liblyricalign_hip.so") if VARIANT else os.path.join(HERE, "liblyricalign_hip.so"))
 ARCH = "gfx950"
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
@@ -37,12 +41,19 @@ NO_SPILL_KERNELS = re.compile(r"gemm_pp_kernel|gemm_pp_persist_kernel|gemm_q4_ke
 REPORT_KERNELS = re.compile(r"gemm_mono_kernel")
 
 
+EXPERIMENTS = "-DLA_EXPERIMENTS" in CXXFLAGS
+
+
 def _sources():
-    return sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.cpp")))
+    srcs = glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.cpp"))
+    if EXPERIMENTS:
+        srcs += glob.glob(os.path.join(CSRC, "lab", "*.hip"))
+    return sorted(srcs)
 
 
 def _headers():
-    return glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
+    return (glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "lab", "*.h")) +
+            glob.glob(os.path.join(HERE, "..", "include", "*.h")))
 
 
 def _parse_resource_usage(stderr: str) -> dict:
@@ -106,6 +117,7 @@ def _compile(src: str, force: bool) -> str:
 
 def build(force: bool = False, jobs: int | None = None) -> str:
     os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(os.path.dirname(os.path.abspath(LIB)), exist_ok=True)
     srcs = _sources()
     jobs = jobs or min(len(srcs), max(1, (os.cpu_count() or 2) - 1))
     with concurrent.futures.ThreadPoolExecutor(jobs) as ex:
@@ -115,6 +127,8 @@ def build(force: bool = False, jobs: int | None = None) -> str:
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    if VARIANT:
+        return os.path.abspath(LIB)
     try:                                   # the C++ consumer example is a check of the header, not a part of the library:
         build_example(force)               # tests/test_gpu_surface.py asserts that it builds, links and runs
     except RuntimeError as e:

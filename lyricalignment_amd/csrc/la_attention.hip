@@ -596,7 +596,7 @@ static int attention_launch(int dtype_arg, AttnParams p, int batch, hipStream_t 
     }
     p.score_scale = qlog2 ? 1.0f : kLog2e;
     p.batch = batch;
-    const char *thr_env = getenv("LA_ATTN_THR");              // developer A/B (read per launch)
+    const char *thr_env = la::dev_env("LA_ATTN_THR");         // experiment build only
     p.defer_thr = thr_env ? (float)atof(thr_env) : 8.0f;
     const dim3 grid(la::cdiv(p.q_len, QT) * p.n_head * batch), block(256);
     if (dtype == LA_BF16 || dtype == LA_F16) {
@@ -604,21 +604,35 @@ static int attention_launch(int dtype_arg, AttnParams p, int batch, hipStream_t 
         // 256-query workgroups of 8 waves where a sequence has at least four of them (the encoder: T = 1500): every K / V tile is
         // staged once for twice the queries -- two LDS-DMA pieces per wave and tile instead of four, and the GEMM knock-outs of
         // round 4 price a piece at 60-185 cycles of issue -- same results, 325 against 333 us per layer alone, -0.25 ms per step
-        // same-box (profiles/r4_ab_attention_8_waves.txt).  LA_ATTN_NW=4 | 8 (read per launch) forces either form.
-        const char *nw_env = getenv("LA_ATTN_NW");
-        const int nw = nw_env ? atoi(nw_env) : (p.q_len >= 1024 ? 8 : 4);
-        if (nw == 8 && p.q_len >= 256) {
-            const dim3 grid8(la::cdiv(p.q_len, 256) * p.n_head * batch), block8(512);
-            const char *opt8 = getenv("LA_ATTN_OPT");
-            if (opt8 && atoi(opt8) == 0) {
-                if (dtype == LA_F16) hipLaunchKernelGGL((attention_bf16_kernel<la::f16_t, 8>), grid8, block8, 0, stream, p);
-                else hipLaunchKernelGGL((attention_bf16_kernel<bf16_t, 8>), grid8, block8, 0, stream, p);
-            } else if (dtype == LA_F16) hipLaunchKernelGGL((attention_bf16_kernel<la::f16_t, 8, false, 0, true>), grid8, block8, 0, stream, p);
-            else if (qlog2 && !(getenv("LA_ATTN_FOLD") && atoi(getenv("LA_ATTN_FOLD")) == 0))
-                hipLaunchKernelGGL((attention_bf16_kernel<bf16_t, 8, false, 0, true, 0, true>), grid8, block8, 0, stream, p);
-            else hipLaunchKernelGGL((attention_bf16_kernel<bf16_t, 8, false, 0, true>), grid8, block8, 0, stream, p);
+        // same-box (profiles/r4_ab_attention_8_waves.txt).  Option attn_nw = 4 | 8 (LA_ATTN_NW) forces either form.
+        const int nw_opt = la::opts().attn_nw;
+        const int nw = nw_opt ? nw_opt : (p.q_len >= 1024 ? 8 : 4);
+        // Shipped forms: the optimistic-maximum tile loop (OPT) in both workgroup sizes; bfloat16 with exp2-domain scores (LA_Q_LOG2)
+        // also folds the running maximum away until one is needed (FOLD).  The experiment build (-DLA_EXPERIMENTS) keeps the A/B
+        // partners behind per-launch switches: LA_ATTN_OPT=0 (per-tile maximum, deferred by LA_ATTN_THR), LA_ATTN_FOLD=0,
+        // LA_ATTN_MSUM (softmax denominator on the matrix pipe).
+        const dim3 grid8(la::cdiv(p.q_len, 256) * p.n_head * batch), block8(512);
+        const bool wide = nw == 8 && p.q_len >= 256;
+#ifdef LA_EXPERIMENTS
+        const char *opt_env = getenv("LA_ATTN_OPT"), *fold_env = getenv("LA_ATTN_FOLD");
+        const bool no_opt = opt_env && atoi(opt_env) == 0, no_fold = fold_env && atoi(fold_env) == 0;
+        if (wide && no_opt) {
+            if (dtype == LA_F16) hipLaunchKernelGGL((attention_bf16_kernel<la::f16_t, 8>), grid8, block8, 0, stream, p);
+            else hipLaunchKernelGGL((attention_bf16_kernel<bf16_t, 8>), grid8, block8, 0, stream, p);
+        } else if (wide && dtype == LA_BF16 && qlog2 && no_fold) {
+            hipLaunchKernelGGL((attention_bf16_kernel<bf16_t, 8, false, 0, true>), grid8, block8, 0, stream, p);
+        } else if (!wide && getenv("LA_ATTN_MSUM")) {
+            if (dtype == LA_F16) hipLaunchKernelGGL((attention_bf16_kernel<la::f16_t, 4, true>), grid, block, 0, stream, p);
+            else hipLaunchKernelGGL((attention_bf16_kernel<bf16_t, 4, true>), grid, block, 0, stream, p);
+        } else if (!wide && no_opt) {
+            if (dtype == LA_F16) hipLaunchKernelGGL((attention_bf16_kernel<la::f16_t, 4>), grid, block, 0, stream, p);
+            else hipLaunchKernelGGL((attention_bf16_kernel<bf16_t, 4>), grid, block, 0, stream, p);
+        } else if (!wide && dtype == LA_BF16 && qlog2 && no_fold) {
+            hipLaunchKernelGGL((attention_bf16_kernel<bf16_t, 4, false, 0, true>), grid, block, 0, stream, p);
+        } else
+#endif
 #ifdef LA_ATTN_KNOCKOUT
-        } else if (const char *ko = getenv("LA_ATTN_KO")) {  // diagnostic build: parts of the tile loop left out (bf16 only)
+        if (const char *ko = getenv("LA_ATTN_KO"); ko && !wide) {  // diagnostic build: parts of the tile loop left out (bf16 only)
             switch (atoi(ko)) {
 #define LA_KO_CASE(n) case n: hipLaunchKernelGGL((attention_bf16_kernel<bf16_t, 4, false, n>), grid, block, 0, stream, p); break;
                 LA_KO_CASE(1) LA_KO_CASE(2) LA_KO_CASE(4) LA_KO_CASE(6) LA_KO_CASE(8) LA_KO_CASE(14) LA_KO_CASE(16) LA_KO_CASE(17)
@@ -634,16 +648,14 @@ static int attention_launch(int dtype_arg, AttnParams p, int batch, hipStream_t 
 #undef LA_KO_PRIO
                 default: hipLaunchKernelGGL((attention_bf16_kernel<bf16_t, 4>), grid, block, 0, stream, p);
             }
+        } else
 #endif
-        } else if (getenv("LA_ATTN_MSUM")) {                 // developer A/B: softmax denominator on the matrix pipe
-            if (dtype == LA_F16) hipLaunchKernelGGL((attention_bf16_kernel<la::f16_t, 4, true>), grid, block, 0, stream, p);
-            else hipLaunchKernelGGL((attention_bf16_kernel<bf16_t, 4, true>), grid, block, 0, stream, p);
-        } else if (const char *opt = getenv("LA_ATTN_OPT"); opt && atoi(opt) == 0) {   // developer A/B: per-tile maximum (deferred, LA_ATTN_THR)
-            if (dtype == LA_F16) hipLaunchKernelGGL((attention_bf16_kernel<la::f16_t, 4>), grid, block, 0, stream, p);
-            else hipLaunchKernelGGL((attention_bf16_kernel<bf16_t, 4>), grid, block, 0, stream, p);
-        } else if (static const bool nofold = getenv("LA_ATTN_FOLD") && atoi(getenv("LA_ATTN_FOLD")) == 0; qlog2 && dtype == LA_BF16 && !nofold) {
-            hipLaunchKernelGGL((attention_bf16_kernel<bf16_t, 4, false, 0, true, 0, true>), grid, block, 0, stream, p);   // exp2-domain scores, no maximum until one is needed
+        if (wide) {
+            if (dtype == LA_F16) hipLaunchKernelGGL((attention_bf16_kernel<la::f16_t, 8, false, 0, true>), grid8, block8, 0, stream, p);
+            else if (qlog2) hipLaunchKernelGGL((attention_bf16_kernel<bf16_t, 8, false, 0, true, 0, true>), grid8, block8, 0, stream, p);
+            else hipLaunchKernelGGL((attention_bf16_kernel<bf16_t, 8, false, 0, true>), grid8, block8, 0, stream, p);
         } else if (dtype == LA_F16) hipLaunchKernelGGL((attention_bf16_kernel<la::f16_t, 4, false, 0, true>), grid, block, 0, stream, p);
+        else if (qlog2) hipLaunchKernelGGL((attention_bf16_kernel<bf16_t, 4, false, 0, true, 0, true>), grid, block, 0, stream, p);   // exp2-domain scores, no maximum until one is needed
         else hipLaunchKernelGGL((attention_bf16_kernel<bf16_t, 4, false, 0, true>), grid, block, 0, stream, p);
     } else {
         static la::DeviceOnce attr_once;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/lyricalign.h"
@@ -14,7 +15,7 @@ char *err_buf();
 void set_error(const char *fmt, ...);
 
 // library-owned scratch for one (device, stream, purpose); nullptr on allocation failure (la_runtime.cpp)
-enum { SCRATCH_SPLITK = 0, SCRATCH_COLSUM = 1 };
+enum { SCRATCH_SPLITK = 0, SCRATCH_COLSUM = 1, SCRATCH_X2 = 2 };
 void *stream_scratch(hipStream_t stream, int purpose, size_t bytes);
 
 #define LA_CHECK_ARG(cond, ...)                \
@@ -42,6 +43,22 @@ void *stream_scratch(hipStream_t stream, int purpose, size_t bytes);
             return LA_EHIP;                                                             \
         }                                                                               \
     } while (0)
+
+// ---- library options (include/lyricalign.h la_set_option): resolved once per process from the environment, read by the launch paths
+struct Options {
+    int gemm_tile = 0, gemm_loop = 0, gemm_splitk = 1, attn_nw = 0, gru_nw = 0, gru_fence = 0, viterbi_dpp = 1, head_clip_cap = 0,
+        ln_fusion = 1, resid_split = 1;
+};
+Options &opts();
+// Developer switches of the experiment build (-DLA_EXPERIMENTS, tools/build_variant.sh): re-read on every launch there, so that
+// tools/kbench.py can flip them between rounds of one process.  The shipped library has none: the call folds to nullptr.
+#ifdef LA_EXPERIMENTS
+inline const char *dev_env(const char *name) { return getenv(name); }
+#define LA_DEV_BIT(word, bits) ((word) & (bits))      // timing probes / A/B forms selected by internal epilogue bits
+#else
+inline const char *dev_env(const char *) { return nullptr; }
+#define LA_DEV_BIT(word, bits) false
+#endif
 
 // ---- a function attribute (dynamic-LDS ceiling) set once per DEVICE, not once per process ----
 // hipFuncSetAttribute applies to the current device's code object: a process driving two devices must set it on both.

@@ -1,0 +1,214 @@
+// la_f32x2.hip -- float32 matrix products on the f16 matrix pipe at float32 accuracy ("f16x2"): the Linear layers of the fine-tune
+// step (train_multitask.py:325-326: loss.backward() through nn.Linear / F.linear in float32 -- forward and both backward products).
+//
+// gfx950 multiplies float32 operands at 1/16 of its 16-bit MFMA rate (v_mfma_f32_16x16x4_f32: 157 TFLOP/s against 2.5 PFLOP/s).  A
+// float32 value scaled by a power of two s (per ROW of its matrix, so that the row's largest magnitude lands in [2^13, 2^14)) splits
+// EXACTLY into two IEEE halves  x s = hi + lo + r,  hi = f16(x s),  lo = f16(x s - hi),  |r| <= 2^-22 |x s|  (elements more than
+// 2^-17 below their row's maximum lose relative -- never absolute -- precision to half's subnormal range: |r| <= 2^-25), and
+//     sum_k a_k w_k  =  (sa sw)^-1  sum_k (a_lo w_hi + a_hi w_lo + a_hi w_hi)  +  O(2^-22)
+// -- three f16 products accumulated in float32 by v_mfma_f32_16x16x32_f16, 3/16 of the float32 pipe's cost.  Measured on the
+// fine-tune shapes (profiles/r5_kbench_f32emu.txt, prototype by K-concatenation on the shipped kernel): 2.5-3.2 x faster than
+// gemm_kernel<float>, error against a float64 product 2-3 x SMALLER than the float32 kernel's own (whose 16x16x4 chains round
+// eight times as often per k as the 16x16x32 instruction).
+//
+//   la_split_f16x2     x [rows][cols] f32  ->  planes [rows][2][kp] f16 (hi plane, lo plane; kp >= cols, zero tail) + inverse scales [rows]
+//   la_split_f16x2_t   the same of x^T: planes [cols][2][mp] + inverse scales [cols]  (weight-gradient operands: contraction over rows)
+//   la_gemm_f16x2      C = epi((A W^T) o sa sw^T): the 256 x 256 f16 kernel over segmented K (la_gemm_pp.h mainloop_duo_seg_asm),
+//                      scales applied in the epilogue; `slots` > 1 cuts K over batch slots (few tiles, long K), summed in a fixed order
+#include <algorithm>
+
+#include "la_gemm_core.h"
+#include "la_gemm_params.h"
+
+using namespace la::gemm;
+
+namespace {
+
+// power of two s with max |x| s in [2^13, 2^14); max == 0 (or not finite) -> 1.  Returns s, *inv = 1 / s (both exact).
+__device__ __forceinline__ float x2_scale(float mx, float *inv) {
+    if (!(mx > 0.f) || !(mx < 3.0e38f)) { *inv = 1.f; return 1.f; }
+    int e;
+    (void)frexpf(mx, &e);                    // mx = m 2^e, m in [0.5, 1)
+    int sh = 14 - e;
+    sh = sh > 126 ? 126 : (sh < -126 ? -126 : sh);
+    *inv = ldexpf(1.f, -sh);
+    return ldexpf(1.f, sh);
+}
+
+__device__ __forceinline__ void x2_split(float xs, unsigned short &hi, unsigned short &lo) {
+    const _Float16 h = (_Float16)xs;
+    const _Float16 l = (_Float16)(xs - (float)h);
+    hi = __builtin_bit_cast(unsigned short, h);
+    lo = __builtin_bit_cast(unsigned short, l);
+}
+
+// one wave per row, four rows per workgroup: pass 1 = the row's largest magnitude, pass 2 (the row is L2-resident) = split + store
+__global__ __launch_bounds__(256) void split_rows_kernel(const float *x, int64_t ldx, int rows, int cols, unsigned short *planes, int64_t kp,
+                                                         float *inv_scale) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float *xr = x + (int64_t)row * ldx;
+    const bool vec = (ldx % 4 == 0) && ((uintptr_t)x % 16 == 0);
+    const int c4 = vec ? cols / 4 : 0;
+    float mx = 0.f;
+    for (int i = lane; i < c4; i += 64) {
+        const float4 v = reinterpret_cast<const float4 *>(xr)[i];
+        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+    for (int i = c4 * 4 + lane; i < cols; i += 64) mx = fmaxf(mx, fabsf(xr[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float inv;
+    const float s = x2_scale(mx, &inv);
+    unsigned short *hi = planes + (int64_t)row * 2 * kp, *lo = hi + kp;
+    for (int i = lane; i < c4; i += 64) {
+        const float4 v = reinterpret_cast<const float4 *>(xr)[i];
+        ushort4 h, l;
+        x2_split(v.x * s, h.x, l.x); x2_split(v.y * s, h.y, l.y); x2_split(v.z * s, h.z, l.z); x2_split(v.w * s, h.w, l.w);
+        reinterpret_cast<ushort4 *>(hi)[i] = h;
+        reinterpret_cast<ushort4 *>(lo)[i] = l;
+    }
+    for (int i = c4 * 4 + lane; i < kp; i += 64) {
+        unsigned short h = 0, l = 0;
+        if (i < cols) x2_split(xr[i] * s, h, l);
+        hi[i] = h; lo[i] = l;
+    }
+    if (lane == 0) inv_scale[row] = inv;
+}
+
+// column maxima of |x| as ordered unsigned bit patterns (|x| >= 0: the float order is the integer order)
+__global__ __launch_bounds__(256) void colmax_kernel(const float *x, int64_t ldx, int rows, int cols, int rows_per_block, unsigned *colmax) {
+    __shared__ float red[4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + cx;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    float mx = 0.f;
+    if (col < cols)
+        for (int r = r0 + ry; r < r1; r += 4) mx = fmaxf(mx, fabsf(x[(int64_t)r * ldx + col]));
+    red[ry][cx] = mx;
+    __syncthreads();
+    if (ry == 0 && col < cols) {
+        mx = fmaxf(fmaxf(red[0][cx], red[1][cx]), fmaxf(red[2][cx], red[3][cx]));
+        if (mx != mx) mx = __uint_as_float(0x7f800000u);            // a NaN column: scale 1 (x2_scale), the NaNs pass through the split
+        atomicMax(colmax + col, __float_as_uint(mx));
+    }
+}
+
+// 64 (rows of x) x 64 (columns of x) tiles through LDS: read along the columns, written along the rows of x (= along the padded
+// contraction dimension of the transposed planes)
+__global__ __launch_bounds__(256) void split_transposed_kernel(const float *x, int64_t ldx, int rows, int cols, const unsigned *colmax,
+                                                               unsigned short *planes, int64_t mp, float *inv_scale) {
+    __shared__ float tile[64][65];
+    const int m0 = blockIdx.y * 64, k0 = blockIdx.x * 64;
+    {
+        const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const int m = m0 + ty * 16 + i, k = k0 + tx;
+            tile[ty * 16 + i][tx] = (m < rows && k < cols) ? x[(int64_t)m * ldx + k] : 0.f;
+        }
+    }
+    __syncthreads();
+    const int kl = threadIdx.x >> 2, mq = threadIdx.x & 3;       // output row k0 + kl, 16 consecutive m each
+    const int k = k0 + kl;
+    if (k >= cols) return;
+    float inv;
+    const float s = x2_scale(__uint_as_float(colmax[k]), &inv);
+    unsigned short *hi = planes + (int64_t)k * 2 * mp + m0 + mq * 16, *lo = hi + mp;
+    if (m0 + mq * 16 < mp) {                                      // (mp is a multiple of 16: whole 16-element pieces)
+        unsigned short h[16], l[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) x2_split(tile[mq * 16 + i][kl] * s, h[i], l[i]);
+        uint4 *ph = reinterpret_cast<uint4 *>(hi), *pl = reinterpret_cast<uint4 *>(lo);
+        ph[0] = *reinterpret_cast<uint4 *>(&h[0]); ph[1] = *reinterpret_cast<uint4 *>(&h[8]);
+        pl[0] = *reinterpret_cast<uint4 *>(&l[0]); pl[1] = *reinterpret_cast<uint4 *>(&l[8]);
+    }
+    if (blockIdx.y == 0 && mq == 0) inv_scale[k] = inv;
+}
+
+// C[m][n] = epi(sum_z P[z][m][n]) in slot order (deterministic); bias / GELU / residual as the GEMM kernels order them
+__global__ void x2_reduce_kernel(const float *P, int S, int M, int N, float *C, int64_t ldc, const float *bias, const float *residual,
+                                 int64_t ldr, int epilogue) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)M * N) return;
+    const int m = (int)(i / N), n = (int)(i - (int64_t)m * N);
+    float v = 0.f;
+    for (int s = 0; s < S; ++s) v += P[(int64_t)s * M * N + i];
+    if ((epilogue & LA_EPI_BIAS) && bias) v += bias[n];
+    if (epilogue & LA_EPI_GELU) v = la::gelu_erf(v);
+    if ((epilogue & LA_EPI_RESIDUAL) && residual) v += residual[(int64_t)m * ldr + n];
+    C[(int64_t)m * ldc + n] = v;
+}
+
+}  // namespace
+
+extern "C" int la_split_f16x2(const float *x, int64_t ldx, int32_t rows, int32_t cols, void *planes, int64_t kp, float *inv_scale,
+                              void *stream_) {
+    if (rows == 0) return LA_OK;
+    LA_CHECK_ARG(x && planes && inv_scale && rows > 0 && cols > 0, "split_f16x2: bad arguments");
+    LA_CHECK_ARG(kp >= cols && kp % 8 == 0 && ldx >= cols && (uintptr_t)planes % 16 == 0, "split_f16x2: kp must be >= cols and a multiple of 8, planes 16-byte aligned");
+    hipStream_t stream = (hipStream_t)stream_;
+    la::TimerScope ts("split_f16x2", stream, (double)rows * cols * 8.0);
+    hipLaunchKernelGGL(split_rows_kernel, dim3(la::cdiv(rows, 4)), dim3(256), 0, stream, x, ldx, rows, cols,
+                       reinterpret_cast<unsigned short *>(planes), kp, inv_scale);
+    LA_LAUNCH_CHECK();
+    return LA_OK;
+}
+
+extern "C" int la_split_f16x2_t(const float *x, int64_t ldx, int32_t rows, int32_t cols, void *planes_t, int64_t mp, float *inv_scale_t,
+                                void *stream_) {
+    if (cols == 0) return LA_OK;
+    LA_CHECK_ARG(x && planes_t && inv_scale_t && rows > 0 && cols > 0, "split_f16x2_t: bad arguments");
+    LA_CHECK_ARG(mp >= rows && mp % 16 == 0 && ldx >= cols && (uintptr_t)planes_t % 16 == 0, "split_f16x2_t: mp must be >= rows and a multiple of 16, planes 16-byte aligned");
+    hipStream_t stream = (hipStream_t)stream_;
+    unsigned *colmax = static_cast<unsigned *>(la::stream_scratch(stream, la::SCRATCH_X2, (size_t)cols * sizeof(unsigned)));
+    if (!colmax) { la::set_error("split_f16x2_t: scratch allocation failed"); return LA_EHIP; }
+    LA_HIP(hipMemsetAsync(colmax, 0, (size_t)cols * sizeof(unsigned), stream));
+    la::TimerScope ts("split_f16x2", stream, (double)rows * cols * 12.0);
+    const int rpb = 512;
+    hipLaunchKernelGGL(colmax_kernel, dim3(la::cdiv(cols, 64), la::cdiv(rows, rpb)), dim3(256), 0, stream, x, ldx, rows, cols, rpb, colmax);
+    LA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(split_transposed_kernel, dim3(la::cdiv(cols, 64), la::cdiv(mp, 64)), dim3(256), 0, stream, x, ldx, rows, cols, colmax,
+                       reinterpret_cast<unsigned short *>(planes_t), mp, inv_scale_t);
+    LA_LAUNCH_CHECK();
+    return LA_OK;
+}
+
+extern "C" int la_gemm_f16x2(int32_t M, int32_t N, int32_t K, int32_t slots, const void *A, const float *sa, const void *W, const float *sw,
+                             float *C, int64_t ldc, const float *bias, const float *residual, int64_t ldr, int32_t epilogue, void *stream_) {
+    if (M == 0 || N == 0) return LA_OK;
+    LA_CHECK_ARG(A && sa && W && sw && C, "gemm_f16x2: null pointer");
+    LA_CHECK_ARG(M > 0 && N > 0 && K > 0 && slots >= 1, "gemm_f16x2: bad sizes");
+    LA_CHECK_ARG((epilogue & ~(LA_EPI_BIAS | LA_EPI_GELU | LA_EPI_RESIDUAL)) == 0, "gemm_f16x2: epilogue takes BIAS, GELU, RESIDUAL only");
+    LA_CHECK_ARG(!(epilogue & LA_EPI_BIAS) || bias, "gemm_f16x2: bias epilogue without pointer");
+    LA_CHECK_ARG(!(epilogue & LA_EPI_RESIDUAL) || residual, "gemm_f16x2: residual epilogue without pointer");
+    LA_CHECK_ARG((uintptr_t)A % 16 == 0 && (uintptr_t)W % 16 == 0, "gemm_f16x2: planes must be 16-byte aligned");
+    const int Kc = K / slots;
+    if (K % slots != 0 || Kc % 128 != 0 || Kc < 256 || N <= 128 || (int64_t)la::cdiv(M, 256) * la::cdiv(N, 256) * slots < 192) {
+        la::set_error("gemm_f16x2: M=%d N=%d K=%d slots=%d outside the 256x256 kernel's domain (K / slots a multiple of 128 and >= 256, N > 128, "
+                      ">= 192 tiles x slots)", M, N, K, slots);
+        return LA_EUNSUPPORTED;
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    float *out = C;
+    int64_t out_ld = ldc, out_stride = 0;
+    int epi = epilogue | LA_EPI_OUT_F32;
+    if (slots > 1) {
+        out = static_cast<float *>(la::stream_scratch(stream, la::SCRATCH_SPLITK, (size_t)slots * M * N * sizeof(float)));
+        if (!out) { la::set_error("gemm_f16x2: split-K scratch allocation failed"); return LA_EHIP; }
+        out_ld = N; out_stride = (int64_t)M * N;
+        epi = LA_EPI_OUT_F32;                          // bias / activation / residual after the slots are summed
+    }
+    GemmParams p{M, N, Kc, A, (int64_t)2 * K, (int64_t)Kc, W, (int64_t)2 * K, (int64_t)Kc, out, out_ld, out_stride,
+                 slots > 1 ? nullptr : bias, 0, slots > 1 ? nullptr : residual, ldr, 0, epi, 0, la::cdiv(N, BN), pick_group(3 * Kc, 2, la::cdiv(N, BN))};
+    p.plane_a = K; p.plane_w = K;
+    p.ln_stats = sa; p.ln_csum = sw;
+    const int rc = launch_x2_f16(p, slots, stream);
+    if (rc != LA_OK || slots == 1) return rc;
+    const int64_t total = (int64_t)M * N;
+    hipLaunchKernelGGL(x2_reduce_kernel, dim3((unsigned)la::cdiv(total, (int64_t)256)), dim3(256), 0, stream, out, slots, M, N, C, ldc, bias,
+                       residual, ldr, epilogue);
+    LA_LAUNCH_CHECK();
+    return LA_OK;
+}

@@ -281,7 +281,7 @@ __device__ __forceinline__ TileCoord tile_coord_mb(int tile, int tiles_m, int ti
     return TileCoord{b * mblock + rem / gw, base_n + rem % gw};
 }
 inline int pick_group(int K, int elem_bytes, int tiles_n) {
-    const char *force = getenv("LA_GEMM_GROUP");   // developer sweep (read per launch: tools/kbench.py flips it between rounds)
+    const char *force = la::dev_env("LA_GEMM_GROUP");   // experiment build only: developer sweep, read per launch
     if (force) { const int g = atoi(force); return g < 1 ? 1 : (g > tiles_n ? tiles_n : g); }
     const int64_t tile_bytes = (int64_t)BN * K * elem_bytes;
     int g = (int)((2 << 20) / tile_bytes);

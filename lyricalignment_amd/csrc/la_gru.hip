@@ -461,7 +461,7 @@ static int gru_forward(int32_t dtype, const float *gi, const void *w_hh, const f
         return LA_EUNSUPPORTED;
     }
     // 16-bit modes: 8-wave workgroups (128 hidden units each) where hidden allows; LA_GRU_NW=4 keeps the 4-wave form (A/B)
-    static const bool force_nw4 = getenv("LA_GRU_NW") && atoi(getenv("LA_GRU_NW")) == 4;
+    const bool force_nw4 = la::opts().gru_nw == 4;
     const bool wide = dtype != LA_F32 && hidden % 128 == 0 && hidden <= 384 && !force_nw4;   // (a 192-register W slice spills at 256)
     const int nw = dtype == LA_F32 ? 2 : (wide ? 8 : 4);
     const int nsplit = hidden / (16 * nw);
@@ -477,7 +477,7 @@ static int gru_forward(int32_t dtype, const float *gi, const void *w_hh, const f
     // Hand-off forms (tools/kbench.py gru, 32 clips, T=1500, H=384; tools/handoff_bench.hip for the bare protocol costs):
     // write-through (sc1 stores, drained; relaxed counter; sc1 loads) 5.4 ms per layer, release / acquire fences 9.0 ms.
     // The write-through form is the default; LA_GRU_FENCE=1 selects the fence form.
-    static const bool use_fence = getenv("LA_GRU_FENCE") != nullptr;
+    const bool use_fence = la::opts().gru_fence != 0;
     LA_CHECK_ARG((int64_t)batch * frames * 2 * hidden * (dtype == LA_F32 ? 4 : 2) < (int64_t)2147483647, "gru_layer: out buffer exceeds the 2 GiB buffer-descriptor range");
     if (dtype == LA_BF16 || dtype == LA_F16) {
         la::TimerScope ts("gru_bf16", stream);

@@ -274,7 +274,7 @@ extern "C" int la_fc_emissions(int32_t dtype, const void *act, int64_t ld_act, c
         typedef Cfg<2, 2> Small;
         typedef Cfg<4, 3> Big;
         static bool attr_bf16 = false, attr_bf16_big = false, attr_f32 = false, attr_pp = false;
-        static const char *force_tile = getenv("LA_GEMM_TILE");
+        const int force_tile = la::opts().gemm_tile;
         const bool pp_ok = dtype != LA_F32 && !force_tile && in_dim % 64 == 0 && in_dim >= 128 && (ld_act * 2) % 16 == 0 &&
                            (int64_t)la::cdiv(rows, PP::TM) * la::cdiv(vocab, PP::TN) >= 192;
         if (!pp_ok) lp.nparts = 2 * pl.tiles_n;      // the 128-column kernels write two strips per tile
@@ -292,14 +292,13 @@ extern "C" int la_fc_emissions(int32_t dtype, const void *act, int64_t ld_act, c
             lp.tiles_n = la::cdiv(vocab, PP::TN);
             lp.group = std::max(1, pick_group(in_dim, es, la::cdiv(vocab, BN)) / 2);
             la::TimerScope ts("fc_lse_bf16", stream);
-            const char *dbg_env = getenv("LA_PP_DBG");               // 99 forces the ping-pong loop (developer A/B, read per launch)
-            const bool duo = in_dim % 128 == 0 && in_dim >= 256 && !(dbg_env && atoi(dbg_env) == 99);
+            const bool duo = in_dim % 128 == 0 && in_dim >= 256 && la::opts().gemm_loop != 99;    // (99: the ping-pong loop everywhere)
             if (duo) {
                 if (dtype == LA_F16) hipLaunchKernelGGL((fc_lse_pp_kernel<la::f16_t, true>), dim3(lp.tiles_m * lp.tiles_n), dim3(PP::THREADS), PP::LDS, stream, lp);
                 else hipLaunchKernelGGL((fc_lse_pp_kernel<bf16_t, true>), dim3(lp.tiles_m * lp.tiles_n), dim3(PP::THREADS), PP::LDS, stream, lp);
             } else if (dtype == LA_F16) hipLaunchKernelGGL(fc_lse_pp_kernel<la::f16_t>, dim3(lp.tiles_m * lp.tiles_n), dim3(PP::THREADS), PP::LDS, stream, lp);
             else hipLaunchKernelGGL(fc_lse_pp_kernel<bf16_t>, dim3(lp.tiles_m * lp.tiles_n), dim3(PP::THREADS), PP::LDS, stream, lp);
-        } else if (dtype == LA_BF16 && rows >= 4096 && getenv("LA_GEMM_TILE") && atoi(getenv("LA_GEMM_TILE")) == 256) {
+        } else if (dtype == LA_BF16 && rows >= 4096 && force_tile == 256) {
             if (!attr_bf16_big) {
                 LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fc_lse_kernel<bf16_t, Big>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, Big::LDS));

@@ -52,8 +52,7 @@ EncBufs carve_encoder(void *ws, int dtype, int batch, int d) {
 
 bool encoder_fused_ln(const la_encoder_weights *w, int batch) {
     if ((w->dtype & 0xff) == LA_F32 || w->n_layer < 1 || !w->blocks[0].wqkv_ln || w->d <= 128) return false;
-    static const char *off = getenv("LA_LN_FUSION");
-    if (off && off[0] == '0') return false;
+    if (!la::opts().ln_fusion) return false;
     const int64_t M = (int64_t)batch * N_CTX;
     // every GEMM of a block (and the batched conv2) must run on the 256x256 kernel the fold is built into: >= 192 tiles
     return la::cdiv(M, 256) * la::cdiv(w->d, 256) >= 192 && (int64_t)la::cdiv(N_CTX, 256) * la::cdiv(w->d, 256) * batch >= 192;
@@ -102,16 +101,15 @@ extern "C" int la_encoder_forward(const la_encoder_weights *w, const float *mel,
     const int epi2 = LA_EPI_BIAS | LA_EPI_GELU | LA_EPI_RESIDUAL | out_f32;
     // With the LayerNorm fold the residual stream is kept SPLIT (la_gemm_split: hi = b.h, the next GEMM's raw operand, + one lo byte
     // per element in the first quarter of b.x) instead of f32 with a 16-bit copy beside it: the residual GEMMs' epilogues are bound
-    // by the stream's bytes.  LA_RESID_SPLIT=0 (read per call) keeps the f32 stream: the A/B partner.
-    const char *split_env = getenv("LA_RESID_SPLIT");
-    const bool split = fused && !(split_env && split_env[0] == '0');
+    // by the stream's bytes.  Option resid_split = 0 (LA_RESID_SPLIT) keeps the f32 stream: the A/B partner.
+    const bool split = fused && la::opts().resid_split;
     unsigned char *lo = reinterpret_cast<unsigned char *>(b.x);
-    // Row statistics of the folded LayerNorms: la_row_stats16 over the stream's hi rows.  LA_LN_STATS=loop (read per call) lets the
-    // consumer GEMM's own main loop take them from the A fragments it multiplies instead (la_gemm_fused_ln with ln_stats = NULL; K = d
-    // a multiple of 128): measured slower -- the extra vector instructions cost the loop more than the pass they remove.
-    const char *stats_env = getenv("LA_LN_STATS");
-    const char *dbg_env = getenv("LA_PP_DBG");
-    const bool stats_in_loop = fused && d % 128 == 0 && d >= 256 && stats_env && strcmp(stats_env, "loop") == 0 &&
+    // Row statistics of the folded LayerNorms: la_row_stats16 over the stream's hi rows.  (Experiment build, LA_LN_STATS=loop, bfloat16:
+    // the consumer GEMM's own main loop takes them from the A fragments it multiplies -- la_gemm_fused_ln with ln_stats = NULL, K = d a
+    // multiple of 128.  Measured slower: the extra vector instructions cost the loop more than the pass they remove.)
+    const char *stats_env = la::dev_env("LA_LN_STATS");
+    const char *dbg_env = la::dev_env("LA_PP_DBG");
+    const bool stats_in_loop = fused && dt == LA_BF16 && d % 128 == 0 && d >= 256 && stats_env && strcmp(stats_env, "loop") == 0 &&
                                !(dbg_env && (atoi(dbg_env) == 99 || atoi(dbg_env) == 73));
     const float *ln_stats = stats_in_loop ? nullptr : b.stats;
     if (split) {
@@ -165,8 +163,8 @@ int head_clip_cap(const la_head_weights *w, int frames) {
     const int64_t by_desc = (int64_t)2147483647 / ((int64_t)frames * 2 * w->hidden * (int64_t)esize(w->dtype));
     int64_t cap = by_cus < by_desc ? by_cus : by_desc;
     if (cap > 256) cap = 256;
-    const char *force = getenv("LA_HEAD_CLIP_CAP");          // test switch: exercise the slicing with a handful of clips
-    if (force && atoi(force) > 0 && atoi(force) < cap) cap = atoi(force);
+    const int force = la::opts().head_clip_cap;               // option head_clip_cap: exercise the slicing with a handful of clips
+    if (force > 0 && force < cap) cap = force;
     return cap < 1 ? 1 : (int)cap;
 }
 

@@ -1,5 +1,6 @@
 // la_runtime.cpp -- library-level entry points: version, error text, arch check, kernel timer.
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include <mutex>
 #include <string>
@@ -46,6 +47,32 @@ void *stream_scratch(hipStream_t stream, int purpose, size_t bytes) {
     if (hipMalloc(&sl.ptr, sl.bytes) != hipSuccess) return nullptr;
     slots.push_back(sl);
     return sl.ptr;
+}
+
+// ---- options --------------------------------------------------------------------
+namespace {
+struct OptionDesc { const char *name, *env; int Options::*field; bool env_inverts; };
+// env_inverts: the variable's presence (LA_GEMM_NO_SPLITK, LA_VITERBI_NO_DPP) switches the option OFF
+const OptionDesc kOptions[] = {
+    {"gemm_tile", "LA_GEMM_TILE", &Options::gemm_tile, false},       {"gemm_loop", "LA_PP_DBG", &Options::gemm_loop, false},
+    {"gemm_splitk", "LA_GEMM_NO_SPLITK", &Options::gemm_splitk, true}, {"attn_nw", "LA_ATTN_NW", &Options::attn_nw, false},
+    {"gru_nw", "LA_GRU_NW", &Options::gru_nw, false},                 {"gru_fence", "LA_GRU_FENCE", &Options::gru_fence, false},
+    {"viterbi_dpp", "LA_VITERBI_NO_DPP", &Options::viterbi_dpp, true}, {"head_clip_cap", "LA_HEAD_CLIP_CAP", &Options::head_clip_cap, false},
+    {"ln_fusion", "LA_LN_FUSION", &Options::ln_fusion, false},       {"resid_split", "LA_RESID_SPLIT", &Options::resid_split, false},
+};
+}  // namespace
+
+Options &opts() {
+    static Options o = [] {
+        Options v;
+        for (const OptionDesc &d : kOptions) {
+            const char *e = getenv(d.env);
+            if (!e) continue;
+            v.*(d.field) = d.env_inverts ? 0 : atoi(e);
+        }
+        return v;
+    }();
+    return o;
 }
 
 // ---- kernel-family timer ------------------------------------------------------
@@ -108,6 +135,36 @@ extern "C" int la_device_arch_ok(void) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
     return strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
+}
+
+extern "C" int la_set_option(const char *name, int64_t value) {
+    LA_CHECK_ARG(name, "set_option: null name");
+    for (const la::OptionDesc &d : la::kOptions)
+        if (strcmp(d.name, name) == 0) {
+            la::opts().*(d.field) = (int)value;
+            return LA_OK;
+        }
+    la::set_error("set_option: unknown option '%s'", name);
+    return LA_EINVAL;
+}
+
+extern "C" int la_get_option(const char *name, int64_t *value) {
+    LA_CHECK_ARG(name && value, "get_option: null pointer");
+    for (const la::OptionDesc &d : la::kOptions)
+        if (strcmp(d.name, name) == 0) {
+            *value = la::opts().*(d.field);
+            return LA_OK;
+        }
+    la::set_error("get_option: unknown option '%s'", name);
+    return LA_EINVAL;
+}
+
+extern "C" int la_has_experiments(void) {
+#ifdef LA_EXPERIMENTS
+    return 1;
+#else
+    return 0;
+#endif
 }
 
 extern "C" int la_timer_enable(const char *name) {

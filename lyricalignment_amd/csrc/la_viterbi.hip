@@ -411,7 +411,7 @@ extern "C" int la_viterbi_batch(const float *em, int64_t em_batch_stride, int64_
     VitParams p{em, em_batch_stride, em_row_stride, labels, labels_stride, n_labels, n_frames, max_frames,
                 max_labels, onset, offset, out_stride, final_score, status,
                 reinterpret_cast<unsigned long long *>(workspace), pl.bt_in_lds ? 1 : 0, nullptr, nullptr};
-    static const bool no_dpp = getenv("LA_VITERBI_NO_DPP") != nullptr;
+    const bool no_dpp = !la::opts().viterbi_dpp;
     if (pl.strip) {
         la::TimerScope ts("viterbi", stream);
 #define LA_STRIP_CASE(RV)                                                                                                  \

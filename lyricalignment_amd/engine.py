@@ -33,7 +33,7 @@ N_CTX = 1500      # encoder positions
 C_PAD = 128       # mel channels padded so 3*C is a multiple of the GEMM K tile
 LN_FUSION = os.environ.get("LA_LN_FUSION", "1") != "0"   # developer switch: 0 = always the separate LayerNorm pass
 # Row statistics of the folded LayerNorm: "pass" (default) = row_stats16 reads the 16-bit rows back (98 MB, 21 us per LayerNorm);
-# "loop" = the CONSUMER GEMM's main loop takes them from the A fragments it multiplies (v_dot2c in MFMA gaps: no pass over the
+# "loop" (experiment build of the library only, tools/build_variant.sh) = the CONSUMER GEMM's main loop takes them from the A fragments it multiplies (v_dot2c in MFMA gaps: no pass over the
 # stream, no statistics loads in its epilogue -- but 16 more vector instructions per k-step in a loop that is issue- and
 # power-bound: the QKV / MLP-up launches run ~7 % slower, 42.7 against 42.2 ms per step, profiles/r4_ab_ln_stats_in_loop.txt);
 # "epilogue" = the producer GEMM takes them per 64-column segment while the rows pass through its registers + a finalize kernel
@@ -325,7 +325,9 @@ class AlignEngine:
             stats = self._get("ln_stats", (M, 2), torch.float32)
             part = self._get("ln_part", (d // 64, M, 2), torch.float32) if (LN_STATS_IN_EPILOGUE and d % 64 == 0) else None
 
-            in_loop = LN_STATS == "loop" and d % 128 == 0 and d >= 256 and os.environ.get("LA_PP_DBG") not in ("99", "73")
+            # (experiment build only, bfloat16: the consumer GEMM's main loop takes the row statistics itself)
+            in_loop = (LN_STATS == "loop" and dt == torch.bfloat16 and d % 128 == 0 and d >= 256 and _lib.has_experiments()
+                       and os.environ.get("LA_PP_DBG") not in ("99", "73"))
             if in_loop:
                 stats = None                                                                  # ln_csum alone: the main loop takes them
 

@@ -9,6 +9,24 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture
+def attn_nw():
+    """Set the library option attn_nw (attention workgroup form) inside a test; restored afterwards."""
+    from lyricalignment_amd import _lib
+    prev = _lib.get_option("attn_nw")
+    yield lambda v: _lib.set_option("attn_nw", int(v))
+    _lib.set_option("attn_nw", prev)
+
+
+@pytest.fixture
+def gemm_loop():
+    """Set the library option gemm_loop (0 = hand-placed loop where it fits, 99 = quadrant ping-pong everywhere); restored afterwards."""
+    from lyricalignment_amd import _lib
+    prev = _lib.get_option("gemm_loop")
+    yield lambda v: _lib.set_option("gemm_loop", int(v))
+    _lib.set_option("gemm_loop", prev)
+
+
 def _rand(*shape, seed=0, scale=1.0):
     g = torch.Generator().manual_seed(seed)
     return (torch.randn(*shape, generator=g) * scale)
@@ -147,11 +165,11 @@ def test_attention(B, T, H, dtype):
 
 
 @pytest.mark.parametrize("nw", ["4", "8"])
-def test_attention_online_rescale_spike(nw, monkeypatch):
+def test_attention_online_rescale_spike(nw, attn_nw):
     """Force the running-max update: one key late in the sequence dominates one query (cdna guide rule 26).  Both workgroup forms
-    of the 16-bit kernels (LA_ATTN_NW: 128-query / 256-query workgroups; the second is the default from 1024 positions on)."""
+    of the 16-bit kernels (option attn_nw: 128-query / 256-query workgroups; the second is the default from 1024 positions on)."""
     from lyricalignment_amd import ops
-    monkeypatch.setenv("LA_ATTN_NW", nw)
+    attn_nw(nw)
     T, H = 300, 1
     qkv = _rand(T, 192, seed=31, scale=0.3)
     qkv[7, :64] = 0.0; qkv[7, 0] = 4.0           # query 7 looks at feature 0
@@ -188,13 +206,13 @@ def test_attention_q_log2(B, T, H, dtype):
 
 
 @pytest.mark.parametrize("nw", ["4", "8"])
-def test_attention_q_log2_extreme_scores(nw, monkeypatch):
+def test_attention_q_log2_extreme_scores(nw, attn_nw):
     """The exp2-domain kernel's two exits from its no-maximum fast path: scores above 2^30 (the redo path installs a maximum and
     the wave subtracts it from then on) and queries whose scores ALL lie below 2^-100 (the sum underflows: the block repeats its
     sweep the textbook way) -- next to ordinary queries in the same block, in the first / a middle / the last tile.  Both
     workgroup forms (LA_ATTN_NW)."""
     from lyricalignment_amd import ops
-    monkeypatch.setenv("LA_ATTN_NW", nw)
+    attn_nw(nw)
     T, H = 300, 1
     qkv = _rand(T, 192, seed=33, scale=0.3)
     qkv[:, 64] = 0.0
@@ -226,9 +244,9 @@ def test_attention_q_log2_extreme_scores(nw, monkeypatch):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("q_log2", [False, True])
-def test_attention_256_query_workgroups_give_the_same_bits(dtype, q_log2, monkeypatch):
+def test_attention_256_query_workgroups_give_the_same_bits(dtype, q_log2, attn_nw):
     """The 8-wave / 256-query workgroup form (default from 1024 positions on: a K / V tile is staged once for twice the queries)
-    against the 4-wave / 128-query form (LA_ATTN_NW=4): every query's sweep over the keys is the same arithmetic in the same
+    against the 4-wave / 128-query form (option attn_nw = 4): every query's sweep over the keys is the same arithmetic in the same
     order, so the outputs are identical -- T = 1500 (the encoder; a partial last query block in both forms) and 1100, peaked scores."""
     from lyricalignment_amd import ops
     for B, T, H in ((2, 1500, 3), (1, 1100, 2)):
@@ -236,20 +254,20 @@ def test_attention_256_query_workgroups_give_the_same_bits(dtype, q_log2, monkey
         qkv = _rand(B * T, 3 * d, seed=40 + T, scale=1.0)
         qkv[:, :d] *= 0.125 * 3.0 * (1.4426950408889634 if q_log2 else 1.0)
         x = qkv.to(dtype).cuda()
-        monkeypatch.setenv("LA_ATTN_NW", "4")
+        attn_nw(4)
         ref = ops.attention(x, B, T, H, q_log2=q_log2).clone()
-        monkeypatch.setenv("LA_ATTN_NW", "8")
+        attn_nw(8)
         out8 = ops.attention(x, B, T, H, q_log2=q_log2).clone()
-        monkeypatch.delenv("LA_ATTN_NW")
+        attn_nw(0)
         out = ops.attention(x, B, T, H, q_log2=q_log2)
         assert torch.equal(out8.view(torch.int16), ref.view(torch.int16))
         assert torch.equal(out.view(torch.int16), ref.view(torch.int16))
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-def test_gemm_hand_placed_loop_matches_ping_pong_in_every_epilogue_mode(dtype, monkeypatch):
+def test_gemm_hand_placed_loop_matches_ping_pong_in_every_epilogue_mode(dtype, gemm_loop):
     """The default main loop of the 256x256 kernel (hand-placed flat stream, K % 128 == 0) against the quadrant ping-pong
-    (LA_PP_DBG=99) -- same bits -- in the epilogue modes the encoder uses beyond the plain ones: the LayerNorm-consumer epilogue
+    (option gemm_loop = 99) -- same bits -- in the epilogue modes the encoder uses beyond the plain ones: the LayerNorm-consumer epilogue
     (row statistics + column sums), the producer epilogue (f32 result + 16-bit copy + per-segment statistics), a batched launch,
     ragged last row / column tiles, both 16-bit operand types, K = 256 (two ring turns: prologue + peeled tail only) and K = 1280."""
     from lyricalignment_amd import ops
@@ -275,13 +293,13 @@ def test_gemm_hand_placed_loop_matches_ping_pong_in_every_epilogue_mode(dtype, m
             outs.append(ob.clone())
             return outs
 
-        monkeypatch.delenv("LA_PP_DBG", raising=False)
+        gemm_loop(0)
         new = run_all()
-        monkeypatch.setenv("LA_PP_DBG", "99")
+        gemm_loop(99)
         old = run_all()
         for x, y in zip(new, old):
             assert torch.equal(x, y)
-        monkeypatch.delenv("LA_PP_DBG", raising=False)
+        gemm_loop(0)
 
 
 @pytest.mark.parametrize("B,T,H", [(1, 1, 64), (3, 7, 64), (32, 50, 128), (40, 23, 384), (2, 300, 384), (20, 11, 128)])
@@ -418,45 +436,6 @@ def test_gemm_fused_layernorm_pieces():
         ops.gemm(xb[:300], wl.cuda(), bias=bl, ln_stats=st[:300].contiguous().cuda(), ln_csum=csum, out_f32=True)
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16])
-def test_gemm_layernorm_consumer_takes_row_statistics_in_its_main_loop(dtype):
-    """la_gemm_fused_ln with ln_csum but NO ln_stats: the hand-placed main loop sums every A row and its squares from the fragments
-    it multiplies (v_dot2c in MFMA gaps) and the epilogue applies mean / rstd from LDS -- against the same launch fed with
-    la_row_stats16's two-pass statistics and against float64 LayerNorm + matmul.  Rows with a large common offset (mean = 30 sigma,
-    the one-pass variance's worst case), an outlier channel, an all-equal row (variance 0), a ragged last row of tiles, GELU."""
-    from lyricalignment_amd import ops
-    M, d, N = 256 * 48 + 40, 1024, 1024
-    g = torch.Generator().manual_seed(6)
-    x = torch.randn(M, d, generator=g) * 1.5 + 0.4
-    x[:, 7] *= 20.0
-    x[100:200] += 45.0                                        # mean = 30 sigma
-    x[300] = 3.25                                             # variance exactly 0
-    xb = x.to(dtype).cuda()
-    xf = xb.float().cpu().double()
-    gamma = 1.0 + 0.1 * torch.randn(d, generator=g); beta = 0.1 * torch.randn(d, generator=g)
-    w = torch.randn(N, d, generator=g) * 0.03; b = torch.randn(N, generator=g) * 0.1
-    wl = (w.double() * gamma.double()[None, :]).to(dtype)
-    csum = wl.double().sum(1).float().cuda()
-    bl = (b.double() + w.double() @ beta.double()).float().cuda()
-    st = ops.row_stats16(xb)
-    for gelu in (False, True):
-        ref = ops.gemm(xb, wl.cuda(), bias=bl, gelu=gelu, ln_stats=st, ln_csum=csum, out_f32=not gelu).float().cpu()
-        out = ops.gemm(xb, wl.cuda(), bias=bl, gelu=gelu, ln_csum=csum, out_f32=not gelu).float().cpu()
-        want = torch.nn.functional.layer_norm(xf, (d,), gamma.double(), beta.double(), 1e-5) @ w.double().T + b.double()
-        if gelu:
-            want = torch.nn.functional.gelu(want)
-        ok = torch.ones(M, dtype=torch.bool); ok[100:200] = False
-        # ordinary rows: the in-loop statistics change the result by far less than the 16-bit operands do
-        assert float((out[ok] - ref[ok]).abs().max()) < (2e-3 if not gelu else 2e-2)
-        np.testing.assert_allclose(out[ok].double().numpy(), want[ok].numpy(), rtol=0, atol=4e-2)
-        assert float((out[ok].double() - want[ok]).abs().mean()) < 4e-3
-        # offset rows: sum x^2 - n mean^2 loses ~3 digits of the variance at mean = 30 sigma; still inside the 16-bit result's own error
-        np.testing.assert_allclose(out[~ok].double().numpy(), want[~ok].numpy(), rtol=0, atol=2.5e-1 if dtype == torch.bfloat16 else 6e-2)
-        assert bool(torch.isfinite(out).all())
-    with pytest.raises(NotImplementedError):                      # K = 192 is not a multiple of 128: no hand-placed main loop
-        ops.gemm(xb[:, :192].contiguous(), wl[:, :192].contiguous().cuda(), bias=bl, ln_csum=csum)
-
-
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (1024, 1024, 3000), (260, 136, 77), (64, 4096, 1500), (1152, 384, 33)])
 def test_gemm_f32_transposed_operands(M, N, K):
     """la_gemm_ex with LA_GEMM_TRANS_A | LA_GEMM_TRANS_W: C[m][n] = sum_k At[k][m] Wt[k][n] reads both operands as [K][rows]
@@ -509,25 +488,46 @@ def test_gemm_gelu_forms_of_the_16_bit_epilogue(dtype, ulp):
     assert not torch.equal(fit, erf)                           # the flag does select another form
 
 
-@pytest.mark.parametrize("variant", [73, 99])
-def test_gemm_main_loop_ab_variants_are_bit_identical(variant, monkeypatch):
-    """The A/B partners of the 256x256 kernel's default hand-placed loop that stay in the library (LA_PP_DBG: 99 = the quadrant
-    ping-pong, 73 = one wave per SIMD with 128x128 wave tiles and its own AGPR-direct epilogue; the other round-2 structures
-    were measured, recorded in DESIGN.md and removed) walk k in the same order per accumulator and apply the same epilogue
-    arithmetic: identical bits, including the ragged last row / column of tiles."""
+def test_gemm_ping_pong_loop_is_bit_identical_to_the_hand_placed_one(gemm_loop):
+    """The A/B partner of the 256x256 kernel's default hand-placed loop that ships (option gemm_loop = 99: the quadrant ping-pong, the
+    loop of every K that is not a multiple of 128) walks k in the same order per accumulator and applies the same epilogue
+    arithmetic: identical bits, including the ragged last row / column of tiles.  (The measured-slower structures -- one wave per
+    SIMD, persistent tiles, four-wave workgroups -- live in the experiment build: tests/test_gpu_lab.py.)"""
     from lyricalignment_amd import ops
     M, N, K = 256 * 49 + 40, 1024 + 64, 1024
     a = _rand(M, K, seed=91).bfloat16().cuda()
     w = _rand(N, K, seed=92, scale=K ** -0.5).bfloat16().cuda()
     bias = _rand(N, seed=93).cuda()
     res = _rand(M, N, seed=94).cuda()
-    monkeypatch.delenv("LA_PP_DBG", raising=False)
+    gemm_loop(0)
     ref16 = ops.gemm(a, w, bias=bias, gelu=True).clone()
     ref32 = ops.gemm(a, w, bias=bias, residual=res, out_f32=True).clone()
-    monkeypatch.setenv("LA_PP_DBG", str(variant))
+    gemm_loop(99)
     for _ in range(3):
         assert torch.equal(ops.gemm(a, w, bias=bias, gelu=True), ref16)
         assert torch.equal(ops.gemm(a, w, bias=bias, residual=res, out_f32=True), ref32)
+
+
+def test_library_options_round_trip_and_shipped_library_has_no_experiments():
+    """la_set_option / la_get_option (include/lyricalign.h): every documented name reads back what was set, unknown names are refused,
+    and the library the tests run on is the shipped one: la_has_experiments() == 0 unless LA_LIB_PATH selects another build."""
+    import os
+    from lyricalignment_amd import _lib
+    for name in ("gemm_tile", "gemm_loop", "gemm_splitk", "attn_nw", "gru_nw", "gru_fence", "viterbi_dpp", "head_clip_cap", "ln_fusion", "resid_split"):
+        before = _lib.get_option(name)
+        with _lib.option(name, 7):
+            assert _lib.get_option(name) == 7
+        assert _lib.get_option(name) == before
+    with pytest.raises(ValueError):
+        _lib.set_option("no_such_option", 1)
+    if not os.environ.get("LA_LIB_PATH"):
+        assert not _lib.has_experiments()
+    with pytest.raises(NotImplementedError):       # in-loop LayerNorm statistics: experiment build only
+        a = torch.zeros(256 * 48, 1024, dtype=torch.bfloat16, device="cuda")
+        from lyricalignment_amd import ops
+        if _lib.has_experiments():
+            raise NotImplementedError
+        ops.gemm(a, a[:1024].contiguous(), ln_csum=torch.zeros(1024, device="cuda"))
 
 
 def test_kernel_timer_sampling_and_work_accounting():
@@ -642,101 +642,3 @@ def test_gemm_split_batched_stem_layout_and_zero_rows():
     dec = ops.split_decode(hi, lo)
     assert float((dec - x).abs().max()) <= float(x.abs().max()) * 1.6e-5
     assert float((dec[:T] - pos).abs().max()) <= float(pos.abs().max()) * 1.6e-5
-
-
-# ------------------------------------------------------------------------------------------------ persistent 256x256 kernel
-@pytest.mark.parametrize("dtype", [torch.bfloat16])
-def test_gemm_persistent_kernel_is_bit_identical_to_one_workgroup_per_tile(dtype):
-    """gemm_pp_persist_kernel (opt-in, LA_GEMM_PERSIST=1 read per launch, bf16: workgroups draw tiles from per-XCD ticket counters and
-    issue the next tile's first stages before the current tile's epilogue) against the one-workgroup-per-tile kernel: the same main loop, the
-    same epilogue arithmetic, so the same bits -- for the plain, LayerNorm-consumer (+ GELU) and split-stream
-    forms, with a partial last row of tiles (M = 48000 = 187.5 x 256: edge tiles break the prefetch chain), five launches each (a
-    race in the ticket / prefetch choreography would show as a differing run), while another stream keeps CUs busy so that some
-    persistent workgroups start late and the tickets have to balance."""
-    from lyricalignment_amd import ops
-    g = torch.Generator(device="cuda").manual_seed(11)
-    M = 48000
-    side = torch.cuda.Stream()
-    sa = torch.randn(8192, 1024, device="cuda", generator=g).to(dtype)
-    sw = torch.randn(4096, 1024, device="cuda", generator=g).to(dtype)
-
-    def both(fn):
-        os.environ.pop("LA_GEMM_PERSIST", None)
-        ref = [t.clone() for t in fn()]
-        for it in range(5):
-            with torch.cuda.stream(side):
-                for _ in range(1 + it % 3):
-                    ops.gemm(sa[: 2048 * (1 + it % 4)], sw)
-            os.environ["LA_GEMM_PERSIST"] = "1"
-            try:
-                out = fn()
-            finally:
-                os.environ.pop("LA_GEMM_PERSIST", None)
-            torch.cuda.synchronize()
-            for a_, b_ in zip(out, ref):
-                assert torch.equal(a_.view(torch.int16) if a_.dtype != torch.float32 and a_.dtype != torch.uint8 else a_,
-                                   b_.view(torch.int16) if b_.dtype != torch.float32 and b_.dtype != torch.uint8 else b_), f"run {it}"
-
-    for N, K in ((3072, 1024), (1024, 4096)):
-        a = torch.randn(M, K, device="cuda", generator=g).to(dtype)
-        w = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(dtype)
-        bias = torch.randn(N, device="cuda", generator=g)
-        csum = torch.randn(N, device="cuda", generator=g)
-        stats = torch.stack([torch.randn(M, device="cuda", generator=g) * 0.1, 1.0 + 0.1 * torch.rand(M, device="cuda", generator=g)], dim=1).contiguous()
-        out16 = torch.empty(M, N, device="cuda", dtype=dtype)
-        both(lambda: [ops.gemm(a, w, out16, bias=bias)])                                                    # plain
-        both(lambda: [ops.gemm(a, w, out16, bias=bias, gelu=True, ln_stats=stats, ln_csum=csum)])          # LayerNorm consumer + GELU
-        hi0 = torch.randn(M, N, device="cuda", generator=g).to(dtype)
-        lo0 = torch.randint(1, 256, (M, N), device="cuda", generator=g, dtype=torch.uint8)
-
-        def split():
-            hi, lo = hi0.clone(), lo0.clone()
-            ops.gemm_split(a, w, hi, lo, bias=bias, in_place=True)
-            return [hi, lo]
-        both(split)                                                                                         # split stream in place
-
-
-# ------------------------------------------------------------------------------------------------ four-wave workgroups, two per CU
-@pytest.mark.parametrize("form", ["1", "2"])
-def test_gemm_four_wave_two_workgroups_per_cu_is_bit_identical(form):
-    """gemm_q4_kernel (opt-in, LA_GEMM_Q4 read per launch, bf16: 256 x 128 tiles (1) or 128 x 256 tiles (2), four waves, a ring of
-    three stages, two workgroups resident per CU) against the 8-wave kernel: the same wave tiles, accumulation order and epilogues, so
-    the same bits -- plain, LayerNorm consumer (+ GELU) and the split stream in place; M with a partial last row of tiles, N with a
-    partial last column tile in the plain form (edge epilogue), K = 256 (loop body never runs), 1024 and 4096."""
-    from lyricalignment_amd import ops
-    g = torch.Generator(device="cuda").manual_seed(12)
-    dtype = torch.bfloat16
-
-    def both(fn):
-        os.environ.pop("LA_GEMM_Q4", None)
-        ref = [t.clone() for t in fn()]
-        os.environ["LA_GEMM_Q4"] = form
-        try:
-            out = fn()
-        finally:
-            os.environ.pop("LA_GEMM_Q4", None)
-        torch.cuda.synchronize()
-        for a_, b_ in zip(out, ref):
-            assert torch.equal(a_.view(torch.int16) if a_.dtype == dtype else a_, b_.view(torch.int16) if b_.dtype == dtype else b_)
-
-    for M, N, K in ((12500, 1024, 256), (6100, 3072, 1024), (12500, 1024, 4096)):       # (>= 192 tiles: the 256x256 kernel's launches)
-        a = torch.randn(M, K, device="cuda", generator=g).to(dtype)
-        w = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(dtype)
-        bias = torch.randn(N, device="cuda", generator=g)
-        csum = torch.randn(N, device="cuda", generator=g)
-        stats = torch.stack([torch.randn(M, device="cuda", generator=g) * 0.1, 1.0 + 0.1 * torch.rand(M, device="cuda", generator=g)], dim=1).contiguous()
-        out16 = torch.empty(M, N, device="cuda", dtype=dtype)
-        both(lambda: [ops.gemm(a, w, out16, bias=bias)])
-        both(lambda: [ops.gemm(a, w, out16, bias=bias, gelu=True, ln_stats=stats, ln_csum=csum)])
-        hi0 = torch.randn(M, N, device="cuda", generator=g).to(dtype)
-        lo0 = torch.randint(1, 256, (M, N), device="cuda", generator=g, dtype=torch.uint8)
-
-        def split():
-            hi, lo = hi0.clone(), lo0.clone()
-            ops.gemm_split(a, w, hi, lo, bias=bias, in_place=True)
-            return [hi, lo]
-        both(split)
-    a = torch.randn(12500, 1024, device="cuda", generator=g).to(dtype)                # partial last column tile (N = 1000)
-    w = (torch.randn(1000, 1024, device="cuda", generator=g) / 32).to(dtype)
-    out16 = torch.empty(12500, 1000, device="cuda", dtype=dtype)
-    both(lambda: [ops.gemm(a, w, out16)])

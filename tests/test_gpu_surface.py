@@ -397,8 +397,8 @@ def test_pipelined_aligner_with_fresh_label_tensors_per_submit():
 def test_model_level_c_entry_points_equal_the_python_sequencing(dtype, monkeypatch):
     """la_encoder_forward / la_align_head_forward (csrc/la_model.cpp: one C call per stage, caller workspace) enqueue the same
     kernels in the same order as the op-by-op sequencing in engine.py (LA_ENGINE_PY=1): bit-identical encoder rows, frames,
-    scores; also with the head sliced over clips inside the C call (LA_HEAD_CLIP_CAP) and on the long-form clip stride."""
-    from lyricalignment_amd import engine as eng_mod
+    scores; also with the head sliced over clips inside the C call (option head_clip_cap) and on the long-form clip stride."""
+    from lyricalignment_amd import _lib, engine as eng_mod
     model = _model(dtype, seed=80)
     eng = model.engine()
     rs = np.random.RandomState(81)
@@ -413,9 +413,8 @@ def test_model_level_c_entry_points_equal_the_python_sequencing(dtype, monkeypat
         monkeypatch.setattr(eng_mod, "ENGINE_PY", False)
         enc_c = eng.encode(mel, out_dtype=torch.float32).clone()
         res_c = [t.clone() for t in eng.align_mel(mel, labels, n_labels, n_frames=700)]
-        monkeypatch.setenv("LA_HEAD_CLIP_CAP", "2")
-        res_sliced = [t.clone() for t in eng.align_mel(mel, labels, n_labels, n_frames=700)]
-        monkeypatch.delenv("LA_HEAD_CLIP_CAP")
+        with _lib.option("head_clip_cap", 2):
+            res_sliced = [t.clone() for t in eng.align_mel(mel, labels, n_labels, n_frames=700)]
         feats = eng.encode(mel)
         two = eng.align_feats(feats, 2, 2900, 3000, labels[:2], n_labels[:2].contiguous(), 1)       # 2 "songs" of 2 chunks each
         monkeypatch.setattr(eng_mod, "ENGINE_PY", True)

@@ -1,7 +1,7 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from lyricalignment_amd import ops
+from lyricalignment_amd import _lib, ops
 torch.manual_seed(0)
 B, T, H = 32, 1500, 16
 qkv = torch.randn(B * T, 3 * H * 64, device="cuda").bfloat16()
@@ -20,6 +20,7 @@ outs = {}
 for rd in range(3):
     for nw in ("4", "8"):
         os.environ["LA_ATTN_NW"] = nw
+        _lib.set_option("attn_nw", int(nw))
         res.setdefault(nw, []).append(timeit(lambda: ops.attention(qkv, B, T, H, out=out, q_log2=True)))
         outs[nw] = out.clone()
 for nw in res:

@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
 """Kernel micro-benchmarks on the config-2 shapes (developer tool; run on the GPU box).
     python tools/kbench.py gemm|attn|gru|fc|all [--iters N]
-Interleaved rounds in one process, random operands (cdna guide rules 24/25)."""
+Interleaved rounds in one process, random operands (cdna guide rules 24/25).
+The A/B modes that flip developer switches per launch (gemm --variants 73, persist, q4, q4w, order, epi, attn_ko / attn variants) need
+the EXPERIMENT build of the library: bash tools/build_variant.sh lab -DLA_EXPERIMENTS; LA_LIB_PATH=$PWD/ab/lab/liblyricalign_hip.so."""
 import argparse, os, sys, time
 import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from lyricalignment_amd import ops
+from lyricalignment_amd import _lib, ops
 
 
 def timeit(fn, iters):
@@ -42,7 +44,8 @@ def bench_gemm_variants(iters, variants, rounds=5):
                 os.environ["LA_GELU_PK"] = "1" if v == 1000 else "2"       # =2 the sigmoid form one value at a time
             else:
                 os.environ.pop("LA_GELU_PK", None)
-            os.environ["LA_PP_DBG"] = str(0 if v >= 1000 else v)
+            os.environ["LA_PP_DBG"] = str(0 if v >= 1000 else v)      # (73 and the pseudo-variants: experiment build, LA_LIB_PATH=ab/lab/...)
+            _lib.set_option("gemm_loop", 99 if v == 99 else 0)
             ops.gemm(a, w, outs[v], bias=bias, residual=res, gelu="gelu" in name, out_f32=f32out)
 
         times = {v: [] for v in variants}
@@ -63,6 +66,7 @@ def bench_gemm_variants(iters, variants, rounds=5):
                   f"{fl/t[len(t)//2]/1e9:7.1f} TF/s  mismatching rounds vs variant {variants[0]}: {bad[v]}/{rounds}", flush=True)
     os.environ.pop("LA_PP_DBG", None)
     os.environ.pop("LA_GELU_PK", None)
+    _lib.set_option("gemm_loop", 0)
 
 
 def bench_gemm(iters):
@@ -208,6 +212,104 @@ def bench_persist(iters, flag_name="LA_GEMM_PERSIST", label="persistent", on="1"
         print(f"{label} {name:30s} N={N} K={K}: {label} {p_*1e3:7.1f} us ({fl/p_/1e9:6.1f} TF/s) | one 8-wave workgroup per tile {o_*1e3:7.1f} us ({fl/o_/1e9:6.1f} TF/s) | {100*(o_/p_-1):+.1f} % | identical bits: {same}", flush=True)
 
 
+def bench_f32emu(iters):
+    """Round-5 verdict item 2: float32 Linear products of the fine-tune step (BASELINE configs[2]; fused accum 8 x 2 clips = 24000
+    rows) on the 16-bit matrix pipe with float32-level error, PROTOTYPED WITHOUT A NEW KERNEL: each f32 operand is split into 16-bit
+    terms, the terms are concatenated along K (small products first) and the existing 256x256 kernel runs one launch with K' = n K,
+    f32 accumulate.  Against gemm_kernel<float> (v_mfma_f32_16x16x4_f32, 1/16 of the 16-bit rate) on the same f32 operands; error
+    of both against a float64 product on a sample of rows: max |err| / max |ref| and rms(err) / rms(ref).
+      bf16x3/6: a = a1 + a2 + a3 (bf16, exact to 2^-24), products (3,1) (2,2) (1,3) (2,1) (1,2) (1,1): 6/16 of the f32 MFMA cost
+      f16x2/3 : rows scaled by a power of two to max 2^14, a = a1 + a2 (f16: 22 bits), products (2,1) (1,2) (1,1): 3/16
+      f16x2/4 : the same with (2,2): 4/16
+    Split / concatenation / row scaling are done by torch OUTSIDE the timing (a product path would fuse them into the producers);
+    the time is the GEMM launch alone.  Shapes: forward (NT), input gradient dX = dY W (as NT on W^T) and weight gradient
+    dW = dY^T X (as NT on the transposed operands, the 24000-long reduction cut into 4 batch slots so that 192 tiles fill the chip,
+    partial sums added afterwards: counted in its time)."""
+    M = 24000
+
+    def split_bf16(x, n):
+        out, r = [], x.clone()
+        for _ in range(n):
+            t = r.to(torch.bfloat16)
+            out.append(t)
+            r = r - t.float()
+        return out
+
+    def row_scale(x):                       # power of two s with max |x s| in (2^13, 2^14] per row
+        mx = x.abs().amax(dim=1, keepdim=True).clamp_min(1e-30)
+        _, e = torch.frexp(mx)              # mx = m 2^e, m in [0.5, 1)
+        return torch.ldexp(torch.ones_like(mx), 14 - e)
+
+    def split_f16(x):
+        s = row_scale(x)
+        xs = x * s
+        a1 = xs.to(torch.float16)
+        a2 = (xs - a1.float()).to(torch.float16)
+        return a1, a2, (1.0 / s).squeeze(1)
+
+    def data(rows, cols, kind, scale=1.0):
+        x = torch.randn(rows, cols, device="cuda")
+        if kind == "heavy":                 # outlier feature columns (x 30) and a log-normal spread of row magnitudes
+            x[:, torch.randperm(cols, device="cuda")[: max(1, cols // 128)]] *= 30.0
+            x *= torch.exp(torch.randn(rows, 1, device="cuda") * 1.5)
+        return x * scale
+
+    def err(c, ref):
+        d = (c.double() - ref)
+        return float(d.abs().max() / ref.abs().max()), float(d.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+
+    cases = [("fwd qkv", M, 3072, 1024, 1), ("fwd mlp-up", M, 4096, 1024, 1), ("fwd out-proj", M, 1024, 1024, 1), ("fwd mlp-down", M, 1024, 4096, 1),
+             ("dX qkv", M, 1024, 3072, 1), ("dX mlp-up", M, 1024, 4096, 1), ("dW qkv", 3072, 1024, 24064, 4), ("dW mlp-down", 1024, 4096, 24064, 4)]
+    for kind in ("gauss", "heavy"):
+        for name, m, n, k, slots in cases:
+            a = data(m, k, kind)
+            w = data(n, k, "gauss", k ** -0.5)
+            rows = torch.randperm(m, device="cuda")[:512]
+            ref = a[rows].double() @ w.double().t()
+            res = {}
+            # native float32
+            out = torch.empty(m, n, device="cuda")
+            t = timeit(lambda: ops.gemm(a, w, out), iters)[0]
+            res["f32 native"] = (t, *err(out[rows], ref))
+
+            def emu(ap, wp, post=None, label=""):
+                """ap / wp: lists of planes in product order (concatenated along K); `slots` > 1 = split-K over batch slots."""
+                kc = k // slots
+                if slots == 1:
+                    A, W = torch.cat(ap, dim=1).contiguous(), torch.cat(wp, dim=1).contiguous()
+                    o = torch.empty(m, n, device="cuda")
+                    fn = lambda: ops.gemm(A, W, o, out_f32=True)
+                else:                            # slot z holds k range z*kc..: [slots][rows][n_terms * kc]
+                    A = torch.stack([torch.cat([p_[:, z * kc:(z + 1) * kc] for p_ in ap], dim=1) for z in range(slots)]).contiguous()
+                    W = torch.stack([torch.cat([p_[:, z * kc:(z + 1) * kc] for p_ in wp], dim=1) for z in range(slots)]).contiguous()
+                    part = torch.empty(slots, m, n, device="cuda")
+                    o = torch.empty(m, n, device="cuda")
+                    kk = A.shape[2]
+                    def fn():
+                        from lyricalignment_amd._lib import lib, ptr, stream_ptr, check, dtype_code
+                        check(lib().la_gemm_ex(dtype_code(A.dtype), m, n, kk, slots, ptr(A), kk, m * kk, ptr(W), kk, n * kk, ptr(part), n, m * n, None, 8, stream_ptr()), "gemm_ex")
+                        torch.sum(part, dim=0, out=o)
+                t_ = timeit(fn, iters)[0]
+                c = o[rows]
+                if post is not None:
+                    c = c * post[0][rows][:, None] * post[1][None, :]
+                res[label] = (t_, *err(c, ref))
+
+            a1, a2, a3 = split_bf16(a, 3)
+            b1, b2, b3 = split_bf16(w, 3)
+            emu([a3, a2, a1, a2, a1, a1], [b1, b2, b3, b1, b2, b1], label="bf16x3/6")
+            del a3, b3
+            fa1, fa2, sa = split_f16(a)
+            fb1, fb2, sb = split_f16(w)
+            emu([fa2, fa1, fa1], [fb1, fb2, fb1], post=(sa, sb), label="f16x2/3")
+            emu([fa2, fa2, fa1, fa1], [fb2, fb1, fb2, fb1], post=(sa, sb), label="f16x2/4")
+            base = res["f32 native"][0]
+            for lab, (t_, emax, erms) in res.items():
+                print(f"f32emu {kind:5s} {name:13s} M={m} N={n} K={k}: {lab:11s} {t_*1e3:8.1f} us ({base/t_:4.2f}x)  max|err|/max|ref| {emax:.2e}  rms {erms:.2e}", flush=True)
+            del a, w, a1, a2, b1, b2, fa1, fa2, fb1, fb2
+            torch.cuda.empty_cache()
+
+
 def bench_attn(iters):
     B, T, H = 32, 1500, 16
     qkv = rnd(B * T, 3 * H * 64)
@@ -218,6 +320,7 @@ def bench_attn(iters):
     for rd in range(3):
         for nw, msum, thr in (("4", False, "0"), ("4", False, "8"), ("4", False, "opt"), ("8", False, "opt"), ("8", False, "8"), ("4", True, "8")):
             os.environ["LA_ATTN_NW"] = nw
+            _lib.set_option("attn_nw", int(nw))
             if thr.startswith("opt"):              # the default: optimistic softmax, no per-tile maximum
                 os.environ.pop("LA_ATTN_OPT", None)
             else:
@@ -313,6 +416,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if a.what == "epi":
         bench_epi_probe(a.iters)
+        sys.exit(0)
+    if a.what == "f32emu":
+        bench_f32emu(a.iters)
         sys.exit(0)
     if a.what == "calib":
         bench_gemm_calib(a.iters)
