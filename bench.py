@@ -323,10 +323,76 @@ def log(msg: str):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
+def _cpu_stage_times(p, n_head: int, audio: np.ndarray, label: np.ndarray) -> dict:
+    """One clip through the CPU oracle stage by stage (SURVEY 8(d) / BASELINE.md section 3 item 1): waveform -> log-mel + pad_or_trim
+    (module/align_model.py:84-90) -> encoder (:91) -> BiGRU / Mish / Linear head (:107) -> emission prep (utils/alignment.py:123-134)
+    -> DP + backtrace (compiled oracle).  Milliseconds, one pass each (the caller has warmed the weights)."""
+    from oracle import alignment_oracle as ao
+    from oracle import model_oracle as mo
+    out = {}
+    with torch.no_grad():
+        t = time.perf_counter(); mel = mo.pad_or_trim(mo.log_mel_spectrogram(audio[None]), 3000); out["mel"] = (time.perf_counter() - t) * 1e3
+        T = mo.frame_count(len(audio) // 160)
+        t = time.perf_counter(); emb = mo.encoder_forward(p, mel, n_head=n_head)[:, :T]; out["encoder"] = (time.perf_counter() - t) * 1e3
+        t = time.perf_counter(); logits = mo.gru_head_forward(p, emb); out["head"] = (time.perf_counter() - t) * 1e3
+        t = time.perf_counter(); lp, ls = mo.emission_prep_ctc(logits); out["emission_prep"] = (time.perf_counter() - t) * 1e3
+        t = time.perf_counter(); rc = ao.align_frames(lp[0].numpy(), ls[0].numpy(), label)[0]; out["dp"] = (time.perf_counter() - t) * 1e3
+    assert rc == 0
+    out["frames"] = int(T)
+    return {k: (round(v, 3) if isinstance(v, float) else v) for k, v in out.items()}, lp[0].numpy(), ls[0].numpy()
+
+
+def cpu_stage_baseline(model, n_head: int) -> dict:
+    """cpu_baseline.stages_ms: the reference's CPU path stage by stage on this node's host cores, one clip (B = 1) each of
+      * whisper-medium, 30 s          (the headline configuration's model),
+      * whisper-tiny, 3.756 s and 30 s (BASELINE configs[0]: the reference's own CPU-runnable case; 3.756 s = the first Opencpop
+                                        test utterance's length),
+    and python_dp_s: the lattice recurrence as plain Python loops (oracle/viterbi_python.py: what the reference's run_viterbi_core
+    costs without numba, utils/alignment.py:73-119) on the medium clip's [1500, 21127] emissions -- the DP's upper bound.
+    Bounded: ~2 s (medium) + ~1 s (tiny) + ~1 s (Python DP) of CPU work after the weights are warm."""
+    from lyricalignment_amd import whisper_compat as wc
+    from oracle import model_oracle as mo
+    from oracle import viterbi_python as vp
+    rs = np.random.RandomState(11)
+    t30 = np.arange(480000) / 16000.0
+    audio30 = (rs.randn(480000) * 0.05 + 0.3 * np.sin(2 * np.pi * 220 * t30)).astype(np.float32)
+    label = make_stage_labels(26)
+    stages = {}
+    pm = {"encoder." + k: v.detach().float().cpu() for k, v in model.whisper_model.encoder.state_dict().items()}
+    pm.update({"align_rnn." + k: v.detach().float().cpu() for k, v in model.align_rnn.state_dict().items()})
+    stages["medium_30s"], lp, ls = _cpu_stage_times(pm, n_head, audio30, label)
+    t = time.perf_counter()
+    vp.viterbi_lattice(lp, ls, label)
+    python_dp_s = time.perf_counter() - t
+    del pm
+    dims = wc.dims_for("tiny")
+    tiny = wc.build_model("tiny", seed=0)
+    pt = {"encoder." + k: v.detach().float().cpu() for k, v in tiny.encoder.state_dict().items()}
+    pt.update(mo.random_head_params(dims.n_audio_state, HIDDEN, VOCAB, seed=1))
+    with torch.no_grad():                                            # warm-up pass (first touch of the tiny weights)
+        mo.gru_head_forward(pt, mo.encoder_forward(pt, mo.pad_or_trim(mo.log_mel_spectrogram(audio30[None, :60096]), 3000), n_head=dims.n_audio_head)[:, :10])
+    stages["tiny_3.756s"] = _cpu_stage_times(pt, dims.n_audio_head, audio30[:60096], make_stage_labels(11))[0]
+    stages["tiny_30s"] = _cpu_stage_times(pt, dims.n_audio_head, audio30, label)[0]
+    return {"stages_ms": stages, "python_dp_s": round(python_dp_s, 3),
+            "stages_note": "one clip (B = 1) per entry through the fp32 CPU oracle, ms per stage: mel = log-mel + pad_or_trim from the "
+                           "waveform, encoder, head = BiGRU + Mish + Linear(21129), emission_prep = log-softmax / logsigmoid over the "
+                           "vocabulary, dp = compiled Viterbi + backtrace (26 / 11 labels); python_dp_s = the same lattice of the medium "
+                           "clip in plain Python loops (the reference's DP without numba)"}
+
+
+def make_stage_labels(n: int) -> np.ndarray:
+    lab = np.random.RandomState(12).randint(2, VOCAB - 2, size=n).astype(np.int64)
+    for i in range(1, n):
+        if lab[i] == lab[i - 1]:
+            lab[i] = 2 + (lab[i] - 1) % (VOCAB - 4)
+    return lab
+
+
 def cpu_baseline(model, mel_cpu: np.ndarray, labels_rows, n_head: int):
     """The oracle (CPU restatement of the reference's fp32 path) timed on this node's host cores on a bounded sample:
     30 s clips of the same workload (same weights), one clip per pass: 1 warm-up pass + 2 timed passes = the first three
-    clips of the batch, so the same ~8 s of CPU work also give the self-check three clips to compare.
+    clips of the batch, so the same ~8 s of CPU work also give the self-check three clips to compare.  Plus the per-stage
+    breakdown (cpu_stage_baseline).
     -> (cpu_baseline object, [per-clip oracle result])."""
     from oracle import alignment_oracle as ao
     from oracle import model_oracle as mo
@@ -351,9 +417,15 @@ def cpu_baseline(model, mel_cpu: np.ndarray, labels_rows, n_head: int):
         results.append(one(i))
         times.append(time.perf_counter() - t0)
     sec = float(np.median(times))
-    return {"value": CLIP_SECONDS / sec, "unit": "audio-sec/sec", "cores": int(torch.get_num_threads()), "kind": "port",
+    base = {"value": CLIP_SECONDS / sec, "unit": "audio-sec/sec", "cores": int(torch.get_num_threads()), "kind": "port",
             "sample": f"{len(times)} x 30 s clips (clips 1..{len(times)} of the batch; clip 0 = warm-up), whisper-{MODEL} fp32 oracle incl. CPU "
-                      f"emission prep + C Viterbi, median {sec:.2f} s per clip"}, results
+                      f"emission prep + C Viterbi, median {sec:.2f} s per clip"}
+    del p
+    if warm < 20:                               # (a host this slow would not finish the stage passes in bounded time)
+        t0 = time.perf_counter()
+        base.update(cpu_stage_baseline(model, n_head))
+        log(f"cpu stage breakdown {time.perf_counter() - t0:.1f} s")
+    return base, results
 
 
 def selfcheck(gpu_onset: np.ndarray, gpu_offset: np.ndarray, cpu_results, Ls, plans=None) -> dict:
@@ -435,7 +507,9 @@ def finetune_mode(args, rank, world, local_rank, device, dist):
     L = _lib.lib()
     L.la_timer_reset()
     L.la_timer_sample(args.timer_period)      # (every launch bracketed = two barrier packets each: ~40 ms of a 0.8 s step)
-    L.la_timer_enable(os.environ.get("LA_BENCH_TIMER", "gemm_f32").encode())
+    from lyricalignment_amd import f32x2
+    x2 = f32x2.ENABLED          # the large Linear products run as three f16 products over split operands (csrc/la_f32x2.hip)
+    L.la_timer_enable(os.environ.get("LA_BENCH_TIMER", "gemm_f16x2" if x2 else "gemm_f32").encode())
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -470,7 +544,8 @@ def finetune_mode(args, rank, world, local_rank, device, dist):
         print(json.dumps({
             "metric": f"fine-tuned audio-sec/sec, Whisper-{args.model} multitask (CTC + CE + decoder CE), DP={world}",
             "value": audio_sec / elapsed, "unit": "audio-sec/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (f16x2 split of the large Linear products: 3 f16 MFMA products per float32 product, f32 accumulate)" if x2 else "f32",
             "data": "synthetic (Gaussian waveforms, random class-id / frame / token labels, random-init weights)",
             "config": {"workload": f"whisper-{args.model} multitask fine-tune step, per-GPU micro-batch {B} x 30 s x accum {args.accum} "
                                    "(BASELINE.json configs[2])", "mode": "finetune", "micro_batch": B, "accum": args.accum, "accum_mode": args.accum_mode,
@@ -482,10 +557,19 @@ def finetune_mode(args, rank, world, local_rank, device, dist):
             "allreduce_exposed_ms": ar_ms,      # what the exchange costs on the compute stream after the overlap (0 at N = 1)
             # bus bandwidth of the ring all-reduce (only meaningful for the blocking form, --allreduce-chunks 0)
             "allreduce_GBps": (2.0 * (world - 1) / world * grad_bytes / (ar_ms * 1e-3) / 1e9) if (world > 1 and ar_ms > 0 and args.allreduce_chunks == 0) else None,
-            "roofline": {"bound": "mfma", "kernel": "gemm_kernel<float> (v_mfma_f32_16x16x4_f32; every Linear forward + both backward products)",
-                         "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s", "frac": achieved / 157.3, "traffic": None,
-                         "launches_per_step": seen.value / max(args.steps, 1), "avg_launch_ms": total_ms.value / max(launches.value, 1),
-                         "timed_launches": launches.value, "linear_gflop_per_step": gemm_flops_step / 1e9},
+            "roofline": ({"bound": "mfma", "kernel": "gemm_pp_kernel<f16, segmented K> (la_gemm_f16x2: the large Linear forward + both backward "
+                                                    "products as a_lo w_hi + a_hi w_lo + a_hi w_hi in v_mfma_f32_16x16x32_f16)",
+                          # achieved = ALGORITHMIC float32 flops (2 M N K) of the bracketed launches / their HIP-event durations; the kernel
+                          # executes three times that in f16 MFMAs (mfma_executed_tflops), priced against the dense f16 peak
+                          "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s", "frac": achieved / 2500.0, "traffic": None,
+                          "mfma_executed_tflops": 3.0 * achieved, "frac_executed": 3.0 * achieved / 2500.0,
+                          "vs_f32_mfma_peak": achieved / 157.3,
+                          "launches_per_step": seen.value / max(args.steps, 1), "avg_launch_ms": total_ms.value / max(launches.value, 1),
+                          "timed_launches": launches.value, "linear_gflop_per_step": gemm_flops_step / 1e9} if x2 else
+                         {"bound": "mfma", "kernel": "gemm_kernel<float> (v_mfma_f32_16x16x4_f32; every Linear forward + both backward products)",
+                          "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s", "frac": achieved / 157.3, "traffic": None,
+                          "launches_per_step": seen.value / max(args.steps, 1), "avg_launch_ms": total_ms.value / max(launches.value, 1),
+                          "timed_launches": launches.value, "linear_gflop_per_step": gemm_flops_step / 1e9}),
             "cpu_baseline": None,
             "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9}), flush=True)
     if dist is not None:

@@ -281,7 +281,7 @@ struct DuoCtx {
     // (lo, hi), (hi, lo), (hi, hi): small terms first -- so stage t of the flat loop reads plane seg_off[t / seg_stages] of this
     // wave's operand at column (t % seg_stages) * 32.
     int seg_stages = 0;
-    unsigned seg_off0 = 0, seg_off1 = 0, seg_off2 = 0;   // byte offset of each segment's plane inside a row (this wave's operand)
+    unsigned seg_off0 = 0, seg_off1 = 0;   // byte offset of the first / second segment's plane inside a row (this wave's operand; the third reads plane 0)
 };
 // source of stage t (32 elements of K = 64 bytes per row) of this wave's operand panel: wave-uniform arithmetic
 template <bool SEG>
@@ -289,9 +289,11 @@ __device__ __forceinline__ const unsigned char *duo_stage_src(const DuoCtx &c, i
     if constexpr (!SEG) {
         return c.src0 + (int64_t)t * 64;
     } else {
+        // (masks, not selects between the context's fields: hipcc turns a select of two loads from the context into an indexed load
+        //  and leaves the whole context in scratch)
         const int n = c.seg_stages;
         const int seg = (t >= n ? 1 : 0) + (t >= 2 * n ? 1 : 0);
-        const unsigned off = seg == 0 ? c.seg_off0 : (seg == 1 ? c.seg_off1 : c.seg_off2);
+        const unsigned off = ((unsigned)-(int)(seg == 0) & c.seg_off0) | ((unsigned)-(int)(seg == 1) & c.seg_off1);
         // (wave-uniform by construction; the DMA's base operand must sit in SGPRs, so say so to the compiler)
         const uint64_t u = (uint64_t)(uintptr_t)(c.src0 + off + (int64_t)(t - seg * n) * 64);
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
@@ -478,7 +480,6 @@ __device__ __forceinline__ void mainloop_duo_seg_asm(const T16 *A, int64_t lda, 
     c.seg_stages = Kc / 32;
     c.seg_off0 = wave < 4 ? 0u : (unsigned)(plane_a * 2);          // W: hi, lo, hi
     c.seg_off1 = wave < 4 ? (unsigned)(plane_w * 2) : 0u;          // A: lo, hi, hi
-    c.seg_off2 = 0u;
     duo_issue_prologue<true>(c);
 #ifdef LA_TILE_STAMPS
     unsigned long long stamp_unused = 0;

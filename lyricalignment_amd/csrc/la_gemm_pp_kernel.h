@@ -141,8 +141,8 @@ int launch_pp_loop(GemmParams p, int batch, hipStream_t stream) {
     if (const char *g = la::dev_env("LA_GEMM_MBLOCK")) p.mblock = atoi(g);
     if (const char *g = la::dev_env("LA_GELU_PK")) p.epilogue |= atoi(g) == 2 ? 8192 : 4096;
     if (const char *g = la::dev_env("LA_EPI_PROBE")) p.epilogue |= (atoi(g) & 7) << 16;
-    // (LNM 6: the f16x2 form of a float32 product -- timed with the float32 family, at its ALGORITHMIC flops: a third of the MFMA work)
-    la::TimerScope ts(LNM == 6 ? "gemm_f32" : "gemm_bf16", stream, 2.0 * p.M * p.N * p.K * batch);
+    // (LNM 6: the f16x2 form of a float32 product -- its own timer family, counted at its ALGORITHMIC flops: a third of the MFMA work)
+    la::TimerScope ts(LNM == 6 ? "gemm_f16x2" : "gemm_bf16", stream, 2.0 * p.M * p.N * p.K * batch);
     hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, batch), dim3(PP::THREADS), PP::LDS, stream, p);
     LA_LAUNCH_CHECK();
     return LA_OK;

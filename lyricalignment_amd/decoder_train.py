@@ -13,7 +13,7 @@ from typing import List, Optional
 
 import torch
 
-from . import _lib, ops
+from . import _lib, f32x2, ops
 from ._lib import check, lib, ptr, stream_ptr
 from .encoder_train import add, attention_bwd, attention_bwd_ex, gelu, gelu_bwd, layernorm_bwd, scale
 from .head_train import colsum, gemm_nn, gemm_tn, grads_to
@@ -62,22 +62,22 @@ class DecoderFunction(torch.autograd.Function):
             wkv_c = torch.cat([wkc, wvc], 0).contiguous()
             bkv_c = torch.cat([torch.zeros_like(bvc), bvc], 0).contiguous()
             h1 = ops.layernorm(x, g1, be1, torch.float32)
-            qkv = ops.gemm(h1, wqkv, bias=bqkv)
+            qkv = f32x2.linear(h1, wqkv, bias=bqkv)
             a = ops.attention_ex(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, n, n, H, causal=True)
-            x1 = ops.gemm(a, wo, bias=bo, residual=x)
+            x1 = f32x2.linear(a, wo, bias=bo, residual=x)
             hc = ops.layernorm(x1, gc, bec, torch.float32)
-            qc = ops.gemm(hc, wq_c, bias=bq_c)
-            kv = ops.gemm(xa2, wkv_c, bias=bkv_c)
+            qc = f32x2.linear(hc, wq_c, bias=bq_c)
+            kv = f32x2.linear(xa2, wkv_c, bias=bkv_c)
             ac = ops.attention_ex(qc, kv[:, :d], kv[:, d:], B, n, Ta, H, causal=False)
-            x2 = ops.gemm(ac, woc, bias=boc, residual=x1)
+            x2 = f32x2.linear(ac, woc, bias=boc, residual=x1)
             h2 = ops.layernorm(x2, g2, be2, torch.float32)
-            u_pre = ops.gemm(h2, w1, bias=b1)
-            x3 = ops.gemm(gelu(u_pre), w2, bias=b2, residual=x2)
+            u_pre = f32x2.linear(h2, w1, bias=b1)
+            x3 = f32x2.linear(gelu(u_pre), w2, bias=b2, residual=x2)
             saved.append((x, h1, qkv, a, x1, hc, qc, kv, ac, x2, h2, u_pre))
             packed.append((g1, wqkv, wo, gc, wq_c, wkv_c, woc, g2, w1, w2))
             x = x3
         hf = ops.layernorm(x, P[-2], P[-1], torch.float32)
-        logits = ops.gemm(hf, tok_emb)
+        logits = f32x2.linear(hf, tok_emb)
         ctx.dims = (B, n, Ta, d, H, V, n_layer, pos.shape[0])
         ctx.saved, ctx.packed = saved, packed
         ctx.tail = (tokens, xa2, x, hf, tok_emb, P[-2])

@@ -21,7 +21,7 @@ import os
 
 import torch
 
-from . import _lib, ops
+from . import _lib, f32x2, ops
 from ._lib import check, lib, ptr, stream_ptr
 from .head_train import _rup, colsum, gemm_nn, gemm_tn, grads_to
 
@@ -197,13 +197,13 @@ class EncoderFunction(torch.autograd.Function):
             wqkv = torch.cat([scale(wq, 0.125), wk, wv], 0).contiguous()          # (head_dim^-0.25)^2 folded into q: exact
             bqkv = torch.cat([scale(bq, 0.125), torch.zeros_like(bq), bv], 0).contiguous()
             h1 = ops.layernorm(x, g1, be1, torch.float32)
-            qkv = ops.gemm(h1, wqkv, bias=bqkv)
+            qkv = f32x2.linear(h1, wqkv, bias=bqkv)
             lse = torch.empty((B, H, N_CTX), dtype=torch.float32, device=qkv.device)        # row statistic for the fused backward
             att = ops.attention_ex(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, N_CTX, N_CTX, H, lse=lse)
-            x_mid = ops.gemm(att, wo, bias=bo, residual=x)
+            x_mid = f32x2.linear(att, wo, bias=bo, residual=x)
             h2 = ops.layernorm(x_mid, g2, be2, torch.float32)
-            u_pre = ops.gemm(h2, w1, bias=b1)
-            x_next = ops.gemm(gelu(u_pre), w2, bias=b2, residual=x_mid)
+            u_pre = f32x2.linear(h2, w1, bias=b1)
+            x_next = f32x2.linear(gelu(u_pre), w2, bias=b2, residual=x_mid)
             saved.append((x, h1, qkv, att, x_mid, h2, u_pre, lse))
             packed.append((g1, wqkv, wo, g2, w1, w2))
             x = x_next

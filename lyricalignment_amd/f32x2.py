@@ -1,0 +1,146 @@
+"""float32 Linear products of the fine-tune step on the f16 matrix pipe at float32 accuracy ("f16x2"; csrc/la_f32x2.hip).
+
+The reference trains in float32 (train_multitask.py:325-326: loss.backward() through nn.Linear); gfx950 multiplies float32
+operands at 1/16 of its 16-bit MFMA rate.  A float32 matrix whose rows are scaled by powers of two splits exactly into two
+IEEE-half planes (hi + lo = 22 bits), and one pass of the 256 x 256 f16 kernel over three K segments accumulates
+a_lo w_hi + a_hi w_lo + a_hi w_hi in float32 -- 3/16 of the float32 pipe's cost, error against a float64 product smaller than
+the float32 kernel's own (profiles/r5_kbench_f32emu.txt).  This module is the host side: which products take that path (the
+large ones: >= 192 tiles of 256 x 256, counting split-K slots), their operand splits, and the three product shapes of a Linear
+
+    linear(x, w, bias, residual)   y  = x w^T (+ bias) (+ residual)          forward
+    gemm_nn(dy, w)                 dx = dy w                                  input gradient
+    gemm_tn(dy, x)                 dw = dy^T x                                weight gradient (contraction over the rows)
+
+with the float32 MFMA kernel (ops.gemm / head_train.gemm_nn / gemm_tn) for every shape outside that domain.
+LA_F32X2=0 keeps every product on the float32 kernel (the A/B partner; read at import).
+"""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import check, lib, ptr, stream_ptr
+
+ENABLED = os.environ.get("LA_F32X2", "1") != "0"
+MIN_TILES = 192          # the 256 x 256 kernel's domain (la_gemm_f16x2)
+
+
+def _rup(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+@dataclass
+class Planes:
+    """Split operand: planes [rows, 2, kp] float16 (hi plane, lo plane), inv_scale [rows] float32; k = the unpadded length."""
+    planes: torch.Tensor
+    inv_scale: torch.Tensor
+    rows: int
+    k: int
+    kp: int
+
+
+def split(x: torch.Tensor, kp: Optional[int] = None) -> Planes:
+    """x [rows, k] float32 (row view, unit inner stride) -> its planes along k, zero-padded to kp (default: k rounded up to 128)."""
+    if x.dtype != torch.float32 or x.dim() != 2 or x.stride(1) != 1:
+        raise ValueError("f32x2.split: a float32 [rows, k] row view is expected")
+    rows, k = x.shape
+    kp = _rup(k, 128) if kp is None else kp
+    planes = torch.empty((rows, 2, kp), dtype=torch.float16, device=x.device)
+    inv = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    check(lib().la_split_f16x2(ptr(x), x.stride(0), rows, k, ptr(planes), kp, ptr(inv), stream_ptr()), "split_f16x2")
+    return Planes(planes, inv, rows, k, kp)
+
+
+def split_t(x: torch.Tensor, mp: Optional[int] = None) -> Planes:
+    """x [m, k] float32 -> the planes of x^T: rows = k, contraction length m zero-padded to mp (default: m rounded up to 128)."""
+    if x.dtype != torch.float32 or x.dim() != 2 or x.stride(1) != 1:
+        raise ValueError("f32x2.split_t: a float32 [m, k] row view is expected")
+    m, k = x.shape
+    mp = _rup(m, 128) if mp is None else mp
+    planes = torch.empty((k, 2, mp), dtype=torch.float16, device=x.device)
+    inv = torch.empty((k,), dtype=torch.float32, device=x.device)
+    check(lib().la_split_f16x2_t(ptr(x), x.stride(0), m, k, ptr(planes), mp, ptr(inv), stream_ptr()), "split_f16x2_t")
+    return Planes(planes, inv, k, m, mp)
+
+
+def slots_for(M: int, N: int) -> int:
+    """Split-K slots that bring a product with few 256 x 256 tiles up to the kernel's domain (1 = none needed)."""
+    tiles = -(-M // 256) * -(-N // 256)
+    return max(1, -(-MIN_TILES // tiles))
+
+
+def eligible(M: int, N: int, K: int) -> bool:
+    """Does C [M, N] = A [M, K] W [N, K]^T take the f16x2 path?  Large products only: N > 128, at least 256 of K per split-K slot and
+    no more than 16 slots (beyond that the partial sums cost more than the float32 kernel)."""
+    if not ENABLED or N <= 128 or K < 256:
+        return False
+    s = slots_for(M, N)
+    return s <= 16 and K // s >= 256
+
+
+def padded_k(M: int, N: int, K: int) -> int:
+    """Plane length both operands of C [M, N] are split to: K rounded up so that every split-K slot is a multiple of 128."""
+    s = slots_for(M, N)
+    return s * _rup(-(-K // s), 128)
+
+
+def gemm(a: Planes, w: Planes, out: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
+         residual: Optional[torch.Tensor] = None, gelu: bool = False) -> torch.Tensor:
+    """out [a.rows, w.rows] f32 = epi(A W^T) from split operands of the same plane length."""
+    if a.kp != w.kp:
+        raise ValueError(f"f32x2.gemm: operands were split to different plane lengths ({a.kp}, {w.kp})")
+    M, N = a.rows, w.rows
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.planes.device)
+    epi = 0
+    if bias is not None:
+        epi |= _lib.EPI_BIAS
+    if residual is not None:
+        epi |= _lib.EPI_RESIDUAL
+    if gelu:
+        epi |= _lib.EPI_GELU
+    check(lib().la_gemm_f16x2(M, N, a.kp, slots_for(M, N), ptr(a.planes), ptr(a.inv_scale), ptr(w.planes), ptr(w.inv_scale), ptr(out),
+                              out.stride(0), ptr(bias), ptr(residual), residual.stride(0) if residual is not None else 0, epi,
+                              stream_ptr()), "gemm_f16x2")
+    return out
+
+
+def _plain2d(t: torch.Tensor) -> bool:
+    return t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1
+
+
+def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = x w^T (+ bias) (+ residual), float32 in and out (F.linear; whisper/model.py Linear)."""
+    from . import ops
+    M, K = x.shape
+    N = w.shape[0]
+    if _plain2d(x) and _plain2d(w) and eligible(M, N, K) and (residual is None or _plain2d(residual)):
+        kp = padded_k(M, N, K)
+        return gemm(split(x, kp), split(w, kp), bias=bias, residual=residual)
+    return ops.gemm(x, w, bias=bias, residual=residual)
+
+
+def gemm_nn(dy: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """dy [M, N] . w [N, K] -> [M, K]: the input gradient of y = x w^T."""
+    from . import head_train
+    M, N = dy.shape
+    K = w.shape[1]
+    if _plain2d(dy) and _plain2d(w) and eligible(M, K, N):
+        np_ = padded_k(M, K, N)
+        return gemm(split(dy, np_), split_t(w, np_))
+    return head_train.gemm_nn_f32(dy, w)
+
+
+def gemm_tn(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """dy [M, N]^T . x [M, K] -> [N, K]: the weight gradient of y = x w^T (contraction over the M rows of both)."""
+    from . import head_train
+    M, N = dy.shape
+    K = x.shape[1]
+    if _plain2d(dy) and _plain2d(x) and eligible(N, K, M):
+        mp = padded_k(N, K, M)
+        return gemm(split_t(dy, mp), split_t(x, mp))
+    return head_train.gemm_tn_f32(dy, x)

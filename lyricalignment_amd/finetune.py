@@ -121,7 +121,15 @@ class OverlappedAllReduce:
     Whisper-medium gradients are ~36 ms of ring all-reduce at the per-link rate against a 0.8 s step, and all but the last chunk
     (the conv stem + first blocks: 1 / min_chunks of it) hides behind the backward.  Elementwise sums are the same sums whatever the
     chunking: with 2 ranks the result is bit-identical to allreduce_mean_ (tests), with more ranks it differs like any other
-    ring order would.  world == 1: nothing is registered, finish() returns 0."""
+    ring order would.  world == 1: nothing is registered, finish() returns 0.
+
+    The ORDER of the collectives is fixed beforehand and the same on every rank -- `order`: the backbone's chunks from the last
+    parameters to the first (the order a backward completes them in), then the head's -- whatever each rank's own batch made ready
+    first: a ready chunk is handed to the backend only once every chunk before it in `order` has been, and finish() issues the rest
+    in that order.  (Collectives of different sizes issued in different orders on different ranks hang or silently mix buffers: a
+    rank whose last micro-batch has no frame-labelled clips gives the head no gradient in that backward while its neighbour's does --
+    train_multitask.py:299-321 with use_ctc_loss off, :226.)  A rank that never completes a chunk holds everything behind it
+    until finish(): correct, merely un-overlapped on that step."""
 
     def __init__(self, groups, grads, world: int, min_chunks: int = 4):
         self.world = world
@@ -130,10 +138,14 @@ class OverlappedAllReduce:
         self._hooks = []
         self._armed = False
         self._pending, self._works, self._launched = [], [], []
+        self._ready, self._next = [], 0
+        self.order: List[int] = []          # chunk indices in the one order every rank issues its collectives in
         self.exposed_ms = 0.0
         if world == 1:
             return
+        group_chunks = []
         for params, flat in zip(groups, grads):
+            first_chunk = len(self.chunks)
             n_chunks = min(len(params), min_chunks if flat.numel() >= (1 << 16) else 1)
             target = flat.numel() / n_chunks
             off = start = made = 0
@@ -148,6 +160,10 @@ class OverlappedAllReduce:
                     for q in members:
                         self._chunk_of[id(q)] = ci
                     start, members = off, []
+            group_chunks.append(list(range(first_chunk, len(self.chunks))))
+        # groups = [head, backbone] (FineTuner): the backbone's chunks back to front, then the head's
+        for cs in reversed(group_chunks):
+            self.order += list(reversed(cs))
         for params in groups:
             for p in params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
@@ -156,9 +172,26 @@ class OverlappedAllReduce:
         """Call right before the LAST backward of the optimizer step (gradients of earlier micro-steps are already in the buckets)."""
         if self.world == 1:
             return
+        if self._armed or self._works:
+            # all-reduces of an earlier armed backward are still in flight (the caller skipped finish() / step()): their chunks are
+            # already being summed in place, dropping the handles would sum them again or race the caller's zeroing of the bucket
+            raise RuntimeError("OverlappedAllReduce.arm(): the previous armed backward was not finished -- call finish() (on every "
+                               "rank) before re-arming, also when the optimizer step is skipped")
         self._pending = [n for _, n in self.chunks]
         self._works, self._launched = [], [False] * len(self.chunks)
+        self._ready, self._next = [False] * len(self.chunks), 0
         self._armed = True
+
+    def _launch_in_order(self, everything: bool = False) -> None:
+        """Hand chunks to the backend strictly in `order`: up to the first one that is not ready yet (all of them from finish())."""
+        import torch.distributed as dist
+        while self._next < len(self.order):
+            ci = self.order[self._next]
+            if not (everything or self._ready[ci]):
+                return
+            self._works.append(dist.all_reduce(self.chunks[ci][0], op=dist.ReduceOp.SUM, async_op=True))
+            self._launched[ci] = True
+            self._next += 1
 
     def _on_grad(self, p) -> None:
         if not self._armed:
@@ -166,9 +199,8 @@ class OverlappedAllReduce:
         ci = self._chunk_of[id(p)]
         self._pending[ci] -= 1
         if self._pending[ci] == 0:
-            import torch.distributed as dist
-            self._works.append(dist.all_reduce(self.chunks[ci][0], op=dist.ReduceOp.SUM, async_op=True))
-            self._launched[ci] = True
+            self._ready[ci] = True
+            self._launch_in_order()
 
     def finish(self) -> float:
         """Wait for the chunks in flight and all-reduce the ones the backward never completed.  What this costs on the device's
@@ -180,10 +212,10 @@ class OverlappedAllReduce:
         if on_gpu:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        armed, self._armed = self._armed, False
-        for ci, (view, _) in enumerate(self.chunks):
-            if not (armed and self._launched[ci]):
-                self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
+        if not self._armed:                  # never armed on this step: every chunk, in the same fixed order
+            self._launched, self._ready, self._next = [False] * len(self.chunks), [False] * len(self.chunks), 0
+        self._armed = False
+        self._launch_in_order(everything=True)
         for w in self._works:
             w.wait()
         self._works = []

@@ -54,9 +54,13 @@ def colsum(a: torch.Tensor) -> torch.Tensor:
 
 
 def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """a [M,K] . w [N,K]^T (+ bias) in float32 on the MFMA kernel; K is zero-padded to the kernel's granule when needed."""
+    """a [M,K] . w [N,K]^T (+ bias), float32 in and out: the large products as three f16 products over split operands (f32x2.linear:
+    float32 accuracy at 3/16 of the float32 pipe's cost), the others on the float32 MFMA kernel (K zero-padded to its granule)."""
     if a.shape[1] != w.shape[1]:
         raise ValueError("gemm_nt: K mismatch")
+    from . import f32x2
+    if f32x2.eligible(a.shape[0], w.shape[0], a.shape[1]):
+        return f32x2.linear(a, w, bias=bias)
     return ops.gemm(_padK(a), _padK(w), bias=bias, out_f32=True)
 
 
@@ -75,6 +79,18 @@ def _gemm_ex_flags(Mg: int, Ng: int, Kg: int, a: torch.Tensor, w: torch.Tensor, 
 
 
 def gemm_tn(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """a [M,N]^T . b [M,K] -> [N,K]: the weight gradient of a Linear.  Large products on the f16x2 path, the rest gemm_tn_f32."""
+    from . import f32x2
+    return f32x2.gemm_tn(a, b)
+
+
+def gemm_nn(a: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """a [M,N] . w [N,K] -> [M,K]: the input gradient of a Linear.  Large products on the f16x2 path, the rest gemm_nn_f32."""
+    from . import f32x2
+    return f32x2.gemm_nn(a, w)
+
+
+def gemm_tn_f32(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """a [M,N]^T . b [M,K] -> [N,K]: the weight-gradient shape (contraction over the rows of both).  Both operands are read
     as they lie (la_gemm_ex, LA_GEMM_TRANS_A | LA_GEMM_TRANS_W); shapes the transposed staging does not take go through
     explicit transposes."""
@@ -85,7 +101,7 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return ops.gemm(transpose_pad(a), transpose_pad(b), out_f32=True)
 
 
-def gemm_nn(a: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+def gemm_nn_f32(a: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     """a [M,N] . w [N,K] -> [M,K]: the input-gradient shape (w read as it lies: LA_GEMM_TRANS_W)."""
     if a.shape[1] != w.shape[0]:
         raise ValueError("gemm_nn: inner size mismatch")

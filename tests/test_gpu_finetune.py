@@ -213,12 +213,17 @@ def test_fused_attention_backward_causal_and_cross_shapes(B, Tq, Tk, H, causal):
     assert _rel(dkv.cpu()[:, :d], kv0.grad[:, :d]) < 2e-4 and _rel(dkv.cpu()[:, d:], kv0.grad[:, d:]) < 2e-4
 
 
-@pytest.mark.parametrize("d,H,L,B", [(64, 1, 1, 1), (128, 2, 2, 2)])
-def test_encoder_backward_matches_torch_autograd(d, H, L, B):
+@pytest.mark.parametrize("d,H,L,B", [(64, 1, 1, 1), (128, 2, 2, 2), (512, 8, 1, 8)])
+def test_encoder_backward_matches_torch_autograd(d, H, L, B, monkeypatch):
     """EncoderFunction (HIP forward + backward) against torch autograd through the oracle's AudioEncoder restatement:
-    output and the gradient of every encoder parameter."""
+    output and the gradient of every encoder parameter.  The last case (12000 rows of width 512) is large enough for the Linear
+    products to take the f16x2 path (f32x2: three f16 products over split operands, split-K slots for the weight gradients) --
+    asserted -- under the same tolerance as the float32 kernels."""
     from oracle import model_oracle as mo
-    from lyricalignment_amd import encoder_train as et
+    from lyricalignment_amd import encoder_train as et, f32x2
+    x2_calls = []
+    real_gemm = f32x2.gemm
+    monkeypatch.setattr(f32x2, "gemm", lambda a, w, *args, **kw: (x2_calls.append((a.rows, w.rows, a.kp)), real_gemm(a, w, *args, **kw))[1])
     p = mo.random_encoder_params(d, L, seed=d + L)
     for i in range(L):                      # sharper attention than the 0.02-std init gives, so softmax' is exercised
         p[f"encoder.blocks.{i}.attn.query.weight"] *= 12
@@ -239,6 +244,7 @@ def test_encoder_backward_matches_torch_autograd(d, H, L, B):
         worst[n] = _rel(t.grad.cpu(), ref_p["encoder." + n].grad)
     bad = {n: e for n, e in worst.items() if e > 1e-3}
     assert not bad, bad
+    assert (len(x2_calls) >= 8) == (d >= 512), x2_calls
 
 
 @pytest.mark.parametrize("B,n,Ta,L", [(2, 37, 1500, 2), (1, 5, 100, 1)])

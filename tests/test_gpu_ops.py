@@ -642,3 +642,85 @@ def test_gemm_split_batched_stem_layout_and_zero_rows():
     dec = ops.split_decode(hi, lo)
     assert float((dec - x).abs().max()) <= float(x.abs().max()) * 1.6e-5
     assert float((dec[:T] - pos).abs().max()) <= float(pos.abs().max()) * 1.6e-5
+
+
+# ------------------------------------------------------------------------------------------------ float32 products as f16x2
+def _heavy(rows, cols, seed, scale=1.0):
+    """Gaussian with outlier columns (x 30) and a log-normal spread of row magnitudes: activation / gradient-like dynamic range."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(rows, cols, generator=g)
+    x[:, torch.randperm(cols, generator=g)[: max(1, cols // 128)]] *= 30.0
+    x *= torch.exp(torch.randn(rows, 1, generator=g) * 1.5)
+    return x * scale
+
+
+def test_split_f16x2_planes_reconstruct_the_float32_values():
+    """la_split_f16x2 / la_split_f16x2_t: (hi + lo) * inv_scale gives x back to 2^-21 of each element (22 bits) or 2^-38 of its row's
+    (column's) largest magnitude, whichever is larger (half's subnormal floor); inverse scales are powers of two that put the largest
+    magnitude in [2^13, 2^14); zero rows, a zero matrix tail (padding) and rows of tiny / huge magnitude included; the transposed
+    form equals the plain form of x^T bit for bit."""
+    from lyricalignment_amd import f32x2
+    x = _heavy(1000, 777, seed=1)
+    x[5] = 0.0
+    x[6] *= 1e-30
+    x[7] *= 1e25
+    x[8, 3] = 0.0
+    xd = x.cuda()
+    for P, ref, axis_max in ((f32x2.split(xd, 896), x, x.abs().amax(dim=1, keepdim=True)),
+                             (f32x2.split_t(xd, 1024), x.t().contiguous(), x.abs().amax(dim=0)[:, None])):
+        planes, inv = P.planes.cpu(), P.inv_scale.cpu()
+        n = ref.shape[1]
+        assert planes.shape == (ref.shape[0], 2, P.kp) and float(planes[:, :, n:].abs().max()) == 0.0
+        rec = (planes[:, 0, :n].double() + planes[:, 1, :n].double()) * inv.double()[:, None]
+        err = (rec - ref.double()).abs()
+        bound = torch.maximum(ref.double().abs() * 2.0 ** -21, axis_max.double() * 2.0 ** -38)
+        assert bool((err <= bound).all()), float((err / bound.clamp_min(1e-300)).max())
+        m, e = torch.frexp(inv)
+        assert bool((m == 0.5).all())                                           # powers of two
+        scaled = axis_max[:, 0].double() / inv.double()
+        nz = axis_max[:, 0] > 0
+        assert bool(((scaled[nz] >= 2.0 ** 13) & (scaled[nz] < 2.0 ** 14)).all()) and bool((inv[~nz] == 1.0).all())
+    a, b = f32x2.split_t(xd, 1024), f32x2.split(xd.t().contiguous(), 1024)
+    assert torch.equal(a.planes.view(torch.int16), b.planes.view(torch.int16)) and torch.equal(a.inv_scale, b.inv_scale)
+
+
+@pytest.mark.parametrize("kind", ["gauss", "heavy"])
+def test_gemm_f16x2_is_at_least_as_accurate_as_the_float32_kernel(kind):
+    """la_gemm_f16x2 (three f16 products over segmented K, scale epilogue) against a float64 product, next to float32 la_gemm on the
+    same operands: max |err| / max |ref| no larger than the float32 kernel's (measured 2-3 x smaller) and below 2e-6; bias + residual
+    epilogue; a ragged last row / column of tiles; K not a multiple of 128 (zero-padded planes)."""
+    from lyricalignment_amd import f32x2, ops
+    M, N, K = 256 * 48 + 40, 1024 + 72, 1056
+    mk = _heavy if kind == "heavy" else (lambda r, c, seed, scale=1.0: _rand(r, c, seed=seed, scale=scale))
+    a, w = mk(M, K, seed=11), _rand(N, K, seed=12, scale=K ** -0.5)
+    bias, res = _rand(N, seed=13), _rand(M, N, seed=14)
+    ad, wd = a.cuda(), w.cuda()
+    assert f32x2.eligible(M, N, K)
+    out = f32x2.linear(ad, wd, bias=bias.cuda(), residual=res.cuda()).cpu()
+    nat = ops.gemm(ad, wd, bias=bias.cuda(), residual=res.cuda()).cpu()
+    rows = torch.cat([torch.arange(0, 512), torch.arange(M - 64, M)])
+    ref = a[rows].double() @ w.double().t() + bias.double() + res[rows].double()
+    e_x2 = float((out[rows].double() - ref).abs().max() / ref.abs().max())
+    e_f32 = float((nat[rows].double() - ref).abs().max() / ref.abs().max())
+    print(f"f16x2 {e_x2:.2e} vs float32 kernel {e_f32:.2e}")
+    assert e_x2 <= max(e_f32, 4e-7) and e_x2 < 2e-6
+
+
+def test_f16x2_gradient_products_with_split_k_slots():
+    """f32x2.gemm_nn (dx = dy w) and gemm_tn (dw = dy^T x: few tiles, the 6000-row contraction cut into split-K slots summed in slot
+    order) against float64 and against the float32 kernels; the slotted product is deterministic (two runs, same bits)."""
+    from lyricalignment_amd import f32x2, head_train
+    M, N, K = 6000, 1536, 512
+    dy, x, w = _heavy(M, N, seed=21, scale=1e-4), _heavy(M, K, seed=22), _rand(N, K, seed=23, scale=K ** -0.5)
+    dyd, xd, wd = dy.cuda(), x.cuda(), w.cuda()
+    assert f32x2.eligible(N, K, M) and f32x2.slots_for(N, K) > 1 and f32x2.eligible(M, K, N)
+    dw = f32x2.gemm_tn(dyd, xd)
+    assert torch.equal(dw, f32x2.gemm_tn(dyd, xd))
+    dx = f32x2.gemm_nn(dyd, wd)
+    ref_dw, ref_dx = dy.double().t() @ x.double(), dy.double() @ w.double()
+    for got, nat, ref in ((dw.cpu(), head_train.gemm_tn_f32(dyd, xd).cpu(), ref_dw), (dx.cpu(), head_train.gemm_nn_f32(dyd, wd).cpu(), ref_dx)):
+        e_x2 = float((got.double() - ref).abs().max() / ref.abs().max())
+        e_f32 = float((nat.double() - ref).abs().max() / ref.abs().max())
+        assert e_x2 <= max(e_f32, 4e-7) and e_x2 < 3e-6, (e_x2, e_f32)
+    with pytest.raises(NotImplementedError):          # outside the 256 x 256 kernel's domain: the C entry point refuses, the wrappers never ask
+        f32x2.gemm(f32x2.split(xd[:300], 512), f32x2.split(wd, 512))

@@ -284,7 +284,7 @@ dist.init_process_group(backend="gloo", init_method="tcp://127.0.0.1:%(port)d", 
 torch.manual_seed(7)
 net = torch.nn.Sequential(*[torch.nn.Linear(96, 96) for _ in range(8)], torch.nn.Linear(96, 4))        # 18 parameters, ~75 k elements
 unused = torch.nn.Parameter(torch.zeros(5000))               # a parameter the backward never reaches (a frozen branch)
-groups = [[net[-1].weight, net[-1].bias], [p for m in net[:-1] for p in m.parameters()] + [unused]]
+groups = [[net[-1].weight, net[-1].bias], [unused] + [p for m in net[:-1] for p in m.parameters()]]
 flat, grad = [], []
 for params in groups:                                        # FineTuner's bucket construction: .data / .grad are views
     n = sum(p.numel() for p in params)
@@ -319,10 +319,11 @@ dist.destroy_process_group()
 
 def test_overlapped_gradient_allreduce_world_size_2_gloo(tmp_path):
     """finetune.OverlappedAllReduce on CPU / gloo, 2 ranks: the flat buckets are cut at parameter boundaries into >= 4 chunks for
-    the large bucket, every chunk whose parameters all received their gradient in the ARMED backward is all-reduced from the
-    post-accumulate hook (during that backward), the chunk holding a parameter the backward never reaches is reduced by
-    finish(); nothing is sent during an un-armed (earlier micro-step's) backward; the result is bit-equal to one blocking
-    all-reduce per bucket, on both ranks, two optimizer steps in a row."""
+    the large bucket, chunks whose parameters all received their gradient in the ARMED backward are all-reduced from the
+    post-accumulate hook (during that backward) in the fixed order -- backbone back to front, then the head --, the chunk holding a
+    parameter the backward never reaches (the backbone's first) and the head's chunk behind it are issued by finish(); nothing is
+    sent during an un-armed (earlier micro-step's) backward; the result is bit-equal to one blocking all-reduce per bucket, on both
+    ranks, two optimizer steps in a row."""
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     script = tmp_path / "worker_ov.py"
@@ -339,6 +340,91 @@ def test_overlapped_gradient_allreduce_world_size_2_gloo(tmp_path):
     for o in outs:
         assert o["same"] and o["chunks"] >= 5                           # head bucket 1 chunk + backbone >= 4
         assert all(0 < n < o["chunks"] for n in o["launched_during"])   # some during the backward, the unreached one at finish()
+    assert outs[0]["sum"] == outs[1]["sum"]
+
+
+_WORKER_OVERLAP_HETERO = r'''
+import os, sys, json
+sys.path.insert(0, %(root)r)
+import torch, torch.distributed as dist
+from lyricalignment_amd.finetune import OverlappedAllReduce, allreduce_mean_
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group(backend="gloo", init_method="tcp://127.0.0.1:%(port)d", rank=rank, world_size=world)
+torch.manual_seed(7)
+body = torch.nn.Sequential(*[torch.nn.Linear(96, 96) for _ in range(8)])        # the "backbone"
+head = torch.nn.Linear(96, 40)                                                  # the "align head": a different size per chunk
+groups = [list(head.parameters()), list(body.parameters())]
+flat, grad = [], []
+for params in groups:
+    n = sum(p.numel() for p in params)
+    f, g = torch.empty(n), torch.zeros(n)
+    off = 0
+    for p in params:
+        f[off: off + p.numel()].copy_(p.detach().reshape(-1)); p.data = f[off: off + p.numel()].view_as(p); p.grad = g[off: off + p.numel()].view_as(p)
+        off += p.numel()
+    flat.append(f); grad.append(g)
+ov = OverlappedAllReduce(groups, grad, world, min_chunks=4)
+x = torch.randn(16, 96, generator=torch.Generator().manual_seed(50 + rank))
+
+def last_backward(step):
+    # the reference's micro-step with use_ctc_loss off (train_multitask.py:226,299-321): a rank whose last micro-batch has only
+    # transcript clips gives the head NO gradient in that backward; its neighbour's last micro-batch has frame labels.  Step 2: a
+    # rank whose last micro-batch is empty runs no backward at all.
+    if step == 2 and rank == 0:
+        return
+    feats = body(x * 0.5)
+    loss = feats.square().sum() if (rank + step) %% 2 == 1 else head(feats).square().sum() + feats.square().sum()
+    loss.backward()
+
+orders, same = [], True
+for step in range(3):
+    for g in grad: g.zero_()
+    head(body(x)).square().sum().backward()                  # an earlier micro-step: both branches, nothing is sent
+    ov.arm()
+    last_backward(step)
+    ov.finish()
+    orders.append([ci for ci in ov.order])
+    mine = [g.clone() for g in grad]
+    for g in grad: g.zero_()
+    head(body(x)).square().sum().backward(); last_backward(step)
+    allreduce_mean_(grad, world)
+    same = same and all(torch.equal(a, b) for a, b in zip(mine, grad))
+try:
+    ov.arm(); ov.arm()
+    rearm = "no error"
+except RuntimeError as e:
+    rearm = "refused"
+ov.finish()
+print(json.dumps({"rank": rank, "same": same, "order": ov.order, "chunks": len(ov.chunks), "rearm": rearm,
+                  "sum": float(sum(float(g.double().sum()) for g in mine))}))
+dist.destroy_process_group()
+'''
+
+
+def test_overlapped_allreduce_with_heterogeneous_last_backwards_keeps_one_order(tmp_path):
+    """Round-4 advisor finding: with use_ctc_loss off a transcript-only last micro-batch gives the head no gradient in the armed
+    backward on one rank while the other rank's gives it one (and a rank's last micro-batch may be empty).  Launching chunks "as
+    they complete" then issues collectives of different sizes in different orders on the two ranks.  OverlappedAllReduce issues them
+    in ONE fixed order (backbone back to front, then the head) on every rank: the run completes (no hang: the worker has a
+    time-out), both ranks agree with the blocking all-reduce bit for bit on three differently shaped steps, and re-arming without
+    finish() is refused."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "worker_ov_hetero.py"
+    script.write_text(_WORKER_OVERLAP_HETERO % {"root": ROOT, "port": port})
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=120)
+        assert p.returncode == 0, e[-2000:]
+        outs.append(json.loads(o.strip().splitlines()[-1]))
+    assert outs[0]["order"] == outs[1]["order"] and sorted(outs[0]["order"]) == list(range(outs[0]["chunks"]))
+    assert outs[0]["order"][-1] == 0                      # the head's chunk goes last
+    for o in outs:
+        assert o["same"] and o["rearm"] == "refused"
     assert outs[0]["sum"] == outs[1]["sum"]
 
 

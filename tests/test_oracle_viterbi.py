@@ -92,3 +92,19 @@ def test_emission_prep(variant):
 def test_get_mae():
     g = load_json("mae.json")
     assert ao.get_mae(g["gt"], g["predict"]) == g["mae"]
+
+
+def test_python_loop_dp_equals_the_c_oracle():
+    """oracle/viterbi_python.py (the recurrence as plain Python loops: what the reference runs per cell without numba; bench.py times
+    it as the DP's upper bound) fills dp / bt exactly as the compiled oracle does -- which is pinned to the reference's own matrices
+    above -- on lattices with repeated labels, a single label, and more states than frames can reach."""
+    from oracle import alignment_oracle as ao, viterbi_python as vp
+    for seed, T, V, L, rep in ((0, 400, 60, 19, 5), (1, 50, 7, 1, None), (2, 30, 40, 26, 3), (3, 1500, 300, 26, 11)):
+        lp, ls, lab = core_inputs(seed, T, L, V, 3.0, rep)
+        dp = np.full((T, 2 * L + 1), -10000000.0)
+        bt = np.zeros((T, 2 * L + 1), dtype=np.int64)
+        dp[0][0] = ls[0][0]
+        dp[0][1] = lp[0][lab[0] - 1]
+        ao.run_viterbi_core(dp, bt, lp, ls, lab)
+        d2, b2 = vp.viterbi_lattice(lp, ls, lab)
+        assert np.array_equal(dp, d2) and np.array_equal(bt, b2)

@@ -310,6 +310,24 @@ def bench_f32emu(iters):
             torch.cuda.empty_cache()
 
 
+def bench_x2(iters):
+    """The shipped f16x2 path (csrc/la_f32x2.hip) on the fine-tune shapes (24000 rows): split kernels (GB/s of their algorithmic bytes:
+    4 B read + 4 B written per element; the transposed form reads twice) and the three products of a Linear next to the float32 kernels."""
+    from lyricalignment_amd import f32x2, head_train
+    M = 24000
+    for name, N, K in (("qkv", 3072, 1024), ("mlp-up", 4096, 1024), ("out-proj", 1024, 1024), ("mlp-down", 1024, 4096)):
+        x, w, dy = torch.randn(M, K, device="cuda"), torch.randn(N, K, device="cuda") * K ** -0.5, torch.randn(M, N, device="cuda") * 1e-3
+        t = timeit(lambda: f32x2.split(x), iters)[0]
+        print(f"x2 {name:9s} split    x [{M},{K}]: {t*1e3:7.1f} us  {M*K*8/t/1e6:7.1f} GB/s", flush=True)
+        t = timeit(lambda: f32x2.split_t(dy, f32x2.padded_k(N, K, M)), iters)[0]
+        print(f"x2 {name:9s} split_t dy [{M},{N}]: {t*1e3:7.1f} us  {M*N*12/t/1e6:7.1f} GB/s", flush=True)
+        for lab, fx, fn, fl in (("fwd y=xW^T", lambda: f32x2.linear(x, w), lambda: ops.gemm(x, w), 2.0 * M * N * K),
+                                ("dx=dy W   ", lambda: f32x2.gemm_nn(dy, w), lambda: head_train.gemm_nn_f32(dy, w), 2.0 * M * N * K),
+                                ("dw=dy^T x ", lambda: f32x2.gemm_tn(dy, x), lambda: head_train.gemm_tn_f32(dy, x), 2.0 * M * N * K)):
+            tx, tn = timeit(fx, iters)[0], timeit(fn, iters)[0]
+            print(f"x2 {name:9s} {lab}: f16x2 incl. splits {tx*1e3:8.1f} us ({fl/tx/1e9:6.1f} TF/s algorithmic) | float32 kernel {tn*1e3:8.1f} us ({fl/tn/1e9:6.1f}) | {tn/tx:4.2f}x", flush=True)
+
+
 def bench_attn(iters):
     B, T, H = 32, 1500, 16
     qkv = rnd(B * T, 3 * H * 64)
@@ -416,6 +434,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if a.what == "epi":
         bench_epi_probe(a.iters)
+        sys.exit(0)
+    if a.what == "x2":
+        bench_x2(a.iters)
         sys.exit(0)
     if a.what == "f32emu":
         bench_f32emu(a.iters)
