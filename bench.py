@@ -463,7 +463,9 @@ def finetune_mode(args, rank, world, local_rank, device, dist):
     _lib.require_gpu()
     log(f"rank {rank}/{world}: building random-init whisper-{args.model} weights (fine-tune mode)")
     dims = wc.dims_for(args.model)
-    wm = wc.build_model(args.model, seed=0, with_decoder=True)
+    t_start = time.perf_counter()
+    wm = build_weights(args.model, True, rank, world, dist)
+    log(f"rank {rank}: weights built in {time.perf_counter() - t_start:.1f} s")
     torch.manual_seed(0)                       # the head's torch-default initialisation: identical on every rank
     model = AlignModel(wm, embed_dim=dims.n_audio_state, hidden_dim=HIDDEN, output_dim=VOCAB, dropout=0.15, train_transcript=True,
                        device=f"cuda:{local_rank}").to(device)
@@ -592,7 +594,7 @@ def other_config_mode(args, rank, world, local_rank, device, dist):
     log(f"rank {rank}/{world}: building random-init whisper-{name} weights ({args.mode} mode)")
     dims = wc.dims_for(name)
     dt = torch.float16 if large else torch.bfloat16
-    model = AlignModel(wc.build_model(name, seed=0), embed_dim=dims.n_audio_state, hidden_dim=HIDDEN, output_dim=VOCAB,
+    model = AlignModel(build_weights(name, False, rank, world, dist), embed_dim=dims.n_audio_state, hidden_dim=HIDDEN, output_dim=VOCAB,
                        device=f"cuda:{local_rank}", compute_dtype=dt).eval()
     with torch.no_grad():
         eng = model.engine()
@@ -672,6 +674,17 @@ def other_config_mode(args, rank, world, local_rank, device, dist):
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def build_weights(name: str, with_decoder: bool, rank: int, world: int, dist):
+    """Random-init weights of the architecture, the same bits on every rank.  With several ranks on the node each generates 1 / world of
+    the tensors and they exchange the pieces through /dev/shm (whisper_compat.build_model_shared) instead of `world` full host builds
+    on cores // world threads each."""
+    from lyricalignment_amd import whisper_compat as wc
+    if world == 1 or dist is None or os.environ.get("LA_BENCH_SHARED_BUILD", "1") == "0":
+        return wc.build_model(name, seed=0, with_decoder=with_decoder)
+    tag = os.environ.get("MASTER_PORT", "0") + "_" + name
+    return wc.build_model_shared(name, 0, with_decoder, rank, world, dist.barrier, tag)
 
 
 def launch_ranks(n: int) -> int:
@@ -774,14 +787,16 @@ def main():
     from lyricalignment_amd.module.align_model import AlignModel
     _lib.require_gpu()
     dims = wc.dims_for(MODEL)
-    wm = wc.build_model(MODEL, seed=0)
+    t_start = time.perf_counter()
+    wm = build_weights(MODEL, False, rank, world, dist)
+    t_built = time.perf_counter()
     model = AlignModel(wm, embed_dim=dims.n_audio_state, hidden_dim=HIDDEN, output_dim=VOCAB, device=f"cuda:{local_rank}",
                        compute_dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float16).eval()
     fit = fit_head(model, device, from_waveform=args.from_waveform)   # a head that has learnt the synthetic songs (linear probe)
     log(f"head fitted: {fit}")
     with torch.no_grad():
         eng = model.engine()
-    log("weights packed on the device")
+    log(f"rank {rank}: start-up {time.perf_counter() - t_start:.1f} s (weights built in {t_built - t_start:.1f} s; head fit + packing on the device the rest)")
     mel, labels, n_labels, Ls, plans = build_inputs(device, seed_offset=0, from_waveform=args.from_waveform)   # same batch on every rank
     wave = None
     if args.from_waveform:

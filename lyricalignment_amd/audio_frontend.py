@@ -43,7 +43,7 @@ def mel_filter_table(n_mels: int = N_MELS) -> np.ndarray:
     return fb.astype(np.float32)
 
 
-@functools.lru_cache(maxsize=2)
+@functools.lru_cache(maxsize=None)
 def _device_tables(device_index: int):
     dev = torch.device("cuda", device_index)
     filt = torch.from_numpy(mel_filter_table()).to(dev)
@@ -51,7 +51,7 @@ def _device_tables(device_index: int):
     return filt, win
 
 
-@functools.lru_cache(maxsize=2)
+@functools.lru_cache(maxsize=None)
 def _device_constants(device_index: int) -> torch.Tensor:
     """The log-mel kernel's constants (windowed DFT matrix in fragment order + padded filter bank), built once per device
     from the two tables above (la_logmel_constants) -- whisper caches its filter asset per process the same way."""

@@ -430,15 +430,208 @@ __global__ __launch_bounds__(NW * 64, 1) void gru_kernel(GruParams p) {
     if (!alive && tid == 0 && p.timeout_flag) *p.timeout_flag = 1;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Granule hand-off form of the 16-bit recurrence (8-wave workgroups, MT = 1): the data IS the flag.
+// The counter form above pays four dependent memory round trips per step -- producers' write-through stores are drained
+// (vmcnt(0)), a barrier, one lane's counter add; the consumer's poll sees the add, a barrier, THEN the h loads go out.  Here
+// every pair of hidden units leaves as ONE naturally aligned 8-byte sc1 store {h[c][2j], h[c][2j+1] | tag = step + 1}
+// (cdna guide Guideline 16, recipe R2: a granule written by one store needs no ordering with anything else) into a ring
+// of two step slots per (group, direction); consumers poll the granules themselves with 16-byte sc1 loads (two granules
+// each) and keep what has the step's tag: no drain, no counter, no atomics -- one barrier per step (LDS double-buffered),
+// the stores fire and are forgotten.  Slot reuse is safe with two slots: a workgroup can write step t + 2 (the slot of step t)
+// only after it has consumed every other workgroup's step t + 1, which those produce only after they have read step t.
+// `out` (the layer's result for the next GEMM / the FC) is written with plain stores off the critical path.
+// Every wait is bounded (abort flag + 3 s).
+struct GruGranuleParams {
+    const float *gi;
+    const void *w_hh;
+    const float *b_hh;
+    void *out, *out_mish;
+    int B, T, H;
+    unsigned long long *xch;   // [groups][2 dirs][2 slots][16 clips][H / 2] granules, zeroed per call
+    int *abort_flag, *timeout_flag;
+    int nsplit;
+    int poll_delay;            // 64-clock sleeps between a step's publish and its first poll (option gru_poll_delay)
+};
+
+#ifndef LA_GRU_PROBE
+#define LA_GRU_PROBE 0      // experiment build: timing-only knock-outs (1 = no gi loads after step 0, 2 = no out / out_mish stores)
+#endif
+template <typename T, int MAXKS>
+__global__ __launch_bounds__(512, 1) void gru_granule_kernel(GruGranuleParams p) {
+    constexpr int NW = 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int slice = blockIdx.x, dir = blockIdx.y, group = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, q = lane >> 4;
+    const int H = p.H, T_ = p.T;
+    const int nks = H / 32;
+    const int j0 = (slice * NW + wave) * 16;
+    const int jcol = j0 + r16;
+    const int b0 = group * GROUP;
+    const int nb = min(GROUP, p.B - b0);
+    const T *Wd = reinterpret_cast<const T *>(p.w_hh) + (int64_t)dir * 3 * H * H;
+    const float *bh = p.b_hh + dir * 3 * H;
+    T *out = reinterpret_cast<T *>(p.out);
+    T *outm = reinterpret_cast<T *>(p.out_mish);
+    const int64_t out_bs = (int64_t)T_ * 2 * H, out_ts = 2 * H;
+    const int64_t gi_bs = (int64_t)T_ * 6 * H, gi_ts = 6 * H;
+    const int gpr = H / 2;                                     // granules per clip row
+    const int slot_bytes = 16 * gpr * 8;
+    unsigned char *xbase = reinterpret_cast<unsigned char *>(p.xch) + ((int64_t)group * 2 + dir) * 2 * slot_bytes;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(xbase, 0, 2 * slot_bytes, 0x00020000);
+
+    uint4 wreg[3][MAXKS];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int ks = 0; ks < MAXKS; ++ks)
+            if (ks < nks)
+                wreg[g][ks] = *reinterpret_cast<const uint4 *>(
+                    reinterpret_cast<const unsigned char *>(Wd + (int64_t)(g * H + jcol) * H) + ks * 64 + q * 16);
+    int *ok_s = reinterpret_cast<int *>(lds);
+    if (tid == 0) *ok_s = 1;
+    const int row_bytes = H * 2, pitch = row_bytes + 16;
+    unsigned char *hl0 = lds + 16, *hl1 = hl0 + 16 * pitch;
+
+    const float bhr = bh[jcol], bhz = bh[H + jcol], bhn = bh[2 * H + jcol];
+    float hprev[4] = {0.f, 0.f, 0.f, 0.f};
+    float gin[4][3];  // prefetched input projections of the coming step
+    auto load_gi = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int bl = min(4 * q + i, nb - 1);
+            const float *g = p.gi + (int64_t)(b0 + bl) * gi_bs + (int64_t)t * gi_ts + dir * 3 * H + jcol;
+            gin[i][0] = g[0]; gin[i][1] = g[H]; gin[i][2] = g[2 * H];
+        }
+    };
+    // h of frame t (this lane's four clips) to `out` / `out_mish`: plain stores, nobody inside this launch reads them
+    auto store_out = [&](int t, const float (&h)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            T h16;
+            la::Elem<T>::store(&h16, h[i]);
+            const unsigned mine = __builtin_bit_cast(unsigned short, h16);
+            const unsigned nbr = (unsigned)__shfl_down((int)mine, 1);
+            const int bl = 4 * q + i;
+            const int64_t o = (int64_t)(b0 + (bl < nb ? bl : 0)) * out_bs + (int64_t)t * out_ts + dir * H + jcol;
+            if (bl < nb && (r16 & 1) == 0) *reinterpret_cast<unsigned *>(out + o) = mine | (nbr << 16);
+            if (outm && bl < nb) la::Elem<T>::store(outm + o, mish_fast(h[i]));
+        }
+    };
+    load_gi(dir == 0 ? 0 : T_ - 1);
+    // this thread's chunks of a slot: 16 bytes = two granules = units 4c' .. 4c'+3 of one clip; chunk id = tid + k * 512
+    constexpr int NCH = (16 * MAXKS * 16 + 511) / 512;          // chunks per thread: 16 clips x (H / 4) chunks, H <= 32 MAXKS
+    const int cpr = H / 4;                                      // chunks per clip row
+    const int nchunks = 16 * cpr;
+    __syncthreads();
+
+    bool alive = true;
+    for (int step = 0; step < T_; ++step) {
+        const int t = dir == 0 ? step : T_ - 1 - step;
+        f32x4 acc[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        unsigned char *hl = (step & 1) ? hl1 : hl0;
+        if (step > 0) {
+            // ---- h_{t-1} of all 16 clips x H units: poll the previous step's slot until every granule carries its tag ----
+            const unsigned want = (unsigned)step;                       // tag of step - 1 is (step - 1) + 1
+            const int sbase = ((step - 1) & 1) * slot_bytes;
+            unsigned pending = 0;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k)
+                if (tid + k * 512 < nchunks) pending |= 1u << k;
+            // The other workgroups published at about the time this one did, and their stores take most of a memory round trip to become
+            // visible: a poll issued at once comes back stale and the retry costs a second full round trip.  A short sleep first lets
+            // the first poll find the data (tools/kbench.py gru_delay).
+            for (int d = 0; d < p.poll_delay; ++d) __builtin_amdgcn_s_sleep(1);
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            unsigned spins = 0;
+            while (pending) {
+                typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+                u32x4 v[NCH];
+#pragma unroll
+                for (int k = 0; k < NCH; ++k)
+                    if (pending & (1u << k)) v[k] = __builtin_amdgcn_raw_buffer_load_b128(xr, sbase + (tid + k * 512) * 16, 0, 16 /* sc1 */);
+#pragma unroll
+                for (int k = 0; k < NCH; ++k)
+                    if ((pending & (1u << k)) && v[k][1] == want && v[k][3] == want) {
+                        const int idx = tid + k * 512;
+                        const int row = idx / cpr, c = idx - row * cpr;
+                        *reinterpret_cast<uint2 *>(hl + row * pitch + c * 8) = make_uint2(v[k][0], v[k][2]);
+                        pending &= ~(1u << k);
+                    }
+                if (pending && (++spins & 63u) == 0) {
+                    if (__hip_atomic_load(p.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { *ok_s = 0; break; }
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > 300000000ull) {
+                        __hip_atomic_store(p.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        *ok_s = 0;
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+            alive = *ok_s != 0;
+            if (!alive) break;
+#pragma unroll
+            for (int ks = 0; ks < MAXKS; ++ks) {
+                if (ks < nks) {
+                    const uint4 a = *reinterpret_cast<const uint4 *>(hl + r16 * pitch + ks * 64 + q * 16);
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) mma_step(a, wreg[g][ks], acc[g], T{});
+                }
+            }
+        }
+        float hnew[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float r = sigm(gin[i][0] + (acc[0][i] + bhr));
+            const float z = sigm(gin[i][1] + (acc[1][i] + bhz));
+            const float hn = acc[2][i] + bhn;
+            const float n = tanh_fast(gin[i][2] + r * hn);
+            hnew[i] = (1.0f - z) * n + z * hprev[i];
+            hprev[i] = hnew[i];
+        }
+        // ---- publish: one 8-byte granule per (clip, unit pair), written by the even lane of the pair; clips beyond nb publish too
+        //      (their rows are copies of clip nb - 1's inputs: consumers read all 16 rows of the slot) ----
+        unsigned pair[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            T h16;
+            la::Elem<T>::store(&h16, hnew[i]);
+            const unsigned mine = __builtin_bit_cast(unsigned short, h16);
+            const unsigned nbr = (unsigned)__shfl_down((int)mine, 1);
+            pair[i] = mine | (nbr << 16);
+        }
+        if ((r16 & 1) == 0) {
+            const int wbase = (step & 1) * slot_bytes;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+                __builtin_amdgcn_raw_buffer_store_b64(u32x2{pair[i], (unsigned)(step + 1)}, xr, wbase + ((4 * q + i) * gpr + (jcol >> 1)) * 8, 0, 16 /* sc1 */);
+            }
+        }
+#if !(LA_GRU_PROBE & 1)
+        if (step + 1 < T_) load_gi(dir == 0 ? t + 1 : t - 1);      // independent of h: in flight during the next poll
+#endif
+#if !(LA_GRU_PROBE & 2)
+        store_out(t, hnew);                                         // nobody's input inside the recurrence: after the hand-off stores
+#endif
+    }
+    if (!alive && tid == 0 && p.timeout_flag) *p.timeout_flag = 1;
+}
+
 }  // namespace
 
 static int gru_groups(int batch) { return la::cdiv(batch, GROUP); }
 static size_t gru_ctr_bytes(int batch, int frames) { return (size_t)la::round_up(16 + (int64_t)gru_groups(batch) * 2 * frames * 4, 256); }
+// granule exchange ring behind the counters: [groups][2][2 slots][16][hidden / 2] x 8 bytes
+static size_t gru_xch_bytes(int batch, int hidden) { return (size_t)gru_groups(batch) * 2 * 2 * 16 * (hidden / 2) * 8; }
 
 extern "C" int la_gru_workspace_bytes(int32_t batch, int32_t frames, int32_t hidden, size_t *bytes) {
     LA_CHECK_ARG(bytes && batch > 0 && frames > 0 && hidden > 0, "gru_workspace_bytes: bad arguments");
-    // [16 B header: abort flag] + counters [groups][2][frames] u32, padded to 256 B
-    *bytes = gru_ctr_bytes(batch, frames);
+    // [16 B header: abort flag] + counters [groups][2][frames] u32, padded to 256 B + the granule exchange ring
+    *bytes = gru_ctr_bytes(batch, frames) + gru_xch_bytes(batch, hidden);
     return LA_OK;
 }
 
@@ -469,7 +662,24 @@ static int gru_forward(int32_t dtype, const float *gi, const void *w_hh, const f
         la::set_error("gru_layer: %d co-resident workgroups needed (batch too large for one launch; split the batch)", nsplit * 2 * groups);
         return LA_EUNSUPPORTED;
     }
-    LA_HIP(hipMemsetAsync(workspace, 0, need, stream));
+    // 16-bit recurrence in 8-wave workgroups: the granule hand-off (option gru_handoff = 0, default) or the counter form (1)
+    const bool granules = wide && !gates && la::opts().gru_handoff == 0 && la::opts().gru_fence == 0 && hidden % 128 == 0;
+    if (granules) {
+        LA_CHECK_ARG(frames < 0x7fffffff, "gru_layer: too many frames");
+        unsigned char *wsb = reinterpret_cast<unsigned char *>(workspace);
+        const size_t ctrb = gru_ctr_bytes(batch, frames);
+        LA_HIP(hipMemsetAsync(wsb, 0, 16, stream));
+        LA_HIP(hipMemsetAsync(wsb + ctrb, 0, gru_xch_bytes(batch, hidden), stream));
+        GruGranuleParams gp{gi, w_hh, b_hh, out, out_mish, batch, frames, hidden, reinterpret_cast<unsigned long long *>(wsb + ctrb),
+                            reinterpret_cast<int *>(workspace), timeout_flag, nsplit, la::opts().gru_poll_delay};
+        const size_t lds_g = 16 + (size_t)2 * 16 * (hidden * 2 + 16);          // flag + two h stages
+        la::TimerScope ts("gru_bf16", stream);
+        if (dtype == LA_F16) hipLaunchKernelGGL((gru_granule_kernel<la::f16_t, 12>), dim3(nsplit, 2, groups), dim3(512), lds_g, stream, gp);
+        else hipLaunchKernelGGL((gru_granule_kernel<bf16_t, 12>), dim3(nsplit, 2, groups), dim3(512), lds_g, stream, gp);
+        LA_LAUNCH_CHECK();
+        return LA_OK;
+    }
+    LA_HIP(hipMemsetAsync(workspace, 0, gru_ctr_bytes(batch, frames), stream));
     GruParams p{gi, w_hh, b_hh, out, out_mish, batch, frames, hidden,
                 reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(workspace) + 16),
                 reinterpret_cast<int *>(workspace), timeout_flag, nsplit, gates};

@@ -57,6 +57,7 @@ const OptionDesc kOptions[] = {
     {"gemm_tile", "LA_GEMM_TILE", &Options::gemm_tile, false},       {"gemm_loop", "LA_PP_DBG", &Options::gemm_loop, false},
     {"gemm_splitk", "LA_GEMM_NO_SPLITK", &Options::gemm_splitk, true}, {"attn_nw", "LA_ATTN_NW", &Options::attn_nw, false},
     {"gru_nw", "LA_GRU_NW", &Options::gru_nw, false},                 {"gru_fence", "LA_GRU_FENCE", &Options::gru_fence, false},
+    {"gru_handoff", "LA_GRU_HANDOFF", &Options::gru_handoff, false}, {"gru_poll_delay", "LA_GRU_POLL_DELAY", &Options::gru_poll_delay, false},
     {"viterbi_dpp", "LA_VITERBI_NO_DPP", &Options::viterbi_dpp, true}, {"head_clip_cap", "LA_HEAD_CLIP_CAP", &Options::head_clip_cap, false},
     {"ln_fusion", "LA_LN_FUSION", &Options::ln_fusion, false},       {"resid_split", "LA_RESID_SPLIT", &Options::resid_split, false},
 };

@@ -12,7 +12,7 @@ If the real `whisper` package is importable, AlignModel accepts its models just 
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Optional
+from typing import Optional, Tuple
 
 import numpy as np
 import torch
@@ -188,12 +188,19 @@ class HostIndependentRng:
         raw = self._bg.random_raw((n + 1) // 2).view(np.uint32)[:n]
         return torch.from_numpy(((raw >> 8).astype(np.float32) * np.float32(2.0 ** -23) - np.float32(1.0)).reshape(tuple(shape)))
 
+    def skip_normal(self, shape) -> None:
+        """Move past the draws normal(shape) would take without making them (PCG64.advance is O(log n)): a rank that builds only its
+        share of a model's tensors still gives every tensor the values the sequential build gives it."""
+        self._bg.advance(int(np.prod(shape)) if len(shape) else 1)
+
 
 def build_model(name: str = "tiny", seed: int = 0, with_decoder: bool = False, std: float = 0.02,
-                dims: Optional[ModelDimensions] = None) -> Whisper:
+                dims: Optional[ModelDimensions] = None, part: Optional[Tuple[int, int]] = None) -> Whisper:
     """Random-init weights of the named architecture (no checkpoints are reachable offline); bit-identical on every host
     (HostIndependentRng), so a bench or test that names a seed means the same model on the build container, the
-    builder's GPU box and the driver's."""
+    builder's GPU box and the driver's.
+    part = (r, w): generate only the parameters whose index is r modulo w (the others stay zero, their draws are skipped): the
+    ranks of one node each build 1 / w of the model and exchange the pieces (build_model_shared) instead of w full host builds."""
     dims = dims or dims_for(name)
     with torch.device("meta"):                      # every parameter is assigned below: skip nn.Module's own initialisation
         model = Whisper(dims, with_decoder=with_decoder)
@@ -209,7 +216,11 @@ def build_model(name: str = "tiny", seed: int = 0, with_decoder: bool = False, s
         model.encoder.positional_embedding.copy_(torch.from_numpy(np.concatenate([np.sin(st), np.cos(st)], axis=1).astype(np.float32)))
     g = HostIndependentRng(seed)
     with torch.no_grad():
-        for n, p in model.named_parameters():
+        for i, (n, p) in enumerate(model.named_parameters()):
+            if part is not None and i % part[1] != part[0]:
+                g.skip_normal(p.shape)
+                p.zero_()
+                continue
             if n.endswith("_ln.weight") or n.endswith("ln_post.weight") or n.endswith("ln.weight"):
                 p.copy_(1.0 + 0.1 * g.normal(p.shape))
             elif "ln" in n.split(".")[-2] and n.endswith("bias"):
@@ -218,6 +229,36 @@ def build_model(name: str = "tiny", seed: int = 0, with_decoder: bool = False, s
                 p.copy_(0.05 * g.normal(p.shape))
             else:
                 p.copy_(std * g.normal(p.shape))
+    return model
+
+
+def build_model_shared(name: str, seed: int, with_decoder: bool, rank: int, world: int, barrier, tag: str,
+                       shm_dir: str = "/dev/shm") -> Whisper:
+    """build_model for the `world` ranks of ONE node: every rank generates the parameters with index = rank (mod world), writes them
+    to a file in shared memory, and reads the others' after `barrier()` -- the same bits as build_model on every rank, 1 / world of the
+    generator work per rank (the generator is a single-threaded stream: 8 full builds on 2 threads each took 11 s apiece).
+    `tag` names this job's files (e.g. the rendezvous port); they are removed after a second barrier."""
+    if world == 1:
+        return build_model(name, seed=seed, with_decoder=with_decoder)
+    import os
+    model = build_model(name, seed=seed, with_decoder=with_decoder, part=(rank, world))
+    params = list(model.named_parameters())
+    path = lambda r: os.path.join(shm_dir, f"la_weights_{tag}_{r}.pt")
+    torch.save({n: p.detach() for i, (n, p) in enumerate(params) if i % world == rank}, path(rank))
+    barrier()
+    with torch.no_grad():
+        for r in range(world):
+            if r == rank:
+                continue
+            piece = torch.load(path(r), map_location="cpu")
+            for i, (n, p) in enumerate(params):
+                if i % world == r:
+                    p.copy_(piece[n])
+    barrier()
+    try:
+        os.remove(path(rank))
+    except OSError:
+        pass
     return model
 
 

@@ -358,12 +358,21 @@ def test_fc_emissions_fused(variant, dtype, B, T, K, V):
         assert torch.equal(em[b, :, 5], em[b, :, 6]) if b == 0 else True  # repeated label -> identical columns
 
 
-@pytest.mark.parametrize("fence", [False, True])
+_GRU_DIGESTS = []
+
+
+@pytest.mark.parametrize("fence", [False, True, "counter"])
 def test_gru_handoff_under_uneven_load(fence):
     """The in-launch inter-workgroup hand-off of the persistent GRU must not depend on timing or placement: 12 runs of the
-    config-2 shape while another stream keeps the chip busy with GEMMs of varying size give bit-identical outputs.
-    fence=False: the default write-through form (sc1 stores, drained; sc1 loads); fence=True: the release / acquire fence
-    form, which the library selects per process (LA_GRU_FENCE=1) -- that case runs this test body in a child process."""
+    config-2 shape while another stream keeps the chip busy with GEMMs of varying size give bit-identical outputs -- the same
+    bits in every hand-off form.  fence=False: the default form (data-tagged 8-byte granules, no counter); "counter": the
+    write-through counter form (option gru_handoff = 1: sc1 stores, drained; counter; sc1 loads); fence=True: the release /
+    acquire fence form, which the library selects per process (LA_GRU_FENCE=1) -- that case runs this test body in a child process."""
+    if fence == "counter":
+        from lyricalignment_amd import _lib
+        with _lib.option("gru_handoff", 1):
+            test_gru_handoff_under_uneven_load(False)
+        return
     if fence:
         import os, subprocess, sys
         if os.environ.get("LA_GRU_FENCE"):
@@ -383,6 +392,10 @@ def test_gru_handoff_under_uneven_load(fence):
     torch.cuda.synchronize()
     assert int(flag.item()) == 0
     ref = ref.clone()
+    import hashlib
+    digest = hashlib.sha256(ref.view(torch.int16).cpu().numpy().tobytes()).hexdigest()
+    _GRU_DIGESTS.append(digest)
+    assert len(set(_GRU_DIGESTS)) == 1, "the hand-off forms disagree"
     side = torch.cuda.Stream()
     a = torch.randn(8192, 1024, device="cuda").bfloat16(); ww = torch.randn(4096, 1024, device="cuda").bfloat16()
     for it in range(12):
@@ -513,7 +526,7 @@ def test_library_options_round_trip_and_shipped_library_has_no_experiments():
     and the library the tests run on is the shipped one: la_has_experiments() == 0 unless LA_LIB_PATH selects another build."""
     import os
     from lyricalignment_amd import _lib
-    for name in ("gemm_tile", "gemm_loop", "gemm_splitk", "attn_nw", "gru_nw", "gru_fence", "viterbi_dpp", "head_clip_cap", "ln_fusion", "resid_split"):
+    for name in ("gemm_tile", "gemm_loop", "gemm_splitk", "attn_nw", "gru_nw", "gru_fence", "gru_handoff", "viterbi_dpp", "head_clip_cap", "ln_fusion", "resid_split"):
         before = _lib.get_option(name)
         with _lib.option(name, 7):
             assert _lib.get_option(name) == 7

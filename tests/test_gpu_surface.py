@@ -319,6 +319,36 @@ def test_plain_bench_gpus_2_starts_its_own_two_ranks(extra):
 
 
 @pytest.mark.parametrize("extra", [[], ["--mode", "finetune", "--model", "tiny", "--accum", "2"]], ids=["align", "finetune"])
+def test_plain_bench_five_ranks_on_one_device_start_up_and_finish_in_bounded_time(extra):
+    """Dress rehearsal of the driver's widest launch on a one-GPU box: plain `python3 bench.py --gpus 5` (the parent starts its own
+    ranks), all five on device 0 over gloo.  Round-4 verdict item 4 asked for eight; this pool admits at most SIX processes on a card
+    at once (a seventh gets the run killed by the box's process guard: it happened with six ranks + this test process, which
+    holds the GPU open too), so five it is -- the control flow is the same at any N:
+    one JSON line from rank 0 with n_gpus = 5, every rank's start-up logged, the synthetic weights built cooperatively (each rank
+    1 / 5 of the tensors, exchanged through /dev/shm: whisper_compat.build_model_shared) rather than five full host builds, and the whole
+    command inside a wall-time budget that leaves the driver's scaling run room (150 s on the GPU box's 16 cores)."""
+    import time
+    env = dict(os.environ, LA_BENCH_SAME_DEVICE="1", LA_BENCH_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "5", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", *extra]
+    t0 = time.perf_counter()
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    wall = time.perf_counter() - t0
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 5 and out["steps"] == 2 and out["value"] > 0
+    for rk in range(5):
+        assert f"rank {rk}/5" in r.stderr
+    assert r.stderr.count("weights built in") >= 5
+    print(f"5 ranks on one device {extra}: wall {wall:.1f} s")
+    assert wall < 150.0, f"{wall:.1f} s"
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("la_weights_")]      # the exchange files are gone
+
+
+@pytest.mark.parametrize("extra", [[], ["--mode", "finetune", "--model", "tiny", "--accum", "2"]], ids=["align", "finetune"])
 def test_bench_process_group_over_rccl_at_world_size_one(extra):
     """The N > 1 runs form their process group over RCCL (backend "nccl", device_id = the rank's GPU) and call barrier() and
     all_reduce(MAX) around the timed region; a one-GPU box cannot hold two RCCL ranks, so this drives exactly those calls

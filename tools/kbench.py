@@ -393,14 +393,41 @@ def bench_attn_occupancy(iters):
 
 
 def bench_gru(iters):
+    """The persistent GRU recurrence, one layer (T = 1500, H = 384, bf16): the two hand-off forms (option gru_handoff: 0 = data-tagged
+    granules, 1 = counter) interleaved in one process, 16 / 32 / 64 clips (KB_GRU_B overrides), bit-identity between the forms."""
     import os
-    B, T, H = int(os.environ.get("KB_GRU_B", "32")), 1500, 384
-    gi = torch.randn(B, T, 2, 3 * H, device="cuda") * 0.5
-    w = rnd(2, 3 * H, H, scale=H ** -0.5)
-    b = torch.randn(2, 3 * H, device="cuda") * 0.1
-    out = torch.empty(B, T, 2 * H, device="cuda", dtype=torch.bfloat16)
-    med, mn = timeit(lambda: ops.gru_layer(gi, w, b, out=out, want_mish=True), max(3, iters // 4))
-    print(f"gru layer B={B} T={T} H={H}: median {med:.2f} ms  ({med*1e3/T:.2f} us/step)", flush=True)
+    T, H = 1500, 384
+    for B in ([int(os.environ["KB_GRU_B"])] if os.environ.get("KB_GRU_B") else [1, 16, 32, 64]):
+        gi = torch.randn(B, T, 2, 3 * H, device="cuda") * 0.5
+        w = rnd(2, 3 * H, H, scale=H ** -0.5)
+        b = torch.randn(2, 3 * H, device="cuda") * 0.1
+        outs = {}
+        for rd in range(2):
+            for form, name in ((0, "granules"), (1, "counter ")):
+                _lib.set_option("gru_handoff", form)
+                out = torch.empty(B, T, 2 * H, device="cuda", dtype=torch.bfloat16)
+                med, mn = timeit(lambda: ops.gru_layer(gi, w, b, out=out, want_mish=True), max(3, iters // 4))
+                outs[form] = out
+                print(f"gru layer B={B} T={T} H={H} hand-off {name}: median {med:.2f} ms  ({med*1e3/T:.2f} us/step)", flush=True)
+        print(f"   outputs of the two forms identical: {torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))}", flush=True)
+    _lib.set_option("gru_handoff", 0)
+
+
+def bench_gru_delay(iters):
+    """Sweep of option gru_poll_delay (64-clock sleeps before a step's first poll of the granule hand-off), interleaved rounds."""
+    import os
+    T, H = 1500, 384
+    for B in ([int(os.environ["KB_GRU_B"])] if os.environ.get("KB_GRU_B") else [1, 32]):
+        gi = torch.randn(B, T, 2, 3 * H, device="cuda") * 0.5
+        w = rnd(2, 3 * H, H, scale=H ** -0.5)
+        b = torch.randn(2, 3 * H, device="cuda") * 0.1
+        out = torch.empty(B, T, 2 * H, device="cuda", dtype=torch.bfloat16)
+        for rd in range(2):
+            for d in (0, 2, 4, 6, 8, 10, 12, 16, 20, 28):
+                _lib.set_option("gru_poll_delay", d)
+                med, mn = timeit(lambda: ops.gru_layer(gi, w, b, out=out, want_mish=True), max(3, iters // 4))
+                print(f"gru layer B={B} poll delay {d:2d} x 64 clk: median {med:.2f} ms  ({med*1e3/T:.2f} us/step)", flush=True)
+    _lib.set_option("gru_poll_delay", 0)
 
 
 def bench_fc(iters):
@@ -449,4 +476,5 @@ if __name__ == "__main__":
     if a.what == "attn_ko": bench_attn_knockout(a.iters)
     if a.what == "attn_occ": bench_attn_occupancy(a.iters)
     if a.what in ("gru", "all"): bench_gru(a.iters)
+    if a.what == "gru_delay": bench_gru_delay(a.iters)
     if a.what in ("fc", "all"): bench_fc(a.iters)
