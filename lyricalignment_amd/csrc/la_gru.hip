@@ -19,6 +19,7 @@
 // barrier -> lane 0 release fence -> counter add; one lane acquires, barrier, plain loads), 1.7x
 // slower per step.  Every wait is bounded.
 // Clips are independent, so batches larger than 16 become extra workgroup groups (grid.z).
+#include <algorithm>
 #include <type_traits>
 
 #include "la_common.h"
@@ -621,12 +622,210 @@ __global__ __launch_bounds__(512, 1) void gru_granule_kernel(GruGranuleParams p)
     if (!alive && tid == 0 && p.timeout_flag) *p.timeout_flag = 1;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Training forward (float32 in / out, gates stored) with the recurrent product on the f16 pipe at float32 accuracy ("f16x2",
+// la_f32x2.hip): W_hh rows scaled by powers of two and split into two IEEE-half fragment sets resident in registers (hi + lo =
+// 22 bits), h (|h| <= 1, fixed scale 2^14) split the same way by its producer, and per k-step the three products
+// h_lo W_hi + h_hi W_lo + h_hi W_hi accumulated in float32 by v_mfma_f32_16x16x32_f16 -- 108 MFMAs of 16 cycles per step and wave
+// instead of the 288 float32 MFMAs of 32 cycles of gru_kernel<float> (3.8 us of its 11.4 us step at 16 clips), with that
+// kernel's per-wave operand loads replaced by the granule hand-off of gru_granule_kernel: h travels as 8-byte
+// {h_hi | h_lo, step tag} granules, polled by the consumers, staged once per workgroup into LDS.
+// 4-wave workgroups (one wave per SIMD: 512 registers; the two W fragment sets are 288), 64 hidden units each.
+struct GruTrainX2Params {
+    const float *gi, *w_hh, *b_hh;
+    float *out, *gates;
+    int B, T, H;
+    unsigned long long *xch;   // [groups][2 dirs][2 slots][16 clips][H] granules, zeroed per call
+    int *abort_flag, *timeout_flag;
+};
+
+__device__ __forceinline__ unsigned x2_pack_hi_lo(float x) {          // x (already scaled) -> f16 hi | f16 lo << 16
+    const _Float16 h = (_Float16)x;
+    const _Float16 l = (_Float16)(x - (float)h);
+    return (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+}
+
+template <int MAXKS>
+__global__ __launch_bounds__(256, 1) void gru_train_x2_kernel(GruTrainX2Params p) {
+    constexpr int NW = 4;
+    typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int slice = blockIdx.x, dir = blockIdx.y, group = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, q = lane >> 4;
+    const int H = p.H, T_ = p.T;
+    const int nks = H / 32;
+    const int jcol = (slice * NW + wave) * 16 + r16;
+    const int b0 = group * GROUP;
+    const int nb = min(GROUP, p.B - b0);
+    const float *Wd = p.w_hh + (int64_t)dir * 3 * H * H;
+    const float *bh = p.b_hh + dir * 3 * H;
+    const int64_t out_bs = (int64_t)T_ * 2 * H, out_ts = 2 * H;
+    const int64_t gi_bs = (int64_t)T_ * 6 * H, gi_ts = 6 * H;
+    const int slot_bytes = 16 * H * 8;
+    unsigned char *xbase = reinterpret_cast<unsigned char *>(p.xch) + ((int64_t)group * 2 + dir) * 2 * slot_bytes;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(xbase, 0, 2 * slot_bytes, 0x00020000);
+
+    // ---- resident W_hh slice as two half-precision fragment sets; row (gate g, unit jcol) scaled to [2^13, 2^14) ----
+    uint4 whi[3][MAXKS], wlo[3][MAXKS];
+    float wscale[3];                                            // 2^-14 (h's scale) x the row's inverse scale
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        const float *wr = Wd + (int64_t)(g * H + jcol) * H + q * 8;
+        float mx = 0.f;
+        for (int ks = 0; ks < nks; ++ks) {
+            const float4 a = *reinterpret_cast<const float4 *>(wr + ks * 32), b = *reinterpret_cast<const float4 *>(wr + ks * 32 + 4);
+            mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))),
+                                 fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w)))));
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sc = 1.f, inv = 1.f;
+        if (mx > 0.f && mx < 3.0e38f) {
+            int e;
+            (void)frexpf(mx, &e);
+            int sh = 14 - e;
+            sh = sh > 100 ? 100 : (sh < -100 ? -100 : sh);
+            sc = ldexpf(1.f, sh);
+            inv = ldexpf(1.f, -sh);
+        }
+        wscale[g] = inv * 6.103515625e-05f;                     // x 2^-14
+#pragma unroll
+        for (int ks = 0; ks < MAXKS; ++ks)
+            if (ks < nks) {
+                const float4 a = *reinterpret_cast<const float4 *>(wr + ks * 32), b = *reinterpret_cast<const float4 *>(wr + ks * 32 + 4);
+                const unsigned p0 = x2_pack_hi_lo(a.x * sc), p1 = x2_pack_hi_lo(a.y * sc), p2 = x2_pack_hi_lo(a.z * sc), p3 = x2_pack_hi_lo(a.w * sc);
+                const unsigned p4 = x2_pack_hi_lo(b.x * sc), p5 = x2_pack_hi_lo(b.y * sc), p6 = x2_pack_hi_lo(b.z * sc), p7 = x2_pack_hi_lo(b.w * sc);
+                whi[g][ks] = make_uint4((p0 & 0xffffu) | (p1 << 16), (p2 & 0xffffu) | (p3 << 16), (p4 & 0xffffu) | (p5 << 16), (p6 & 0xffffu) | (p7 << 16));
+                wlo[g][ks] = make_uint4((p0 >> 16) | (p1 & 0xffff0000u), (p2 >> 16) | (p3 & 0xffff0000u), (p4 >> 16) | (p5 & 0xffff0000u),
+                                        (p6 >> 16) | (p7 & 0xffff0000u));
+            }
+    }
+    int *ok_s = reinterpret_cast<int *>(lds);
+    if (tid == 0) *ok_s = 1;
+    const int row_bytes = H * 2, pitch = row_bytes + 16;
+    // LDS: two step stages x (hi plane, lo plane) of [16 clips][H halves]
+    auto stage = [&](int st, int plane) { return lds + 16 + (size_t)((st * 2 + plane) * 16) * pitch; };
+
+    const float bhr = bh[jcol], bhz = bh[H + jcol], bhn = bh[2 * H + jcol];
+    float hprev[4] = {0.f, 0.f, 0.f, 0.f};
+    float gin[4][3];
+    auto load_gi = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int bl = min(4 * q + i, nb - 1);
+            const float *g = p.gi + (int64_t)(b0 + bl) * gi_bs + (int64_t)t * gi_ts + dir * 3 * H + jcol;
+            gin[i][0] = g[0]; gin[i][1] = g[H]; gin[i][2] = g[2 * H];
+        }
+    };
+    load_gi(dir == 0 ? 0 : T_ - 1);
+    constexpr int NCH = (16 * MAXKS * 32 / 2 + 255) / 256;      // 16-byte chunks (two granules = two units of one clip) per thread
+    const int cpr = H / 2;
+    const int nchunks = 16 * cpr;
+    __syncthreads();
+
+    bool alive = true;
+    for (int step = 0; step < T_; ++step) {
+        const int t = dir == 0 ? step : T_ - 1 - step;
+        f32x4 acc[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (step > 0) {
+            unsigned char *shi = stage(step & 1, 0), *slo = stage(step & 1, 1);
+            const unsigned want = (unsigned)step;
+            const int sbase = ((step - 1) & 1) * slot_bytes;
+            unsigned pending = 0;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k)
+                if (tid + k * 256 < nchunks) pending |= 1u << k;
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            unsigned spins = 0;
+            while (pending) {
+                typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+                u32x4 v[NCH];
+#pragma unroll
+                for (int k = 0; k < NCH; ++k)
+                    if (pending & (1u << k)) v[k] = __builtin_amdgcn_raw_buffer_load_b128(xr, sbase + (tid + k * 256) * 16, 0, 16 /* sc1 */);
+#pragma unroll
+                for (int k = 0; k < NCH; ++k)
+                    if ((pending & (1u << k)) && v[k][1] == want && v[k][3] == want) {
+                        const int idx = tid + k * 256;
+                        const int row = idx / cpr, c = idx - row * cpr;
+                        *reinterpret_cast<unsigned *>(shi + row * pitch + c * 4) = (v[k][0] & 0xffffu) | (v[k][2] << 16);
+                        *reinterpret_cast<unsigned *>(slo + row * pitch + c * 4) = (v[k][0] >> 16) | (v[k][2] & 0xffff0000u);
+                        pending &= ~(1u << k);
+                    }
+                if (pending && (++spins & 63u) == 0) {
+                    if (__hip_atomic_load(p.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { *ok_s = 0; break; }
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > 300000000ull) {
+                        __hip_atomic_store(p.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        *ok_s = 0;
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+            alive = *ok_s != 0;
+            if (!alive) break;
+#pragma unroll
+            for (int ks = 0; ks < MAXKS; ++ks) {
+                if (ks < nks) {
+                    const uint4 ah = *reinterpret_cast<const uint4 *>(shi + r16 * pitch + ks * 64 + q * 16);
+                    const uint4 al = *reinterpret_cast<const uint4 *>(slo + r16 * pitch + ks * 64 + q * 16);
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) {           // small products first
+                        acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, al), __builtin_bit_cast(f16x8, whi[g][ks]), acc[g], 0, 0, 0);
+                        acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, wlo[g][ks]), acc[g], 0, 0, 0);
+                        acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, whi[g][ks]), acc[g], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        float hnew[4], gr[4], gz[4], gn[4], ghn[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float r = sigm(gin[i][0] + (acc[0][i] * wscale[0] + bhr));
+            const float z = sigm(gin[i][1] + (acc[1][i] * wscale[1] + bhz));
+            const float hn = acc[2][i] * wscale[2] + bhn;
+            const float n = tanh_fast(gin[i][2] + r * hn);
+            hnew[i] = (1.0f - z) * n + z * hprev[i];
+            hprev[i] = hnew[i];
+            gr[i] = r; gz[i] = z; gn[i] = n; ghn[i] = hn;
+        }
+        {   // publish: one granule per (clip, unit): {f16 hi | f16 lo of h x 2^14, step + 1}
+            const int wbase = (step & 1) * slot_bytes;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+                __builtin_amdgcn_raw_buffer_store_b64(u32x2{x2_pack_hi_lo(hnew[i] * 16384.0f), (unsigned)(step + 1)}, xr,
+                                                      wbase + ((4 * q + i) * H + jcol) * 8, 0, 16 /* sc1 */);
+            }
+        }
+        if (step + 1 < T_) load_gi(dir == 0 ? t + 1 : t - 1);
+        // layer output and the saved gates of the backward sweep: plain stores, nobody inside this launch reads them
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int bl = 4 * q + i;
+            if (bl < nb) {
+                p.out[(int64_t)(b0 + bl) * out_bs + (int64_t)t * out_ts + dir * H + jcol] = hnew[i];
+                float *gp = p.gates + (((int64_t)(b0 + bl) * T_ + t) * 2 + dir) * 4 * H + jcol;
+                gp[0] = gr[i]; gp[H] = gz[i]; gp[2 * H] = gn[i]; gp[3 * H] = ghn[i];
+            }
+        }
+    }
+    if (!alive && tid == 0 && p.timeout_flag) *p.timeout_flag = 1;
+}
+
 }  // namespace
 
 static int gru_groups(int batch) { return la::cdiv(batch, GROUP); }
 static size_t gru_ctr_bytes(int batch, int frames) { return (size_t)la::round_up(16 + (int64_t)gru_groups(batch) * 2 * frames * 4, 256); }
-// granule exchange ring behind the counters: [groups][2][2 slots][16][hidden / 2] x 8 bytes
-static size_t gru_xch_bytes(int batch, int hidden) { return (size_t)gru_groups(batch) * 2 * 2 * 16 * (hidden / 2) * 8; }
+// granule exchange ring behind the counters: [groups][2][2 slots][16][granules per clip row] x 8 bytes
+// (sized for the largest user: the backward sweep's reduce-scatter blocks, (hidden / 64)^2 pairs of 16 x 64 granules per slot; the float32
+//  training forward uses 16 x hidden granules per slot, the 16-bit inference form half of that)
+static size_t gru_xch_fwd_bytes(int batch, int hidden) { return (size_t)gru_groups(batch) * 2 * 2 * 16 * hidden * 8; }
+static size_t gru_xch_bwd_bytes(int batch, int hidden) { return (size_t)gru_groups(batch) * 2 * 2 * (hidden / 64) * (hidden / 64) * 16 * 64 * 8; }
+static size_t gru_xch_bytes(int batch, int hidden) { return std::max(gru_xch_fwd_bytes(batch, hidden), hidden % 64 == 0 ? gru_xch_bwd_bytes(batch, hidden) : (size_t)0); }
 
 extern "C" int la_gru_workspace_bytes(int32_t batch, int32_t frames, int32_t hidden, size_t *bytes) {
     LA_CHECK_ARG(bytes && batch > 0 && frames > 0 && hidden > 0, "gru_workspace_bytes: bad arguments");
@@ -662,6 +861,22 @@ static int gru_forward(int32_t dtype, const float *gi, const void *w_hh, const f
         la::set_error("gru_layer: %d co-resident workgroups needed (batch too large for one launch; split the batch)", nsplit * 2 * groups);
         return LA_EUNSUPPORTED;
     }
+    // float32 training forward (gates stored): recurrent product as f16x2 with the granule hand-off (gru_train_x2_kernel); option
+    // gru_handoff = 1 keeps gru_kernel<float> (float32 MFMA, counter form): the A/B partner
+    if (dtype == LA_F32 && gates && hidden % 64 == 0 && hidden <= 384 && la::opts().gru_handoff == 0 && la::opts().gru_fence == 0 &&
+        (hidden / 64) * 2 * groups <= 224) {
+        unsigned char *wsb = reinterpret_cast<unsigned char *>(workspace);
+        const size_t ctrb = gru_ctr_bytes(batch, frames);
+        LA_HIP(hipMemsetAsync(wsb, 0, 16, stream));
+        LA_HIP(hipMemsetAsync(wsb + ctrb, 0, gru_xch_fwd_bytes(batch, hidden), stream));
+        GruTrainX2Params tp{gi, reinterpret_cast<const float *>(w_hh), b_hh, reinterpret_cast<float *>(out), gates, batch, frames, hidden,
+                            reinterpret_cast<unsigned long long *>(wsb + ctrb), reinterpret_cast<int *>(workspace), timeout_flag};
+        const size_t lds_t = 16 + (size_t)2 * 2 * 16 * (hidden * 2 + 16);
+        la::TimerScope ts("gru_f32", stream);
+        hipLaunchKernelGGL((gru_train_x2_kernel<12>), dim3(hidden / 64, 2, groups), dim3(256), lds_t, stream, tp);
+        LA_LAUNCH_CHECK();
+        return LA_OK;
+    }
     // 16-bit recurrence in 8-wave workgroups: the granule hand-off (option gru_handoff = 0, default) or the counter form (1)
     const bool granules = wide && !gates && la::opts().gru_handoff == 0 && la::opts().gru_fence == 0 && hidden % 128 == 0;
     if (granules) {
@@ -669,7 +884,7 @@ static int gru_forward(int32_t dtype, const float *gi, const void *w_hh, const f
         unsigned char *wsb = reinterpret_cast<unsigned char *>(workspace);
         const size_t ctrb = gru_ctr_bytes(batch, frames);
         LA_HIP(hipMemsetAsync(wsb, 0, 16, stream));
-        LA_HIP(hipMemsetAsync(wsb + ctrb, 0, gru_xch_bytes(batch, hidden), stream));
+        LA_HIP(hipMemsetAsync(wsb + ctrb, 0, gru_xch_fwd_bytes(batch, hidden), stream));
         GruGranuleParams gp{gi, w_hh, b_hh, out, out_mish, batch, frames, hidden, reinterpret_cast<unsigned long long *>(wsb + ctrb),
                             reinterpret_cast<int *>(workspace), timeout_flag, nsplit, la::opts().gru_poll_delay};
         const size_t lds_g = 16 + (size_t)2 * 16 * (hidden * 2 + 16);          // flag + two h stages
@@ -942,6 +1157,250 @@ __global__ __launch_bounds__(128, 1) void gru_bwd_kernel(GruBwdParams p) {
     if (!alive && tid == 0 && p.timeout_flag) *p.timeout_flag = 1;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Backward sweep with the recurrent product on the f16 pipe at float32 accuracy and a REDUCE-SCATTER hand-off.
+// gru_bwd_kernel above is an all-gather: every workgroup fetches the whole dgh of the step before (16 clips x 3H floats: 74 KB
+// at H = 384, per wave) and multiplies it with its columns of W_hh on the float32 matrix pipe (288 MFMAs of 32 cycles): 15.5 us
+// per step at 16 clips.  Here a workgroup owns 64 hidden units on BOTH sides of the product
+//     dh[b][k] = sum_j dgh[b][j] W_hh[j][k],   j over the 3H gate columns:
+// it multiplies ITS OWN 192 columns of dgh (its units' dr, dz, dn r: produced in its own registers, never exchanged) with the
+// matching 192 rows of W_hh for ALL H output units k -- [16 x 192] x [192 x H], K = 192 -- and hands each partial sum to the
+// workgroup that owns unit k: 16 x 64 floats per pair of workgroups and step (40 KB received at H = 384 instead of 147 KB
+// fetched), as 8-byte {float, step tag} granules polled by the receiver (Guideline 16, R2: no counter, no drain).  The owner adds
+// the partials in workgroup order (deterministic).  The product runs as f16x2 (la_f32x2.hip): the W rows of a workgroup, scaled per
+// output column by powers of two, sit in registers as two half-precision fragment sets; the workgroup's dgh block is scaled per
+// clip (its largest magnitude over the 192 local columns: known locally) and split into two half planes in LDS; three MFMA
+// 16x16x32 f16 products per k-step and 16-column tile, float32 accumulate: 108 MFMAs of 16 cycles per wave and step.
+struct GruBwdX2Params {
+    const float *gates, *out, *dout, *w_hh;
+    float *dgi, *dgh;
+    int B, T, H;
+    unsigned long long *xch;   // [groups][2 dirs][2 slots][NS dest][NS src][16 clips][64 units] granules, zeroed per call
+    int *abort_flag, *timeout_flag;
+};
+
+template <int NS>                                               // NS = H / 64: workgroups per (group, direction) = column tiles per wave
+__global__ __launch_bounds__(256, 1) void gru_bwd_x2_kernel(GruBwdX2Params p) {
+    constexpr int NW = 4, MAXT = NS;                            // 4 waves x 16 units
+    typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int s_wg = blockIdx.x, dir = blockIdx.y, group = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, q = lane >> 4;
+    const int H = p.H, T_ = p.T;
+    const int ul = wave * 16 + r16;                             // this lane's unit inside the workgroup's 64
+    const int kcol = s_wg * 64 + ul;                            // ... and in the layer
+    const int b0 = group * GROUP;
+    const int nb = min(GROUP, p.B - b0);
+    const float *Wd = p.w_hh + (int64_t)dir * 3 * H * H;
+    const int64_t g4 = 4 * (int64_t)H, g3 = 3 * (int64_t)H;
+    const int pair_bytes = 16 * 64 * 8;                         // one (dest, src) block of a slot
+    const int slot_bytes = NS * NS * pair_bytes;
+    unsigned char *xbase = reinterpret_cast<unsigned char *>(p.xch) + ((int64_t)group * 2 + dir) * 2 * slot_bytes;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(xbase, 0, 2 * slot_bytes, 0x00020000);
+
+    // LDS: [16 B flag][cmax: 4 waves x 16 clips f32][A_hi, A_lo: 16 clips x (192 halves + 8 pad)][part: NS x 16 clips x 64 units f32]
+    int *ok_s = reinterpret_cast<int *>(lds);
+    float *cmax = reinterpret_cast<float *>(lds + 16);
+    constexpr int APITCH = 192 * 2 + 16;
+    unsigned char *a_hi = lds + 16 + 4 * 16 * 4, *a_lo = a_hi + 16 * APITCH;
+    float *part = reinterpret_cast<float *>(a_lo + 16 * APITCH);
+    if (tid == 0) *ok_s = 1;
+
+    // ---- resident rows of W_hh: local reduction index j = g * 64 + u  <->  row g * H + 64 s_wg + u; B fragments of tile tau hold
+    //      column k = (wave * NS + tau) * 16 + r16, eight consecutive j per lane; per-column power-of-two scale ----
+    uint4 whi[MAXT][6], wlo[MAXT][6];
+    float wscale[MAXT];
+#pragma unroll
+    for (int tau = 0; tau < MAXT; ++tau) {
+        wscale[tau] = 1.f;
+        if (tau < NS) {
+            const int k = (wave * NS + tau) * 16 + r16;
+            auto wj = [&](int j) { return Wd[(int64_t)((j >> 6) * H + s_wg * 64 + (j & 63)) * H + k]; };
+            float mx = 0.f;
+            for (int ks = 0; ks < 6; ++ks)
+                for (int e = 0; e < 8; ++e) mx = fmaxf(mx, fabsf(wj(ks * 32 + q * 8 + e)));
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            float sc = 1.f, inv = 1.f;
+            if (mx > 0.f && mx < 3.0e38f) {
+                int e2;
+                (void)frexpf(mx, &e2);
+                int sh = 14 - e2;
+                sh = sh > 100 ? 100 : (sh < -100 ? -100 : sh);
+                sc = ldexpf(1.f, sh);
+                inv = ldexpf(1.f, -sh);
+            }
+            wscale[tau] = inv;
+#pragma unroll
+            for (int ks = 0; ks < 6; ++ks) {
+                unsigned pk[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pk[e] = x2_pack_hi_lo(wj(ks * 32 + q * 8 + e) * sc);
+                whi[tau][ks] = make_uint4((pk[0] & 0xffffu) | (pk[1] << 16), (pk[2] & 0xffffu) | (pk[3] << 16), (pk[4] & 0xffffu) | (pk[5] << 16),
+                                          (pk[6] & 0xffffu) | (pk[7] << 16));
+                wlo[tau][ks] = make_uint4((pk[0] >> 16) | (pk[1] & 0xffff0000u), (pk[2] >> 16) | (pk[3] & 0xffff0000u),
+                                          (pk[4] >> 16) | (pk[5] & 0xffff0000u), (pk[6] >> 16) | (pk[7] & 0xffff0000u));
+            }
+        }
+    }
+    float carry[4] = {0.f, 0.f, 0.f, 0.f};
+    const int nrecv = (NS - 1) * 512;                           // 16-byte chunks (two granules) to receive per step
+    __syncthreads();
+
+    bool alive = true;
+    for (int step = 0; step < T_; ++step) {
+        const int t = dir == 0 ? T_ - 1 - step : step;
+        const int tprev = dir == 0 ? t - 1 : t + 1;
+        float g_r[4], g_z[4], g_n[4], g_hn[4], g_hp[4], g_do[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int b = b0 + min(4 * q + i, nb - 1);
+            const float *gp = p.gates + (((int64_t)b * T_ + t) * 2 + dir) * g4 + kcol;
+            g_r[i] = gp[0]; g_z[i] = gp[H]; g_n[i] = gp[2 * H]; g_hn[i] = gp[3 * H];
+            g_hp[i] = (tprev >= 0 && tprev < T_) ? p.out[((int64_t)b * T_ + tprev) * 2 * H + dir * H + kcol] : 0.f;
+            g_do[i] = p.dout[((int64_t)b * T_ + t) * 2 * H + dir * H + kcol];
+        }
+        float rec[4] = {0.f, 0.f, 0.f, 0.f};                     // sum_j dgh[step - 1][clip][j] W[j][kcol]
+        if (step > 0) {
+            // ---- the other workgroups' partial sums for this workgroup's 64 units: poll until every granule carries the step's tag ----
+            const unsigned want = (unsigned)step;
+            const int rbase = ((step - 1) & 1) * slot_bytes + s_wg * NS * pair_bytes;        // dest = this workgroup
+            constexpr int NCH = NS > 1 ? 2 * (NS - 1) : 1;
+            unsigned pending = 0;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k)
+                if (tid + k * 256 < nrecv) pending |= 1u << k;
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            unsigned spins = 0;
+            while (pending) {
+                typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+                u32x4 v[NCH];
+#pragma unroll
+                for (int k = 0; k < NCH; ++k)
+                    if (pending & (1u << k)) {
+                        const int c = tid + k * 256;
+                        int src = c >> 9;
+                        src += src >= s_wg ? 1 : 0;              // (own block skipped)
+                        v[k] = __builtin_amdgcn_raw_buffer_load_b128(xr, rbase + src * pair_bytes + (c & 511) * 16, 0, 16 /* sc1 */);
+                    }
+#pragma unroll
+                for (int k = 0; k < NCH; ++k)
+                    if ((pending & (1u << k)) && v[k][1] == want && v[k][3] == want) {
+                        const int c = tid + k * 256;
+                        int src = c >> 9;
+                        src += src >= s_wg ? 1 : 0;
+                        *reinterpret_cast<float2 *>(part + src * 1024 + (c & 511) * 2) = make_float2(__uint_as_float(v[k][0]), __uint_as_float(v[k][2]));
+                        pending &= ~(1u << k);
+                    }
+                if (pending && (++spins & 63u) == 0) {
+                    if (__hip_atomic_load(p.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { *ok_s = 0; break; }
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > 300000000ull) {
+                        __hip_atomic_store(p.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        *ok_s = 0;
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+            alive = *ok_s != 0;
+            if (!alive) break;
+            for (int src = 0; src < NS; ++src)                   // fixed order: deterministic sums
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rec[i] += part[src * 1024 + (4 * q + i) * 64 + ul];
+        }
+        // ---- gate gradients of this step (lane-local) ----
+        float x[4][3];
+        float cm[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int bl = 4 * q + i;
+            const int b = b0 + min(bl, nb - 1);
+            const float r = g_r[i], z = g_z[i], n = g_n[i], hn = g_hn[i], hp = g_hp[i];
+            const float dh = g_do[i] + rec[i] + carry[i];
+            const float dn_pre = dh * (1.0f - z) * (1.0f - n * n);
+            const float dz_pre = dh * (hp - n) * z * (1.0f - z);
+            const float dr_pre = dn_pre * hn * r * (1.0f - r);
+            carry[i] = dh * z;
+            x[i][0] = dr_pre; x[i][1] = dz_pre; x[i][2] = dn_pre * r;
+            cm[i] = fmaxf(fmaxf(fabsf(x[i][0]), fabsf(x[i][1])), fabsf(x[i][2]));
+            if (bl < nb) {
+                const int64_t o = (((int64_t)b * T_ + t) * 2 + dir) * g3 + kcol;
+                p.dgi[o] = dr_pre; p.dgi[o + H] = dz_pre; p.dgi[o + 2 * H] = dn_pre;
+                p.dgh[o] = x[i][0]; p.dgh[o + H] = x[i][1]; p.dgh[o + 2 * H] = x[i][2];
+            }
+        }
+        if (step + 1 == T_) break;                               // nobody consumes the last step's products
+        // ---- per-clip scale of the workgroup's 16 x 192 block: max over the 16 units of the wave (DPP row), then over the 4 waves ----
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float m = cm[i];
+            m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2)); m = fmaxf(m, __shfl_xor(m, 4)); m = fmaxf(m, __shfl_xor(m, 8));
+            if (r16 == 0) cmax[wave * 16 + 4 * q + i] = m;
+        }
+        __syncthreads();
+        float inv_c[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = 4 * q + i;
+            const float m = fmaxf(fmaxf(cmax[c], cmax[16 + c]), fmaxf(cmax[32 + c], cmax[48 + c]));
+            float sc = 1.f, inv = 1.f;
+            if (m > 0.f && m < 3.0e38f) {
+                int e2;
+                (void)frexpf(m, &e2);
+                int sh = 14 - e2;
+                sh = sh > 100 ? 100 : (sh < -100 ? -100 : sh);
+                sc = ldexpf(1.f, sh);
+                inv = ldexpf(1.f, -sh);
+            }
+            inv_c[i] = inv;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                const unsigned pk = x2_pack_hi_lo(x[i][g] * sc);
+                *reinterpret_cast<unsigned short *>(a_hi + c * APITCH + (g * 64 + ul) * 2) = (unsigned short)(pk & 0xffffu);
+                *reinterpret_cast<unsigned short *>(a_lo + c * APITCH + (g * 64 + ul) * 2) = (unsigned short)(pk >> 16);
+            }
+        }
+        __syncthreads();
+        // ---- partial dh for all H units from the local 192 columns: three f16 products per k-step and tile ----
+        f32x4 acc[MAXT];
+#pragma unroll
+        for (int tau = 0; tau < MAXT; ++tau) acc[tau] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) {
+            const uint4 ah = *reinterpret_cast<const uint4 *>(a_hi + r16 * APITCH + ks * 64 + q * 16);
+            const uint4 al = *reinterpret_cast<const uint4 *>(a_lo + r16 * APITCH + ks * 64 + q * 16);
+#pragma unroll
+            for (int tau = 0; tau < MAXT; ++tau)
+                if (tau < NS) {
+                    acc[tau] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, al), __builtin_bit_cast(f16x8, whi[tau][ks]), acc[tau], 0, 0, 0);
+                    acc[tau] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, wlo[tau][ks]), acc[tau], 0, 0, 0);
+                    acc[tau] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, whi[tau][ks]), acc[tau], 0, 0, 0);
+                }
+        }
+        // ---- hand every partial to the owner of its unit: own units through LDS, the others as {float, tag} granules ----
+        const int wbase = (step & 1) * slot_bytes;
+#pragma unroll
+        for (int tau = 0; tau < MAXT; ++tau)
+            if (tau < NS) {
+                const int k0 = (wave * NS + tau) * 16;
+                const int dest = k0 >> 6, u = (k0 & 63) + r16;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float v = acc[tau][i] * (inv_c[i] * wscale[tau]);
+                    if (dest == s_wg) {
+                        part[s_wg * 1024 + (4 * q + i) * 64 + u] = v;
+                    } else {
+                        typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+                        __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(v), (unsigned)(step + 1)}, xr,
+                                                              wbase + (dest * NS + s_wg) * pair_bytes + ((4 * q + i) * 64 + u) * 8, 0, 16 /* sc1 */);
+                    }
+                }
+            }
+    }
+    if (!alive && tid == 0 && p.timeout_flag) *p.timeout_flag = 1;
+}
+
 }  // namespace
 
 extern "C" int la_gru_layer_bwd(const float *gates, const float *out, const float *dout, const float *w_hh, float *dgi,
@@ -955,6 +1414,28 @@ extern "C" int la_gru_layer_bwd(const float *gates, const float *out, const floa
     la_gru_workspace_bytes(batch, frames, hidden, &need);
     LA_CHECK_ARG(workspace_bytes >= need && (uintptr_t)workspace % 16 == 0, "gru_layer_bwd: workspace too small");
     const int groups = gru_groups(batch);
+    // default: the f16x2 product with the reduce-scatter granule hand-off (gru_bwd_x2_kernel); option gru_handoff = 1 keeps the
+    // float32-MFMA all-gather kernel below (the A/B partner).  <= 4 clips stay on it too: its v_fma path beats a 16-row MFMA tile there.
+    if (la::opts().gru_handoff == 0 && batch > 4 && (hidden / 64) * 2 * groups <= 224) {
+        unsigned char *wsb = reinterpret_cast<unsigned char *>(workspace);
+        const size_t ctrb = gru_ctr_bytes(batch, frames);
+        LA_HIP(hipMemsetAsync(wsb, 0, 16, stream));
+        LA_HIP(hipMemsetAsync(wsb + ctrb, 0, gru_xch_bwd_bytes(batch, hidden), stream));
+        GruBwdX2Params xp{gates, out, dout, w_hh, dgi, dgh, batch, frames, hidden, reinterpret_cast<unsigned long long *>(wsb + ctrb),
+                          reinterpret_cast<int *>(workspace), timeout_flag};
+        const size_t lds_x = 16 + 4 * 16 * 4 + (size_t)2 * 16 * (192 * 2 + 16) + (size_t)(hidden / 64) * 1024 * 4;
+        la::TimerScope ts("gru_bwd_f32", stream);
+        switch (hidden / 64) {
+            case 1: hipLaunchKernelGGL(gru_bwd_x2_kernel<1>, dim3(1, 2, groups), dim3(256), lds_x, stream, xp); break;
+            case 2: hipLaunchKernelGGL(gru_bwd_x2_kernel<2>, dim3(2, 2, groups), dim3(256), lds_x, stream, xp); break;
+            case 3: hipLaunchKernelGGL(gru_bwd_x2_kernel<3>, dim3(3, 2, groups), dim3(256), lds_x, stream, xp); break;
+            case 4: hipLaunchKernelGGL(gru_bwd_x2_kernel<4>, dim3(4, 2, groups), dim3(256), lds_x, stream, xp); break;
+            case 5: hipLaunchKernelGGL(gru_bwd_x2_kernel<5>, dim3(5, 2, groups), dim3(256), lds_x, stream, xp); break;
+            default: hipLaunchKernelGGL(gru_bwd_x2_kernel<6>, dim3(6, 2, groups), dim3(256), lds_x, stream, xp); break;
+        }
+        LA_LAUNCH_CHECK();
+        return LA_OK;
+    }
     const int nsplit = hidden / 32;
     LA_CHECK_ARG(nsplit * 2 * groups <= 224, "gru_layer_bwd: batch too large for one co-resident launch");
     LA_CHECK_ARG((int64_t)batch * frames * 2 * 3 * hidden * 4 < (int64_t)2147483647, "gru_layer_bwd: dgh exceeds the 2 GiB buffer-descriptor range");

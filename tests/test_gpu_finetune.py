@@ -82,7 +82,8 @@ def _ref_rnn(D, H, V, seed):
     return gru, fc
 
 
-@pytest.mark.parametrize("B,T,D,H,V", [(3, 20, 64, 64, 50), (2, 150, 128, 128, 333), (33, 9, 64, 64, 40), (4, 12, 64, 64, 30), (20, 6, 64, 64, 30)])
+@pytest.mark.parametrize("B,T,D,H,V", [(3, 20, 64, 64, 50), (2, 150, 128, 128, 333), (33, 9, 64, 64, 40), (4, 12, 64, 64, 30), (20, 6, 64, 64, 30),
+                                         (6, 40, 128, 128, 60), (17, 25, 128, 384, 50), (7, 30, 64, 192, 40)])
 def test_head_backward_matches_torch_autograd(B, T, D, H, V):
     """HeadFunction (HIP forward + backward of GRUx2 -> Mish -> Linear) vs torch autograd on nn.GRU / nn.Mish / nn.Linear."""
     from lyricalignment_amd.head_train import HeadFunction
