@@ -89,6 +89,12 @@ SYMBOLS = {
     "la_layernorm_bwd_f32": (c_int32, [_P, _P, _P, _I32, _I32, _P, _P, _P]),
     "la_softmax_rows_f32": (c_int32, [_P, _I64, _I64, _I32, _I32, _P]),
     "la_attention_bwd_workspace_bytes": (c_int32, [_I32, _I32, _I32, POINTER(_SZ)]),
+    "la_attention_bwd_x2_workspace_bytes": (c_int32, [_I32, _I32, _I32, _I32, POINTER(_SZ)]),
+    "la_attention_bwd_x2_f32": (c_int32, [_P, _I64, _P, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _P,
+                                          _SZ, _P]),
+    "la_attention_x2_workspace_bytes": (c_int32, [_I32, _I32, _I32, _I32, POINTER(_SZ)]),
+    "la_attention_x2_lse_f32": (c_int32, [_P, _I64, _P, _P, _I64, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _P, _SZ, _P]),
+    "la_attention_bwd_stats_f32": (c_int32, [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P]),
     "la_attention_bwd_f32": (c_int32, [_P, _I64, _P, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _P,
                                        _SZ, _P]),
     "la_attention_lse_f32": (c_int32, [_P, _I64, _P, _P, _I64, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _P]),

@@ -329,6 +329,18 @@ extern "C" int la_attention_bwd_workspace_bytes(int32_t batch, int32_t q_len, in
     return LA_OK;
 }
 
+// The statistics launch alone (lse unless handed in, D = sum dO o O per query row): shared with la_attention_bwd_x2_f32.
+extern "C" int la_attention_bwd_stats_f32(const float *q, int64_t ld_q, const float *k, int64_t ld_kv, const float *o, int64_t ld_o, const float *dout,
+                                          int64_t ld_do, int32_t batch, int32_t q_len, int32_t kv_len, int32_t n_head, int32_t causal,
+                                          const float *lse_in, float *lse, float *dvec, void *stream_) {
+    LA_CHECK_ARG(q && k && o && dout && lse && dvec && batch > 0 && q_len > 0 && kv_len > 0 && n_head > 0, "attention_bwd_stats: bad arguments");
+    BwdParams p{q, k, nullptr, o, dout, nullptr, nullptr, nullptr, ld_q, ld_kv, ld_o, ld_do, 0, 0, batch, q_len, kv_len, n_head, causal ? 1 : 0,
+                lse_in ? const_cast<float *>(lse_in) : lse, dvec, lse_in ? 1 : 0};
+    hipLaunchKernelGGL(attn_stats_kernel, dim3(la::cdiv(q_len, BT), n_head, batch), dim3(256), 2 * TILE * 4, (hipStream_t)stream_, p);
+    LA_LAUNCH_CHECK();
+    return LA_OK;
+}
+
 extern "C" int la_attention_bwd_f32(const float *q, int64_t ld_q, const float *k, const float *v, int64_t ld_kv, const float *o, int64_t ld_o,
                                     const float *dout, int64_t ld_do, float *dq, int64_t ld_dq, float *dk, float *dv, int64_t ld_dkv,
                                     int32_t batch, int32_t q_len, int32_t kv_len, int32_t n_head, int32_t causal, const float *lse_in,

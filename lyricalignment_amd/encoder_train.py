@@ -88,6 +88,8 @@ def transpose_batched(src, ld_in, bs_in, rows, cols, out, ld_out, bs_out, out_ro
 
 
 ATTN_BWD_COMPOSED = os.environ.get("LA_ATTN_BWD", "fused") == "composed"     # developer A/B: the round-1 composition of batched GEMMs
+# The fused backward's products on the f16 pipe at float32 accuracy (la_attention_bwd_x2_f32); LA_ATTN_BWD_X2=0 keeps the float32-MFMA sweeps
+ATTN_BWD_X2 = os.environ.get("LA_ATTN_BWD_X2", "1") != "0" and os.environ.get("LA_F32X2", "1") != "0"
 
 
 def attention_bwd_ex(q, k, v, do, dq, dk, dv, B: int, Tq: int, Tk: int, H: int, causal: bool = False, o=None, lse=None) -> None:
@@ -99,6 +101,14 @@ def attention_bwd_ex(q, k, v, do, dq, dk, dv, B: int, Tq: int, Tk: int, H: int, 
     if o is not None and not ATTN_BWD_COMPOSED and k.stride(0) == v.stride(0) and dk.stride(0) == dv.stride(0):
         import ctypes
         need = ctypes.c_size_t(0)
+        if ATTN_BWD_X2 and Tq % 4 == 0 and Tk % 4 == 0 and Tq * Tk >= 64 * 64:
+            check(lib().la_attention_bwd_x2_workspace_bytes(B, Tq, Tk, H, ctypes.byref(need)), "attention_bwd_x2_workspace_bytes")
+            ws = torch.empty((need.value + 256,), dtype=torch.uint8, device=q.device)
+            off = (-ws.data_ptr()) % 256
+            check(lib().la_attention_bwd_x2_f32(ptr(q), q.stride(0), ptr(k), ptr(v), k.stride(0), ptr(o), o.stride(0), ptr(do), do.stride(0),
+                                                ptr(dq), dq.stride(0), ptr(dk), ptr(dv), dk.stride(0), B, Tq, Tk, H, 1 if causal else 0,
+                                                ptr(lse) if lse is not None else None, ws.data_ptr() + off, need.value, stream_ptr()), "attention_bwd_x2")
+            return
         check(lib().la_attention_bwd_workspace_bytes(B, Tq, H, ctypes.byref(need)), "attention_bwd_workspace_bytes")
         ws = torch.empty((need.value // 4,), dtype=torch.float32, device=q.device)
         check(lib().la_attention_bwd_f32(ptr(q), q.stride(0), ptr(k), ptr(v), k.stride(0), ptr(o), o.stride(0), ptr(do), do.stride(0),

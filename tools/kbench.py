@@ -328,6 +328,66 @@ def bench_x2(iters):
             print(f"x2 {name:9s} {lab}: f16x2 incl. splits {tx*1e3:8.1f} us ({fl/tx/1e9:6.1f} TF/s algorithmic) | float32 kernel {tn*1e3:8.1f} us ({fl/tn/1e9:6.1f}) | {tn/tx:4.2f}x", flush=True)
 
 
+def bench_attn_bwd(iters):
+    """Fused float32 attention backward: the f16x2 sweeps (la_attention_bwd_x2_f32) against the float32-MFMA sweeps (la_attention_bwd_f32) --
+    time per layer at the fine-tune shape (16 clips x 1500 frames x 16 heads), and max |err| / max |ref| of dq / dk / dv of both against
+    torch autograd in float64 on 1 clip x 2 heads."""
+    from lyricalignment_amd import encoder_train as et
+    for (B, T, H, check) in ((1, 1500, 2, True), (16, 1500, 16, False)):
+        d = 64 * H
+        g = torch.Generator(device="cuda").manual_seed(3)
+        qkv = torch.randn(B * T, 3 * d, device="cuda", generator=g)
+        qkv[:, :d] *= 0.35
+        datt = torch.randn(B * T, d, device="cuda", generator=g) * torch.exp(torch.randn(B * T, 1, device="cuda", generator=g) * 1.5) * 1e-3
+        lse = torch.empty((B, H, T), dtype=torch.float32, device="cuda")
+        o = ops.attention_ex(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, T, T, H, lse=lse)
+        res = {}
+        for name, flag in (("f16x2", True), ("f32  ", False)):
+            et.ATTN_BWD_X2 = flag
+            t = timeit(lambda: et.attention_bwd(qkv, datt, B, T, H, att=o, lse=lse), iters)[0]
+            res[name] = (t, et.attention_bwd(qkv, datt, B, T, H, att=o, lse=lse))
+        et.ATTN_BWD_X2 = True
+        line = f"attn bwd B={B} T={T} H={H}: " + " | ".join(f"{n} {t * 1e3:8.1f} us" for n, (t, _) in res.items()) + f" | {res['f32  '][0] / res['f16x2'][0]:.2f}x"
+        if check:
+            x = qkv.double().requires_grad_(True)
+            q, k, v = [t_.view(B, T, H, 64).permute(0, 2, 1, 3) for t_ in x.split(d, dim=1)]
+            oo = (torch.softmax(q @ k.transpose(-1, -2), dim=-1) @ v).permute(0, 2, 1, 3).reshape(B * T, d)
+            oo.backward(datt.double())
+            for n, (_, got) in res.items():
+                errs = [float((got[:, sl].double() - x.grad[:, sl]).abs().max() / x.grad[:, sl].abs().max()) for sl in (slice(0, d), slice(d, 2 * d), slice(2 * d, 3 * d))]
+                line += f" | {n} err dq {errs[0]:.2e} dk {errs[1]:.2e} dv {errs[2]:.2e}"
+        print(line, flush=True)
+
+
+def bench_attn_fwd(iters):
+    """float32 training forward of the attention (out + lse): the f16x2 kernel (la_attention_x2_lse_f32) against the float32-MFMA kernel
+    (la_attention_lse_f32): time per layer at the fine-tune shape and max |err| / max |ref| of out, max |err| of lse against float64."""
+    from lyricalignment_amd import ops as ops_mod
+    for (B, T, H, check) in ((1, 1500, 2, True), (16, 1500, 16, False)):
+        d = 64 * H
+        g = torch.Generator(device="cuda").manual_seed(4)
+        qkv = torch.randn(B * T, 3 * d, device="cuda", generator=g)
+        qkv[:, :d] *= 0.35
+        res = {}
+        for name, flag in (("f16x2", True), ("f32  ", False)):
+            ops_mod.ATTN_FWD_X2 = flag
+            lse = torch.empty((B, H, T), dtype=torch.float32, device="cuda")
+            fn = lambda: ops.attention_ex(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, T, T, H, lse=lse)
+            t = timeit(fn, iters)[0]
+            res[name] = (t, fn().clone(), lse.clone())
+        ops_mod.ATTN_FWD_X2 = True
+        line = f"attn fwd B={B} T={T} H={H}: " + " | ".join(f"{n} {t * 1e3:8.1f} us" for n, (t, _, _) in res.items()) + f" | {res['f32  '][0] / res['f16x2'][0]:.2f}x"
+        if check:
+            x = qkv.double()
+            q, k, v = [t_.view(B, T, H, 64).permute(0, 2, 1, 3) for t_ in x.split(d, dim=1)]
+            sc = q @ k.transpose(-1, -2)
+            ref = (torch.softmax(sc, dim=-1) @ v).permute(0, 2, 1, 3).reshape(B * T, d)
+            rl = torch.logsumexp(sc, dim=-1)
+            for n, (_, o, l) in res.items():
+                line += f" | {n} out {float((o.double() - ref).abs().max() / ref.abs().max()):.2e} lse {float((l.double() - rl).abs().max()):.2e}"
+        print(line, flush=True)
+
+
 def bench_attn(iters):
     B, T, H = 32, 1500, 16
     qkv = rnd(B * T, 3 * H * 64)
@@ -461,6 +521,12 @@ if __name__ == "__main__":
         sys.exit(0)
     if a.what == "epi":
         bench_epi_probe(a.iters)
+        sys.exit(0)
+    if a.what == "attn_fwd":
+        bench_attn_fwd(a.iters)
+        sys.exit(0)
+    if a.what == "attn_bwd":
+        bench_attn_bwd(a.iters)
         sys.exit(0)
     if a.what == "x2":
         bench_x2(a.iters)
