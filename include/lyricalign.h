@@ -490,21 +490,7 @@ int la_attention_bwd_f32(const float *q, int64_t ld_q, const float *k, const flo
                          const float *dout, int64_t ld_do, float *dq, int64_t ld_dq, float *dk, float *dv, int64_t ld_dkv,
                          int32_t batch, int32_t q_len, int32_t kv_len, int32_t n_head, int32_t causal, const float *lse,
                          void *workspace, size_t workspace_bytes, void *stream);
-/* The same gradients with the five products of the sweeps on the f16 matrix pipe at float32 accuracy (the f16x2 scheme of
- * la_gemm_f16x2: q, k, v, dO split once per call into row-scaled and column-scaled transposed half planes; P with the fixed scale
- * 2^14, dS with a scale from the bound 2 |dO_i| max_j |v_j|).  q_len and kv_len multiples of 4, else LA_EUNSUPPORTED (keep
- * la_attention_bwd_f32).  Workspace: la_attention_bwd_x2_workspace_bytes (the operand planes: ~28 bytes per token and channel). */
-int la_attention_bwd_x2_workspace_bytes(int32_t batch, int32_t q_len, int32_t kv_len, int32_t n_head, size_t *bytes);
-int la_attention_bwd_x2_f32(const float *q, int64_t ld_q, const float *k, const float *v, int64_t ld_kv, const float *o, int64_t ld_o,
-                            const float *dout, int64_t ld_do, float *dq, int64_t ld_dq, float *dk, float *dv, int64_t ld_dkv,
-                            int32_t batch, int32_t q_len, int32_t kv_len, int32_t n_head, int32_t causal, const float *lse_in,
-                            void *workspace, size_t workspace_bytes, void *stream);
-/* la_attention_lse_f32 (out and lse of the float32 training forward) on the same scheme: q, k row-scaled planes, v column-scaled
- * transposed planes, P split with the fixed scale 2^14 relative to the running maximum. */
-int la_attention_x2_workspace_bytes(int32_t batch, int32_t q_len, int32_t kv_len, int32_t n_head, size_t *bytes);
-int la_attention_x2_lse_f32(const float *q, int64_t ld_q, const float *k, const float *v, int64_t ld_kv, float *out, int64_t ld_out,
-                            int32_t batch, int32_t q_len, int32_t kv_len, int32_t n_head, int32_t causal, float *lse, void *workspace,
-                            size_t workspace_bytes, void *stream);
+/* The statistics launch of la_attention_bwd_f32 alone (lse unless handed in, D = sum dO o O per query row). */
 int la_attention_bwd_stats_f32(const float *q, int64_t ld_q, const float *k, int64_t ld_kv, const float *o, int64_t ld_o, const float *dout,
                                int64_t ld_do, int32_t batch, int32_t q_len, int32_t kv_len, int32_t n_head, int32_t causal,
                                const float *lse_in, float *lse, float *dvec, void *stream);

@@ -1,4 +1,11 @@
-// la_attention_bwd_x2.hip -- the fused float32 attention backward (la_attention_bwd.hip: statistics, key-block sweep for dK / dV,
+// la_attention_x2.hip -- EXPERIMENT build only (tools/build_variant.sh lab -DLA_EXPERIMENTS; not part of the shipped library).
+// Parity-green and as accurate as the float32 kernels, but only 1.07 x (backward) / 1.12 x (forward) faster per layer and no measurable
+// gain on the fine-tune step (profiles/r5_kbench_attn_*_x2.txt, r5_ab_finetune_attention_x2.txt): with the products 5 x cheaper the
+// sweeps are bound by memory latency at ONE workgroup per CU (the key sweep holds eight two-plane tiles: 147 KB of LDS; forcing two
+// workgroups per CU on the query sweep spilled 40 registers and lost 20 %).  profiles/NOTES.md "Attention on the f16x2 scheme" has
+// the per-kernel numbers and what a second attempt should change (separate dV / dK sweeps at two workgroups per CU).
+//
+// The fused float32 attention backward (la_attention_bwd.hip: statistics, key-block sweep for dK / dV,
 // query-block sweep for dQ; nothing of size Tq x Tk leaves the CU, no atomics) with its five products on the f16 matrix pipe at
 // float32 accuracy (la_f32x2.hip: x s = hi + lo in IEEE half, a b = a_lo b_hi + a_hi b_lo + a_hi b_hi in float32 accumulate).
 // After the Linear layers moved to that scheme the float32-MFMA sweeps were 22 % of the fine-tune optimizer step (16x16x4 f32: 1/16 of
@@ -20,7 +27,12 @@
 // v_mfma_f32_16x16x32_f16 (96 cycles) instead of sixteen v_mfma_f32_16x16x4_f32 (512).  The operand orientation of a product is
 // chosen so that a lane holds four consecutive elements ALONG the next product's contraction index: P^T / dS^T leave the
 // accumulators as 8-byte half rows.
-#include "la_x2.h"
+#ifndef LA_EXPERIMENTS
+#error "lab/la_attention_x2.hip belongs to the experiment build (-DLA_EXPERIMENTS, tools/build_variant.sh)"
+#endif
+#include <algorithm>
+
+#include "../la_x2.h"
 
 extern "C" int la_split_f16x2(const float *x, int64_t ldx, int32_t rows, int32_t cols, void *planes, int64_t kp, float *inv_scale, void *stream);
 extern "C" int la_split_f16x2_t(const float *x, int64_t ldx, int32_t rows, int32_t cols, void *planes_t, int64_t mp, float *inv_scale_t, void *stream);
@@ -267,8 +279,10 @@ __global__ __launch_bounds__(NT) void attn_bwd_kv_x2_kernel(X2Params p) {
 // ---- dQ: one workgroup per query block, sweeping the key blocks -----------------------------------------------------------------
 __global__ __launch_bounds__(NT) void attn_bwd_q_x2_kernel(X2Params p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    unsigned char *Qt = lds, *dOt = lds + TILE2, *Kt = lds + 2 * TILE2, *Vt = lds + 3 * TILE2, *KTt = lds + 4 * TILE2, *dSt = lds + 5 * TILE2;
-    float *s_rk = reinterpret_cast<float *>(lds + 6 * TILE2), *s_rv = s_rk + 64;
+    // Q / dO are only staged to be read back as this wave's loop-invariant B fragments: their tiles share the space of K / V (74 KB per
+    // workgroup: two workgroups per CU, so one's memory round trips hide under the other's products)
+    unsigned char *Qt = lds, *dOt = lds + TILE2, *Kt = lds, *Vt = lds + TILE2, *KTt = lds + 2 * TILE2, *dSt = lds + 3 * TILE2;
+    float *s_rk = reinterpret_cast<float *>(lds + 4 * TILE2), *s_rv = s_rk + 64;
     const int i0 = blockIdx.x * BT, h = blockIdx.y, b = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r16 = lane & 15, q = lane >> 4, wm = w >> 2, wn = w & 3;
     const int64_t C = 64 * (int64_t)p.H;
@@ -586,7 +600,7 @@ extern "C" int la_attention_bwd_x2_f32(const float *q, int64_t ld_q, const float
     X2Params p{Hp(pl.qp), Hp(pl.kp), Hp(pl.vp), Hp(pl.dop), F(pl.rq), F(pl.rk), F(pl.rv), F(pl.rdo), Hp(pl.qt), Hp(pl.dot), Hp(pl.kt),
                F(pl.cq), F(pl.cdo), F(pl.ck), pl.mpq, pl.mpk, dq, dk, dv, ld_dq, ld_dkv, batch, q_len, kv_len, n_head, causal ? 1 : 0,
                lse_in ? lse_in : lse, dvec, F(pl.nrm), reinterpret_cast<const unsigned *>(ws + pl.vmax)};
-    constexpr int LDS_KV = 8 * TILE2 + 5 * 64 * 4, LDS_Q = 6 * TILE2 + 2 * 64 * 4;
+    constexpr int LDS_KV = 8 * TILE2 + 5 * 64 * 4, LDS_Q = 4 * TILE2 + 2 * 64 * 4;
     static la::DeviceOnce attr_once;
     if (attr_once.pending()) {
         LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_kv_x2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_KV));

@@ -88,8 +88,9 @@ def transpose_batched(src, ld_in, bs_in, rows, cols, out, ld_out, bs_out, out_ro
 
 
 ATTN_BWD_COMPOSED = os.environ.get("LA_ATTN_BWD", "fused") == "composed"     # developer A/B: the round-1 composition of batched GEMMs
-# The fused backward's products on the f16 pipe at float32 accuracy (la_attention_bwd_x2_f32); LA_ATTN_BWD_X2=0 keeps the float32-MFMA sweeps
-ATTN_BWD_X2 = os.environ.get("LA_ATTN_BWD_X2", "1") != "0" and os.environ.get("LA_F32X2", "1") != "0"
+# Experiment build of the library only (csrc/lab/la_attention_x2.hip, LA_ATTN_BWD_X2=1): the fused backward's products on the f16 pipe at
+# float32 accuracy -- parity-green, 1.07 x per layer, nothing on the step (profiles/NOTES.md): not shipped
+ATTN_BWD_X2 = os.environ.get("LA_ATTN_BWD_X2", "0") == "1"
 
 
 def attention_bwd_ex(q, k, v, do, dq, dk, dv, B: int, Tq: int, Tk: int, H: int, causal: bool = False, o=None, lse=None) -> None:
@@ -101,7 +102,7 @@ def attention_bwd_ex(q, k, v, do, dq, dk, dv, B: int, Tq: int, Tk: int, H: int, 
     if o is not None and not ATTN_BWD_COMPOSED and k.stride(0) == v.stride(0) and dk.stride(0) == dv.stride(0):
         import ctypes
         need = ctypes.c_size_t(0)
-        if ATTN_BWD_X2 and Tq % 4 == 0 and Tk % 4 == 0 and Tq * Tk >= 64 * 64:
+        if ATTN_BWD_X2 and _lib.has_experiments() and Tq % 4 == 0 and Tk % 4 == 0 and Tq * Tk >= 64 * 64:
             check(lib().la_attention_bwd_x2_workspace_bytes(B, Tq, Tk, H, ctypes.byref(need)), "attention_bwd_x2_workspace_bytes")
             ws = torch.empty((need.value + 256,), dtype=torch.uint8, device=q.device)
             off = (-ws.data_ptr()) % 256

@@ -161,16 +161,12 @@ def _rel(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
 
 
-@pytest.mark.parametrize("fused", [True, False, "f32"])
+@pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("B,T,H", [(1, 96, 2), (2, 1500, 1), (1, 333, 3), (3, 64, 2), (2, 130, 1)])
-def test_attention_backward_matches_torch_autograd(B, T, H, fused, monkeypatch):
-    """dQ/dK/dV against torch autograd: the fused sweeps (forward output given: scores recomputed per 64 x 64 tile) -- on the f16 pipe
-    at float32 accuracy where the lengths are multiples of 4 (la_attention_bwd_x2_f32: T = 96, 1500, 64), "f32" pins the float32-MFMA
-    sweeps (la_attention_bwd_f32) -- and the round-1 composition (batched f32 MFMA GEMMs over whole score tiles + row softmax kernels)."""
-    if fused == "f32":
-        from lyricalignment_amd import encoder_train
-        monkeypatch.setattr(encoder_train, "ATTN_BWD_X2", False)
-        fused = True
+def test_attention_backward_matches_torch_autograd(B, T, H, fused):
+    """dQ/dK/dV against torch autograd: the fused kernel la_attention_bwd_f32 (forward output given: scores recomputed per 64 x 64
+    tile) and the round-1 composition (batched f32 MFMA GEMMs over whole score tiles + row softmax kernels).  (With the experiment
+    build and LA_ATTN_BWD_X2 / LA_ATTN_FWD_X2 = 1 the same test runs the f16x2 sweeps: tests/test_gpu_lab.py.)"""
     from lyricalignment_amd import encoder_train as et
     d = 64 * H
     g = torch.Generator().manual_seed(T)
@@ -197,9 +193,9 @@ def test_attention_backward_matches_torch_autograd(B, T, H, fused, monkeypatch):
 @pytest.mark.parametrize("B,Tq,Tk,H,causal", [(2, 37, 37, 2, True), (2, 5, 1500, 2, False), (1, 70, 200, 1, False), (3, 129, 129, 1, True),
                                               (2, 64, 64, 2, True), (1, 132, 132, 1, True), (2, 8, 1500, 2, False), (1, 72, 200, 3, False)])
 def test_fused_attention_backward_causal_and_cross_shapes(B, Tq, Tk, H, causal):
-    """la_attention_bwd_f32 / la_attention_bwd_x2_f32 on the text decoder's shapes: causal self-attention and cross-attention
-    (q_len != kv_len, ragged last tiles, operands as column slices of packed projections) against torch autograd.  Lengths that
-    are multiples of 4 take the f16x2 sweeps (the last four cases), the others the float32-MFMA ones."""
+    """la_attention_bwd_f32 on the text decoder's shapes: causal self-attention and cross-attention (q_len != kv_len, ragged last
+    tiles, operands as column slices of packed projections) against torch autograd.  (The last four cases have lengths that are
+    multiples of 4: what the experiment build's f16x2 sweeps take, tests/test_gpu_lab.py.)"""
     from lyricalignment_amd import encoder_train as et
     d = 64 * H
     g = torch.Generator().manual_seed(Tq * 7 + Tk)
