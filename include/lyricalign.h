@@ -317,8 +317,9 @@ int la_mel_to_rows(const float *mel, int64_t mel_batch_stride, int64_t mel_row_s
  * b_hh [2][3H] f32.  out [batch][frames][2H] (`dtype`) receives h_t (forward in
  * columns 0..H-1, reverse in H..2H-1); out_mish (optional, same shape) receives
  * Mish(h_t) (module/align_model.py:37).  Persistent kernel: 2 * H/128 (16-bit modes, H % 128 == 0, H <= 384; else 2 * H/64) workgroups
- * per 16 clips exchange h through `out` with write-through (sc1) stores and per-step
- * arrival counters in `workspace` (zeroed on the stream by this call).  H % 64 == 0;
+ * per 16 clips exchange h in `workspace` (zeroed on the stream by this call): by default as data-tagged 8-byte granules
+ * {h, h | step} polled by the consumers (16-bit modes; option gru_handoff = 1: through `out` with write-through (sc1)
+ * stores and per-step arrival counters).  H % 64 == 0;
  * at most 224 workgroups may be co-resident (16-bit modes, H=384: 8-wave workgroups, 2 * 3 per 16 clips).
  * `timeout_flag` (device int32, optional) is set non-zero if a bounded wait
  * gave up; the host wrapper maps it to LA_ETIMEOUT.

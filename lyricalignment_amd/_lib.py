@@ -23,15 +23,6 @@ EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_OUT_F32, EPI_MISH = 1, 2, 4, 8, 16
 EPI_GELU_ERF = 4096
 GEMM_TRANS_A, GEMM_TRANS_W = 512, 1024        # la_gemm_ex operand layout flags (float32)
 
-# symbols of the EXPERIMENT build only (csrc/lab/; bound when the loaded library has them: tools/build_variant.sh lab -DLA_EXPERIMENTS)
-LAB_SYMBOLS = {
-    "la_attention_bwd_x2_workspace_bytes": (c_int32, [_I32, _I32, _I32, _I32, POINTER(_SZ)]),
-    "la_attention_bwd_x2_f32": (c_int32, [_P, _I64, _P, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _P,
-                                          _SZ, _P]),
-    "la_attention_x2_workspace_bytes": (c_int32, [_I32, _I32, _I32, _I32, POINTER(_SZ)]),
-    "la_attention_x2_lse_f32": (c_int32, [_P, _I64, _P, _P, _I64, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _P, _SZ, _P]),
-}
-
 # every symbol include/lyricalign.h declares: (name, restype, argtypes)
 _I32, _I64, _P, _SZ = c_int32, c_int64, c_void_p, c_size_t
 SYMBOLS = {
@@ -114,6 +105,16 @@ SYMBOLS = {
     "la_align_head_forward": (c_int32, [_P, _P, _I64, _I64, _I32, _I32, _I32, _P, _I32, _P, _I32, _P, _P, _I32, _P, _P, _P, _P, _SZ, _P, _P]),
     "la_cast_bf16_to_f32": (c_int32, [_P, _P, _I64, _P]),
 }
+
+# symbols of the EXPERIMENT build only (csrc/lab/; bound when the loaded library has them: tools/build_variant.sh lab -DLA_EXPERIMENTS)
+LAB_SYMBOLS = {
+    "la_attention_bwd_x2_workspace_bytes": (c_int32, [_I32, _I32, _I32, _I32, POINTER(_SZ)]),
+    "la_attention_bwd_x2_f32": (c_int32, [_P, _I64, _P, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _P,
+                                          _SZ, _P]),
+    "la_attention_x2_workspace_bytes": (c_int32, [_I32, _I32, _I32, _I32, POINTER(_SZ)]),
+    "la_attention_x2_lse_f32": (c_int32, [_P, _I64, _P, _P, _I64, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _P, _SZ, _P]),
+}
+
 
 
 

@@ -47,8 +47,10 @@ def test_argument_validation_without_gpu():
     assert L.la_viterbi_workspace_bytes(1, 100, 600, ctypes.byref(need)) == _lib.LA_OK and need.value == 100 * 2 * 32 * 8
     assert L.la_viterbi_workspace_bytes(2, 100, 4095, ctypes.byref(need)) == _lib.LA_OK and need.value == 2 * 100 * 8 * 32 * 8
     assert L.la_viterbi_workspace_bytes(1, 100, 4096, ctypes.byref(need)) == _lib.LA_EUNSUPPORTED and "4095" in _lib.last_error()
-    # header + arrival counters [groups of 16 clips][2 directions][frames] u32, padded to 256 B
-    assert L.la_gru_workspace_bytes(32, 1500, 384, ctypes.byref(need)) == _lib.LA_OK and need.value == (16 + 2 * 2 * 1500 * 4 + 255) // 256 * 256
+    # header + arrival counters [groups of 16 clips][2 directions][frames] u32, padded to 256 B, + the granule exchange ring sized for
+    # its largest user (the backward sweep's reduce-scatter: [groups][2 directions][2 slots][(hidden / 64)^2 pairs][16 clips][64 units] x 8 B)
+    assert L.la_gru_workspace_bytes(32, 1500, 384, ctypes.byref(need)) == _lib.LA_OK
+    assert need.value == (16 + 2 * 2 * 1500 * 4 + 255) // 256 * 256 + 2 * 2 * 2 * 36 * 16 * 64 * 8
     # entry points added for the training / decoding rows: the same host-side rejection before any HIP call
     P = 16                                                            # a non-null, 16-byte aligned stand-in pointer
     assert L.la_gemm_ex(_lib.LA_F32, 64, 64, 64, 1, P, 64, 0, P, 32, 0, P, 64, 0, 0, 0, 0) == _lib.LA_EINVAL       # ldw < K
