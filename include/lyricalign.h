@@ -116,8 +116,9 @@ int la_timer_read_work(double *total_ms, int64_t *timed_launches, double *timed_
  *   "attn_nw"         LA_ATTN_NW          0 = 256-query workgroups from 1024 positions on (default) | 4 = 128-query | 8 = 256-query
  *   "gru_nw"          LA_GRU_NW           0 = 8-wave workgroups (default) | 4 = 4-wave workgroups of the persistent recurrence
  *   "gru_fence"       LA_GRU_FENCE        0 = write-through hand-off (default) | 1 = release / acquire fences
- *   "gru_handoff"     LA_GRU_HANDOFF      0 = data-tagged 8-byte granules, no counter (default; 16-bit, 8-wave workgroups) | 1 = the
- *                                         counter form (write-through stores, drain, barrier, counter add; poll, barrier, loads)
+ *   "gru_handoff"     LA_GRU_HANDOFF      0 = data-tagged 8-byte granules, no counter, from 17 clips on (default; 16-bit, 8-wave workgroups;
+ *                                         float32 training sweeps: always) | 1 = the counter form everywhere (write-through stores, drain,
+ *                                         barrier, counter add; poll, barrier, loads) | 2 = granules for every batch
  *   "viterbi_dpp"     LA_VITERBI_NO_DPP   1 = DPP wave shifts (default) | 0 = the LDS-exchange form
  *   "head_clip_cap"   LA_HEAD_CLIP_CAP    0 = by residency (default) | n = clips per head launch set of la_align_head_forward
  *   "ln_fusion"       LA_LN_FUSION        1 = LayerNorm folded into the 16-bit encoder GEMMs where they run on the 256 x 256 kernel | 0 = never

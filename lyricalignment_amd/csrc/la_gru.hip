@@ -878,7 +878,10 @@ static int gru_forward(int32_t dtype, const float *gi, const void *w_hh, const f
         return LA_OK;
     }
     // 16-bit recurrence in 8-wave workgroups: the granule hand-off (option gru_handoff = 0, default) or the counter form (1)
-    const bool granules = wide && !gates && la::opts().gru_handoff == 0 && la::opts().gru_fence == 0 && hidden % 128 == 0;
+    // (measured, tools/kbench.py gru: 3.28 against 3.38 us per step at 32 - 64 clips, level at 16, 2.86 against 2.64 at one clip -- the counter
+    //  form keeps the single 16-clip group; gru_handoff = 2 forces granules for every batch)
+    const bool granules = wide && !gates && la::opts().gru_fence == 0 && hidden % 128 == 0 &&
+                          (la::opts().gru_handoff == 2 || (la::opts().gru_handoff == 0 && batch > 16));
     if (granules) {
         LA_CHECK_ARG(frames < 0x7fffffff, "gru_layer: too many frames");
         unsigned char *wsb = reinterpret_cast<unsigned char *>(workspace);

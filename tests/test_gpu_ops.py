@@ -326,6 +326,14 @@ def test_gru_layer(B, T, H, dtype):
     tol = {torch.float32: 2e-5, torch.bfloat16: 2e-2, torch.float16: 3e-3}[dtype]  # 16-bit: h is rounded before every recurrent product
     np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), rtol=0, atol=tol)
     np.testing.assert_allclose(out_mish.float().cpu().numpy(), torch.nn.functional.mish(ref).numpy(), rtol=0, atol=tol)
+    if dtype != torch.float32 and H % 128 == 0:
+        # both hand-off forms on every batch size (the default takes the granules from 17 clips on): identical bits
+        from lyricalignment_amd import _lib
+        for form in (1, 2):
+            with _lib.option("gru_handoff", form):
+                o2, m2, f2 = ops.gru_layer(gi.contiguous().cuda(), w_hh.to(dtype).contiguous().cuda(), b_hh.contiguous().cuda(), want_mish=True)
+            assert int(f2.item()) == 0
+            assert torch.equal(o2.view(torch.int16), out.view(torch.int16)) and torch.equal(m2.view(torch.int16), out_mish.view(torch.int16)), form
 
 
 @pytest.mark.parametrize("variant", ["ctc", "plain"])
@@ -365,7 +373,7 @@ _GRU_DIGESTS = []
 def test_gru_handoff_under_uneven_load(fence):
     """The in-launch inter-workgroup hand-off of the persistent GRU must not depend on timing or placement: 12 runs of the
     config-2 shape while another stream keeps the chip busy with GEMMs of varying size give bit-identical outputs -- the same
-    bits in every hand-off form.  fence=False: the default form (data-tagged 8-byte granules, no counter); "counter": the
+    bits in every hand-off form.  fence=False: the default form at 32 clips (data-tagged 8-byte granules, no counter); "counter": the
     write-through counter form (option gru_handoff = 1: sc1 stores, drained; counter; sc1 loads); fence=True: the release /
     acquire fence form, which the library selects per process (LA_GRU_FENCE=1) -- that case runs this test body in a child process."""
     if fence == "counter":
