@@ -64,6 +64,17 @@ __device__ __forceinline__ float mish_fast(float x) {      // x tanh(log(1 + e^x
     return x > 20.0f ? x : x * n * __builtin_amdgcn_rcpf(n + 2.0f);
 }
 
+// h rounded to the 16-bit storage type from its FLOAT32 value (as the reference's half-precision nn.GRU hands h on): the empty asm keeps
+// hipcc from fusing the gate's last fma with the conversion (v_fma_mixlo_f16 rounds the unrounded fma result once -- a different
+// half in ~1 % of the cases, and only in some of the kernels that share this code: the hand-off forms then disagreed in float16)
+template <typename T>
+__device__ __forceinline__ unsigned short round16(float v) {
+    asm volatile("" : "+v"(v));
+    T h;
+    la::Elem<T>::store(&h, v);
+    return __builtin_bit_cast(unsigned short, h);
+}
+
 // bounded wait for `*ctr >= target`; returns false on timeout / abort
 __device__ __forceinline__ bool wait_counter(unsigned *ctr, unsigned target, int *abort_flag) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
@@ -389,9 +400,7 @@ __global__ __launch_bounds__(NW * 64, 1) void gru_kernel(GruParams p) {
                 if constexpr (WT) {
                     if constexpr (sizeof(T) == 2) {
                         // pair (jcol, jcol+1) -> one 4-byte write-through store by the even lane (neighbour = lane + 1)
-                        T h16;
-                        la::Elem<T>::store(&h16, hnew[mt][i]);
-                        const unsigned mine = __builtin_bit_cast(unsigned short, h16);
+                        const unsigned mine = round16<T>(hnew[mt][i]);
                         const unsigned nb_bits = (unsigned)__shfl_down((int)mine, 1);
                         if (bl < nb && (r16 & 1) == 0)
                             __builtin_amdgcn_raw_buffer_store_b32(mine | (nb_bits << 16), out_rsrc, (int)(o * 2), 0, 16 /* sc1 */);
@@ -400,7 +409,8 @@ __global__ __launch_bounds__(NW * 64, 1) void gru_kernel(GruParams p) {
                             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hnew[mt][i]), out_rsrc, (int)(o * 4), 0, 16 /* sc1 */);
                     }
                 } else if (bl < nb) {
-                    la::Elem<T>::store(out + o, hnew[mt][i]);
+                    if constexpr (sizeof(T) == 2) *reinterpret_cast<unsigned short *>(out + o) = round16<T>(hnew[mt][i]);
+                    else la::Elem<T>::store(out + o, hnew[mt][i]);
                 }
             }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -510,9 +520,7 @@ __global__ __launch_bounds__(512, 1) void gru_granule_kernel(GruGranuleParams p)
     auto store_out = [&](int t, const float (&h)[4]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            T h16;
-            la::Elem<T>::store(&h16, h[i]);
-            const unsigned mine = __builtin_bit_cast(unsigned short, h16);
+            const unsigned mine = round16<T>(h[i]);
             const unsigned nbr = (unsigned)__shfl_down((int)mine, 1);
             const int bl = 4 * q + i;
             const int64_t o = (int64_t)(b0 + (bl < nb ? bl : 0)) * out_bs + (int64_t)t * out_ts + dir * H + jcol;
@@ -598,9 +606,7 @@ __global__ __launch_bounds__(512, 1) void gru_granule_kernel(GruGranuleParams p)
         unsigned pair[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            T h16;
-            la::Elem<T>::store(&h16, hnew[i]);
-            const unsigned mine = __builtin_bit_cast(unsigned short, h16);
+            const unsigned mine = round16<T>(hnew[i]);
             const unsigned nbr = (unsigned)__shfl_down((int)mine, 1);
             pair[i] = mine | (nbr << 16);
         }
