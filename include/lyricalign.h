@@ -119,6 +119,7 @@ int la_timer_read_work(double *total_ms, int64_t *timed_launches, double *timed_
  *   "gru_handoff"     LA_GRU_HANDOFF      0 = data-tagged 8-byte granules, no counter, from 17 clips on (default; 16-bit, 8-wave workgroups;
  *                                         float32 training sweeps: always) | 1 = the counter form everywhere (write-through stores, drain,
  *                                         barrier, counter add; poll, barrier, loads) | 2 = granules for every batch
+ *   "gru_poll_delay"  LA_GRU_POLL_DELAY   0 (default) = poll at once | n = n x 64 clocks of sleep before a step's first poll of the granule hand-off
  *   "viterbi_dpp"     LA_VITERBI_NO_DPP   1 = DPP wave shifts (default) | 0 = the LDS-exchange form
  *   "head_clip_cap"   LA_HEAD_CLIP_CAP    0 = by residency (default) | n = clips per head launch set of la_align_head_forward
  *   "ln_fusion"       LA_LN_FUSION        1 = LayerNorm folded into the 16-bit encoder GEMMs where they run on the 256 x 256 kernel | 0 = never

@@ -241,6 +241,19 @@ def build_model_shared(name: str, seed: int, with_decoder: bool, rank: int, worl
     if world == 1:
         return build_model(name, seed=seed, with_decoder=with_decoder)
     import os
+    import shutil
+    import tempfile
+    dims = dims_for(name)
+    # room for the whole model in the exchange directory?  (every rank of the node sees the same numbers; a container's /dev/shm can be 64 MB)
+    need = 4 * (12 * dims.n_audio_layer * dims.n_audio_state ** 2 + (16 * dims.n_text_layer * dims.n_text_state ** 2 + dims.n_vocab * dims.n_text_state
+                                                                      if with_decoder else 0)) + (64 << 20)
+    try:
+        if shutil.disk_usage(shm_dir).free < 2 * need:
+            shm_dir = tempfile.gettempdir()
+        if shutil.disk_usage(shm_dir).free < 2 * need:
+            return build_model(name, seed=seed, with_decoder=with_decoder)      # no room anywhere: every rank builds the whole model
+    except OSError:
+        return build_model(name, seed=seed, with_decoder=with_decoder)
     model = build_model(name, seed=seed, with_decoder=with_decoder, part=(rank, world))
     params = list(model.named_parameters())
     path = lambda r: os.path.join(shm_dir, f"la_weights_{tag}_{r}.pt")

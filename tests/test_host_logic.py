@@ -934,3 +934,33 @@ def test_transcribe_prompt_reset_drops_the_window_it_is_meant_to_drop(monkeypatc
     assert len(prompts) == 2 and prompts[0] == []
     assert prompts[1] == ([] if expect_reset else [ts, 101, 201, ts + 1500])
     assert [t for t in out["tokens"] if t < tok.eot] == [101, 201, 102, 202]
+
+
+def test_cooperative_weight_build_gives_every_rank_the_sequential_model(tmp_path):
+    """whisper_compat.build_model_shared (bench.py with N > 1 ranks on a node): every rank generates the parameters with index = rank
+    (mod world) -- the others' draws skipped with PCG64.advance --, the pieces are exchanged through files in a shared directory, and
+    every rank ends with the bits of the sequential build_model.  Three ranks as threads around one barrier, tiny dims, with decoder."""
+    import threading
+    from lyricalignment_amd import whisper_compat as wc
+    ref = wc.build_model("tiny", seed=3, with_decoder=True)
+    world = 3
+    bar = threading.Barrier(world)
+    out, errs = [None] * world, []
+
+    def rank(r):
+        try:
+            out[r] = wc.build_model_shared("tiny", 3, True, r, world, bar.wait, f"test{os.getpid()}", shm_dir=str(tmp_path))
+        except Exception as e:          # noqa: BLE001
+            errs.append(e)
+            bar.abort()
+
+    ts = [threading.Thread(target=rank, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=300)
+    assert not errs, errs
+    for m in out:
+        for (n, p), (_, q) in zip(ref.named_parameters(), m.named_parameters()):
+            assert torch.equal(p, q), n
+    assert not list(tmp_path.iterdir())            # the exchange files are removed
