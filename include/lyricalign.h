@@ -459,6 +459,10 @@ int la_row_stats16(int32_t dtype, const void *x, int64_t ldx, int32_t M, int32_t
  *                      ceil(M/256) ceil(N/256) slots >= 192 -- else LA_EUNSUPPORTED (the caller keeps float32 la_gemm for small shapes). */
 int la_split_f16x2(const float *x, int64_t ldx, int32_t rows, int32_t cols, void *planes, int64_t kp, float *inv_scale, void *stream);
 int la_split_f16x2_t(const float *x, int64_t ldx, int32_t rows, int32_t cols, void *planes_t, int64_t mp, float *inv_scale_t, void *stream);
+/* the same with an activation applied to the values before the split (act: 0 = none, 1 = exact-erf GELU): the MLP's hidden operand
+ * gelu(u) goes from u into its planes without a float32 copy of its own (forward product and weight gradient) */
+int la_split_f16x2_act(const float *x, int64_t ldx, int32_t rows, int32_t cols, void *planes, int64_t kp, float *inv_scale, int32_t act, void *stream);
+int la_split_f16x2_t_act(const float *x, int64_t ldx, int32_t rows, int32_t cols, void *planes_t, int64_t mp, float *inv_scale_t, int32_t act, void *stream);
 int la_gemm_f16x2(int32_t M, int32_t N, int32_t K, int32_t slots, const void *A, const float *sa, const void *W, const float *sw,
                   float *C, int64_t ldc, const float *bias, const float *residual, int64_t ldr, int32_t epilogue, void *stream);
 

@@ -42,9 +42,13 @@ __device__ __forceinline__ void x2_split(float xs, unsigned short &hi, unsigned 
     lo = __builtin_bit_cast(unsigned short, l);
 }
 
+// optional activation applied to the float32 values before they are split (act: 0 none, 1 exact-erf GELU): the MLP's hidden operand
+// gelu(u) is never materialised in float32 -- the forward and the weight-gradient products split it straight from u
+__device__ __forceinline__ float x2_act(float v, int act) { return act == 1 ? la::gelu_erf(v) : v; }
+
 // one wave per row, four rows per workgroup: pass 1 = the row's largest magnitude, pass 2 (the row is L2-resident) = split + store
 __global__ __launch_bounds__(256) void split_rows_kernel(const float *x, int64_t ldx, int rows, int cols, unsigned short *planes, int64_t kp,
-                                                         float *inv_scale) {
+                                                         float *inv_scale, int act) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -54,9 +58,9 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float *x, int64_t
     float mx = 0.f;
     for (int i = lane; i < c4; i += 64) {
         const float4 v = reinterpret_cast<const float4 *>(xr)[i];
-        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(x2_act(v.x, act)), fabsf(x2_act(v.y, act))), fmaxf(fabsf(x2_act(v.z, act)), fabsf(x2_act(v.w, act)))));
     }
-    for (int i = c4 * 4 + lane; i < cols; i += 64) mx = fmaxf(mx, fabsf(xr[i]));
+    for (int i = c4 * 4 + lane; i < cols; i += 64) mx = fmaxf(mx, fabsf(x2_act(xr[i], act)));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
     float inv;
@@ -65,27 +69,28 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float *x, int64_t
     for (int i = lane; i < c4; i += 64) {
         const float4 v = reinterpret_cast<const float4 *>(xr)[i];
         ushort4 h, l;
-        x2_split(v.x * s, h.x, l.x); x2_split(v.y * s, h.y, l.y); x2_split(v.z * s, h.z, l.z); x2_split(v.w * s, h.w, l.w);
+        x2_split(x2_act(v.x, act) * s, h.x, l.x); x2_split(x2_act(v.y, act) * s, h.y, l.y); x2_split(x2_act(v.z, act) * s, h.z, l.z);
+        x2_split(x2_act(v.w, act) * s, h.w, l.w);
         reinterpret_cast<ushort4 *>(hi)[i] = h;
         reinterpret_cast<ushort4 *>(lo)[i] = l;
     }
     for (int i = c4 * 4 + lane; i < kp; i += 64) {
         unsigned short h = 0, l = 0;
-        if (i < cols) x2_split(xr[i] * s, h, l);
+        if (i < cols) x2_split(x2_act(xr[i], act) * s, h, l);
         hi[i] = h; lo[i] = l;
     }
     if (lane == 0) inv_scale[row] = inv;
 }
 
 // column maxima of |x| as ordered unsigned bit patterns (|x| >= 0: the float order is the integer order)
-__global__ __launch_bounds__(256) void colmax_kernel(const float *x, int64_t ldx, int rows, int cols, int rows_per_block, unsigned *colmax) {
+__global__ __launch_bounds__(256) void colmax_kernel(const float *x, int64_t ldx, int rows, int cols, int rows_per_block, unsigned *colmax, int act) {
     __shared__ float red[4][64];
     const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + cx;
     const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
     float mx = 0.f;
     if (col < cols)
-        for (int r = r0 + ry; r < r1; r += 4) mx = fmaxf(mx, fabsf(x[(int64_t)r * ldx + col]));
+        for (int r = r0 + ry; r < r1; r += 4) mx = fmaxf(mx, fabsf(x2_act(x[(int64_t)r * ldx + col], act)));
     red[ry][cx] = mx;
     __syncthreads();
     if (ry == 0 && col < cols) {
@@ -98,7 +103,7 @@ __global__ __launch_bounds__(256) void colmax_kernel(const float *x, int64_t ldx
 // 64 (rows of x) x 64 (columns of x) tiles through LDS: read along the columns, written along the rows of x (= along the padded
 // contraction dimension of the transposed planes)
 __global__ __launch_bounds__(256) void split_transposed_kernel(const float *x, int64_t ldx, int rows, int cols, const unsigned *colmax,
-                                                               unsigned short *planes, int64_t mp, float *inv_scale) {
+                                                               unsigned short *planes, int64_t mp, float *inv_scale, int act) {
     __shared__ float tile[64][65];
     const int m0 = blockIdx.y * 64, k0 = blockIdx.x * 64;
     {
@@ -106,7 +111,7 @@ __global__ __launch_bounds__(256) void split_transposed_kernel(const float *x, i
 #pragma unroll 4
         for (int i = 0; i < 16; ++i) {
             const int m = m0 + ty * 16 + i, k = k0 + tx;
-            tile[ty * 16 + i][tx] = (m < rows && k < cols) ? x[(int64_t)m * ldx + k] : 0.f;
+            tile[ty * 16 + i][tx] = (m < rows && k < cols) ? x2_act(x[(int64_t)m * ldx + k], act) : 0.f;
         }
     }
     __syncthreads();
@@ -143,22 +148,28 @@ __global__ void x2_reduce_kernel(const float *P, int S, int M, int N, float *C, 
 
 }  // namespace
 
-extern "C" int la_split_f16x2(const float *x, int64_t ldx, int32_t rows, int32_t cols, void *planes, int64_t kp, float *inv_scale,
-                              void *stream_) {
+extern "C" int la_split_f16x2_act(const float *x, int64_t ldx, int32_t rows, int32_t cols, void *planes, int64_t kp, float *inv_scale,
+                                  int32_t act, void *stream_) {
     if (rows == 0) return LA_OK;
+    LA_CHECK_ARG(act == 0 || act == 1, "split_f16x2: act is 0 (none) or 1 (GELU)");
     LA_CHECK_ARG(x && planes && inv_scale && rows > 0 && cols > 0, "split_f16x2: bad arguments");
     LA_CHECK_ARG(kp >= cols && kp % 8 == 0 && ldx >= cols && (uintptr_t)planes % 16 == 0, "split_f16x2: kp must be >= cols and a multiple of 8, planes 16-byte aligned");
     hipStream_t stream = (hipStream_t)stream_;
     la::TimerScope ts("split_f16x2", stream, (double)rows * cols * 8.0);
     hipLaunchKernelGGL(split_rows_kernel, dim3(la::cdiv(rows, 4)), dim3(256), 0, stream, x, ldx, rows, cols,
-                       reinterpret_cast<unsigned short *>(planes), kp, inv_scale);
+                       reinterpret_cast<unsigned short *>(planes), kp, inv_scale, act);
     LA_LAUNCH_CHECK();
     return LA_OK;
 }
 
-extern "C" int la_split_f16x2_t(const float *x, int64_t ldx, int32_t rows, int32_t cols, void *planes_t, int64_t mp, float *inv_scale_t,
-                                void *stream_) {
+extern "C" int la_split_f16x2(const float *x, int64_t ldx, int32_t rows, int32_t cols, void *planes, int64_t kp, float *inv_scale, void *stream_) {
+    return la_split_f16x2_act(x, ldx, rows, cols, planes, kp, inv_scale, 0, stream_);
+}
+
+extern "C" int la_split_f16x2_t_act(const float *x, int64_t ldx, int32_t rows, int32_t cols, void *planes_t, int64_t mp, float *inv_scale_t,
+                                    int32_t act, void *stream_) {
     if (cols == 0) return LA_OK;
+    LA_CHECK_ARG(act == 0 || act == 1, "split_f16x2_t: act is 0 (none) or 1 (GELU)");
     LA_CHECK_ARG(x && planes_t && inv_scale_t && rows > 0 && cols > 0, "split_f16x2_t: bad arguments");
     LA_CHECK_ARG(mp >= rows && mp % 16 == 0 && ldx >= cols && (uintptr_t)planes_t % 16 == 0, "split_f16x2_t: mp must be >= rows and a multiple of 16, planes 16-byte aligned");
     hipStream_t stream = (hipStream_t)stream_;
@@ -167,12 +178,16 @@ extern "C" int la_split_f16x2_t(const float *x, int64_t ldx, int32_t rows, int32
     LA_HIP(hipMemsetAsync(colmax, 0, (size_t)cols * sizeof(unsigned), stream));
     la::TimerScope ts("split_f16x2", stream, (double)rows * cols * 12.0);
     const int rpb = 512;
-    hipLaunchKernelGGL(colmax_kernel, dim3(la::cdiv(cols, 64), la::cdiv(rows, rpb)), dim3(256), 0, stream, x, ldx, rows, cols, rpb, colmax);
+    hipLaunchKernelGGL(colmax_kernel, dim3(la::cdiv(cols, 64), la::cdiv(rows, rpb)), dim3(256), 0, stream, x, ldx, rows, cols, rpb, colmax, act);
     LA_LAUNCH_CHECK();
     hipLaunchKernelGGL(split_transposed_kernel, dim3(la::cdiv(cols, 64), la::cdiv(mp, 64)), dim3(256), 0, stream, x, ldx, rows, cols, colmax,
-                       reinterpret_cast<unsigned short *>(planes_t), mp, inv_scale_t);
+                       reinterpret_cast<unsigned short *>(planes_t), mp, inv_scale_t, act);
     LA_LAUNCH_CHECK();
     return LA_OK;
+}
+
+extern "C" int la_split_f16x2_t(const float *x, int64_t ldx, int32_t rows, int32_t cols, void *planes_t, int64_t mp, float *inv_scale_t, void *stream_) {
+    return la_split_f16x2_t_act(x, ldx, rows, cols, planes_t, mp, inv_scale_t, 0, stream_);
 }
 
 extern "C" int la_gemm_f16x2(int32_t M, int32_t N, int32_t K, int32_t slots, const void *A, const float *sa, const void *W, const float *sw,

@@ -72,7 +72,7 @@ class DecoderFunction(torch.autograd.Function):
             x2 = f32x2.linear(ac, woc, bias=boc, residual=x1)
             h2 = ops.layernorm(x2, g2, be2, torch.float32)
             u_pre = f32x2.linear(h2, w1, bias=b1)
-            x3 = f32x2.linear(gelu(u_pre), w2, bias=b2, residual=x2)
+            x3 = f32x2.linear(u_pre, w2, bias=b2, residual=x2, x_act="gelu")
             saved.append((x, h1, qkv, a, x1, hc, qc, kv, ac, x2, h2, u_pre))
             packed.append((g1, wqkv, wo, gc, wq_c, wkv_c, woc, g2, w1, w2))
             x = x3
@@ -101,7 +101,7 @@ class DecoderFunction(torch.autograd.Function):
             g1, wqkv, wo, gc, wq_c, wkv_c, woc, g2, w1, w2 = ctx.packed[i]
             G = [None] * NB
             # MLP
-            G[22], G[23] = gemm_tn(dx, gelu(u_pre)), colsum(dx)
+            G[22], G[23] = gemm_tn(dx, u_pre, b_act="gelu"), colsum(dx)
             du_pre = gelu_bwd(u_pre, gemm_nn(dx, w2))
             G[20], G[21] = gemm_tn(du_pre, h2), colsum(du_pre)
             dln, G[18], G[19] = layernorm_bwd(x2, gemm_nn(du_pre, w1), g2)

@@ -214,7 +214,7 @@ class EncoderFunction(torch.autograd.Function):
             x_mid = f32x2.linear(att, wo, bias=bo, residual=x)
             h2 = ops.layernorm(x_mid, g2, be2, torch.float32)
             u_pre = f32x2.linear(h2, w1, bias=b1)
-            x_next = f32x2.linear(gelu(u_pre), w2, bias=b2, residual=x_mid)
+            x_next = f32x2.linear(u_pre, w2, bias=b2, residual=x_mid, x_act="gelu")
             saved.append((x, h1, qkv, att, x_mid, h2, u_pre, lse))
             packed.append((g1, wqkv, wo, g2, w1, w2))
             x = x_next
@@ -237,7 +237,7 @@ class EncoderFunction(torch.autograd.Function):
             g1, wqkv, wo, g2, w1, w2 = ctx.packed[i]
             G = [None] * 15
             # x_next = x_mid + gelu(u_pre) W2^T + b2
-            G[13], G[14] = gemm_tn(dx, gelu(u_pre)), colsum(dx)
+            G[13], G[14] = gemm_tn(dx, u_pre, b_act="gelu"), colsum(dx)
             du_pre = gelu_bwd(u_pre, gemm_nn(dx, w2))
             G[11], G[12] = gemm_tn(du_pre, h2), colsum(du_pre)
             dln, G[9], G[10] = layernorm_bwd(x_mid, gemm_nn(du_pre, w1), g2)

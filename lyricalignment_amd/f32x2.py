@@ -12,7 +12,9 @@ large ones: >= 192 tiles of 256 x 256, counting split-K slots), their operand sp
     gemm_tn(dy, x)                 dw = dy^T x                                weight gradient (contraction over the rows)
 
 with the float32 MFMA kernel (ops.gemm / head_train.gemm_nn / gemm_tn) for every shape outside that domain.
-LA_F32X2=0 keeps every product on the float32 kernel (the A/B partner; read at import).
+LA_F32X2=0 keeps every product on the float32 kernel (the A/B partner; read at import).  The MLP's gelu(u) operand is split
+straight from u (x_act / act = "gelu": the activation runs inside the split kernels, no float32 buffer of gelu(u) in the forward
+or in the weight gradient); LA_F32X2_ACT=0 goes through the buffer (same bits).
 """
 from __future__ import annotations
 
@@ -26,6 +28,7 @@ from . import _lib
 from ._lib import check, lib, ptr, stream_ptr
 
 ENABLED = os.environ.get("LA_F32X2", "1") != "0"
+FUSE_ACT = os.environ.get("LA_F32X2_ACT", "1") != "0"     # 0: gelu(x) through its own float32 buffer before the split (A/B partner)
 MIN_TILES = 192          # the 256 x 256 kernel's domain (la_gemm_f16x2)
 
 
@@ -43,27 +46,31 @@ class Planes:
     kp: int
 
 
-def split(x: torch.Tensor, kp: Optional[int] = None) -> Planes:
-    """x [rows, k] float32 (row view, unit inner stride) -> its planes along k, zero-padded to kp (default: k rounded up to 128)."""
+ACT = {None: 0, "gelu": 1}
+
+
+def split(x: torch.Tensor, kp: Optional[int] = None, act: Optional[str] = None) -> Planes:
+    """x [rows, k] float32 (row view, unit inner stride) -> its planes along k, zero-padded to kp (default: k rounded up to 128).
+    act = "gelu": the planes of gelu(x) (exact erf), applied inside the split."""
     if x.dtype != torch.float32 or x.dim() != 2 or x.stride(1) != 1:
         raise ValueError("f32x2.split: a float32 [rows, k] row view is expected")
     rows, k = x.shape
     kp = _rup(k, 128) if kp is None else kp
     planes = torch.empty((rows, 2, kp), dtype=torch.float16, device=x.device)
     inv = torch.empty((rows,), dtype=torch.float32, device=x.device)
-    check(lib().la_split_f16x2(ptr(x), x.stride(0), rows, k, ptr(planes), kp, ptr(inv), stream_ptr()), "split_f16x2")
+    check(lib().la_split_f16x2_act(ptr(x), x.stride(0), rows, k, ptr(planes), kp, ptr(inv), ACT[act], stream_ptr()), "split_f16x2")
     return Planes(planes, inv, rows, k, kp)
 
 
-def split_t(x: torch.Tensor, mp: Optional[int] = None) -> Planes:
-    """x [m, k] float32 -> the planes of x^T: rows = k, contraction length m zero-padded to mp (default: m rounded up to 128)."""
+def split_t(x: torch.Tensor, mp: Optional[int] = None, act: Optional[str] = None) -> Planes:
+    """x [m, k] float32 -> the planes of x^T (of act(x)^T): rows = k, contraction length m zero-padded to mp (default: m rounded up to 128)."""
     if x.dtype != torch.float32 or x.dim() != 2 or x.stride(1) != 1:
         raise ValueError("f32x2.split_t: a float32 [m, k] row view is expected")
     m, k = x.shape
     mp = _rup(m, 128) if mp is None else mp
     planes = torch.empty((k, 2, mp), dtype=torch.float16, device=x.device)
     inv = torch.empty((k,), dtype=torch.float32, device=x.device)
-    check(lib().la_split_f16x2_t(ptr(x), x.stride(0), m, k, ptr(planes), mp, ptr(inv), stream_ptr()), "split_f16x2_t")
+    check(lib().la_split_f16x2_t_act(ptr(x), x.stride(0), m, k, ptr(planes), mp, ptr(inv), ACT[act], stream_ptr()), "split_f16x2_t")
     return Planes(planes, inv, k, m, mp)
 
 
@@ -113,15 +120,26 @@ def _plain2d(t: torch.Tensor) -> bool:
     return t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1
 
 
-def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """y = x w^T (+ bias) (+ residual), float32 in and out (F.linear; whisper/model.py Linear)."""
+def _apply(x: torch.Tensor, act: Optional[str]) -> torch.Tensor:
+    if act is None:
+        return x
+    from .encoder_train import gelu
+    return gelu(x)
+
+
+def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+           x_act: Optional[str] = None) -> torch.Tensor:
+    """y = act(x) w^T (+ bias) (+ residual), float32 in and out (F.linear; whisper/model.py Linear; x_act = "gelu": the MLP's second
+    Linear on gelu(x), the activation applied inside the operand split)."""
     from . import ops
     M, K = x.shape
     N = w.shape[0]
     if _plain2d(x) and _plain2d(w) and eligible(M, N, K) and (residual is None or _plain2d(residual)):
         kp = padded_k(M, N, K)
-        return gemm(split(x, kp), split(w, kp), bias=bias, residual=residual)
-    return ops.gemm(x, w, bias=bias, residual=residual)
+        if not FUSE_ACT:
+            x, x_act = _apply(x, x_act), None
+        return gemm(split(x, kp, act=x_act), split(w, kp), bias=bias, residual=residual)
+    return ops.gemm(_apply(x, x_act), w, bias=bias, residual=residual)
 
 
 def gemm_nn(dy: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
@@ -135,12 +153,14 @@ def gemm_nn(dy: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     return head_train.gemm_nn_f32(dy, w)
 
 
-def gemm_tn(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
-    """dy [M, N]^T . x [M, K] -> [N, K]: the weight gradient of y = x w^T (contraction over the M rows of both)."""
+def gemm_tn(dy: torch.Tensor, x: torch.Tensor, x_act: Optional[str] = None) -> torch.Tensor:
+    """dy [M, N]^T . act(x) [M, K] -> [N, K]: the weight gradient of y = act(x) w^T (contraction over the M rows of both)."""
     from . import head_train
     M, N = dy.shape
     K = x.shape[1]
     if _plain2d(dy) and _plain2d(x) and eligible(N, K, M):
         mp = padded_k(N, K, M)
-        return gemm(split_t(dy, mp), split_t(x, mp))
-    return head_train.gemm_tn_f32(dy, x)
+        if not FUSE_ACT:
+            x, x_act = _apply(x, x_act), None
+        return gemm(split_t(dy, mp), split_t(x, mp, act=x_act))
+    return head_train.gemm_tn_f32(dy, _apply(x, x_act))

@@ -78,10 +78,11 @@ def _gemm_ex_flags(Mg: int, Ng: int, Kg: int, a: torch.Tensor, w: torch.Tensor, 
     return out
 
 
-def gemm_tn(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-    """a [M,N]^T . b [M,K] -> [N,K]: the weight gradient of a Linear.  Large products on the f16x2 path, the rest gemm_tn_f32."""
+def gemm_tn(a: torch.Tensor, b: torch.Tensor, b_act: Optional[str] = None) -> torch.Tensor:
+    """a [M,N]^T . act(b) [M,K] -> [N,K]: the weight gradient of a Linear (b_act = "gelu": of the MLP's second Linear, whose operand is
+    gelu(b)).  Large products on the f16x2 path, the rest gemm_tn_f32."""
     from . import f32x2
-    return f32x2.gemm_tn(a, b)
+    return f32x2.gemm_tn(a, b, x_act=b_act)
 
 
 def gemm_nn(a: torch.Tensor, w: torch.Tensor) -> torch.Tensor:

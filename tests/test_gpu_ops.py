@@ -705,6 +705,27 @@ def test_split_f16x2_planes_reconstruct_the_float32_values():
     assert torch.equal(a.planes.view(torch.int16), b.planes.view(torch.int16)) and torch.equal(a.inv_scale, b.inv_scale)
 
 
+def test_split_f16x2_with_gelu_equals_the_split_of_the_gelu_buffer():
+    """act = "gelu" (la_split_f16x2_act / la_split_f16x2_t_act): the planes and scales of gelu(x) without its float32 buffer are, bit
+    for bit, those of splitting la_gelu_f32's output (same erf form in both); f32x2.linear / gemm_tn with the activation inside the
+    split give the bits of the two-step form; an unknown activation code is refused."""
+    from lyricalignment_amd import encoder_train, f32x2
+    from lyricalignment_amd._lib import lib, ptr
+    x = (_heavy(3000, 1100, seed=31, scale=0.02)).cuda()
+    gx = encoder_train.gelu(x)
+    for fn, pad in ((f32x2.split, 1152), (f32x2.split_t, 3072)):
+        a, b = fn(x, pad, act="gelu"), fn(gx, pad)
+        assert torch.equal(a.planes.view(torch.int16), b.planes.view(torch.int16)) and torch.equal(a.inv_scale, b.inv_scale)
+    w, dy = _rand(1536, 1100, seed=32, scale=0.03).cuda(), _heavy(3000, 1536, seed=33, scale=1e-3).cuda()
+    assert f32x2.eligible(3000, 1536, 1100) and f32x2.eligible(1536, 1100, 3000)
+    assert torch.equal(f32x2.linear(x, w, x_act="gelu"), f32x2.linear(gx, w))
+    assert torch.equal(f32x2.gemm_tn(dy, x, x_act="gelu"), f32x2.gemm_tn(dy, gx))
+    small = x[:64, :192].contiguous()                                           # outside the f16x2 domain: the float32 kernel on gelu(x)
+    assert torch.equal(f32x2.linear(small, w[:, :192].contiguous(), x_act="gelu"), f32x2.linear(encoder_train.gelu(small), w[:, :192].contiguous()))
+    P = f32x2.split(x, 1152)
+    assert lib().la_split_f16x2_act(ptr(x), x.stride(0), 3000, 1100, ptr(P.planes), 1152, ptr(P.inv_scale), 7, None) != 0
+
+
 @pytest.mark.parametrize("kind", ["gauss", "heavy"])
 def test_gemm_f16x2_is_at_least_as_accurate_as_the_float32_kernel(kind):
     """la_gemm_f16x2 (three f16 products over segmented K, scale epilogue) against a float64 product, next to float32 la_gemm on the
