@@ -505,6 +505,14 @@ int la_attention_bwd_stats_f32(const float *q, int64_t ld_q, const float *k, int
  * handed to la_attention_bwd_f32 (`lse`; NULL there = recomputed by one more sweep over the scores). */
 int la_attention_lse_f32(const float *q, int64_t ld_q, const float *k, const float *v, int64_t ld_kv, float *out, int64_t ld_out,
                          int32_t batch, int32_t q_len, int32_t kv_len, int32_t n_head, int32_t causal, float *lse, void *stream);
+/* la_attention_lse_f32 with both products on the f16 matrix pipe at float32 accuracy (the f16x2 scheme of la_gemm_f16x2: operands split
+ * into half planes with one power-of-two scale per (clip, head), three 32x32x16 f16 MFMAs per product, float32 accumulate and softmax;
+ * csrc/la_attention_f16x2.hip).  Same arguments and results; workspace (256-byte aligned) of la_attention_f16x2_workspace_bytes bytes
+ * holds the planes of q, k, v. */
+int la_attention_f16x2_workspace_bytes(int32_t batch, int32_t q_len, int32_t kv_len, int32_t n_head, size_t *bytes);
+int la_attention_lse_f16x2(const float *q, int64_t ld_q, const float *k, const float *v, int64_t ld_kv, float *out, int64_t ld_out,
+                           int32_t batch, int32_t q_len, int32_t kv_len, int32_t n_head, int32_t causal, float *lse, void *workspace,
+                           size_t workspace_bytes, void *stream);
 /* Text-decoder training pieces (whisper/model.py TextDecoder; train_multitask.py:285,308 decoder cross-entropy):
  * gradient of token + learned positional embedding (dtok accumulates, dpos [n][d] is written), and
  * F.cross_entropy(logits [rows][vocab], target, ignore_index=-100, 'mean'): loss2[0] = loss, loss2[1] = 1/count;

@@ -15,9 +15,9 @@ from ._lib import (EPI_BIAS, EPI_GELU, EPI_GELU_ERF, EPI_MISH, EPI_OUT_F32, EPI_
                    LA_VARIANT_PLAIN, check, dtype_code, lib, ptr, stream_ptr)
 
 
-# Experiment build of the library only (csrc/lab/la_attention_x2.hip, LA_ATTN_FWD_X2=1): the float32 training forward of the attention on
-# the f16x2 scheme -- parity-green, 1.12 x per layer (profiles/NOTES.md): not shipped
-ATTN_FWD_X2 = os.environ.get("LA_ATTN_FWD_X2", "0") == "1"
+# The float32 training forward of the attention on the f16 matrix pipe at float32 accuracy (la_attention_lse_f16x2;
+# csrc/la_attention_f16x2.hip): sequences of at least 128 queries and keys.  LA_ATTN_F16X2=0 keeps the float32-MFMA kernel (A/B partner).
+ATTN_F16X2 = os.environ.get("LA_ATTN_F16X2", "1") != "0"
 
 
 def _dev(t: torch.Tensor, name: str, dtype=None):
@@ -400,14 +400,13 @@ def attention_ex(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, 
         _dev(lse, "lse", torch.float32)
         if q.dtype != torch.float32 or lse.numel() < batch * n_head * q_len or not lse.is_contiguous():
             raise ValueError("attention_ex: lse goes with float32 operands, [batch, n_head, q_len] contiguous")
-        if ATTN_FWD_X2 and _lib.has_experiments() and q_len % 4 == 0 and kv_len % 4 == 0 and q_len * kv_len >= 64 * 64:
-            # the two products on the f16 pipe at float32 accuracy (la_attention_x2_lse_f32; csrc/la_attention_bwd_x2.hip)
+        if ATTN_F16X2 and q_len >= 128 and kv_len >= 128:
             need = ctypes.c_size_t(0)
-            check(lib().la_attention_x2_workspace_bytes(batch, q_len, kv_len, n_head, ctypes.byref(need)), "attention_x2_workspace_bytes")
+            check(lib().la_attention_f16x2_workspace_bytes(batch, q_len, kv_len, n_head, ctypes.byref(need)), "attention_f16x2_workspace_bytes")
             ws = torch.empty((need.value + 256,), dtype=torch.uint8, device=q.device)
             off = (-ws.data_ptr()) % 256
-            check(lib().la_attention_x2_lse_f32(ptr(q), q.stride(0), ptr(k), ptr(v), k.stride(0), ptr(out), out.stride(0), batch, q_len, kv_len,
-                                                n_head, 1 if causal else 0, ptr(lse), ws.data_ptr() + off, need.value, stream_ptr()), "attention_x2_lse")
+            check(lib().la_attention_lse_f16x2(ptr(q), q.stride(0), ptr(k), ptr(v), k.stride(0), ptr(out), out.stride(0), batch, q_len, kv_len,
+                                               n_head, 1 if causal else 0, ptr(lse), ws.data_ptr() + off, need.value, stream_ptr()), "attention_lse_f16x2")
             return out
         check(lib().la_attention_lse_f32(ptr(q), q.stride(0), ptr(k), ptr(v), k.stride(0), ptr(out), out.stride(0), batch, q_len, kv_len,
                                          n_head, 1 if causal else 0, ptr(lse), stream_ptr()), "attention_lse")

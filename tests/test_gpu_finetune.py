@@ -166,7 +166,7 @@ def _rel(a, b):
 def test_attention_backward_matches_torch_autograd(B, T, H, fused):
     """dQ/dK/dV against torch autograd: the fused kernel la_attention_bwd_f32 (forward output given: scores recomputed per 64 x 64
     tile) and the round-1 composition (batched f32 MFMA GEMMs over whole score tiles + row softmax kernels).  (With the experiment
-    build and LA_ATTN_BWD_X2 / LA_ATTN_FWD_X2 = 1 the same test runs the f16x2 sweeps: tests/test_gpu_lab.py.)"""
+    build and LA_ATTN_BWD_X2 = 1 the same test runs the lab's f16x2 sweeps: tests/test_gpu_lab.py.)"""
     from lyricalignment_amd import encoder_train as et
     d = 64 * H
     g = torch.Generator().manual_seed(T)
@@ -188,6 +188,49 @@ def test_attention_backward_matches_torch_autograd(B, T, H, fused):
     got = et.attention_bwd(qkv.cuda(), datt.cuda(), B, T, H, att=o.detach().cuda() if fused else None, lse=lse).cpu()
     for name, sl in (("dq", slice(0, d)), ("dk", slice(d, 2 * d)), ("dv", slice(2 * d, 3 * d))):
         assert _rel(got[:, sl], ref_in.grad[:, sl]) < 2e-4, name     # float32 tolerance (north_star: 1e-3)
+
+
+@pytest.mark.parametrize("B,Tq,Tk,H,causal,spread", [(2, 1500, 1500, 2, False, 1.0), (1, 333, 333, 3, True, 1.0), (3, 130, 1500, 1, False, 1.0),
+                                                     (1, 256, 128, 2, False, 1.0), (2, 448, 448, 8, True, 1e-4), (1, 700, 515, 2, False, 3e3)])
+def test_attention_forward_f16x2_matches_float64_at_float32_accuracy(B, Tq, Tk, H, causal, spread):
+    """la_attention_lse_f16x2 (operands as half planes with one power-of-two scale per clip and head, three f16 MFMAs per product)
+    against a float64 attention, next to the float32-MFMA kernel la_attention_lse_f32 on the same operands: out and lse no further
+    from float64 than 1.5 x the float32 kernel's error (+ 1e-7 of the largest magnitude), and inside the float32 tolerance of the
+    other attention tests.  Ragged last query / key tiles, causal masks, cross shapes (q_len != kv_len), 8 heads (the XCD-aware
+    block order), operands as column slices of packed projections, heads of very different magnitude (`spread`: every other head's
+    k and v scaled -- the per-head scales), a key / value row of zeros."""
+    from lyricalignment_amd import ops
+    d = 64 * H
+    g = torch.Generator().manual_seed(Tq * 3 + Tk)
+    q0 = torch.randn(B * Tq, d, generator=g) * 0.35
+    kv0 = torch.randn(B * Tk, 2 * d, generator=g)
+    kv0[7] = 0.0
+    if H > 1:
+        for hh in range(1, H, 2):
+            kv0[:, d + 64 * hh: d + 64 * hh + 64] *= spread            # v of the odd heads
+            kv0[:, 64 * hh: 64 * hh + 64] *= min(spread, 1.0) ** 0.5   # k of the odd heads (kept from saturating the softmax)
+    q = q0.double().view(B, Tq, H, 64).permute(0, 2, 1, 3)
+    k, v = [t.view(B, Tk, H, 64).permute(0, 2, 1, 3) for t in kv0.double().split(d, dim=1)]
+    sc = q @ k.transpose(-1, -2)
+    if causal:
+        sc = sc + torch.full((Tq, Tk), float("-inf"), dtype=torch.float64).triu(1)
+    ref = (torch.softmax(sc, dim=-1) @ v).permute(0, 2, 1, 3).reshape(B * Tq, d)
+    ref_lse = torch.logsumexp(sc, dim=-1)
+    qd, kvd = q0.cuda(), kv0.cuda()
+    res = {}
+    for name, flag in (("f16x2", True), ("f32", False)):
+        ops.ATTN_F16X2 = flag
+        try:
+            lse = torch.empty((B, H, Tq), dtype=torch.float32, device="cuda")
+            out = ops.attention_ex(qd, kvd[:, :d], kvd[:, d:], B, Tq, Tk, H, causal=causal, lse=lse)
+        finally:
+            ops.ATTN_F16X2 = True
+        # per head: the heads differ by orders of magnitude
+        eo = ((out.cpu().double() - ref).abs().view(B * Tq, H, 64).amax(dim=(0, 2)) / ref.abs().view(B * Tq, H, 64).amax(dim=(0, 2))).max()
+        res[name] = (float(eo), float((lse.cpu().double() - ref_lse).abs().max()))
+    print(res)
+    assert res["f16x2"][0] <= 1.5 * res["f32"][0] + 1e-7 and res["f16x2"][0] < 2e-5, res
+    assert res["f16x2"][1] <= 1.5 * res["f32"][1] + 5e-7 and res["f16x2"][1] < 2e-5, res
 
 
 @pytest.mark.parametrize("B,Tq,Tk,H,causal", [(2, 37, 37, 2, True), (2, 5, 1500, 2, False), (1, 70, 200, 1, False), (3, 129, 129, 1, True),
