@@ -513,6 +513,15 @@ int la_attention_f16x2_workspace_bytes(int32_t batch, int32_t q_len, int32_t kv_
 int la_attention_lse_f16x2(const float *q, int64_t ld_q, const float *k, const float *v, int64_t ld_kv, float *out, int64_t ld_out,
                            int32_t batch, int32_t q_len, int32_t kv_len, int32_t n_head, int32_t causal, float *lse, void *workspace,
                            size_t workspace_bytes, void *stream);
+/* la_attention_bwd_f32 with its seven products on the f16 matrix pipe at float32 accuracy (key sweep and query sweep in the
+ * register-resident form of la_attention_lse_f16x2; q, k, v, dout split into half planes per clip and head; P split with 2^13, dS with a
+ * scale from the bound 2 |dO_i| |v_j|).  Same arguments and results; lse may be NULL (recomputed); workspace (256-byte aligned) of
+ * la_attention_bwd_f16x2_workspace_bytes bytes. */
+int la_attention_bwd_f16x2_workspace_bytes(int32_t batch, int32_t q_len, int32_t kv_len, int32_t n_head, size_t *bytes);
+int la_attention_bwd_f16x2(const float *q, int64_t ld_q, const float *k, const float *v, int64_t ld_kv, const float *o, int64_t ld_o,
+                           const float *dout, int64_t ld_do, float *dq, int64_t ld_dq, float *dk, float *dv, int64_t ld_dkv,
+                           int32_t batch, int32_t q_len, int32_t kv_len, int32_t n_head, int32_t causal, const float *lse,
+                           void *workspace, size_t workspace_bytes, void *stream);
 /* Text-decoder training pieces (whisper/model.py TextDecoder; train_multitask.py:285,308 decoder cross-entropy):
  * gradient of token + learned positional embedding (dtok accumulates, dpos [n][d] is written), and
  * F.cross_entropy(logits [rows][vocab], target, ignore_index=-100, 'mean'): loss2[0] = loss, loss2[1] = 1/count;

@@ -97,6 +97,9 @@ SYMBOLS = {
     "la_attention_lse_f32": (c_int32, [_P, _I64, _P, _P, _I64, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _P]),
     "la_attention_f16x2_workspace_bytes": (c_int32, [_I32, _I32, _I32, _I32, POINTER(_SZ)]),
     "la_attention_lse_f16x2": (c_int32, [_P, _I64, _P, _P, _I64, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _P, _SZ, _P]),
+    "la_attention_bwd_f16x2_workspace_bytes": (c_int32, [_I32, _I32, _I32, _I32, POINTER(_SZ)]),
+    "la_attention_bwd_f16x2": (c_int32, [_P, _I64, _P, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _P,
+                                         _SZ, _P]),
     "la_embed_tokens_bwd_f32": (c_int32, [_P, _P, _I32, _I32, _I32, _I32, _P, _P, _P]),
     "la_cross_entropy_f32": (c_int32, [_P, _I64, _I32, _I32, _P, ctypes.c_float, _P, _P, _P, _I64, _P]),
     "la_softmax_bwd_rows_f32": (c_int32, [_P, _P, _I64, _I64, _I32, _P]),

@@ -127,8 +127,10 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned &hi, unsig
     const h2 hv = {(_Float16)a, (_Float16)b};
     hi = __builtin_bit_cast(unsigned, hv);
     // one asm statement: the hazard recognizer does not look inside -- a wait state after a transcendental producer of a / b
-    // (v_exp_f32) and one between the two partial writes of the destination, as hipcc places them around its own v_fma_mix
-    asm("s_nop 0\n\tv_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\ts_nop 0\n\tv_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+    // (v_exp_f32), one between the two partial writes of the destination (as hipcc places them around its own v_fma_mix), and two
+    // before a matrix instruction may read the result (vector write -> MFMA operand: without them the key sweep's dK came out
+    // different from run to run whenever hipcc placed the consuming MFMA right behind)
+    asm("s_nop 0\n\tv_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\ts_nop 0\n\tv_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\ts_nop 1"
         : "=&v"(lo)
         : "v"(hi), "v"(a), "v"(b));
 }
@@ -331,6 +333,358 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_x2_fwd_kernel(FwdParams 
     }
 }
 
+// =======================================================================================================================================
+// Backward: dQ, dK, dV of O = softmax(Q K^T) V from dO (whisper/model.py MultiHeadAttention.qkv_attention under train_multitask.py:325-326
+// `loss.backward()`), the two sweeps of la_attention_bwd.hip (no atomics, nothing of size Tq x Tk leaves the CU) in the register-resident
+// form of the forward above, every product three f16 MFMAs:
+//   key sweep    a wave owns 32 keys -- K, V fragments (B operands) and the dV^T, dK^T accumulators live in registers -- and walks the query
+//                tiles:  S = Q K^T,  dP = dO V^T  (A operands: row fragments of the Q / dO images),  P = exp(S - lse),
+//                dS = P o (dP - D),  dV^T += dO^T P,  dK^T += Q^T dS  (A operands: transposed fragments, ds_read_b64_tr_b16)
+//   query sweep  a wave owns 32 queries -- Q, dO fragments and dQ^T -- and walks the key tiles:  S^T = K Q^T,  dP^T = V dO^T,
+//                dS^T = P^T o (dP^T - D),  dQ^T += K^T dS^T
+// A lane holds one key's (query's) column of the score tile, so P and dS leave the accumulators as the next product's B operand.
+// Operands: q, k, v, dO as half planes with one power-of-two scale per (clip, head) (heads_split_kernel).  P is split with the scale 2^13
+// (folded into the exponent).  dS is split with a scale from a bound that needs no reduction: |dS_ij| <= |dP_ij| + |D_i| <=
+// 2 |dO_i| |v_j| <= 128 max|dO| max|v| < 2^35 / (s_dO s_v), so dS 2^-20 s_dO s_v < 2^15 -- in terms of the raw dP accumulator
+// (= dP s_dO s_v) that is  P (dP_acc 2^-20 - D 2^-20 s_dO s_v); entries far below the bound lose relative, never absolute, precision
+// (half's subnormal range: 2^-39 of the bound).  An image that is read both ways (rows for one product, transposed for another) is staged
+// twice, once per swizzle: LDS 128 KiB (key sweep) / 96 KiB (query sweep), one workgroup of eight waves per CU.
+struct BwdParams {
+    const unsigned short *qp, *kp, *vp, *dop;    // planes [token][2][C]
+    const float *sq, *sk, *sv, *sdo;             // inverse scales [batch][n_head]
+    const float *lse, *dvec;                     // [batch][n_head][q_len]
+    float *dq, *dk, *dv;
+    int64_t ld_dq, ld_dkv;
+    int q_len, kv_len, n_head, causal, batch;
+};
+
+// fragment readers.  Row fragment (A operand, M = token row of the image, K = 16 columns of the head dimension: c): ds_read_b128
+__device__ __forceinline__ f16x8 row_frag(const unsigned char *img, int row, int c, int h) {
+    return __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4 *>(img + row * 128 + (((2 * c + h) ^ kswz(row)) << 4)));
+}
+// Transposed fragment (A operand, M = 32 columns of the head dimension: b, K = 16 token rows tok0 ..): lane (col = 32b + 16(g&1) + (lane&15),
+// half g>>1) gets token rows tok0 + 4(g>>1) + {0..3} and + 8
+struct TrLane { int g, q4, pp; };
+__device__ __forceinline__ f16x8 tr_frag(const unsigned char *img, int tok0, int b, const TrLane &L) {
+    const int key0 = tok0 + 4 * (L.g >> 1);
+    const int slot = b * 4 + 2 * (L.g & 1) + (L.pp >> 1);
+    const int r0 = key0 + L.q4, r1 = key0 + 8 + L.q4;
+    typedef __attribute__((address_space(3))) s16x4 *lds_s16x4;
+    const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(img + r0 * 128 + ((slot ^ vswz(r0)) << 4) + (L.pp & 1) * 8));
+    const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(img + r1 * 128 + ((slot ^ vswz(r1)) << 4) + (L.pp & 1) * 8));
+    return __builtin_bit_cast(f16x8, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+// acc += A B with both operands as (hi, lo): small terms first
+__device__ __forceinline__ f32x16 mma3(f16x8 ah, f16x8 al, f16x8 bh, f16x8 bl, f32x16 acc) {
+    acc = mfma(al, bh, acc);
+    acc = mfma(ah, bl, acc);
+    return mfma(ah, bh, acc);
+}
+// eight consecutive accumulator registers (a K-step of 16 token rows) -> B operand (hi, lo)
+__device__ __forceinline__ void split8(const f32x16 &s, int ks, f16x8 &hi, f16x8 &lo) {
+    uint4 ph, pl;
+    split_pair(s[8 * ks + 0], s[8 * ks + 1], ph.x, pl.x);
+    split_pair(s[8 * ks + 2], s[8 * ks + 3], ph.y, pl.y);
+    split_pair(s[8 * ks + 4], s[8 * ks + 5], ph.z, pl.z);
+    split_pair(s[8 * ks + 6], s[8 * ks + 7], ph.w, pl.w);
+    hi = __builtin_bit_cast(f16x8, ph);
+    lo = __builtin_bit_cast(f16x8, pl);
+}
+
+constexpr int BWD_NW = 8;
+constexpr int KV_BUF = 8 * IMG;                 // Q rows hi|lo, Q transposed hi|lo, dO rows hi|lo, dO transposed hi|lo
+constexpr int KV_LDS = 2 * KV_BUF + 2 * 2 * 64 * 4;
+constexpr int Q_BUF = 6 * IMG;                  // K rows hi|lo, K transposed hi|lo, V rows hi|lo
+constexpr int Q_LDS = 2 * Q_BUF;
+
+__global__ __launch_bounds__(64 * BWD_NW, 2) void attention_x2_bwd_kv_kernel(BwdParams p) {
+    constexpr int NW = BWD_NW, KB = 32 * NW, PER = 8 / NW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    float *stats = reinterpret_cast<float *>(lds + 2 * KV_BUF);      // [buf][nl | ds][64]
+    const int Tq = p.q_len, Tk = p.kv_len;
+    const int64_t C = 64 * (int64_t)p.n_head;
+    const BlockCoord bc = block_coord((Tk + KB - 1) / KB, p.n_head, p.batch);
+    const int kt = bc.qt, head = bc.head, clip = bc.clip;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i32 = lane & 31, h = lane >> 5;
+    const TrLane L{lane >> 4, (lane & 15) >> 2, lane & 3};
+    const unsigned short *qbase = p.qp + (int64_t)clip * Tq * 2 * C + head * 64;
+    const unsigned short *dobase = p.dop + (int64_t)clip * Tq * 2 * C + head * 64;
+    const int bh = clip * p.n_head + head;
+    const float isq = p.sq[bh], isk = p.sk[bh], isv = p.sv[bh], isdo = p.sdo[bh];
+    const float kScale = isq * isk * kLog2e;
+    const float dscale = 0x1p-33f / (isdo * isv);          // D -> D s_dS 2^-13 (P carries 2^13)
+    const float *lse_b = p.lse + (int64_t)bh * Tq, *dvec_b = p.dvec + (int64_t)bh * Tq;
+
+    // K and V fragments (B operands): lane (key = i32, h) holds K[key][16c + 8h .. +8] of both planes
+    const int krow_true = kt * KB + wave * 32 + i32;
+    const bool k_valid = krow_true < Tk;
+    const int krow = k_valid ? krow_true : Tk - 1;
+    uint4 kh[4], kl[4], vh[4], vl[4];
+    {
+        const unsigned short *kb = p.kp + ((int64_t)clip * Tk + krow) * 2 * C + head * 64 + 8 * h;
+        const unsigned short *vb = p.vp + ((int64_t)clip * Tk + krow) * 2 * C + head * 64 + 8 * h;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            kh[c] = *reinterpret_cast<const uint4 *>(kb + 16 * c);
+            kl[c] = *reinterpret_cast<const uint4 *>(kb + C + 16 * c);
+            vh[c] = *reinterpret_cast<const uint4 *>(vb + 16 * c);
+            vl[c] = *reinterpret_cast<const uint4 *>(vb + C + 16 * c);
+        }
+    }
+    f32x16 dv[2], dk[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dv[b][r] = 0.f; dk[b][r] = 0.f; }
+
+    const int nq = (Tq + KT - 1) / KT;
+    const int t0 = p.causal ? (kt * KB) / KT : 0;            // causal: query tiles wholly before the block's first key see none of its keys
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(la::lds_addr_u32(lds));
+    const KvOff<PER> off_full = kv_offsets<PER>(C, 0, KT, wave, lane);
+    const KvOff<PER> off_last = kv_offsets<PER>(C, (nq - 1) * KT, Tq, wave, lane);
+    auto stage = [&](int t, unsigned buf) __attribute__((always_inline)) {
+        const KvOff<PER> &o = t == nq - 1 ? off_last : off_full;
+        stage_tile<PER>(qbase, C, t * KT, o.k, buf, wave);
+        stage_tile<PER>(qbase, C, t * KT, o.v, buf + 2 * IMG, wave);
+        stage_tile<PER>(dobase, C, t * KT, o.k, buf + 4 * IMG, wave);
+        stage_tile<PER>(dobase, C, t * KT, o.v, buf + 6 * IMG, wave);
+    };
+    // row statistics of a query tile: threads 0..63 bring 13 - lse log2 e, threads 64..127 D s_dS 2^-13 (rows past the end: 0, masked below)
+    auto stat_load = [&](int t) -> float {
+        float v = 0.f;
+        if (tid < 128) {
+            const int q = t * KT + (tid & 63);
+            if (q < Tq) v = tid < 64 ? 13.0f - lse_b[q] * kLog2e : dvec_b[q] * dscale;
+        }
+        return v;
+    };
+    if (t0 < nq) {
+        stage(t0, lds0);
+        const float sv0 = stat_load(t0);
+        if (tid < 128) stats[tid] = sv0;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {          // (fragment loads waited for here, not inside the loop: see the forward kernel)
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 a0 = __builtin_bit_cast(u32x4, kh[c]), a1 = __builtin_bit_cast(u32x4, kl[c]), a2 = __builtin_bit_cast(u32x4, vh[c]), a3 = __builtin_bit_cast(u32x4, vl[c]);
+        asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+        kh[c] = __builtin_bit_cast(uint4, a0); kl[c] = __builtin_bit_cast(uint4, a1); vh[c] = __builtin_bit_cast(uint4, a2); vl[c] = __builtin_bit_cast(uint4, a3);
+    }
+    __syncthreads();
+
+    auto tile = [&](int t, auto curc, auto maskc) __attribute__((always_inline)) {
+        constexpr int cur = decltype(curc)::value;
+        const unsigned char *qr = lds + cur * KV_BUF, *qtr = qr + 2 * IMG, *dor = qr + 4 * IMG, *dotr = qr + 6 * IMG;
+        const float *st = stats + cur * 128;
+        float sv_next = 0.f;
+        if (t + 1 < nq) {
+            stage(t + 1, lds0 + (cur ^ 1) * KV_BUF);
+            sv_next = stat_load(t + 1);
+        }
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int row = sub * 32 + i32;
+            // ---- S = Q K^T and dP = dO V^T for 32 queries x this wave's 32 keys (lane = key, registers = queries) ----
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f16x8 ah = row_frag(qr, row, c, h), al = row_frag(qr + IMG, row, c, h);
+                s = mma3(ah, al, __builtin_bit_cast(f16x8, kh[c]), __builtin_bit_cast(f16x8, kl[c]), s);
+                const f16x8 gh = row_frag(dor, row, c, h), gl = row_frag(dor + IMG, row, c, h);
+                dp = mma3(gh, gl, __builtin_bit_cast(f16x8, vh[c]), __builtin_bit_cast(f16x8, vl[c]), dp);
+            }
+            // ---- P 2^13 = exp2(s - lse + 13) (in s), dS s_dS = P 2^13 (dP_acc 2^-33 - D s_dS 2^-13) (in dp); rows = queries ----
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const float4 nl = *reinterpret_cast<const float4 *>(st + sub * 32 + 8 * r4 + 4 * h);
+                const float4 ds = *reinterpret_cast<const float4 *>(st + 64 + sub * 32 + 8 * r4 + 4 * h);
+                const float nlv[4] = {nl.x, nl.y, nl.z, nl.w}, dsv[4] = {ds.x, ds.y, ds.z, ds.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * r4 + e;
+                    float a = fmaf(s[r], kScale, nlv[e]);
+                    if constexpr (decltype(maskc)::value) {
+                        const int q = t * KT + sub * 32 + 8 * r4 + 4 * h + e;
+                        if (q >= Tq || (p.causal && krow_true > q)) a = -INFINITY;
+                    }
+                    const float pv = __builtin_amdgcn_exp2f(a);
+                    s[r] = pv;
+                    dp[r] = pv * fmaf(dp[r], 0x1p-33f, -dsv[e]);
+                }
+            }
+            // ---- dV^T += dO^T P,  dK^T += Q^T dS ----
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                f16x8 ph, pl, sh, sl;
+                split8(s, ks, ph, pl);
+                split8(dp, ks, sh, sl);
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    dv[b] = mma3(tr_frag(dotr, sub * 32 + 16 * ks, b, L), tr_frag(dotr + IMG, sub * 32 + 16 * ks, b, L), ph, pl, dv[b]);
+                    dk[b] = mma3(tr_frag(qtr, sub * 32 + 16 * ks, b, L), tr_frag(qtr + IMG, sub * 32 + 16 * ks, b, L), sh, sl, dk[b]);
+                }
+            }
+        }
+        if (t + 1 < nq && tid < 128) stats[(cur ^ 1) * 128 + tid] = sv_next;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+    auto step = [&](int t, auto curc) __attribute__((always_inline)) {
+        // masked: the tile holds rows past the last query or, causal, queries before some key of the block
+        if (__builtin_expect((t + 1) * KT > Tq || (p.causal && t * KT < kt * KB + KB), 0)) tile(t, curc, std::true_type{});
+        else tile(t, curc, std::false_type{});
+    };
+    for (int t = t0; t < nq; t += 2) {
+        step(t, std::integral_constant<int, 0>{});
+        if (t + 1 < nq) step(t + 1, std::integral_constant<int, 1>{});
+    }
+
+    // ---- epilogue: dV = dV^T s_dO^-1 2^-13,  dK = dK^T s_q^-1 s_dS^-1 (s_dS = 2^-20 s_dO s_v in terms of the scales) ----
+    if (k_valid) {
+        const float cv = isdo * 0x1p-13f, ck = isq * 0x1p20f * isdo * isv;
+        float *dvrow = p.dv + ((int64_t)clip * Tk + krow) * p.ld_dkv + head * 64;
+        float *dkrow = p.dk + ((int64_t)clip * Tk + krow) * p.ld_dkv + head * 64;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                *reinterpret_cast<float4 *>(dvrow + 32 * b + 8 * r4 + 4 * h) =
+                    make_float4(dv[b][4 * r4 + 0] * cv, dv[b][4 * r4 + 1] * cv, dv[b][4 * r4 + 2] * cv, dv[b][4 * r4 + 3] * cv);
+                *reinterpret_cast<float4 *>(dkrow + 32 * b + 8 * r4 + 4 * h) =
+                    make_float4(dk[b][4 * r4 + 0] * ck, dk[b][4 * r4 + 1] * ck, dk[b][4 * r4 + 2] * ck, dk[b][4 * r4 + 3] * ck);
+            }
+    }
+}
+
+__global__ __launch_bounds__(64 * BWD_NW, 2) void attention_x2_bwd_q_kernel(BwdParams p) {
+    constexpr int NW = BWD_NW, QT = 32 * NW, PER = 8 / NW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int Tq = p.q_len, T = p.kv_len;
+    const int64_t C = 64 * (int64_t)p.n_head;
+    const BlockCoord bc = block_coord((Tq + QT - 1) / QT, p.n_head, p.batch);
+    const int qt = bc.qt, head = bc.head, clip = bc.clip;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i32 = lane & 31, h = lane >> 5;
+    const TrLane L{lane >> 4, (lane & 15) >> 2, lane & 3};
+    const unsigned short *kbase = p.kp + (int64_t)clip * T * 2 * C + head * 64;
+    const unsigned short *vbase = p.vp + (int64_t)clip * T * 2 * C + head * 64;
+    const int bh = clip * p.n_head + head;
+    const float isq = p.sq[bh], isk = p.sk[bh], isv = p.sv[bh], isdo = p.sdo[bh];
+    const float kScale = isq * isk * kLog2e;
+
+    int qrow = qt * QT + wave * 32 + i32;
+    const bool q_valid = qrow < Tq;
+    qrow = q_valid ? qrow : Tq - 1;
+    uint4 qh[4], ql[4], gh[4], gl[4];
+    {
+        const unsigned short *qb = p.qp + ((int64_t)clip * Tq + qrow) * 2 * C + head * 64 + 8 * h;
+        const unsigned short *gb = p.dop + ((int64_t)clip * Tq + qrow) * 2 * C + head * 64 + 8 * h;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            qh[c] = *reinterpret_cast<const uint4 *>(qb + 16 * c);
+            ql[c] = *reinterpret_cast<const uint4 *>(qb + C + 16 * c);
+            gh[c] = *reinterpret_cast<const uint4 *>(gb + 16 * c);
+            gl[c] = *reinterpret_cast<const uint4 *>(gb + C + 16 * c);
+        }
+    }
+    const float nl = 13.0f - p.lse[(int64_t)bh * Tq + qrow] * kLog2e;
+    const float dsq = p.dvec[(int64_t)bh * Tq + qrow] * (0x1p-33f / (isdo * isv));
+    f32x16 dq[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[b][r] = 0.f;
+
+    int nkv = (T + KT - 1) / KT;
+    const int nkv_all = nkv;
+    if (p.causal) nkv = min(nkv, (min(Tq, (qt + 1) * QT) - 1) / KT + 1);   // tiles above the block's diagonal are all masked
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(la::lds_addr_u32(lds));
+    const KvOff<PER> off_full = kv_offsets<PER>(C, 0, KT, wave, lane);
+    const KvOff<PER> off_last = kv_offsets<PER>(C, (nkv_all - 1) * KT, T, wave, lane);
+    auto stage = [&](int t, unsigned buf) __attribute__((always_inline)) {
+        const KvOff<PER> &o = t == nkv_all - 1 ? off_last : off_full;
+        stage_tile<PER>(kbase, C, t * KT, o.k, buf, wave);
+        stage_tile<PER>(kbase, C, t * KT, o.v, buf + 2 * IMG, wave);
+        stage_tile<PER>(vbase, C, t * KT, o.k, buf + 4 * IMG, wave);
+    };
+    stage(0, lds0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 a0 = __builtin_bit_cast(u32x4, qh[c]), a1 = __builtin_bit_cast(u32x4, ql[c]), a2 = __builtin_bit_cast(u32x4, gh[c]), a3 = __builtin_bit_cast(u32x4, gl[c]);
+        asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+        qh[c] = __builtin_bit_cast(uint4, a0); ql[c] = __builtin_bit_cast(uint4, a1); gh[c] = __builtin_bit_cast(uint4, a2); gl[c] = __builtin_bit_cast(uint4, a3);
+    }
+    __syncthreads();
+
+    auto tile = [&](int t, auto curc, auto maskc) __attribute__((always_inline)) {
+        constexpr int cur = decltype(curc)::value;
+        const unsigned char *kr = lds + cur * Q_BUF, *ktr = kr + 2 * IMG, *vr = kr + 4 * IMG;
+        if (t + 1 < nkv) stage(t + 1, lds0 + (cur ^ 1) * Q_BUF);
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int row = sub * 32 + i32;
+            // ---- S^T = K Q^T and dP^T = V dO^T for 32 keys x this wave's 32 queries (lane = query, registers = keys) ----
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f16x8 ah = row_frag(kr, row, c, h), al = row_frag(kr + IMG, row, c, h);
+                s = mma3(ah, al, __builtin_bit_cast(f16x8, qh[c]), __builtin_bit_cast(f16x8, ql[c]), s);
+                const f16x8 bh_ = row_frag(vr, row, c, h), bl_ = row_frag(vr + IMG, row, c, h);
+                dp = mma3(bh_, bl_, __builtin_bit_cast(f16x8, gh[c]), __builtin_bit_cast(f16x8, gl[c]), dp);
+            }
+            const int kmax = p.causal ? min(T - 1, qrow) : T - 1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float a = fmaf(s[r], kScale, nl);
+                if constexpr (decltype(maskc)::value)
+                    if (t * KT + sub * 32 + acc_row(r, h) > kmax) a = -INFINITY;
+                const float pv = __builtin_amdgcn_exp2f(a);
+                dp[r] = pv * fmaf(dp[r], 0x1p-33f, -dsq);
+            }
+            // ---- dQ^T += K^T dS^T ----
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                f16x8 sh, sl;
+                split8(dp, ks, sh, sl);
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    dq[b] = mma3(tr_frag(ktr, sub * 32 + 16 * ks, b, L), tr_frag(ktr + IMG, sub * 32 + 16 * ks, b, L), sh, sl, dq[b]);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+    auto step = [&](int t, auto curc) __attribute__((always_inline)) {
+        if (__builtin_expect((t + 1) * KT > T || p.causal, 0)) tile(t, curc, std::true_type{});
+        else tile(t, curc, std::false_type{});
+    };
+    for (int t = 0; t < nkv; t += 2) {
+        step(t, std::integral_constant<int, 0>{});
+        if (t + 1 < nkv) step(t + 1, std::integral_constant<int, 1>{});
+    }
+
+    if (q_valid) {
+        const float cq = isk * 0x1p20f * isdo * isv;
+        float *dqrow = p.dq + ((int64_t)clip * Tq + qrow) * p.ld_dq + head * 64;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4)
+                *reinterpret_cast<float4 *>(dqrow + 32 * b + 8 * r4 + 4 * h) =
+                    make_float4(dq[b][4 * r4 + 0] * cq, dq[b][4 * r4 + 1] * cq, dq[b][4 * r4 + 2] * cq, dq[b][4 * r4 + 3] * cq);
+    }
+}
+
 struct FwdWorkspace {
     unsigned short *qp, *kp, *vp;
     float *sq, *sk, *sv;
@@ -376,6 +730,79 @@ extern "C" int la_attention_lse_f16x2(const float *q, int64_t ld_q, const float 
     hipLaunchKernelGGL(heads_split_kernel, dim3(n_head, batch), dim3(1024), 0, stream, v, ld_kv, kv_len, n_head, ws.vp, ws.sv);
     FwdParams p{ws.qp, ws.kp, ws.vp, ws.sq, ws.sk, ws.sv, out, ld_out, lse, q_len, kv_len, n_head, causal ? 1 : 0, batch};
     hipLaunchKernelGGL((attention_x2_fwd_kernel<8>), dim3(la::cdiv(q_len, 256) * n_head * batch), dim3(512), 0, stream, p);
+    LA_LAUNCH_CHECK();
+    return LA_OK;
+}
+
+namespace {
+struct BwdWorkspace {
+    unsigned short *qp, *kp, *vp, *dop;
+    float *sq, *sk, *sv, *sdo, *lse, *dvec;
+    size_t bytes;
+};
+BwdWorkspace bwd_workspace(void *base, int B, int Tq, int Tk, int H) {
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t C = 64 * (size_t)H;
+    size_t off = 0;
+    auto take = [&](size_t n) { size_t o = off; off += up(n); return o; };
+    const size_t oq = take((size_t)B * Tq * 2 * C * 2), ok = take((size_t)B * Tk * 2 * C * 2), ov = take((size_t)B * Tk * 2 * C * 2),
+                 og = take((size_t)B * Tq * 2 * C * 2);
+    const size_t osq = take((size_t)B * H * 4), osk = take((size_t)B * H * 4), osv = take((size_t)B * H * 4), osg = take((size_t)B * H * 4);
+    const size_t ol = take((size_t)B * H * Tq * 4), od = take((size_t)B * H * Tq * 4);
+    char *b = reinterpret_cast<char *>(base);
+    auto us = [&](size_t o) { return reinterpret_cast<unsigned short *>(b + o); };
+    auto fl = [&](size_t o) { return reinterpret_cast<float *>(b + o); };
+    return BwdWorkspace{us(oq), us(ok), us(ov), us(og), fl(osq), fl(osk), fl(osv), fl(osg), fl(ol), fl(od), off};
+}
+}  // namespace
+
+extern "C" int la_attention_bwd_stats_f32(const float *q, int64_t ld_q, const float *k, int64_t ld_kv, const float *o, int64_t ld_o, const float *dout,
+                                          int64_t ld_do, int32_t batch, int32_t q_len, int32_t kv_len, int32_t n_head, int32_t causal,
+                                          const float *lse_in, float *lse, float *dvec, void *stream);
+
+extern "C" int la_attention_bwd_f16x2_workspace_bytes(int32_t batch, int32_t q_len, int32_t kv_len, int32_t n_head, size_t *bytes) {
+    LA_CHECK_ARG(bytes && batch >= 0 && q_len >= 0 && kv_len >= 0 && n_head > 0, "attention_bwd_f16x2_workspace_bytes: bad arguments");
+    *bytes = bwd_workspace(nullptr, batch, q_len, kv_len, n_head).bytes;
+    return LA_OK;
+}
+
+// la_attention_bwd_f32 (la_attention_bwd.hip) with its seven products on the f16 matrix pipe: same arguments and results (dq, dk, dv) to
+// float32 accuracy; workspace (256-byte aligned) of la_attention_bwd_f16x2_workspace_bytes bytes for the operand planes and row statistics.
+extern "C" int la_attention_bwd_f16x2(const float *q, int64_t ld_q, const float *k, const float *v, int64_t ld_kv, const float *o, int64_t ld_o,
+                                      const float *dout, int64_t ld_do, float *dq, int64_t ld_dq, float *dk, float *dv, int64_t ld_dkv,
+                                      int32_t batch, int32_t q_len, int32_t kv_len, int32_t n_head, int32_t causal, const float *lse,
+                                      void *workspace, size_t workspace_bytes, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (batch == 0 || q_len == 0 || kv_len == 0) return LA_OK;
+    LA_CHECK_ARG(q && k && v && o && dout && dq && dk && dv && workspace, "attention_bwd_f16x2: null pointer");
+    LA_CHECK_ARG(batch > 0 && q_len > 0 && kv_len > 0 && n_head > 0, "attention_bwd_f16x2: bad sizes");
+    LA_CHECK_ARG(!causal || q_len == kv_len, "attention_bwd_f16x2: the causal mask needs q_len == kv_len");
+    LA_CHECK_ARG(ld_q % 4 == 0 && ld_kv % 4 == 0 && ld_o % 4 == 0 && ld_do % 4 == 0 && ld_dq % 4 == 0 && ld_dkv % 4 == 0 &&
+                     ld_q >= n_head * 64 && ld_kv >= n_head * 64 && ld_o >= n_head * 64 && ld_do >= n_head * 64 && ld_dq >= n_head * 64 &&
+                     ld_dkv >= n_head * 64, "attention_bwd_f16x2: leading dimensions must be multiples of 4 and at least n_head * 64");
+    LA_CHECK_ARG(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)dout | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) % 16 == 0,
+                 "attention_bwd_f16x2: operands must be 16-byte aligned");
+    const BwdWorkspace ws = bwd_workspace(workspace, batch, q_len, kv_len, n_head);
+    LA_CHECK_ARG((uintptr_t)workspace % 256 == 0 && workspace_bytes >= ws.bytes, "attention_bwd_f16x2: workspace misaligned or too small");
+    static la::DeviceOnce attr_once;
+    if (attr_once.pending()) {
+        LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_x2_bwd_kv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, KV_LDS));
+        LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_x2_bwd_q_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS));
+        attr_once.mark();
+    }
+    // row statistics: D = sum dO o O per query (and lse unless the forward handed it over)
+    const int rc = la_attention_bwd_stats_f32(q, ld_q, k, ld_kv, o, ld_o, dout, ld_do, batch, q_len, kv_len, n_head, causal, lse, ws.lse, ws.dvec, stream_);
+    if (rc != LA_OK) return rc;
+    la::TimerScope ts("attention_bwd_f16x2", stream);
+    const dim3 sg(n_head, batch), sb(1024);
+    hipLaunchKernelGGL(heads_split_kernel, sg, sb, 0, stream, q, ld_q, q_len, n_head, ws.qp, ws.sq);
+    hipLaunchKernelGGL(heads_split_kernel, sg, sb, 0, stream, k, ld_kv, kv_len, n_head, ws.kp, ws.sk);
+    hipLaunchKernelGGL(heads_split_kernel, sg, sb, 0, stream, v, ld_kv, kv_len, n_head, ws.vp, ws.sv);
+    hipLaunchKernelGGL(heads_split_kernel, sg, sb, 0, stream, dout, ld_do, q_len, n_head, ws.dop, ws.sdo);
+    BwdParams p{ws.qp, ws.kp, ws.vp, ws.dop, ws.sq, ws.sk, ws.sv, ws.sdo, lse ? lse : ws.lse, ws.dvec, dq, dk, dv, ld_dq, ld_dkv, q_len, kv_len, n_head, causal ? 1 : 0, batch};
+    constexpr int KB = 32 * BWD_NW;
+    hipLaunchKernelGGL(attention_x2_bwd_kv_kernel, dim3(la::cdiv(kv_len, KB) * n_head * batch), dim3(64 * BWD_NW), KV_LDS, stream, p);
+    hipLaunchKernelGGL(attention_x2_bwd_q_kernel, dim3(la::cdiv(q_len, KB) * n_head * batch), dim3(64 * BWD_NW), Q_LDS, stream, p);
     LA_LAUNCH_CHECK();
     return LA_OK;
 }

@@ -110,6 +110,16 @@ def attention_bwd_ex(q, k, v, do, dq, dk, dv, B: int, Tq: int, Tk: int, H: int, 
                                                 ptr(dq), dq.stride(0), ptr(dk), ptr(dv), dk.stride(0), B, Tq, Tk, H, 1 if causal else 0,
                                                 ptr(lse) if lse is not None else None, ws.data_ptr() + off, need.value, stream_ptr()), "attention_bwd_x2")
             return
+        from . import ops
+        if ops.ATTN_F16X2 and Tq >= 128 and Tk >= 128:
+            # the seven products on the f16 pipe at float32 accuracy (la_attention_bwd_f16x2; csrc/la_attention_f16x2.hip)
+            check(lib().la_attention_bwd_f16x2_workspace_bytes(B, Tq, Tk, H, ctypes.byref(need)), "attention_bwd_f16x2_workspace_bytes")
+            ws = torch.empty((need.value + 256,), dtype=torch.uint8, device=q.device)
+            off = (-ws.data_ptr()) % 256
+            check(lib().la_attention_bwd_f16x2(ptr(q), q.stride(0), ptr(k), ptr(v), k.stride(0), ptr(o), o.stride(0), ptr(do), do.stride(0),
+                                               ptr(dq), dq.stride(0), ptr(dk), ptr(dv), dk.stride(0), B, Tq, Tk, H, 1 if causal else 0,
+                                               ptr(lse) if lse is not None else None, ws.data_ptr() + off, need.value, stream_ptr()), "attention_bwd_f16x2")
+            return
         check(lib().la_attention_bwd_workspace_bytes(B, Tq, H, ctypes.byref(need)), "attention_bwd_workspace_bytes")
         ws = torch.empty((need.value // 4,), dtype=torch.float32, device=q.device)
         check(lib().la_attention_bwd_f32(ptr(q), q.stride(0), ptr(k), ptr(v), k.stride(0), ptr(o), o.stride(0), ptr(do), do.stride(0),

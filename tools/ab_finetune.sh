@@ -1,7 +1,7 @@
 # same-box A/B of the fine-tune step (BASELINE configs[2]): env switches of the round-5 changes, interleaved rounds
 #   LA_F32X2=0       float32 Linear products on the float32 MFMA kernel instead of the f16x2 path
 #   LA_F32X2_ACT=0   gelu(u) through its own float32 buffer instead of inside the operand split
-#   LA_ATTN_F16X2=0  float32-MFMA attention forward instead of the f16x2 kernel
+#   LA_ATTN_F16X2=0  float32-MFMA attention forward and backward sweeps instead of the f16x2 kernels
 #   LA_GRU_HANDOFF=1 float32 GRU training forward on gru_kernel<float> (float32 MFMA, counter hand-off) instead of gru_train_x2_kernel
 for i in 1 2; do
   for cfg in "LA_F32X2=1" "LA_ATTN_F16X2=0" "LA_F32X2=0 LA_ATTN_F16X2=0 LA_GRU_HANDOFF=1"; do
