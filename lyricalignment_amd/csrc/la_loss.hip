@@ -184,6 +184,142 @@ __global__ __launch_bounds__(NT) void ctc_lattice_kernel(const float *logits, in
     }
 }
 
+// ---- the same lattice for S <= 64: one WAVE per utterance --------------------------------------------------------------------------------
+// The recursion is a dependency chain of T steps (1500 for a 30 s clip) per utterance, and a fine-tune micro-batch holds two CTC clips: the
+// launch is two waves on the whole chip and its time is the chain's latency -- 0.78 us per step with the workgroup form above (LDS exchange
+// + barrier, float64 exp / log1p: 37 ms of a 450 ms optimizer step).  Here a step is: neighbours by DPP wave shifts (no LDS), ONE three-way
+// log-sum-exp with its maximum in float64 and the correction log(sum exp(x - max)) in float32 -- the correction lies in [0, ln 3], so its
+// float32 rounding is <= 1e-7 ABSOLUTE per step (the path scores themselves, ~ -1e4, stay float64: the reason the lattice is float64 at
+// all) -- and the emissions / stored alpha rows prefetched a block of 8 steps ahead of the chain.
+__device__ __forceinline__ double wave_shr1(double x, double fill) {      // lane i <- lane i-1, lane 0 <- fill
+    const int lo = __double2loint(x), hi = __double2hiint(x), flo = __double2loint(fill), fhi = __double2hiint(fill);
+    return __hiloint2double(__builtin_amdgcn_update_dpp(fhi, hi, 0x138, 0xf, 0xf, false), __builtin_amdgcn_update_dpp(flo, lo, 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ double wave_shl1(double x, double fill) {      // lane i <- lane i+1, lane 63 <- fill
+    const int lo = __double2loint(x), hi = __double2hiint(x), flo = __double2loint(fill), fhi = __double2hiint(fill);
+    return __hiloint2double(__builtin_amdgcn_update_dpp(fhi, hi, 0x130, 0xf, 0xf, false), __builtin_amdgcn_update_dpp(flo, lo, 0x130, 0xf, 0xf, false));
+}
+// log(exp(a) + exp(b) + exp(c)), -inf safe
+__device__ __forceinline__ double log_add3(double a, double b, double c) {
+    const double m = fmax(a, fmax(b, c));
+    if (m == -INFINITY) return -INFINITY;
+    const float sum = __expf((float)(a - m)) + __expf((float)(b - m)) + __expf((float)(c - m));
+    return m + (double)__logf(sum);
+}
+
+__global__ __launch_bounds__(64) void ctc_lattice_wave_kernel(const float *logits, int64_t ld_b, int64_t ldl, int T, int V, const float *lse_all,
+                                                              const int32_t *labels, int labels_stride, const int32_t *n_labels, double *alpha_ws,
+                                                              int S_pad, float *dlogits, int64_t ldd_b, int64_t ldd, float scale, int batch,
+                                                              LossAcc *acc, float *nll_out, int reuse_alpha) {
+    constexpr int U = 8;                  // steps per prefetch block
+    const int b = blockIdx.x, s = threadIdx.x;
+    const int L = n_labels[b];
+    const int S = 2 * L + 1;
+    if (L <= 0 || S > 64) {
+        if (s == 0) nll_out[b] = 0.f;
+        return;
+    }
+    const bool valid = s < S;
+    const int32_t *lab = labels + (int64_t)b * labels_stride;
+    const int cls = (valid && (s & 1)) ? lab[s >> 1] : 0;
+    const bool can_skip = valid && (s & 1) && s >= 3 && lab[s >> 1] != lab[(s >> 1) - 1];
+    const bool can_skip_fwd_from = valid && (s & 1) && (s + 2 < S) && lab[(s >> 1) + 1] != lab[s >> 1];
+    const bool live = valid && cls >= 0 && cls < V;        // lanes with an emission; the others carry -inf
+    const float *xb = logits + (int64_t)b * ld_b + (live ? cls : 0);
+    const float *lseb = lse_all + (int64_t)b * T;
+    double *aw = alpha_ws + (int64_t)b * T * S_pad + (valid ? s : 0);
+    const double NEG = -INFINITY;
+    double nll;
+    if (reuse_alpha) {
+        const double a_last = aw[(int64_t)(T - 1) * S_pad];
+        const double f0 = __shfl(a_last, S - 1), f1 = S > 1 ? __shfl(a_last, S - 2) : NEG;
+        nll = -log_add(f0, f1);
+    } else {
+        // ---- alpha ----
+        double a = (s <= 1 && live) ? (double)xb[0] - (double)lseb[0] : NEG;
+        if (valid) aw[0] = a;
+        float xv[U], lv[U];
+        auto fetch = [&](int t0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int t = min(t0 + u, T - 1);
+                xv[u] = xb[(int64_t)t * ldl];
+                lv[u] = lseb[t];
+            }
+        };
+        fetch(1);
+        for (int t0 = 1; t0 < T; t0 += U) {
+            float xc[U], lc[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { xc[u] = xv[u]; lc[u] = lv[u]; }
+            if (t0 + U < T) fetch(t0 + U);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int t = t0 + u;
+                if (t < T) {                                          // wave-uniform
+                    const double a1 = wave_shr1(a, NEG);
+                    double a2 = wave_shr1(a1, NEG);
+                    if (!can_skip) a2 = NEG;
+                    const double lp = (double)xc[u] - (double)lc[u];
+                    a = live ? log_add3(a, a1, a2) + lp : NEG;
+                    if (valid) aw[(int64_t)t * S_pad] = a;
+                }
+            }
+        }
+        const double f0 = __shfl(a, S - 1), f1 = S > 1 ? __shfl(a, S - 2) : NEG;
+        nll = -log_add(f0, f1);
+        if (s == 0) {
+            nll_out[b] = (float)nll;
+            if (isinf(nll)) atomicAdd(&acc->v[4], 1.0);
+            atomicAdd(&acc->v[3], nll / (double)L);
+        }
+    }
+    if (!dlogits) return;
+    // ---- beta + occupancy scatter (see ctc_lattice_kernel) ----
+    const float w = scale / ((float)batch * (float)L);
+    float *db = dlogits + (int64_t)b * ldd_b + (live ? cls : 0);
+    const bool scatter = live && !isinf(nll);
+    double be = NEG;
+    float xv[U], lv[U];
+    double av[U];
+    auto fetch = [&](int t0) {                                        // steps t0, t0 - 1, ..., t0 - U + 1
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = max(t0 - u, 0);
+            xv[u] = xb[(int64_t)t * ldl];
+            lv[u] = lseb[t];
+            av[u] = aw[(int64_t)t * S_pad];
+        }
+    };
+    fetch(T - 1);
+    for (int t0 = T - 1; t0 >= 0; t0 -= U) {
+        float xc[U], lc[U];
+        double ac[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { xc[u] = xv[u]; lc[u] = lv[u]; ac[u] = av[u]; }
+        if (t0 - U >= 0) fetch(t0 - U);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = t0 - u;
+            if (t >= 0) {                                             // wave-uniform
+                const double lp = (double)xc[u] - (double)lc[u];
+                if (t == T - 1) {
+                    be = (live && (s == S - 1 || s == S - 2)) ? lp : NEG;
+                } else {
+                    const double b1 = wave_shl1(be, NEG);
+                    double b2 = wave_shl1(b1, NEG);
+                    if (!can_skip_fwd_from) b2 = NEG;
+                    be = live ? log_add3(be, b1, b2) + lp : NEG;
+                }
+                if (scatter) {
+                    const float occ = __expf((float)(ac[u] + be + nll - lp));   // alpha and beta both include lp_t(s) once
+                    if (occ != 0.f) atomicAdd(&db[(int64_t)t * ldd], -w * occ);
+                }
+            }
+        }
+    }
+}
+
 // ---- dense gradient ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void dense_grad_kernel(const float *logits, int64_t ldl, int rows, int T, int V,
                                                          const float *lse_all, const float *lse_ce,
@@ -285,7 +421,10 @@ extern "C" int la_multitask_loss(const float *logits, int64_t batch_stride, int6
     hipLaunchKernelGGL((ctc_lattice_kernel<NTV>), dim3(batch), dim3(NTV), 0, stream, logits, batch_stride, row_stride, frames,  \
                        vocab, lse_all, ctc_labels, labels_stride, n_labels, alpha_ws, S_pad, dl, d_batch_stride, d_row_stride,   \
                        scale, batch, dl ? acc + 1 : acc, nll, dl ? 1 : 0)
-        if (S <= 64) LA_CTC_CASE(64);
+        if (S <= 64)
+            hipLaunchKernelGGL(ctc_lattice_wave_kernel, dim3(batch), dim3(64), 0, stream, logits, batch_stride, row_stride, frames, vocab, lse_all,
+                               ctc_labels, labels_stride, n_labels, alpha_ws, S_pad, dl, d_batch_stride, d_row_stride, scale, batch,
+                               dl ? acc + 1 : acc, nll, dl ? 1 : 0);
         else if (S <= 128) LA_CTC_CASE(128);
         else if (S <= 256) LA_CTC_CASE(256);
         else if (S <= 512) LA_CTC_CASE(512);
