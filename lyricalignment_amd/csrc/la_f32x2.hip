@@ -46,7 +46,10 @@ __device__ __forceinline__ void x2_split(float xs, unsigned short &hi, unsigned 
 // gelu(u) is never materialised in float32 -- the forward and the weight-gradient products split it straight from u
 __device__ __forceinline__ float x2_act(float v, int act) { return act == 1 ? la::gelu_erf(v) : v; }
 
-// one wave per row, four rows per workgroup: pass 1 = the row's largest magnitude, pass 2 (the row is L2-resident) = split + store
+// one wave per row, four rows per workgroup: pass 1 = the row's largest magnitude, pass 2 = split + store.  Rows of up to 4096 columns
+// (every operand of the encoder) stay in registers between the passes -- 16 float4 per lane, all loads in flight at once: one read of x
+// (91 -> ~55 us per 24000 x 1024 operand: the two-pass form was bound by its two dependent round trips per wave, not by bytes); longer
+// rows are read twice (the second time from L2).
 __global__ __launch_bounds__(256) void split_rows_kernel(const float *x, int64_t ldx, int rows, int cols, unsigned short *planes, int64_t kp,
                                                          float *inv_scale, int act) {
     const int lane = threadIdx.x & 63;
@@ -55,24 +58,54 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float *x, int64_t
     const float *xr = x + (int64_t)row * ldx;
     const bool vec = (ldx % 4 == 0) && ((uintptr_t)x % 16 == 0);
     const int c4 = vec ? cols / 4 : 0;
+    unsigned short *hi = planes + (int64_t)row * 2 * kp, *lo = hi + kp;
     float mx = 0.f;
-    for (int i = lane; i < c4; i += 64) {
-        const float4 v = reinterpret_cast<const float4 *>(xr)[i];
-        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(x2_act(v.x, act)), fabsf(x2_act(v.y, act))), fmaxf(fabsf(x2_act(v.z, act)), fabsf(x2_act(v.w, act)))));
+    constexpr int NV = 16;
+    const bool cached = c4 <= 64 * NV;
+    float4 v[NV];
+    if (cached) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = lane + 64 * j;
+            v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < c4) v[j] = reinterpret_cast<const float4 *>(xr)[i];
+        }
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            if (act) v[j] = make_float4(x2_act(v[j].x, act), x2_act(v[j].y, act), x2_act(v[j].z, act), x2_act(v[j].w, act));
+            mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[j].x), fabsf(v[j].y)), fmaxf(fabsf(v[j].z), fabsf(v[j].w))));
+        }
+    } else {
+        for (int i = lane; i < c4; i += 64) {
+            const float4 w = reinterpret_cast<const float4 *>(xr)[i];
+            mx = fmaxf(mx, fmaxf(fmaxf(fabsf(x2_act(w.x, act)), fabsf(x2_act(w.y, act))), fmaxf(fabsf(x2_act(w.z, act)), fabsf(x2_act(w.w, act)))));
+        }
     }
     for (int i = c4 * 4 + lane; i < cols; i += 64) mx = fmaxf(mx, fabsf(x2_act(xr[i], act)));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
     float inv;
     const float s = x2_scale(mx, &inv);
-    unsigned short *hi = planes + (int64_t)row * 2 * kp, *lo = hi + kp;
-    for (int i = lane; i < c4; i += 64) {
-        const float4 v = reinterpret_cast<const float4 *>(xr)[i];
-        ushort4 h, l;
-        x2_split(x2_act(v.x, act) * s, h.x, l.x); x2_split(x2_act(v.y, act) * s, h.y, l.y); x2_split(x2_act(v.z, act) * s, h.z, l.z);
-        x2_split(x2_act(v.w, act) * s, h.w, l.w);
-        reinterpret_cast<ushort4 *>(hi)[i] = h;
-        reinterpret_cast<ushort4 *>(lo)[i] = l;
+    if (cached) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = lane + 64 * j;
+            if (i < c4) {
+                ushort4 h, l;
+                x2_split(v[j].x * s, h.x, l.x); x2_split(v[j].y * s, h.y, l.y); x2_split(v[j].z * s, h.z, l.z); x2_split(v[j].w * s, h.w, l.w);
+                reinterpret_cast<ushort4 *>(hi)[i] = h;
+                reinterpret_cast<ushort4 *>(lo)[i] = l;
+            }
+        }
+    } else {
+        for (int i = lane; i < c4; i += 64) {
+            const float4 w = reinterpret_cast<const float4 *>(xr)[i];
+            ushort4 h, l;
+            x2_split(x2_act(w.x, act) * s, h.x, l.x); x2_split(x2_act(w.y, act) * s, h.y, l.y); x2_split(x2_act(w.z, act) * s, h.z, l.z);
+            x2_split(x2_act(w.w, act) * s, h.w, l.w);
+            reinterpret_cast<ushort4 *>(hi)[i] = h;
+            reinterpret_cast<ushort4 *>(lo)[i] = l;
+        }
     }
     for (int i = c4 * 4 + lane; i < kp; i += 64) {
         unsigned short h = 0, l = 0;
@@ -97,6 +130,42 @@ __global__ __launch_bounds__(256) void colmax_kernel(const float *x, int64_t ldx
         mx = fmaxf(fmaxf(red[0][cx], red[1][cx]), fmaxf(red[2][cx], red[3][cx]));
         if (mx != mx) mx = __uint_as_float(0x7f800000u);            // a NaN column: scale 1 (x2_scale), the NaNs pass through the split
         atomicMax(colmax + col, __float_as_uint(mx));
+    }
+}
+
+// the same with 16-byte loads: a lane owns four consecutive columns, a workgroup 256 columns x rows_per_block rows (four row phases of 64
+// lanes: 1 KiB contiguous per row and phase, four rows in flight per lane)
+__global__ __launch_bounds__(256) void colmax4_kernel(const float *x, int64_t ldx, int rows, int cols, int rows_per_block, unsigned *colmax, int act) {
+    __shared__ float4 red[4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int col = blockIdx.x * 256 + cx * 4;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    float4 mx = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto take = [&](const float4 &v) {
+        mx.x = fmaxf(mx.x, fabsf(x2_act(v.x, act))); mx.y = fmaxf(mx.y, fabsf(x2_act(v.y, act)));
+        mx.z = fmaxf(mx.z, fabsf(x2_act(v.z, act))); mx.w = fmaxf(mx.w, fabsf(x2_act(v.w, act)));
+    };
+    if (col < cols) {                                   // cols is a multiple of 4 here: the quad is whole
+        const float *p = x + col;
+        int r = r0 + ry;
+        for (; r + 12 < r1; r += 16) {
+            const float4 a = *reinterpret_cast<const float4 *>(p + (int64_t)r * ldx), b = *reinterpret_cast<const float4 *>(p + (int64_t)(r + 4) * ldx);
+            const float4 c = *reinterpret_cast<const float4 *>(p + (int64_t)(r + 8) * ldx), d = *reinterpret_cast<const float4 *>(p + (int64_t)(r + 12) * ldx);
+            take(a); take(b); take(c); take(d);
+        }
+        for (; r < r1; r += 4) take(*reinterpret_cast<const float4 *>(p + (int64_t)r * ldx));
+    }
+    red[ry][cx] = mx;
+    __syncthreads();
+    if (ry == 0 && col < cols) {
+        const float4 a = red[0][cx], b = red[1][cx], c = red[2][cx], d = red[3][cx];
+        float m[4] = {fmaxf(fmaxf(a.x, b.x), fmaxf(c.x, d.x)), fmaxf(fmaxf(a.y, b.y), fmaxf(c.y, d.y)), fmaxf(fmaxf(a.z, b.z), fmaxf(c.z, d.z)),
+                      fmaxf(fmaxf(a.w, b.w), fmaxf(c.w, d.w))};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (m[e] != m[e]) m[e] = __uint_as_float(0x7f800000u);
+            atomicMax(colmax + col + e, __float_as_uint(m[e]));
+        }
     }
 }
 
@@ -178,7 +247,10 @@ extern "C" int la_split_f16x2_t_act(const float *x, int64_t ldx, int32_t rows, i
     LA_HIP(hipMemsetAsync(colmax, 0, (size_t)cols * sizeof(unsigned), stream));
     la::TimerScope ts("split_f16x2", stream, (double)rows * cols * 12.0);
     const int rpb = 512;
-    hipLaunchKernelGGL(colmax_kernel, dim3(la::cdiv(cols, 64), la::cdiv(rows, rpb)), dim3(256), 0, stream, x, ldx, rows, cols, rpb, colmax, act);
+    if (cols % 4 == 0 && ldx % 4 == 0 && (uintptr_t)x % 16 == 0)
+        hipLaunchKernelGGL(colmax4_kernel, dim3(la::cdiv(cols, 256), la::cdiv(rows, 128)), dim3(256), 0, stream, x, ldx, rows, cols, 128, colmax, act);
+    else
+        hipLaunchKernelGGL(colmax_kernel, dim3(la::cdiv(cols, 64), la::cdiv(rows, rpb)), dim3(256), 0, stream, x, ldx, rows, cols, rpb, colmax, act);
     LA_LAUNCH_CHECK();
     hipLaunchKernelGGL(split_transposed_kernel, dim3(la::cdiv(cols, 64), la::cdiv(mp, 64)), dim3(256), 0, stream, x, ldx, rows, cols, colmax,
                        reinterpret_cast<unsigned short *>(planes_t), mp, inv_scale_t, act);
