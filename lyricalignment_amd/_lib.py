@@ -114,13 +114,7 @@ SYMBOLS = {
 }
 
 # symbols of the EXPERIMENT build only (csrc/lab/; bound when the loaded library has them: tools/build_variant.sh lab -DLA_EXPERIMENTS)
-LAB_SYMBOLS = {
-    "la_attention_bwd_x2_workspace_bytes": (c_int32, [_I32, _I32, _I32, _I32, POINTER(_SZ)]),
-    "la_attention_bwd_x2_f32": (c_int32, [_P, _I64, _P, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _P,
-                                          _SZ, _P]),
-    "la_attention_x2_workspace_bytes": (c_int32, [_I32, _I32, _I32, _I32, POINTER(_SZ)]),
-    "la_attention_x2_lse_f32": (c_int32, [_P, _I64, _P, _P, _I64, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _P, _SZ, _P]),
-}
+LAB_SYMBOLS = {}     # (none at present: the experiments left in csrc/lab/ are alternative kernels behind la_gemm's own entry points)
 
 
 

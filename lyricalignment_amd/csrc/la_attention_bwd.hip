@@ -329,7 +329,7 @@ extern "C" int la_attention_bwd_workspace_bytes(int32_t batch, int32_t q_len, in
     return LA_OK;
 }
 
-// The statistics launch alone (lse unless handed in, D = sum dO o O per query row): shared with la_attention_bwd_x2_f32.
+// The statistics launch alone (lse unless handed in, D = sum dO o O per query row): shared with la_attention_bwd_f16x2 (la_attention_f16x2.hip).
 extern "C" int la_attention_bwd_stats_f32(const float *q, int64_t ld_q, const float *k, int64_t ld_kv, const float *o, int64_t ld_o, const float *dout,
                                           int64_t ld_do, int32_t batch, int32_t q_len, int32_t kv_len, int32_t n_head, int32_t causal,
                                           const float *lse_in, float *lse, float *dvec, void *stream_) {

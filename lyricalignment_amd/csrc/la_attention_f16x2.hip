@@ -7,7 +7,7 @@
 // Forward (this file's first half): the register-resident flash form of the 16-bit inference kernel (la_attention.hip: the score tile is
 // computed transposed, S^T = K Q^T, so a lane holds one query's scores; the exponentiated tile is directly the B operand of
 // O^T += V^T P^T; K and V tiles staged by LDS-DMA into swizzled images, V^T fragments by ds_read_b64_tr_b16) with every product as three
-// 32x32x16 f16 MFMAs.  An earlier attempt built on the 64 x 64 LDS-tiled float32 kernels (lab/la_attention_x2.hip) was bound by LDS round
+// 32x32x16 f16 MFMAs.  An earlier attempt built on the 64 x 64 LDS-tiled float32 kernels (round 5, profiles/NOTES.md) was bound by LDS round
 // trips at one workgroup per CU and gained 1.1 x; this form keeps Q, the scores, P and O in registers.
 //
 // Operands.  q (pre-scaled by the caller as for the float32 kernel), k, v are split once per call into planes [token][2][64 H] f16 with ONE

@@ -88,29 +88,18 @@ def transpose_batched(src, ld_in, bs_in, rows, cols, out, ld_out, bs_out, out_ro
 
 
 ATTN_BWD_COMPOSED = os.environ.get("LA_ATTN_BWD", "fused") == "composed"     # developer A/B: the round-1 composition of batched GEMMs
-# Experiment build of the library only (csrc/lab/la_attention_x2.hip, LA_ATTN_BWD_X2=1): the fused backward's products on the f16 pipe at
-# float32 accuracy -- parity-green, 1.07 x per layer, nothing on the step (profiles/NOTES.md): not shipped
-ATTN_BWD_X2 = os.environ.get("LA_ATTN_BWD_X2", "0") == "1"
 
 
 def attention_bwd_ex(q, k, v, do, dq, dk, dv, B: int, Tq: int, Tk: int, H: int, causal: bool = False, o=None, lse=None) -> None:
     """Row views q/do/dq [B*Tq, >=64H], k/v/dk/dv [B*Tk, >=64H] (column slices of packed projections are fine; q pre-scaled
-    by 1/8).  With the forward output `o` given: the fused kernel la_attention_bwd_f32 (scores recomputed per 64 x 64 tile, nothing
-    of size Tq x Tk materialised, all clips in three launches).  Without it (or LA_ATTN_BWD=composed), per clip, for all heads
+    by 1/8).  With the forward output `o` given: the fused sweeps (scores recomputed per tile, nothing of size Tq x Tk materialised, all
+    clips at once) -- la_attention_bwd_f16x2 (the seven products on the f16 pipe at float32 accuracy) from 128 queries and keys on,
+    la_attention_bwd_f32 (float32 MFMA) below that or with LA_ATTN_F16X2=0.  Without it (or LA_ATTN_BWD=composed), per clip, for all heads
     at once: S = q k^T and P = softmax(S) are recomputed as whole [H, Tq, Tk] tiles,
     dP = dO v^T, dS = P o (dP - rowsum(dP o P)), dQ = dS k, dK = dS^T q, dV = P^T dO."""
     if o is not None and not ATTN_BWD_COMPOSED and k.stride(0) == v.stride(0) and dk.stride(0) == dv.stride(0):
         import ctypes
         need = ctypes.c_size_t(0)
-        if ATTN_BWD_X2 and _lib.has_experiments() and Tq % 4 == 0 and Tk % 4 == 0 and Tq * Tk >= 64 * 64:
-            check(lib().la_attention_bwd_x2_workspace_bytes(B, Tq, Tk, H, ctypes.byref(need)), "attention_bwd_x2_workspace_bytes")
-            ws = torch.empty((need.value + 256,), dtype=torch.uint8, device=q.device)
-            off = (-ws.data_ptr()) % 256
-            check(lib().la_attention_bwd_x2_f32(ptr(q), q.stride(0), ptr(k), ptr(v), k.stride(0), ptr(o), o.stride(0), ptr(do), do.stride(0),
-                                                ptr(dq), dq.stride(0), ptr(dk), ptr(dv), dk.stride(0), B, Tq, Tk, H, 1 if causal else 0,
-                                                ptr(lse) if lse is not None else None, ws.data_ptr() + off, need.value, stream_ptr()), "attention_bwd_x2")
-            return
-        from . import ops
         if ops.ATTN_F16X2 and Tq >= 128 and Tk >= 128:
             # the seven products on the f16 pipe at float32 accuracy (la_attention_bwd_f16x2; csrc/la_attention_f16x2.hip)
             check(lib().la_attention_bwd_f16x2_workspace_bytes(B, Tq, Tk, H, ctypes.byref(need)), "attention_bwd_f16x2_workspace_bytes")

@@ -165,8 +165,8 @@ def _rel(a, b):
 @pytest.mark.parametrize("B,T,H", [(1, 96, 2), (2, 1500, 1), (1, 333, 3), (3, 64, 2), (2, 130, 1)])
 def test_attention_backward_matches_torch_autograd(B, T, H, fused):
     """dQ/dK/dV against torch autograd: the fused kernel la_attention_bwd_f32 (forward output given: scores recomputed per 64 x 64
-    tile) and the round-1 composition (batched f32 MFMA GEMMs over whole score tiles + row softmax kernels).  (With the experiment
-    build and LA_ATTN_BWD_X2 = 1 the same test runs the lab's f16x2 sweeps: tests/test_gpu_lab.py.)"""
+    tile; from 128 queries and keys on la_attention_bwd_f16x2, the same sweeps on the f16 pipe) and the round-1 composition (batched f32 MFMA
+    GEMMs over whole score tiles + row softmax kernels)."""
     from lyricalignment_amd import encoder_train as et
     d = 64 * H
     g = torch.Generator().manual_seed(T)
@@ -269,8 +269,7 @@ def test_attention_backward_f16x2_is_deterministic_and_matches_the_float32_sweep
                                               (2, 64, 64, 2, True), (1, 132, 132, 1, True), (2, 8, 1500, 2, False), (1, 72, 200, 3, False)])
 def test_fused_attention_backward_causal_and_cross_shapes(B, Tq, Tk, H, causal):
     """la_attention_bwd_f32 on the text decoder's shapes: causal self-attention and cross-attention (q_len != kv_len, ragged last
-    tiles, operands as column slices of packed projections) against torch autograd.  (The last four cases have lengths that are
-    multiples of 4: what the experiment build's f16x2 sweeps take, tests/test_gpu_lab.py.)"""
+    tiles, operands as column slices of packed projections) against torch autograd."""
     from lyricalignment_amd import encoder_train as et
     d = 64 * H
     g = torch.Generator().manual_seed(Tq * 7 + Tk)

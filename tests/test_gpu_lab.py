@@ -36,19 +36,6 @@ def test_experiment_build_in_a_child_process():
     assert r.returncode == 0 and " passed" in r.stdout and "skipped" not in r.stdout.splitlines()[-1], r.stdout[-3000:] + r.stderr[-2000:]
 
 
-def test_attention_on_the_f16x2_scheme_in_a_child_process():
-    """csrc/lab/la_attention_x2.hip (float32 attention forward + fused backward with their products on the f16 pipe): the attention
-    parity tests of tests/test_gpu_finetune.py re-run on the experiment build with LA_ATTN_BWD_X2 = 1 -- the same
-    tolerances as the float32 kernels (2e-4 of the largest gradient; lse / out 2e-5)."""
-    if os.environ.get("LA_LIB_PATH"):
-        pytest.skip("already inside a child")
-    if not os.path.exists(LAB_LIB):
-        pytest.skip("experiment build not present (bash tools/build_variant.sh lab -DLA_EXPERIMENTS)")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_finetune.py"), "-q", "-x", "-m", "gpu", "-k", "attention"],
-                       env=dict(os.environ, LA_LIB_PATH=LAB_LIB, LA_ATTN_BWD_X2="1"), capture_output=True, text=True, timeout=1500)
-    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
-
-
 @pytest.fixture(autouse=True)
 def _needs_experiments(request):
     if "child_process" in request.node.name:
