@@ -463,6 +463,11 @@ int la_split_f16x2_t(const float *x, int64_t ldx, int32_t rows, int32_t cols, vo
  * gelu(u) goes from u into its planes without a float32 copy of its own (forward product and weight gradient) */
 int la_split_f16x2_act(const float *x, int64_t ldx, int32_t rows, int32_t cols, void *planes, int64_t kp, float *inv_scale, int32_t act, void *stream);
 int la_split_f16x2_t_act(const float *x, int64_t ldx, int32_t rows, int32_t cols, void *planes_t, int64_t mp, float *inv_scale_t, int32_t act, void *stream);
+/* la_split_f16x2_t_act that also returns colsum[c] = sum_r x[r][c] (NULL: not wanted; act must be 0): the bias gradient sum_r dy next to
+ * the weight gradient dy^T x whose operand the split makes, from the same pass over dy (float64 partials per row block, added in order:
+ * deterministic, as la_colsum_f32) */
+int la_split_f16x2_t_colsum(const float *x, int64_t ldx, int32_t rows, int32_t cols, void *planes_t, int64_t mp, float *inv_scale_t, int32_t act,
+                            float *colsum, void *stream);
 int la_gemm_f16x2(int32_t M, int32_t N, int32_t K, int32_t slots, const void *A, const float *sa, const void *W, const float *sw,
                   float *C, int64_t ldc, const float *bias, const float *residual, int64_t ldr, int32_t epilogue, void *stream);
 

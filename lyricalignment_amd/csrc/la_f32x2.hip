@@ -135,8 +135,14 @@ __global__ __launch_bounds__(256) void colmax_kernel(const float *x, int64_t ldx
 
 // the same with 16-byte loads: a lane owns four consecutive columns, a workgroup 256 columns x rows_per_block rows (four row phases of 64
 // lanes: 1 KiB contiguous per row and phase, four rows in flight per lane)
-__global__ __launch_bounds__(256) void colmax4_kernel(const float *x, int64_t ldx, int rows, int cols, int rows_per_block, unsigned *colmax, int act) {
+// SUMS: also the column sums of x (the bias gradient that goes with a weight gradient dy^T x: the same pass over dy) as float64 partials
+// per row block, part[blockIdx.y][col]; colsum_blocks_kernel adds the blocks in order (deterministic, as la_colsum_f32)
+template <bool SUMS>
+__global__ __launch_bounds__(256) void colmax4_kernel(const float *x, int64_t ldx, int rows, int cols, int rows_per_block, unsigned *colmax, int act,
+                                                      double *part) {
     __shared__ float4 red[4][64];
+    __shared__ double reds[SUMS ? 4 : 1][SUMS ? 64 : 1][4];
+    double sm[4] = {0.0, 0.0, 0.0, 0.0};
     const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
     const int col = blockIdx.x * 256 + cx * 4;
     const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
@@ -144,6 +150,7 @@ __global__ __launch_bounds__(256) void colmax4_kernel(const float *x, int64_t ld
     auto take = [&](const float4 &v) {
         mx.x = fmaxf(mx.x, fabsf(x2_act(v.x, act))); mx.y = fmaxf(mx.y, fabsf(x2_act(v.y, act)));
         mx.z = fmaxf(mx.z, fabsf(x2_act(v.z, act))); mx.w = fmaxf(mx.w, fabsf(x2_act(v.w, act)));
+        if constexpr (SUMS) { sm[0] += (double)v.x; sm[1] += (double)v.y; sm[2] += (double)v.z; sm[3] += (double)v.w; }
     };
     if (col < cols) {                                   // cols is a multiple of 4 here: the quad is whole
         const float *p = x + col;
@@ -156,8 +163,16 @@ __global__ __launch_bounds__(256) void colmax4_kernel(const float *x, int64_t ld
         for (; r < r1; r += 4) take(*reinterpret_cast<const float4 *>(p + (int64_t)r * ldx));
     }
     red[ry][cx] = mx;
+    if constexpr (SUMS) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) reds[ry][cx][e] = sm[e];
+    }
     __syncthreads();
     if (ry == 0 && col < cols) {
+        if constexpr (SUMS) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) part[(int64_t)blockIdx.y * cols + col + e] = (reds[0][cx][e] + reds[1][cx][e]) + (reds[2][cx][e] + reds[3][cx][e]);
+        }
         const float4 a = red[0][cx], b = red[1][cx], c = red[2][cx], d = red[3][cx];
         float m[4] = {fmaxf(fmaxf(a.x, b.x), fmaxf(c.x, d.x)), fmaxf(fmaxf(a.y, b.y), fmaxf(c.y, d.y)), fmaxf(fmaxf(a.z, b.z), fmaxf(c.z, d.z)),
                       fmaxf(fmaxf(a.w, b.w), fmaxf(c.w, d.w))};
@@ -167,6 +182,20 @@ __global__ __launch_bounds__(256) void colmax4_kernel(const float *x, int64_t ld
             atomicMax(colmax + col + e, __float_as_uint(m[e]));
         }
     }
+}
+
+// out[c] = sum of the row blocks' partials in a fixed order: 64 columns per workgroup, four threads per column take every fourth block each,
+// their sums are added as ((0 + 1) + (2 + 3))
+__global__ __launch_bounds__(256) void colsum_blocks_kernel(const double *part, int blocks, int cols, float *out) {
+    __shared__ double red[4][64];
+    const int cx = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    double s = 0.0;
+    if (c < cols)
+        for (int k = ph; k < blocks; k += 4) s += part[(int64_t)k * cols + c];
+    red[ph][cx] = s;
+    __syncthreads();
+    if (ph == 0 && c < cols) out[c] = (float)((red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]));
 }
 
 // 64 (rows of x) x 64 (columns of x) tiles through LDS: read along the columns, written along the rows of x (= along the padded
@@ -235,10 +264,15 @@ extern "C" int la_split_f16x2(const float *x, int64_t ldx, int32_t rows, int32_t
     return la_split_f16x2_act(x, ldx, rows, cols, planes, kp, inv_scale, 0, stream_);
 }
 
-extern "C" int la_split_f16x2_t_act(const float *x, int64_t ldx, int32_t rows, int32_t cols, void *planes_t, int64_t mp, float *inv_scale_t,
-                                    int32_t act, void *stream_) {
+extern "C" int la_colsum_f32(const float *in, int64_t ld, int32_t rows, int32_t cols, float *out, void *stream);
+
+// colsum != NULL (act must be 0): also out[c] = sum_r x[r][c] -- the bias gradient next to the weight gradient whose operand this split
+// makes, from the same pass over x that finds the column maxima
+extern "C" int la_split_f16x2_t_colsum(const float *x, int64_t ldx, int32_t rows, int32_t cols, void *planes_t, int64_t mp, float *inv_scale_t,
+                                       int32_t act, float *colsum, void *stream_) {
     if (cols == 0) return LA_OK;
     LA_CHECK_ARG(act == 0 || act == 1, "split_f16x2_t: act is 0 (none) or 1 (GELU)");
+    LA_CHECK_ARG(!colsum || act == 0, "split_f16x2_t: column sums are those of x itself (act = 0)");
     LA_CHECK_ARG(x && planes_t && inv_scale_t && rows > 0 && cols > 0, "split_f16x2_t: bad arguments");
     LA_CHECK_ARG(mp >= rows && mp % 16 == 0 && ldx >= cols && (uintptr_t)planes_t % 16 == 0, "split_f16x2_t: mp must be >= rows and a multiple of 16, planes 16-byte aligned");
     hipStream_t stream = (hipStream_t)stream_;
@@ -247,15 +281,33 @@ extern "C" int la_split_f16x2_t_act(const float *x, int64_t ldx, int32_t rows, i
     LA_HIP(hipMemsetAsync(colmax, 0, (size_t)cols * sizeof(unsigned), stream));
     la::TimerScope ts("split_f16x2", stream, (double)rows * cols * 12.0);
     const int rpb = 512;
-    if (cols % 4 == 0 && ldx % 4 == 0 && (uintptr_t)x % 16 == 0)
-        hipLaunchKernelGGL(colmax4_kernel, dim3(la::cdiv(cols, 256), la::cdiv(rows, 128)), dim3(256), 0, stream, x, ldx, rows, cols, 128, colmax, act);
-    else
+    if (cols % 4 == 0 && ldx % 4 == 0 && (uintptr_t)x % 16 == 0) {
+        const dim3 grid(la::cdiv(cols, 256), la::cdiv(rows, 128));
+        if (colsum) {
+            double *part = static_cast<double *>(la::stream_scratch(stream, la::SCRATCH_COLSUM, sizeof(double) * (size_t)grid.y * cols));
+            if (!part) { la::set_error("split_f16x2_t: scratch allocation failed"); return LA_EHIP; }
+            hipLaunchKernelGGL(colmax4_kernel<true>, grid, dim3(256), 0, stream, x, ldx, rows, cols, 128, colmax, act, part);
+            hipLaunchKernelGGL(colsum_blocks_kernel, dim3(la::cdiv(cols, 64)), dim3(256), 0, stream, part, (int)grid.y, cols, colsum);
+        } else {
+            hipLaunchKernelGGL(colmax4_kernel<false>, grid, dim3(256), 0, stream, x, ldx, rows, cols, 128, colmax, act, (double *)nullptr);
+        }
+    } else {
         hipLaunchKernelGGL(colmax_kernel, dim3(la::cdiv(cols, 64), la::cdiv(rows, rpb)), dim3(256), 0, stream, x, ldx, rows, cols, rpb, colmax, act);
+        if (colsum) {
+            const int rc = la_colsum_f32(x, ldx, rows, cols, colsum, stream_);
+            if (rc != LA_OK) return rc;
+        }
+    }
     LA_LAUNCH_CHECK();
     hipLaunchKernelGGL(split_transposed_kernel, dim3(la::cdiv(cols, 64), la::cdiv(mp, 64)), dim3(256), 0, stream, x, ldx, rows, cols, colmax,
                        reinterpret_cast<unsigned short *>(planes_t), mp, inv_scale_t, act);
     LA_LAUNCH_CHECK();
     return LA_OK;
+}
+
+extern "C" int la_split_f16x2_t_act(const float *x, int64_t ldx, int32_t rows, int32_t cols, void *planes_t, int64_t mp, float *inv_scale_t,
+                                    int32_t act, void *stream_) {
+    return la_split_f16x2_t_colsum(x, ldx, rows, cols, planes_t, mp, inv_scale_t, act, nullptr, stream_);
 }
 
 extern "C" int la_split_f16x2_t(const float *x, int64_t ldx, int32_t rows, int32_t cols, void *planes_t, int64_t mp, float *inv_scale_t, void *stream_) {

@@ -16,7 +16,7 @@ import torch
 from . import _lib, f32x2, ops
 from ._lib import check, lib, ptr, stream_ptr
 from .encoder_train import add, attention_bwd, attention_bwd_ex, gelu, gelu_bwd, layernorm_bwd, scale
-from .head_train import colsum, gemm_nn, gemm_tn, grads_to
+from .head_train import colsum, gemm_nn, gemm_tn, grads_to, linear_grads
 
 PER_BLOCK = ("attn_ln.weight", "attn_ln.bias", "attn.query.weight", "attn.query.bias", "attn.key.weight", "attn.value.weight",
              "attn.value.bias", "attn.out.weight", "attn.out.bias",
@@ -101,19 +101,19 @@ class DecoderFunction(torch.autograd.Function):
             g1, wqkv, wo, gc, wq_c, wkv_c, woc, g2, w1, w2 = ctx.packed[i]
             G = [None] * NB
             # MLP
-            G[22], G[23] = gemm_tn(dx, u_pre, b_act="gelu"), colsum(dx)
+            G[22], G[23] = linear_grads(dx, u_pre, x_act="gelu")
             du_pre = gelu_bwd(u_pre, gemm_nn(dx, w2))
-            G[20], G[21] = gemm_tn(du_pre, h2), colsum(du_pre)
+            G[20], G[21] = linear_grads(du_pre, h2)
             dln, G[18], G[19] = layernorm_bwd(x2, gemm_nn(du_pre, w1), g2)
             dx2 = add(dx, dln)
             # cross-attention to the audio features
-            G[16], G[17] = gemm_tn(dx2, ac), colsum(dx2)
+            G[16], G[17] = linear_grads(dx2, ac)
             dac = gemm_nn(dx2, woc)
             dqc = torch.empty((M, d), dtype=torch.float32, device=dev)
             dkv = torch.empty((B * Ta, 2 * d), dtype=torch.float32, device=dev)
             attention_bwd_ex(qc, kv[:, :d], kv[:, d:], dac, dqc, dkv[:, :d], dkv[:, d:], B, n, Ta, H, causal=False, o=ac)
             G[11], G[12] = scale(gemm_tn(dqc, hc), 0.125), scale(colsum(dqc), 0.125)
-            dwkv, dbkv = gemm_tn(dkv, xa2), colsum(dkv)
+            dwkv, dbkv = linear_grads(dkv, xa2)
             G[13], G[14], G[15] = dwkv[:d], dwkv[d:], dbkv[d:]
             if ctx.xa_needs_grad:
                 t = gemm_nn(dkv, wkv_c)
@@ -121,9 +121,9 @@ class DecoderFunction(torch.autograd.Function):
             dln, G[9], G[10] = layernorm_bwd(x1, gemm_nn(dqc, wq_c), gc)
             dx1 = add(dx2, dln)
             # causal self-attention
-            G[7], G[8] = gemm_tn(dx1, a), colsum(dx1)
+            G[7], G[8] = linear_grads(dx1, a)
             dqkv = attention_bwd(qkv, gemm_nn(dx1, wo), B, n, H, causal=True, att=a)
-            dwqkv, dbqkv = gemm_tn(dqkv, h1), colsum(dqkv)
+            dwqkv, dbqkv = linear_grads(dqkv, h1)
             G[2], G[3] = scale(dwqkv[:d], 0.125), scale(dbqkv[:d], 0.125)
             G[4], G[5], G[6] = dwqkv[d:2 * d], dwqkv[2 * d:], dbqkv[2 * d:]
             dln, G[0], G[1] = layernorm_bwd(x, gemm_nn(dqkv, wqkv), g1)

@@ -23,7 +23,7 @@ import torch
 
 from . import _lib, f32x2, ops
 from ._lib import check, lib, ptr, stream_ptr
-from .head_train import _rup, colsum, gemm_nn, gemm_tn, grads_to
+from .head_train import _rup, colsum, gemm_nn, gemm_tn, grads_to, linear_grads
 
 N_FRAMES, N_CTX, C_PAD = 3000, 1500, 128
 LA_F32 = 0
@@ -236,15 +236,15 @@ class EncoderFunction(torch.autograd.Function):
             g1, wqkv, wo, g2, w1, w2 = ctx.packed[i]
             G = [None] * 15
             # x_next = x_mid + gelu(u_pre) W2^T + b2
-            G[13], G[14] = gemm_tn(dx, u_pre, b_act="gelu"), colsum(dx)
+            G[13], G[14] = linear_grads(dx, u_pre, x_act="gelu")
             du_pre = gelu_bwd(u_pre, gemm_nn(dx, w2))
-            G[11], G[12] = gemm_tn(du_pre, h2), colsum(du_pre)
+            G[11], G[12] = linear_grads(du_pre, h2)
             dln, G[9], G[10] = layernorm_bwd(x_mid, gemm_nn(du_pre, w1), g2)
             dx_mid = add(dx, dln)
             # x_mid = x + att Wo^T + bo
-            G[7], G[8] = gemm_tn(dx_mid, att), colsum(dx_mid)
+            G[7], G[8] = linear_grads(dx_mid, att)
             dqkv = attention_bwd(qkv, gemm_nn(dx_mid, wo), B, N_CTX, H, att=att, lse=lse)
-            dwqkv, dbqkv = gemm_tn(dqkv, h1), colsum(dqkv)
+            dwqkv, dbqkv = linear_grads(dqkv, h1)
             G[2], G[3] = scale(dwqkv[:d], 0.125), scale(dbqkv[:d], 0.125)
             G[4], G[5], G[6] = dwqkv[d:2 * d], dwqkv[2 * d:], dbqkv[2 * d:]
             dln, G[0], G[1] = layernorm_bwd(x, gemm_nn(dqkv, wqkv), g1)

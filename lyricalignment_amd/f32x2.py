@@ -62,15 +62,16 @@ def split(x: torch.Tensor, kp: Optional[int] = None, act: Optional[str] = None) 
     return Planes(planes, inv, rows, k, kp)
 
 
-def split_t(x: torch.Tensor, mp: Optional[int] = None, act: Optional[str] = None) -> Planes:
-    """x [m, k] float32 -> the planes of x^T (of act(x)^T): rows = k, contraction length m zero-padded to mp (default: m rounded up to 128)."""
+def split_t(x: torch.Tensor, mp: Optional[int] = None, act: Optional[str] = None, colsum: Optional[torch.Tensor] = None) -> Planes:
+    """x [m, k] float32 -> the planes of x^T (of act(x)^T): rows = k, contraction length m zero-padded to mp (default: m rounded up to 128).
+    colsum [k] float32 (act None): also filled with the column sums of x, from the pass that finds the column maxima."""
     if x.dtype != torch.float32 or x.dim() != 2 or x.stride(1) != 1:
         raise ValueError("f32x2.split_t: a float32 [m, k] row view is expected")
     m, k = x.shape
     mp = _rup(m, 128) if mp is None else mp
     planes = torch.empty((k, 2, mp), dtype=torch.float16, device=x.device)
     inv = torch.empty((k,), dtype=torch.float32, device=x.device)
-    check(lib().la_split_f16x2_t_act(ptr(x), x.stride(0), m, k, ptr(planes), mp, ptr(inv), ACT[act], stream_ptr()), "split_f16x2_t")
+    check(lib().la_split_f16x2_t_colsum(ptr(x), x.stride(0), m, k, ptr(planes), mp, ptr(inv), ACT[act], ptr(colsum), stream_ptr()), "split_f16x2_t")
     return Planes(planes, inv, k, m, mp)
 
 
@@ -153,8 +154,9 @@ def gemm_nn(dy: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     return head_train.gemm_nn_f32(dy, w)
 
 
-def gemm_tn(dy: torch.Tensor, x: torch.Tensor, x_act: Optional[str] = None) -> torch.Tensor:
-    """dy [M, N]^T . act(x) [M, K] -> [N, K]: the weight gradient of y = act(x) w^T (contraction over the M rows of both)."""
+def gemm_tn(dy: torch.Tensor, x: torch.Tensor, x_act: Optional[str] = None, colsum: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dy [M, N]^T . act(x) [M, K] -> [N, K]: the weight gradient of y = act(x) w^T (contraction over the M rows of both).
+    colsum [N] float32: also filled with the bias gradient sum_m dy[m, :] (from the split's pass over dy, or la_colsum_f32)."""
     from . import head_train
     M, N = dy.shape
     K = x.shape[1]
@@ -162,5 +164,7 @@ def gemm_tn(dy: torch.Tensor, x: torch.Tensor, x_act: Optional[str] = None) -> t
         mp = padded_k(N, K, M)
         if not FUSE_ACT:
             x, x_act = _apply(x, x_act), None
-        return gemm(split_t(dy, mp), split_t(x, mp, act=x_act))
+        return gemm(split_t(dy, mp, colsum=colsum), split_t(x, mp, act=x_act))
+    if colsum is not None:
+        check(lib().la_colsum_f32(ptr(dy), dy.stride(0), M, N, ptr(colsum), stream_ptr()), "colsum")
     return head_train.gemm_tn_f32(dy, _apply(x, x_act))

@@ -78,6 +78,14 @@ def _gemm_ex_flags(Mg: int, Ng: int, Kg: int, a: torch.Tensor, w: torch.Tensor, 
     return out
 
 
+def linear_grads(dy: torch.Tensor, x: torch.Tensor, x_act: Optional[str] = None):
+    """(dw, db) of y = act(x) w^T + b from dy [M, N] and x [M, K]: dw = dy^T act(x), db = the column sums of dy -- on the f16x2 path from the
+    one pass over dy that the operand split makes anyway (la_split_f16x2_t_colsum), otherwise la_colsum_f32."""
+    from . import f32x2
+    db = torch.empty((dy.shape[1],), dtype=torch.float32, device=dy.device)
+    return f32x2.gemm_tn(dy, x, x_act=x_act, colsum=db), db
+
+
 def gemm_tn(a: torch.Tensor, b: torch.Tensor, b_act: Optional[str] = None) -> torch.Tensor:
     """a [M,N]^T . act(b) [M,K] -> [N,K]: the weight gradient of a Linear (b_act = "gelu": of the MLP's second Linear, whose operand is
     gelu(b)).  Large products on the f16x2 path, the rest gemm_tn_f32."""

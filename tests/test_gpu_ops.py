@@ -764,5 +764,14 @@ def test_f16x2_gradient_products_with_split_k_slots():
         e_x2 = float((got.double() - ref).abs().max() / ref.abs().max())
         e_f32 = float((nat.double() - ref).abs().max() / ref.abs().max())
         assert e_x2 <= max(e_f32, 4e-7) and e_x2 < 3e-6, (e_x2, e_f32)
+    # the bias gradient from the same pass over dy (la_split_f16x2_t_colsum): float64 partials per row block, added in order
+    dw2, db = head_train.linear_grads(dyd, xd)
+    assert torch.equal(dw2, dw) and torch.equal(db, head_train.linear_grads(dyd, xd)[1])
+    ref_db = dy.double().sum(0)
+    assert float((db.cpu().double() - ref_db).abs().max()) <= 1e-6 * float(dy.abs().sum(0).max())
+    assert float((head_train.colsum(dyd).cpu().double() - ref_db).abs().max()) <= 1e-6 * float(dy.abs().sum(0).max())
+    odd = dyd[:, :1534].contiguous()                 # columns not a multiple of 4 / products outside the f16x2 domain: la_colsum_f32 behind the same call
+    _, db_odd = head_train.linear_grads(odd[:200], xd[:200])
+    assert float((db_odd.cpu().double() - dy[:200, :1534].double().sum(0)).abs().max()) <= 1e-6 * float(dy[:200].abs().sum(0).max())
     with pytest.raises(NotImplementedError):          # outside the 256 x 256 kernel's domain: the C entry point refuses, the wrappers never ask
         f32x2.gemm(f32x2.split(xd[:300], 512), f32x2.split(wd, 512))
