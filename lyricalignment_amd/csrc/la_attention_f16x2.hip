@@ -338,7 +338,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_x2_fwd_kernel(FwdParams 
 // `loss.backward()`), the two sweeps of la_attention_bwd.hip (no atomics, nothing of size Tq x Tk leaves the CU) in the register-resident
 // form of the forward above, every product three f16 MFMAs:
 //   key sweep    a wave owns 32 keys -- K, V fragments (B operands) and the dV^T, dK^T accumulators live in registers -- and walks the query
-//                tiles:  S = Q K^T,  dP = dO V^T  (A operands: row fragments of the Q / dO images),  P = exp(S - lse),
+//                tiles (launched as a dV sweep and a dK sweep, see attention_x2_bwd_kv_kernel):  S = Q K^T,  dP = dO V^T  (A operands: row fragments of the Q / dO images),  P = exp(S - lse),
 //                dS = P o (dP - D),  dV^T += dO^T P,  dK^T += Q^T dS  (A operands: transposed fragments, ds_read_b64_tr_b16)
 //   query sweep  a wave owns 32 queries -- Q, dO fragments and dQ^T -- and walks the key tiles:  S^T = K Q^T,  dP^T = V dO^T,
 //                dS^T = P^T o (dP^T - D),  dQ^T += K^T dS^T
@@ -397,7 +397,13 @@ constexpr int KV_LDS = 2 * KV_BUF + 2 * 2 * 64 * 4;
 constexpr int Q_BUF = 6 * IMG;                  // K rows hi|lo, K transposed hi|lo, V rows hi|lo
 constexpr int Q_LDS = 2 * Q_BUF;
 
+// MODE 1: dV alone (K fragments, dV^T, scores); MODE 2: dK alone (K, V fragments, dK^T, scores, dP); MODE 3: both in one sweep.  The
+// library launches the PAIR: one sweep for both holds 160 resident registers + fragments and hipcc spills 63 of them (1359 us per layer of
+// 16 clips); the pair recomputes the scores once more (60 instead of 48 MFMAs per 32 queries), stages 4 + 6 instead of 8 images per tile
+// and does not spill: 499 + 720 us (profiles/r5_attention_f16x2_backward.txt).
+template <int MODE>
 __global__ __launch_bounds__(64 * BWD_NW, 2) void attention_x2_bwd_kv_kernel(BwdParams p) {
+    constexpr bool DV = MODE & 1, DK = MODE & 2;
     constexpr int NW = BWD_NW, KB = 32 * NW, PER = 8 / NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     float *stats = reinterpret_cast<float *>(lds + 2 * KV_BUF);      // [buf][nl | ds][64]
@@ -429,8 +435,12 @@ __global__ __launch_bounds__(64 * BWD_NW, 2) void attention_x2_bwd_kv_kernel(Bwd
         for (int c = 0; c < 4; ++c) {
             kh[c] = *reinterpret_cast<const uint4 *>(kb + 16 * c);
             kl[c] = *reinterpret_cast<const uint4 *>(kb + C + 16 * c);
-            vh[c] = *reinterpret_cast<const uint4 *>(vb + 16 * c);
-            vl[c] = *reinterpret_cast<const uint4 *>(vb + C + 16 * c);
+            if constexpr (DK) {
+                vh[c] = *reinterpret_cast<const uint4 *>(vb + 16 * c);
+                vl[c] = *reinterpret_cast<const uint4 *>(vb + C + 16 * c);
+            } else {
+                vh[c] = vl[c] = make_uint4(0u, 0u, 0u, 0u);
+            }
         }
     }
     f32x16 dv[2], dk[2];
@@ -447,16 +457,16 @@ __global__ __launch_bounds__(64 * BWD_NW, 2) void attention_x2_bwd_kv_kernel(Bwd
     auto stage = [&](int t, unsigned buf) __attribute__((always_inline)) {
         const KvOff<PER> &o = t == nq - 1 ? off_last : off_full;
         stage_tile<PER>(qbase, C, t * KT, o.k, buf, wave);
-        stage_tile<PER>(qbase, C, t * KT, o.v, buf + 2 * IMG, wave);
-        stage_tile<PER>(dobase, C, t * KT, o.k, buf + 4 * IMG, wave);
-        stage_tile<PER>(dobase, C, t * KT, o.v, buf + 6 * IMG, wave);
+        if constexpr (DK) stage_tile<PER>(qbase, C, t * KT, o.v, buf + 2 * IMG, wave);
+        if constexpr (DK) stage_tile<PER>(dobase, C, t * KT, o.k, buf + 4 * IMG, wave);
+        if constexpr (DV) stage_tile<PER>(dobase, C, t * KT, o.v, buf + 6 * IMG, wave);
     };
     // row statistics of a query tile: threads 0..63 bring 13 - lse log2 e, threads 64..127 D s_dS 2^-13 (rows past the end: 0, masked below)
     auto stat_load = [&](int t) -> float {
         float v = 0.f;
         if (tid < 128) {
             const int q = t * KT + (tid & 63);
-            if (q < Tq) v = tid < 64 ? 13.0f - lse_b[q] * kLog2e : dvec_b[q] * dscale;
+            if (q < Tq) v = tid < 64 ? 13.0f - lse_b[q] * kLog2e : (DK ? dvec_b[q] * dscale : 0.f);
         }
         return v;
     };
@@ -495,14 +505,16 @@ __global__ __launch_bounds__(64 * BWD_NW, 2) void attention_x2_bwd_kv_kernel(Bwd
             for (int c = 0; c < 4; ++c) {
                 const f16x8 ah = row_frag(qr, row, c, h), al = row_frag(qr + IMG, row, c, h);
                 s = mma3(ah, al, __builtin_bit_cast(f16x8, kh[c]), __builtin_bit_cast(f16x8, kl[c]), s);
-                const f16x8 gh = row_frag(dor, row, c, h), gl = row_frag(dor + IMG, row, c, h);
-                dp = mma3(gh, gl, __builtin_bit_cast(f16x8, vh[c]), __builtin_bit_cast(f16x8, vl[c]), dp);
+                if constexpr (DK) {
+                    const f16x8 gh = row_frag(dor, row, c, h), gl = row_frag(dor + IMG, row, c, h);
+                    dp = mma3(gh, gl, __builtin_bit_cast(f16x8, vh[c]), __builtin_bit_cast(f16x8, vl[c]), dp);
+                }
             }
             // ---- P 2^13 = exp2(s - lse + 13) (in s), dS s_dS = P 2^13 (dP_acc 2^-33 - D s_dS 2^-13) (in dp); rows = queries ----
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
                 const float4 nl = *reinterpret_cast<const float4 *>(st + sub * 32 + 8 * r4 + 4 * h);
-                const float4 ds = *reinterpret_cast<const float4 *>(st + 64 + sub * 32 + 8 * r4 + 4 * h);
+                const float4 ds = DK ? *reinterpret_cast<const float4 *>(st + 64 + sub * 32 + 8 * r4 + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
                 const float nlv[4] = {nl.x, nl.y, nl.z, nl.w}, dsv[4] = {ds.x, ds.y, ds.z, ds.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -514,19 +526,19 @@ __global__ __launch_bounds__(64 * BWD_NW, 2) void attention_x2_bwd_kv_kernel(Bwd
                     }
                     const float pv = __builtin_amdgcn_exp2f(a);
                     s[r] = pv;
-                    dp[r] = pv * fmaf(dp[r], 0x1p-33f, -dsv[e]);
+                    if constexpr (DK) dp[r] = pv * fmaf(dp[r], 0x1p-33f, -dsv[e]);
                 }
             }
             // ---- dV^T += dO^T P,  dK^T += Q^T dS ----
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 f16x8 ph, pl, sh, sl;
-                split8(s, ks, ph, pl);
-                split8(dp, ks, sh, sl);
+                if constexpr (DV) split8(s, ks, ph, pl);
+                if constexpr (DK) split8(dp, ks, sh, sl);
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
-                    dv[b] = mma3(tr_frag(dotr, sub * 32 + 16 * ks, b, L), tr_frag(dotr + IMG, sub * 32 + 16 * ks, b, L), ph, pl, dv[b]);
-                    dk[b] = mma3(tr_frag(qtr, sub * 32 + 16 * ks, b, L), tr_frag(qtr + IMG, sub * 32 + 16 * ks, b, L), sh, sl, dk[b]);
+                    if constexpr (DV) dv[b] = mma3(tr_frag(dotr, sub * 32 + 16 * ks, b, L), tr_frag(dotr + IMG, sub * 32 + 16 * ks, b, L), ph, pl, dv[b]);
+                    if constexpr (DK) dk[b] = mma3(tr_frag(qtr, sub * 32 + 16 * ks, b, L), tr_frag(qtr + IMG, sub * 32 + 16 * ks, b, L), sh, sl, dk[b]);
                 }
             }
         }
@@ -553,10 +565,12 @@ __global__ __launch_bounds__(64 * BWD_NW, 2) void attention_x2_bwd_kv_kernel(Bwd
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
-                *reinterpret_cast<float4 *>(dvrow + 32 * b + 8 * r4 + 4 * h) =
-                    make_float4(dv[b][4 * r4 + 0] * cv, dv[b][4 * r4 + 1] * cv, dv[b][4 * r4 + 2] * cv, dv[b][4 * r4 + 3] * cv);
-                *reinterpret_cast<float4 *>(dkrow + 32 * b + 8 * r4 + 4 * h) =
-                    make_float4(dk[b][4 * r4 + 0] * ck, dk[b][4 * r4 + 1] * ck, dk[b][4 * r4 + 2] * ck, dk[b][4 * r4 + 3] * ck);
+                if constexpr (DV)
+                    *reinterpret_cast<float4 *>(dvrow + 32 * b + 8 * r4 + 4 * h) =
+                        make_float4(dv[b][4 * r4 + 0] * cv, dv[b][4 * r4 + 1] * cv, dv[b][4 * r4 + 2] * cv, dv[b][4 * r4 + 3] * cv);
+                if constexpr (DK)
+                    *reinterpret_cast<float4 *>(dkrow + 32 * b + 8 * r4 + 4 * h) =
+                        make_float4(dk[b][4 * r4 + 0] * ck, dk[b][4 * r4 + 1] * ck, dk[b][4 * r4 + 2] * ck, dk[b][4 * r4 + 3] * ck);
             }
     }
 }
@@ -786,7 +800,8 @@ extern "C" int la_attention_bwd_f16x2(const float *q, int64_t ld_q, const float 
     LA_CHECK_ARG((uintptr_t)workspace % 256 == 0 && workspace_bytes >= ws.bytes, "attention_bwd_f16x2: workspace misaligned or too small");
     static la::DeviceOnce attr_once;
     if (attr_once.pending()) {
-        LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_x2_bwd_kv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, KV_LDS));
+        LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_x2_bwd_kv_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, KV_LDS));
+        LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_x2_bwd_kv_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, KV_LDS));
         LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_x2_bwd_q_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS));
         attr_once.mark();
     }
@@ -801,7 +816,9 @@ extern "C" int la_attention_bwd_f16x2(const float *q, int64_t ld_q, const float 
     hipLaunchKernelGGL(heads_split_kernel, sg, sb, 0, stream, dout, ld_do, q_len, n_head, ws.dop, ws.sdo);
     BwdParams p{ws.qp, ws.kp, ws.vp, ws.dop, ws.sq, ws.sk, ws.sv, ws.sdo, lse ? lse : ws.lse, ws.dvec, dq, dk, dv, ld_dq, ld_dkv, q_len, kv_len, n_head, causal ? 1 : 0, batch};
     constexpr int KB = 32 * BWD_NW;
-    hipLaunchKernelGGL(attention_x2_bwd_kv_kernel, dim3(la::cdiv(kv_len, KB) * n_head * batch), dim3(64 * BWD_NW), KV_LDS, stream, p);
+    const dim3 gkv(la::cdiv(kv_len, KB) * n_head * batch), blk(64 * BWD_NW);
+    hipLaunchKernelGGL(attention_x2_bwd_kv_kernel<1>, gkv, blk, KV_LDS, stream, p);
+    hipLaunchKernelGGL(attention_x2_bwd_kv_kernel<2>, gkv, blk, KV_LDS, stream, p);
     hipLaunchKernelGGL(attention_x2_bwd_q_kernel, dim3(la::cdiv(q_len, KB) * n_head * batch), dim3(64 * BWD_NW), Q_LDS, stream, p);
     LA_LAUNCH_CHECK();
     return LA_OK;
