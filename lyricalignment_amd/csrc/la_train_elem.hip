@@ -128,6 +128,88 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float *x, cons
     }
 }
 
+// The same with the two column sums taken on the way (dgamma = sum_r dy xhat, dbeta = sum_r dy): a row lives in registers (NV float4 per
+// lane, d = 256 NV), x and dy are read once, dy * xhat is never written.  A workgroup takes 128 rows, 32 per wave; a lane adds its columns'
+// terms over its wave's rows in float32 (32 terms), the four waves' sums are added in float64 in wave order and written per workgroup;
+// ln_sums_final_kernel adds the workgroups in order (deterministic).  137 us + two column-sum passes -> one pass.
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_bwd_sums_kernel(const float *x, const float *dy, const float *gamma, int M, float *dx,
+                                                                 double *part) {
+    constexpr int d = 256 * NV;
+    __shared__ float red[2][4][d];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row0 = blockIdx.x * 128 + wave * 32;
+    float4 gm[NV], sg_[NV], sb_[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        gm[j] = reinterpret_cast<const float4 *>(gamma)[lane + 64 * j];
+        sg_[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        sb_[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int i = 0; i < 32; ++i) {
+        const int row = row0 + i;
+        if (row >= M) break;                                   // wave-uniform
+        const float4 *xr = reinterpret_cast<const float4 *>(x + (int64_t)row * d), *gr = reinterpret_cast<const float4 *>(dy + (int64_t)row * d);
+        float4 xv[NV], gv[NV];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) { xv[j] = xr[lane + 64 * j]; gv[j] = gr[lane + 64 * j]; }
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) s += (xv[j].x + xv[j].y) + (xv[j].z + xv[j].w);
+        const float mean = wsum(s) / (float)d;
+        float sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            xv[j].x -= mean; xv[j].y -= mean; xv[j].z -= mean; xv[j].w -= mean;
+            sq += (xv[j].x * xv[j].x + xv[j].y * xv[j].y) + (xv[j].z * xv[j].z + xv[j].w * xv[j].w);
+        }
+        const float rstd = 1.0f / sqrtf(wsum(sq) / (float)d + 1e-5f);
+        float sg = 0.f, sgx = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            xv[j].x *= rstd; xv[j].y *= rstd; xv[j].z *= rstd; xv[j].w *= rstd;          // xhat
+            const float4 g = make_float4(gv[j].x * gm[j].x, gv[j].y * gm[j].y, gv[j].z * gm[j].z, gv[j].w * gm[j].w);
+            sg += (g.x + g.y) + (g.z + g.w);
+            sgx += (g.x * xv[j].x + g.y * xv[j].y) + (g.z * xv[j].z + g.w * xv[j].w);
+        }
+        const float mg = wsum(sg) / (float)d, mgx = wsum(sgx) / (float)d;
+        float4 *dr = reinterpret_cast<float4 *>(dx + (int64_t)row * d);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const float4 xh = xv[j], gy = gv[j];
+            dr[lane + 64 * j] = make_float4(rstd * (gy.x * gm[j].x - mg - xh.x * mgx), rstd * (gy.y * gm[j].y - mg - xh.y * mgx),
+                                            rstd * (gy.z * gm[j].z - mg - xh.z * mgx), rstd * (gy.w * gm[j].w - mg - xh.w * mgx));
+            sg_[j].x += gy.x * xh.x; sg_[j].y += gy.y * xh.y; sg_[j].z += gy.z * xh.z; sg_[j].w += gy.w * xh.w;
+            sb_[j].x += gy.x; sb_[j].y += gy.y; sb_[j].z += gy.z; sb_[j].w += gy.w;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        reinterpret_cast<float4 *>(red[0][wave])[lane + 64 * j] = sg_[j];
+        reinterpret_cast<float4 *>(red[1][wave])[lane + 64 * j] = sb_[j];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * d; c += 256) {
+        const int which = c / d, col = c % d;
+        part[((int64_t)blockIdx.x * 2 + which) * d + col] =
+            ((double)red[which][0][col] + (double)red[which][1][col]) + ((double)red[which][2][col] + (double)red[which][3][col]);
+    }
+}
+__global__ __launch_bounds__(256) void ln_sums_final_kernel(const double *part, int blocks, int d, float *dgamma, float *dbeta) {
+    __shared__ double red[4][64];
+    const int cx = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;                      // over 2 d columns: [dgamma | dbeta]
+    double s = 0.0;
+    if (c < 2 * d)
+        for (int k = ph; k < blocks; k += 4) s += part[(int64_t)k * 2 * d + c];
+    red[ph][cx] = s;
+    __syncthreads();
+    if (ph == 0 && c < 2 * d) {
+        const float v = (float)((red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]));
+        if (c < d) dgamma[c] = v; else dbeta[c - d] = v;
+    }
+}
+
 // in-place row softmax over the first `cols` columns of rows with pitch ld (pad columns are set to 0)
 __global__ __launch_bounds__(256) void softmax_rows_kernel(float *s, int64_t ld, int64_t rows, int cols_all, int causal_q_len) {
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -339,6 +421,37 @@ extern "C" int la_layernorm_bwd_f32(const float *x, const float *dy, const float
                                     float *dy_xhat, void *stream_) {
     LA_CHECK_ARG(x && dy && gamma && dx && dy_xhat && M > 0 && d > 0, "layernorm_bwd: bad arguments");
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(la::cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream_, x, dy, gamma, M, d, dx, dy_xhat);
+    LA_LAUNCH_CHECK();
+    return LA_OK;
+}
+extern "C" int la_colsum_f32(const float *in, int64_t ld, int32_t rows, int32_t cols, float *out, void *stream_);
+
+// LayerNorm backward with its parameter gradients: dx, dgamma [d] = sum_r dy xhat, dbeta [d] = sum_r dy.  d = 256, 512, ... 2048 with
+// 16-byte aligned rows: one pass (layernorm_bwd_sums_kernel); otherwise la_layernorm_bwd_f32 into `scratch` (M x d floats, required then)
+// and two la_colsum_f32.
+extern "C" int la_layernorm_bwd_sums_f32(const float *x, const float *dy, const float *gamma, int32_t M, int32_t d, float *dx, float *dgamma,
+                                         float *dbeta, float *scratch, void *stream_) {
+    LA_CHECK_ARG(x && dy && gamma && dx && dgamma && dbeta && M > 0 && d > 0, "layernorm_bwd_sums: bad arguments");
+    hipStream_t st = (hipStream_t)stream_;
+    const bool fast = d % 256 == 0 && d <= 2048 && ((uintptr_t)x | (uintptr_t)dy | (uintptr_t)gamma | (uintptr_t)dx) % 16 == 0;
+    if (!fast) {
+        LA_CHECK_ARG(scratch, "layernorm_bwd_sums: this width needs the M x d scratch buffer");
+        hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(la::cdiv(M, 4)), dim3(256), 0, st, x, dy, gamma, M, d, dx, scratch);
+        LA_LAUNCH_CHECK();
+        int rc = la_colsum_f32(scratch, d, M, d, dgamma, stream_);
+        if (rc == LA_OK) rc = la_colsum_f32(dy, d, M, d, dbeta, stream_);
+        return rc;
+    }
+    const int blocks = la::cdiv(M, 128);
+    double *part = static_cast<double *>(la::stream_scratch(st, la::SCRATCH_COLSUM, sizeof(double) * (size_t)blocks * 2 * d));
+    if (!part) { la::set_error("layernorm_bwd_sums: scratch allocation failed"); return LA_EHIP; }
+    switch (d / 256) {
+#define LA_LN_CASE(nv) case nv: hipLaunchKernelGGL(layernorm_bwd_sums_kernel<nv>, dim3(blocks), dim3(256), 0, st, x, dy, gamma, M, dx, part); break;
+        LA_LN_CASE(1) LA_LN_CASE(2) LA_LN_CASE(3) LA_LN_CASE(4) LA_LN_CASE(5) LA_LN_CASE(6) LA_LN_CASE(7) LA_LN_CASE(8)
+#undef LA_LN_CASE
+    }
+    LA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ln_sums_final_kernel, dim3(la::cdiv(2 * d, 64)), dim3(256), 0, st, part, blocks, d, dgamma, dbeta);
     LA_LAUNCH_CHECK();
     return LA_OK;
 }

@@ -10,7 +10,7 @@ keeps the per-block activations.  Backward is a composition of
                                           the packed [T][3d] projections for the attention gradients,
   * la_transpose_pad(_batched)_f32        zero-padded transposes feeding them,
   * la_softmax_rows_f32 / la_softmax_bwd_rows_f32 on score tiles recomputed per clip (P is not kept by the forward kernel),
-  * la_layernorm_bwd_f32, la_gelu_bwd_f32, la_col2im3_f32, la_colsum_f32, la_add_f32, la_scale_f32.
+  * la_layernorm_bwd_sums_f32, la_gelu_bwd_f32, la_col2im3_f32, la_colsum_f32, la_add_f32, la_scale_f32.
 Host code only sequences kernels and moves / pads buffers.
 """
 from __future__ import annotations
@@ -72,9 +72,14 @@ def scale(x: torch.Tensor, alpha: float) -> torch.Tensor:
 def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor):
     """-> dx [M,d], dgamma [d], dbeta [d]"""
     M, d = x.shape
-    dx, t = torch.empty_like(x), torch.empty_like(x)
-    check(lib().la_layernorm_bwd_f32(ptr(x), ptr(dy), ptr(gamma), M, d, ptr(dx), ptr(t), stream_ptr()), "layernorm_bwd")
-    return dx, colsum(t), colsum(dy)
+    dx = torch.empty_like(x)
+    dg, db = torch.empty((d,), dtype=torch.float32, device=x.device), torch.empty((d,), dtype=torch.float32, device=x.device)
+    x, dy, gamma = x.contiguous(), dy.contiguous(), gamma.contiguous()
+    # la_layernorm_bwd_sums_f32: x and dy read once, no dy * xhat buffer (these widths, 16-byte aligned rows)
+    one_pass = d % 256 == 0 and d <= 2048 and all(t_.data_ptr() % 16 == 0 for t_ in (x, dy, gamma, dx))
+    t = None if one_pass else torch.empty_like(x)
+    check(lib().la_layernorm_bwd_sums_f32(ptr(x), ptr(dy), ptr(gamma), M, d, ptr(dx), ptr(dg), ptr(db), ptr(t), stream_ptr()), "layernorm_bwd_sums")
+    return dx, dg, db
 
 
 def gemm_ex(M, N, K, batch, a, lda, stride_a, w, ldw, stride_w, c, ldc, stride_c, flags: int = 0):
