@@ -547,7 +547,7 @@ def finetune_mode(args, rank, world, local_rank, device, dist):
             "metric": f"fine-tuned audio-sec/sec, Whisper-{args.model} multitask (CTC + CE + decoder CE), DP={world}",
             "value": audio_sec / elapsed, "unit": "audio-sec/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (f16x2 split of the large Linear products: 3 f16 MFMA products per float32 product, f32 accumulate)" if x2 else "f32",
+            "dtype": "f32 (f16x2 split of the large Linear and attention products: 3 f16 MFMA products per float32 product, f32 accumulate)" if x2 else "f32",
             "data": "synthetic (Gaussian waveforms, random class-id / frame / token labels, random-init weights)",
             "config": {"workload": f"whisper-{args.model} multitask fine-tune step, per-GPU micro-batch {B} x 30 s x accum {args.accum} "
                                    "(BASELINE.json configs[2])", "mode": "finetune", "micro_batch": B, "accum": args.accum, "accum_mode": args.accum_mode,
