@@ -15,6 +15,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
+from . import head_train
 from ._lib import check, lib, ptr, stream_ptr
 
 
@@ -303,6 +304,9 @@ class FineTuner:
         self.opt = FlatAdamW(opt_groups, weight_decay=weight_decay)
         # the exchange step, overlapped with the last backward (allreduce_chunks = 0: the single blocking all-reduce per bucket)
         self.overlap = OverlappedAllReduce(self.groups, self.grad, self.world, allreduce_chunks) if allreduce_chunks > 0 else None
+        # head and decoder branch on two streams (module/align_model.py): single process only -- with more ranks the gradient chunks
+        # leave for the all-reduce from inside the backward, on whatever stream produced the last of them
+        model._branch_streams = self.world == 1
 
     @property
     def allreduce_exposed_ms(self) -> float:
@@ -366,6 +370,7 @@ class FineTuner:
                 roots.append(trans_logit); grads.append(dl)
             if roots:
                 torch.autograd.backward(roots, grads)
+            head_train.check_deferred_flags()                     # GRU time-out flags of a head that ran beside the decoder
         if has_tr:
             if last and self.overlap is not None:
                 self.overlap.arm()
@@ -382,6 +387,7 @@ class FineTuner:
                 roots.append(align_logit); grads.append(dlog)
             if roots:
                 torch.autograd.backward(roots, grads)
+            head_train.check_deferred_flags()                     # GRU time-out flags of a head that ran beside the decoder
         self._check_grad_views()
         return out
 
@@ -481,6 +487,7 @@ class FineTuner:
             if self.overlap is not None and accum == len(micro_batches):    # the one backward of the whole optimizer step
                 self.overlap.arm()
             torch.autograd.backward(roots, grads)
+            head_train.check_deferred_flags()                     # GRU time-out flags of a head that ran beside the decoder
         self._check_grad_views()
         return out
 

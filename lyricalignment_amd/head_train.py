@@ -131,6 +131,31 @@ def _gru_ws(B: int, T: int, H: int, device):
     return torch.empty((need.value,), dtype=torch.uint8, device=device), need.value
 
 
+# The persistent GRU kernels report a timed-out inter-workgroup wait through a device flag.  Reading it (flag.item()) synchronises the
+# host with the stream, which is what keeps the head from running BESIDE the decoder branch (module/align_model.py): with
+# DEFER_FLAG_CHECKS set around HeadFunction.apply the flags of that forward and of its backward are parked here and read by
+# check_deferred_flags() -- FineTuner calls it after the backward of the step.
+DEFER_FLAG_CHECKS = False
+_deferred_flags: List = []
+
+
+def _flag_check(flag: torch.Tensor, what: str, defer: bool) -> None:
+    if defer:
+        _deferred_flags.append((flag, what))
+    elif int(flag.item()) != 0:
+        raise TimeoutError(what)
+
+
+def check_deferred_flags() -> None:
+    pending, bad = list(_deferred_flags), None
+    del _deferred_flags[:]
+    for flag, what in pending:
+        if int(flag.item()) != 0:
+            bad = what
+    if bad:
+        raise TimeoutError(bad)
+
+
 class HeadFunction(torch.autograd.Function):
     """logits = Linear(Mish(GRU(x))) with gradients for the head parameters (and for x when it requires grad)."""
 
@@ -173,8 +198,8 @@ class HeadFunction(torch.autograd.Function):
         act = torch.empty_like(out1)
         check(lib().la_mish_f32(ptr(out1), ptr(act), act.numel(), stream_ptr()), "mish")
         logits = gemm_nt(act, w_fc, bias=b_fc)
-        if int(flag.item()) != 0:
-            raise TimeoutError("persistent GRU kernel: a bounded inter-workgroup wait timed out")
+        ctx.defer = bool(DEFER_FLAG_CHECKS)
+        _flag_check(flag, "persistent GRU kernel: a bounded inter-workgroup wait timed out", ctx.defer)
         ctx.layers, ctx.w_fc, ctx.saved, ctx.mask, ctx.act = layers, w_fc, saved, mask, act
         ctx.dims, ctx.p, ctx.x_needs_grad = (B, T, D, H), float(dropout_p) if training else 0.0, x.requires_grad
         return logits.view(B, T, -1)
@@ -239,8 +264,7 @@ class HeadFunction(torch.autograd.Function):
                 else:
                     dx = dxin.view(B, T, D)
         grads[16], grads[17] = dw_fc, db_fc
-        if int(flag.item()) != 0:
-            raise TimeoutError("persistent GRU backward kernel: a bounded inter-workgroup wait timed out")
+        _flag_check(flag, "persistent GRU backward kernel: a bounded inter-workgroup wait timed out", ctx.defer)
         return (dx, None, None, *grads_to(grads, ctx.param_devices))
 
 

@@ -15,6 +15,7 @@ There is no PyTorch / CPU fallback: without the HIP library and a gfx950 device 
 """
 from __future__ import annotations
 
+import os
 import weakref
 from typing import List, Optional, Sequence
 
@@ -54,6 +55,9 @@ def song_major_chunks(mel: torch.Tensor, plan) -> torch.Tensor:
         out[:, c, :, : e0 - s0] = mel[:, :, s0:e0]
     return out.view(S * C, mel.shape[1], N_FRAMES)
 
+
+# LA_BRANCH_STREAMS=0: alignment head and text decoder of the training forward / backward on one stream (A/B partner; read at import)
+BRANCH_STREAMS = os.environ.get("LA_BRANCH_STREAMS", "1") != "0"
 
 class RNN(nn.Module):
     """GRU(2 layers, bidirectional) -> Mish -> Linear; parameters live in nn.GRU / nn.Linear so the
@@ -216,6 +220,30 @@ class AlignModel(torch.nn.Module):
                     mel = self._mel_of(audios)
             embed, embed_pad = self._encoder_train_features(mel, get_orig_len)
             align_logit = transcribe_logit = None
+            both = self.train_alignment and self.train_transcript and y_in is not None
+            if both and embed.is_cuda and getattr(self, "_branch_streams", True) and BRANCH_STREAMS:
+                # The two branches are independent until their losses, and the head's GRU sweeps are 2 x 1500 dependent steps on 12
+                # workgroups (13 ms forward, 19 ms backward with the other 244 CUs idle): the head runs on a stream of its own beside
+                # the decoder.  autograd runs a node's backward on the stream of its forward and joins the streams where gradients
+                # meet (the encoder output), so the backward sweeps overlap the decoder's backward the same way.
+                cur = torch.cuda.current_stream(embed.device)
+                side = getattr(self, "_head_stream", None)
+                if side is None or side.device != embed.device:
+                    side = self._head_stream = torch.cuda.Stream(device=embed.device)
+                from .. import head_train
+                head_train.check_deferred_flags()                           # (of an earlier forward whose backward never ran)
+                side.wait_stream(cur)
+                head_train.DEFER_FLAG_CHECKS = True                         # the GRU time-out flags are read after the backward: no host
+                try:                                                        # synchronisation between the two branches' launches
+                    with torch.cuda.stream(side):
+                        align_logit = HeadFunction.apply(embed, float(self.align_rnn.rnn.dropout), True, *head_params(self.align_rnn))
+                finally:
+                    head_train.DEFER_FLAG_CHECKS = False
+                embed.record_stream(side)
+                transcribe_logit = self._decoder_train_logits(y_in, embed_pad)
+                cur.wait_stream(side)
+                align_logit.record_stream(cur)
+                return align_logit, transcribe_logit
             if self.train_alignment:
                 align_logit = HeadFunction.apply(embed, float(self.align_rnn.rnn.dropout), True, *head_params(self.align_rnn))
             if self.train_transcript and y_in is not None:
