@@ -232,6 +232,9 @@ enum {
     LA_EPI_RESIDUAL = 4,  /* + residual[m][n] (f32, own strides; batch stride may be 0) */
     LA_EPI_OUT_F32 = 8,   /* C is f32 regardless of the operand dtype                 */
     LA_EPI_MISH = 16,     /* x * tanh(softplus(x)) after the bias                     */
+    LA_EPI_RES_GELU_GRAD = 32, /* la_gemm_f16x2 only, with LA_EPI_RESIDUAL: the result is MULTIPLIED by gelu'(residual[m][n]) instead of having
+                           * it added -- the input gradient of the MLP's second Linear times the GELU derivative at the saved
+                           * pre-activation (la_gelu_bwd_f32 without its pass over the [rows][4 d] buffer) */
     LA_EPI_GELU_ERF = 4096, /* with LA_EPI_GELU and a 16-bit result: the erfc-based form (max absolute error 1.3e-6, 20 x closer to
                            * F.gelu than the sigmoid fit) at ~40 % more epilogue issue slots.  (LA_GELU_PK=1 in the environment sets
                            * it on every launch: the developer A/B switch.) */

@@ -21,6 +21,7 @@ LA_Q_LOG2 = 0x100        # modifier on the attention entry points' dtype / la_en
 LA_VARIANT_PLAIN, LA_VARIANT_CTC = 0, 1
 EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_OUT_F32, EPI_MISH = 1, 2, 4, 8, 16
 EPI_GELU_ERF = 4096
+EPI_RES_GELU_GRAD = 32        # la_gemm_f16x2: result * gelu'(residual) instead of + residual
 GEMM_TRANS_A, GEMM_TRANS_W = 512, 1024        # la_gemm_ex operand layout flags (float32)
 
 # every symbol include/lyricalign.h declares: (name, restype, argtypes)

@@ -215,6 +215,13 @@ __device__ __forceinline__ float erf_fast(float x) {
 // exact (erf) GELU of whisper's nn.GELU(); abs error of the erf fit <= 1.2e-7
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
 
+// d/dx of the erf GELU: Phi(x) + x phi(x)  (la_gelu_bwd_f32, and the LA_EPI_RES_GELU_GRAD epilogue of la_gemm_f16x2)
+__device__ __forceinline__ float gelu_erf_grad(float v) {
+    const float cdf = 0.5f * (1.0f + erf_fast(v * 0.70710678118654752440f));
+    const float pdf = 0.3989422804014327f * __expf(-0.5f * v * v);
+    return cdf + v * pdf;
+}
+
 // GELU for results that are rounded to bf16 anyway, two values per lane on the packed-FP32 pipe (v_pk_fma_f32 /
 // v_pk_mul_f32 / v_pk_add_f32: 2 lanes per issue).  Same erfc form, degree-5 fit (fractional error of erfc <= 2.8e-5
 // everywhere, i.e. 1/140 of a bf16 ulp; max abs error of gelu 1.3e-6), log2(e) folded into the coefficients so the

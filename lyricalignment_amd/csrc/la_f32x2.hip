@@ -240,7 +240,10 @@ __global__ void x2_reduce_kernel(const float *P, int S, int M, int N, float *C, 
     for (int s = 0; s < S; ++s) v += P[(int64_t)s * M * N + i];
     if ((epilogue & LA_EPI_BIAS) && bias) v += bias[n];
     if (epilogue & LA_EPI_GELU) v = la::gelu_erf(v);
-    if ((epilogue & LA_EPI_RESIDUAL) && residual) v += residual[(int64_t)m * ldr + n];
+    if ((epilogue & LA_EPI_RESIDUAL) && residual) {
+        const float t = residual[(int64_t)m * ldr + n];
+        v = (epilogue & LA_EPI_RES_GELU_GRAD) ? v * la::gelu_erf_grad(t) : v + t;
+    }
     C[(int64_t)m * ldc + n] = v;
 }
 
@@ -319,7 +322,9 @@ extern "C" int la_gemm_f16x2(int32_t M, int32_t N, int32_t K, int32_t slots, con
     if (M == 0 || N == 0) return LA_OK;
     LA_CHECK_ARG(A && sa && W && sw && C, "gemm_f16x2: null pointer");
     LA_CHECK_ARG(M > 0 && N > 0 && K > 0 && slots >= 1, "gemm_f16x2: bad sizes");
-    LA_CHECK_ARG((epilogue & ~(LA_EPI_BIAS | LA_EPI_GELU | LA_EPI_RESIDUAL)) == 0, "gemm_f16x2: epilogue takes BIAS, GELU, RESIDUAL only");
+    LA_CHECK_ARG((epilogue & ~(LA_EPI_BIAS | LA_EPI_GELU | LA_EPI_RESIDUAL | LA_EPI_RES_GELU_GRAD)) == 0,
+                 "gemm_f16x2: epilogue takes BIAS, GELU, RESIDUAL, RES_GELU_GRAD only");
+    LA_CHECK_ARG(!(epilogue & LA_EPI_RES_GELU_GRAD) || (epilogue & LA_EPI_RESIDUAL), "gemm_f16x2: RES_GELU_GRAD reads the residual operand (set RESIDUAL too)");
     LA_CHECK_ARG(!(epilogue & LA_EPI_BIAS) || bias, "gemm_f16x2: bias epilogue without pointer");
     LA_CHECK_ARG(!(epilogue & LA_EPI_RESIDUAL) || residual, "gemm_f16x2: residual epilogue without pointer");
     LA_CHECK_ARG((uintptr_t)A % 16 == 0 && (uintptr_t)W % 16 == 0, "gemm_f16x2: planes must be 16-byte aligned");

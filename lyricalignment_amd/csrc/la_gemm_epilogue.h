@@ -190,7 +190,12 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams &p, int z, f32x4 
                     f32x4 v = STG == 0 ? *reinterpret_cast<const f32x4 *>(reg + rl * PITCH + r * 16)
                                        : *reinterpret_cast<const f32x4 *>(reg + rl * 256 + ((r ^ rl) << 4));
                     epi_quad<OUT_F32, EQ>(v, b4, cs4, LNC ? st[it] : make_float2(0.f, 0.f), has_bias, do_gelu, epi);
-                    if constexpr (RES) { v[0] += t[it].x; v[1] += t[it].y; v[2] += t[it].z; v[3] += t[it].w; }
+                    if constexpr (RES) {
+                        if (LNM == 6 && (epi & LA_EPI_RES_GELU_GRAD)) {     // f16x2 products only: dX of the MLP's second Linear times gelu'(u)
+                            v[0] *= la::gelu_erf_grad(t[it].x); v[1] *= la::gelu_erf_grad(t[it].y);
+                            v[2] *= la::gelu_erf_grad(t[it].z); v[3] *= la::gelu_erf_grad(t[it].w);
+                        } else { v[0] += t[it].x; v[1] += t[it].y; v[2] += t[it].z; v[3] += t[it].w; }
+                    }
                     const int64_t off = (int64_t)(h * RP + rl) * p.ldc;
                     TC *c = cw + off;
                     if constexpr (sizeof(TC) == 4) {
@@ -244,7 +249,9 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams &p, int z, f32x4 
             const int nv = min(4, p.N - n);
             if (do_res) {
                 const float *rr = R + (int64_t)m * p.ldr + n;
-                if (fast_r && nv == 4) {
+                if (LNM == 6 && (epi & LA_EPI_RES_GELU_GRAD)) {
+                    for (int j = 0; j < nv; ++j) v[j] *= la::gelu_erf_grad(rr[j]);
+                } else if (fast_r && nv == 4) {
                     const float4 t = *reinterpret_cast<const float4 *>(rr);
                     v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
                 } else {

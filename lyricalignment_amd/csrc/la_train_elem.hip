@@ -76,10 +76,7 @@ __global__ void gelu_fwd_kernel(const float *x, float *y, int64_t n) {
 }
 __global__ void gelu_bwd_kernel(const float *x, const float *dy, float *dx, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const float v = x[i];
-        const float cdf = 0.5f * (1.0f + la::erf_fast(v * 0.70710678118654752440f));
-        const float pdf = 0.3989422804014327f * __expf(-0.5f * v * v);
-        dx[i] = dy[i] * (cdf + v * pdf);
+        dx[i] = dy[i] * la::gelu_erf_grad(x[i]);
     }
 }
 __global__ void scale_kernel(const float *x, float alpha, float *y, int64_t n) {

@@ -102,7 +102,7 @@ class DecoderFunction(torch.autograd.Function):
             G = [None] * NB
             # MLP
             G[22], G[23] = linear_grads(dx, u_pre, x_act="gelu")
-            du_pre = gelu_bwd(u_pre, gemm_nn(dx, w2))
+            du_pre = gemm_nn(dx, w2, gelu_grad_of=u_pre)
             G[20], G[21] = linear_grads(du_pre, h2)
             dln, G[18], G[19] = layernorm_bwd(x2, gemm_nn(du_pre, w1), g2)
             dx2 = add(dx, dln)

@@ -242,7 +242,7 @@ class EncoderFunction(torch.autograd.Function):
             G = [None] * 15
             # x_next = x_mid + gelu(u_pre) W2^T + b2
             G[13], G[14] = linear_grads(dx, u_pre, x_act="gelu")
-            du_pre = gelu_bwd(u_pre, gemm_nn(dx, w2))
+            du_pre = gemm_nn(dx, w2, gelu_grad_of=u_pre)
             G[11], G[12] = linear_grads(du_pre, h2)
             dln, G[9], G[10] = layernorm_bwd(x_mid, gemm_nn(du_pre, w1), g2)
             dx_mid = add(dx, dln)

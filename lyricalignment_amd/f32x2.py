@@ -97,8 +97,9 @@ def padded_k(M: int, N: int, K: int) -> int:
 
 
 def gemm(a: Planes, w: Planes, out: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
-         residual: Optional[torch.Tensor] = None, gelu: bool = False) -> torch.Tensor:
-    """out [a.rows, w.rows] f32 = epi(A W^T) from split operands of the same plane length."""
+         residual: Optional[torch.Tensor] = None, gelu: bool = False, gelu_grad_of: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out [a.rows, w.rows] f32 = epi(A W^T) from split operands of the same plane length.  gelu_grad_of = u [a.rows, w.rows]: the
+    product is multiplied by gelu'(u) in the epilogue (LA_EPI_RES_GELU_GRAD; u takes the residual operand's place)."""
     if a.kp != w.kp:
         raise ValueError(f"f32x2.gemm: operands were split to different plane lengths ({a.kp}, {w.kp})")
     M, N = a.rows, w.rows
@@ -107,6 +108,11 @@ def gemm(a: Planes, w: Planes, out: Optional[torch.Tensor] = None, bias: Optiona
     epi = 0
     if bias is not None:
         epi |= _lib.EPI_BIAS
+    if gelu_grad_of is not None:
+        if residual is not None:
+            raise ValueError("f32x2.gemm: gelu_grad_of takes the residual operand's place")
+        residual = gelu_grad_of
+        epi |= _lib.EPI_RES_GELU_GRAD
     if residual is not None:
         epi |= _lib.EPI_RESIDUAL
     if gelu:
@@ -143,15 +149,24 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     return ops.gemm(_apply(x, x_act), w, bias=bias, residual=residual)
 
 
-def gemm_nn(dy: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
-    """dy [M, N] . w [N, K] -> [M, K]: the input gradient of y = x w^T."""
+def gemm_nn(dy: torch.Tensor, w: torch.Tensor, gelu_grad_of: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dy [M, N] . w [N, K] -> [M, K]: the input gradient of y = x w^T.  gelu_grad_of = u [M, K]: times gelu'(u) -- the gradient at the
+    pre-activation u of x = gelu(u), in the product's epilogue on the f16x2 path (la_gelu_bwd_f32 on the result otherwise)."""
     from . import head_train
     M, N = dy.shape
     K = w.shape[1]
+    fused = gelu_grad_of is not None and FUSE_ACT and _plain2d(gelu_grad_of)
     if _plain2d(dy) and _plain2d(w) and eligible(M, K, N):
         np_ = padded_k(M, K, N)
-        return gemm(split(dy, np_), split_t(w, np_))
-    return head_train.gemm_nn_f32(dy, w)
+        dx = gemm(split(dy, np_), split_t(w, np_), gelu_grad_of=gelu_grad_of if fused else None)
+        if fused:
+            return dx
+    else:
+        dx = head_train.gemm_nn_f32(dy, w)
+    if gelu_grad_of is not None:
+        from .encoder_train import gelu_bwd
+        dx = gelu_bwd(gelu_grad_of, dx)
+    return dx
 
 
 def gemm_tn(dy: torch.Tensor, x: torch.Tensor, x_act: Optional[str] = None, colsum: Optional[torch.Tensor] = None) -> torch.Tensor:

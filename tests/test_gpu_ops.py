@@ -764,6 +764,10 @@ def test_f16x2_gradient_products_with_split_k_slots():
         e_x2 = float((got.double() - ref).abs().max() / ref.abs().max())
         e_f32 = float((nat.double() - ref).abs().max() / ref.abs().max())
         assert e_x2 <= max(e_f32, 4e-7) and e_x2 < 3e-6, (e_x2, e_f32)
+    # dx times gelu'(u) in the product's epilogue (LA_EPI_RES_GELU_GRAD): the bits of la_gelu_bwd_f32 on the plain product
+    from lyricalignment_amd import encoder_train
+    u = _rand(M, K, seed=24, scale=1.5).cuda()
+    assert torch.equal(f32x2.gemm_nn(dyd, wd, gelu_grad_of=u), encoder_train.gelu_bwd(u, dx))
     # the bias gradient from the same pass over dy (la_split_f16x2_t_colsum): float64 partials per row block, added in order
     dw2, db = head_train.linear_grads(dyd, xd)
     assert torch.equal(dw2, dw) and torch.equal(db, head_train.linear_grads(dyd, xd)[1])
