@@ -492,9 +492,10 @@ int la_layernorm_bwd_f32(const float *x, const float *dy, const float *gamma, in
                          void *stream);
 /* la_layernorm_bwd_f32 together with the parameter gradients dgamma [d] = sum_r dy xhat and dbeta [d] = sum_r dy: one pass over x and dy for
  * d = 256 ... 2048 in steps of 256 (rows in registers, float64 partials per 128-row block added in order); other widths run
- * la_layernorm_bwd_f32 into `scratch` (M x d floats, required then, may be NULL otherwise) and two la_colsum_f32. */
-int la_layernorm_bwd_sums_f32(const float *x, const float *dy, const float *gamma, int32_t M, int32_t d, float *dx, float *dgamma, float *dbeta,
-                              float *scratch, void *stream);
+ * la_layernorm_bwd_f32 into `scratch` (M x d floats, required then, may be NULL otherwise) and two la_colsum_f32.  residual [M][d] (or
+ * NULL): added to dx -- the gradient that reaches the block's input past it (pre-norm residual connection). */
+int la_layernorm_bwd_sums_f32(const float *x, const float *dy, const float *gamma, const float *residual, int32_t M, int32_t d, float *dx,
+                              float *dgamma, float *dbeta, float *scratch, void *stream);
 /* causal_q_len > 0: row r is query (r mod causal_q_len) and sees keys 0 .. (r mod causal_q_len) + cols - causal_q_len */
 int la_softmax_rows_f32(float *s, int64_t ld, int64_t rows, int32_t cols, int32_t causal_q_len, void *stream);
 int la_softmax_bwd_rows_f32(const float *p, float *dp, int64_t ld, int64_t rows, int32_t cols, void *stream);

@@ -91,7 +91,7 @@ SYMBOLS = {
     "la_add_f32": (c_int32, [_P, _P, _P, _I64, _P]),
     "la_scale_f32": (c_int32, [_P, ctypes.c_float, _P, _I64, _P]),
     "la_layernorm_bwd_f32": (c_int32, [_P, _P, _P, _I32, _I32, _P, _P, _P]),
-    "la_layernorm_bwd_sums_f32": (c_int32, [_P, _P, _P, _I32, _I32, _P, _P, _P, _P, _P]),
+    "la_layernorm_bwd_sums_f32": (c_int32, [_P, _P, _P, _P, _I32, _I32, _P, _P, _P, _P, _P]),
     "la_softmax_rows_f32": (c_int32, [_P, _I64, _I64, _I32, _I32, _P]),
     "la_attention_bwd_workspace_bytes": (c_int32, [_I32, _I32, _I32, POINTER(_SZ)]),
     "la_attention_bwd_stats_f32": (c_int32, [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P]),

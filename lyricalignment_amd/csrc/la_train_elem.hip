@@ -130,8 +130,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float *x, cons
 // terms over its wave's rows in float32 (32 terms), the four waves' sums are added in float64 in wave order and written per workgroup;
 // ln_sums_final_kernel adds the workgroups in order (deterministic).  137 us + two column-sum passes -> one pass.
 template <int NV>
-__global__ __launch_bounds__(256) void layernorm_bwd_sums_kernel(const float *x, const float *dy, const float *gamma, int M, float *dx,
-                                                                 double *part) {
+__global__ __launch_bounds__(256) void layernorm_bwd_sums_kernel(const float *x, const float *dy, const float *gamma, const float *resid, int M,
+                                                                 float *dx, double *part) {
     constexpr int d = 256 * NV;
     __shared__ float red[2][4][d];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -171,11 +171,17 @@ __global__ __launch_bounds__(256) void layernorm_bwd_sums_kernel(const float *x,
         }
         const float mg = wsum(sg) / (float)d, mgx = wsum(sgx) / (float)d;
         float4 *dr = reinterpret_cast<float4 *>(dx + (int64_t)row * d);
+        const float4 *rr = resid ? reinterpret_cast<const float4 *>(resid + (int64_t)row * d) : nullptr;
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const float4 xh = xv[j], gy = gv[j];
-            dr[lane + 64 * j] = make_float4(rstd * (gy.x * gm[j].x - mg - xh.x * mgx), rstd * (gy.y * gm[j].y - mg - xh.y * mgx),
-                                            rstd * (gy.z * gm[j].z - mg - xh.z * mgx), rstd * (gy.w * gm[j].w - mg - xh.w * mgx));
+            float4 o = make_float4(rstd * (gy.x * gm[j].x - mg - xh.x * mgx), rstd * (gy.y * gm[j].y - mg - xh.y * mgx),
+                                   rstd * (gy.z * gm[j].z - mg - xh.z * mgx), rstd * (gy.w * gm[j].w - mg - xh.w * mgx));
+            if (rr) {                                            // the gradient that reaches x past the block (residual connection)
+                const float4 t = rr[lane + 64 * j];
+                o = make_float4(t.x + o.x, t.y + o.y, t.z + o.z, t.w + o.w);
+            }
+            dr[lane + 64 * j] = o;
             sg_[j].x += gy.x * xh.x; sg_[j].y += gy.y * xh.y; sg_[j].z += gy.z * xh.z; sg_[j].w += gy.w * xh.w;
             sb_[j].x += gy.x; sb_[j].y += gy.y; sb_[j].z += gy.z; sb_[j].w += gy.w;
         }
@@ -423,27 +429,31 @@ extern "C" int la_layernorm_bwd_f32(const float *x, const float *dy, const float
 }
 extern "C" int la_colsum_f32(const float *in, int64_t ld, int32_t rows, int32_t cols, float *out, void *stream_);
 
-// LayerNorm backward with its parameter gradients: dx, dgamma [d] = sum_r dy xhat, dbeta [d] = sum_r dy.  d = 256, 512, ... 2048 with
+// LayerNorm backward with its parameter gradients: dx (+ residual, if given: the gradient that bypasses the block), dgamma [d] = sum_r dy xhat,
+// dbeta [d] = sum_r dy.  d = 256, 512, ... 2048 with
 // 16-byte aligned rows: one pass (layernorm_bwd_sums_kernel); otherwise la_layernorm_bwd_f32 into `scratch` (M x d floats, required then)
 // and two la_colsum_f32.
-extern "C" int la_layernorm_bwd_sums_f32(const float *x, const float *dy, const float *gamma, int32_t M, int32_t d, float *dx, float *dgamma,
-                                         float *dbeta, float *scratch, void *stream_) {
+extern "C" int la_add_f32(const float *a, const float *b, float *y, int64_t n, void *stream_);
+
+extern "C" int la_layernorm_bwd_sums_f32(const float *x, const float *dy, const float *gamma, const float *residual, int32_t M, int32_t d, float *dx,
+                                         float *dgamma, float *dbeta, float *scratch, void *stream_) {
     LA_CHECK_ARG(x && dy && gamma && dx && dgamma && dbeta && M > 0 && d > 0, "layernorm_bwd_sums: bad arguments");
     hipStream_t st = (hipStream_t)stream_;
-    const bool fast = d % 256 == 0 && d <= 2048 && ((uintptr_t)x | (uintptr_t)dy | (uintptr_t)gamma | (uintptr_t)dx) % 16 == 0;
+    const bool fast = d % 256 == 0 && d <= 2048 && ((uintptr_t)x | (uintptr_t)dy | (uintptr_t)gamma | (uintptr_t)dx | (uintptr_t)residual) % 16 == 0;
     if (!fast) {
         LA_CHECK_ARG(scratch, "layernorm_bwd_sums: this width needs the M x d scratch buffer");
         hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(la::cdiv(M, 4)), dim3(256), 0, st, x, dy, gamma, M, d, dx, scratch);
         LA_LAUNCH_CHECK();
         int rc = la_colsum_f32(scratch, d, M, d, dgamma, stream_);
         if (rc == LA_OK) rc = la_colsum_f32(dy, d, M, d, dbeta, stream_);
+        if (rc == LA_OK && residual) rc = la_add_f32(residual, dx, dx, (int64_t)M * d, stream_);
         return rc;
     }
     const int blocks = la::cdiv(M, 128);
     double *part = static_cast<double *>(la::stream_scratch(st, la::SCRATCH_COLSUM, sizeof(double) * (size_t)blocks * 2 * d));
     if (!part) { la::set_error("layernorm_bwd_sums: scratch allocation failed"); return LA_EHIP; }
     switch (d / 256) {
-#define LA_LN_CASE(nv) case nv: hipLaunchKernelGGL(layernorm_bwd_sums_kernel<nv>, dim3(blocks), dim3(256), 0, st, x, dy, gamma, M, dx, part); break;
+#define LA_LN_CASE(nv) case nv: hipLaunchKernelGGL(layernorm_bwd_sums_kernel<nv>, dim3(blocks), dim3(256), 0, st, x, dy, gamma, residual, M, dx, part); break;
         LA_LN_CASE(1) LA_LN_CASE(2) LA_LN_CASE(3) LA_LN_CASE(4) LA_LN_CASE(5) LA_LN_CASE(6) LA_LN_CASE(7) LA_LN_CASE(8)
 #undef LA_LN_CASE
     }

@@ -104,8 +104,7 @@ class DecoderFunction(torch.autograd.Function):
             G[22], G[23] = linear_grads(dx, u_pre, x_act="gelu")
             du_pre = gemm_nn(dx, w2, gelu_grad_of=u_pre)
             G[20], G[21] = linear_grads(du_pre, h2)
-            dln, G[18], G[19] = layernorm_bwd(x2, gemm_nn(du_pre, w1), g2)
-            dx2 = add(dx, dln)
+            dx2, G[18], G[19] = layernorm_bwd(x2, gemm_nn(du_pre, w1), g2, residual=dx)
             # cross-attention to the audio features
             G[16], G[17] = linear_grads(dx2, ac)
             dac = gemm_nn(dx2, woc)
@@ -118,16 +117,14 @@ class DecoderFunction(torch.autograd.Function):
             if ctx.xa_needs_grad:
                 t = gemm_nn(dkv, wkv_c)
                 dxa = t if dxa is None else add(dxa, t)
-            dln, G[9], G[10] = layernorm_bwd(x1, gemm_nn(dqc, wq_c), gc)
-            dx1 = add(dx2, dln)
+            dx1, G[9], G[10] = layernorm_bwd(x1, gemm_nn(dqc, wq_c), gc, residual=dx2)
             # causal self-attention
             G[7], G[8] = linear_grads(dx1, a)
             dqkv = attention_bwd(qkv, gemm_nn(dx1, wo), B, n, H, causal=True, att=a)
             dwqkv, dbqkv = linear_grads(dqkv, h1)
             G[2], G[3] = scale(dwqkv[:d], 0.125), scale(dbqkv[:d], 0.125)
             G[4], G[5], G[6] = dwqkv[d:2 * d], dwqkv[2 * d:], dbqkv[2 * d:]
-            dln, G[0], G[1] = layernorm_bwd(x, gemm_nn(dqkv, wqkv), g1)
-            dx = add(dx1, dln)
+            dx, G[0], G[1] = layernorm_bwd(x, gemm_nn(dqkv, wqkv), g1, residual=dx1)
             grads[2 + NB * i: 2 + NB * (i + 1)] = G
             ctx.saved[i] = None
         # embeddings: token rows accumulate on top of the tied-projection gradient, positions are summed over the batch

@@ -69,16 +69,18 @@ def scale(x: torch.Tensor, alpha: float) -> torch.Tensor:
     return y
 
 
-def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor):
-    """-> dx [M,d], dgamma [d], dbeta [d]"""
+def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, residual: Optional[torch.Tensor] = None):
+    """-> dx [M,d] (+ residual: the gradient that bypasses the block), dgamma [d], dbeta [d]"""
     M, d = x.shape
     dx = torch.empty_like(x)
     dg, db = torch.empty((d,), dtype=torch.float32, device=x.device), torch.empty((d,), dtype=torch.float32, device=x.device)
     x, dy, gamma = x.contiguous(), dy.contiguous(), gamma.contiguous()
+    residual = residual.contiguous() if residual is not None else None
     # la_layernorm_bwd_sums_f32: x and dy read once, no dy * xhat buffer (these widths, 16-byte aligned rows)
-    one_pass = d % 256 == 0 and d <= 2048 and all(t_.data_ptr() % 16 == 0 for t_ in (x, dy, gamma, dx))
+    one_pass = d % 256 == 0 and d <= 2048 and all(t_.data_ptr() % 16 == 0 for t_ in (x, dy, gamma, dx) + ((residual,) if residual is not None else ()))
     t = None if one_pass else torch.empty_like(x)
-    check(lib().la_layernorm_bwd_sums_f32(ptr(x), ptr(dy), ptr(gamma), M, d, ptr(dx), ptr(dg), ptr(db), ptr(t), stream_ptr()), "layernorm_bwd_sums")
+    check(lib().la_layernorm_bwd_sums_f32(ptr(x), ptr(dy), ptr(gamma), ptr(residual), M, d, ptr(dx), ptr(dg), ptr(db), ptr(t), stream_ptr()),
+          "layernorm_bwd_sums")
     return dx, dg, db
 
 
@@ -244,16 +246,14 @@ class EncoderFunction(torch.autograd.Function):
             G[13], G[14] = linear_grads(dx, u_pre, x_act="gelu")
             du_pre = gemm_nn(dx, w2, gelu_grad_of=u_pre)
             G[11], G[12] = linear_grads(du_pre, h2)
-            dln, G[9], G[10] = layernorm_bwd(x_mid, gemm_nn(du_pre, w1), g2)
-            dx_mid = add(dx, dln)
+            dx_mid, G[9], G[10] = layernorm_bwd(x_mid, gemm_nn(du_pre, w1), g2, residual=dx)
             # x_mid = x + att Wo^T + bo
             G[7], G[8] = linear_grads(dx_mid, att)
             dqkv = attention_bwd(qkv, gemm_nn(dx_mid, wo), B, N_CTX, H, att=att, lse=lse)
             dwqkv, dbqkv = linear_grads(dqkv, h1)
             G[2], G[3] = scale(dwqkv[:d], 0.125), scale(dbqkv[:d], 0.125)
             G[4], G[5], G[6] = dwqkv[d:2 * d], dwqkv[2 * d:], dbqkv[2 * d:]
-            dln, G[0], G[1] = layernorm_bwd(x, gemm_nn(dqkv, wqkv), g1)
-            dx = add(dx_mid, dln)
+            dx, G[0], G[1] = layernorm_bwd(x, gemm_nn(dqkv, wqkv), g1, residual=dx_mid)
             grads[4 + 15 * i: 4 + 15 * (i + 1)] = G
             ctx.saved[i] = None
         # ---- stem ----
