@@ -471,6 +471,15 @@ int la_split_f16x2_t_act(const float *x, int64_t ldx, int32_t rows, int32_t cols
  * deterministic, as la_colsum_f32) */
 int la_split_f16x2_t_colsum(const float *x, int64_t ldx, int32_t rows, int32_t cols, void *planes_t, int64_t mp, float *inv_scale_t, int32_t act,
                             float *colsum, void *stream);
+/* An operand that is split both ways (dy: plain for dx = dy w, transposed for dw = dy^T x; an activation: plain in the forward, transposed
+ * for its weight gradient) needs no second pass for the transposed planes' scales: la_split_f16x2_max is la_split_f16x2_act that also
+ * leaves the operand's largest magnitude in tmax (2048 words ZEROED by the caller: 64 are used, one per 128-byte line, filled with atomicMax), and la_split_f16x2_t_tmax with
+ * that tmax gives the transposed planes ONE power-of-two scale for the whole operand (tmax NULL = la_split_f16x2_t_colsum: a scale per
+ * column).  Entries more than 2^17 below the operand's maximum lose relative, never absolute (2^-39 of the maximum), precision. */
+int la_split_f16x2_max(const float *x, int64_t ldx, int32_t rows, int32_t cols, void *planes, int64_t kp, float *inv_scale, int32_t act,
+                       uint32_t *tmax, void *stream);
+int la_split_f16x2_t_tmax(const float *x, int64_t ldx, int32_t rows, int32_t cols, void *planes_t, int64_t mp, float *inv_scale_t, int32_t act,
+                          float *colsum, const uint32_t *tmax, void *stream);
 int la_gemm_f16x2(int32_t M, int32_t N, int32_t K, int32_t slots, const void *A, const float *sa, const void *W, const float *sw,
                   float *C, int64_t ldc, const float *bias, const float *residual, int64_t ldr, int32_t epilogue, void *stream);
 

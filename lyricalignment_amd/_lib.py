@@ -41,6 +41,8 @@ SYMBOLS = {
     "la_split_f16x2_act": (c_int32, [_P, _I64, _I32, _I32, _P, _I64, _P, _I32, _P]),
     "la_split_f16x2_t_act": (c_int32, [_P, _I64, _I32, _I32, _P, _I64, _P, _I32, _P]),
     "la_split_f16x2_t_colsum": (c_int32, [_P, _I64, _I32, _I32, _P, _I64, _P, _I32, _P, _P]),
+    "la_split_f16x2_max": (c_int32, [_P, _I64, _I32, _I32, _P, _I64, _P, _I32, _P, _P]),
+    "la_split_f16x2_t_tmax": (c_int32, [_P, _I64, _I32, _I32, _P, _I64, _P, _I32, _P, _P, _P]),
     "la_gemm_f16x2": (c_int32, [_I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _I64, _P, _P, _I64, _I32, _P]),
     "la_set_option": (c_int32, [c_char_p, c_int64]),
     "la_get_option": (c_int32, [c_char_p, POINTER(c_int64)]),

@@ -50,8 +50,10 @@ __device__ __forceinline__ float x2_act(float v, int act) { return act == 1 ? la
 // (every operand of the encoder) stay in registers between the passes -- 16 float4 per lane, all loads in flight at once: one read of x
 // (91 -> ~55 us per 24000 x 1024 operand: the two-pass form was bound by its two dependent round trips per wave, not by bytes); longer
 // rows are read twice (the second time from L2).
+// tmax (or NULL): 64 words that collect the largest magnitude of the whole operand (bit patterns, atomicMax; word = workgroup mod 64) --
+// what a later TRANSPOSED split of the same operand scales with instead of making its own pass for column maxima
 __global__ __launch_bounds__(256) void split_rows_kernel(const float *x, int64_t ldx, int rows, int cols, unsigned short *planes, int64_t kp,
-                                                         float *inv_scale, int act) {
+                                                         float *inv_scale, int act, unsigned *tmax) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -86,6 +88,9 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float *x, int64_t
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
     float inv;
     const float s = x2_scale(mx, &inv);
+    // one atomic per row into 64 words that lie 128 B apart (all 64 in one or two cache lines made the rows' 24000 atomics queue on one
+    // L2 channel: +34 us per operand, more than the pass they were to save)
+    if (tmax && lane == 0) atomicMax(tmax + (row & 63) * 32, __float_as_uint(mx != mx ? __uint_as_float(0x7f800000u) : mx));
     if (cached) {
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
@@ -187,21 +192,25 @@ __global__ __launch_bounds__(256) void colmax4_kernel(const float *x, int64_t ld
 // out[c] = sum of the row blocks' partials in a fixed order: 64 columns per workgroup, four threads per column take every fourth block each,
 // their sums are added as ((0 + 1) + (2 + 3))
 __global__ __launch_bounds__(256) void colsum_blocks_kernel(const double *part, int blocks, int cols, float *out) {
-    __shared__ double red[4][64];
-    const int cx = threadIdx.x & 63, ph = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cx;
+    __shared__ double red[8][32];
+    const int cx = threadIdx.x & 31, ph = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cx;
     double s = 0.0;
     if (c < cols)
-        for (int k = ph; k < blocks; k += 4) s += part[(int64_t)k * cols + c];
+        for (int k = ph; k < blocks; k += 8) s += part[(int64_t)k * cols + c];
     red[ph][cx] = s;
     __syncthreads();
-    if (ph == 0 && c < cols) out[c] = (float)((red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]));
+    if (ph == 0 && c < cols)
+        out[c] = (float)(((red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx])) + ((red[4][cx] + red[5][cx]) + (red[6][cx] + red[7][cx])));
 }
 
 // 64 (rows of x) x 64 (columns of x) tiles through LDS: read along the columns, written along the rows of x (= along the padded
 // contraction dimension of the transposed planes)
+// TMAX: one scale for the whole operand, from the 64 words a plain split of the same operand left (split_rows_kernel tmax), instead of one per
+// column from a pass of its own.  SUMS: the column sums of x as float64 partials per 64-row block, part[blockIdx.y][col] (act = 0).
+template <bool TMAX, bool SUMS>
 __global__ __launch_bounds__(256) void split_transposed_kernel(const float *x, int64_t ldx, int rows, int cols, const unsigned *colmax,
-                                                               unsigned short *planes, int64_t mp, float *inv_scale, int act) {
+                                                               unsigned short *planes, int64_t mp, float *inv_scale, int act, double *part) {
     __shared__ float tile[64][65];
     const int m0 = blockIdx.y * 64, k0 = blockIdx.x * 64;
     {
@@ -212,17 +221,35 @@ __global__ __launch_bounds__(256) void split_transposed_kernel(const float *x, i
             tile[ty * 16 + i][tx] = (m < rows && k < cols) ? x2_act(x[(int64_t)m * ldx + k], act) : 0.f;
         }
     }
+    unsigned tm = 0;
+    if constexpr (TMAX) {
+        tm = colmax[(threadIdx.x & 63) * 32];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) tm = max(tm, (unsigned)__shfl_xor((int)tm, o));
+    }
     __syncthreads();
     const int kl = threadIdx.x >> 2, mq = threadIdx.x & 3;       // output row k0 + kl, 16 consecutive m each
     const int k = k0 + kl;
+    float tv[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tv[i] = tile[mq * 16 + i][kl];
+    if constexpr (SUMS) {
+        float s4[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) s4[g] = (tv[4 * g] + tv[4 * g + 1]) + (tv[4 * g + 2] + tv[4 * g + 3]);
+        double sm = ((double)s4[0] + (double)s4[1]) + ((double)s4[2] + (double)s4[3]);
+        sm += __shfl_xor(sm, 1);
+        sm += __shfl_xor(sm, 2);
+        if (mq == 0 && k < cols) part[(int64_t)blockIdx.y * cols + k] = sm;
+    }
     if (k >= cols) return;
     float inv;
-    const float s = x2_scale(__uint_as_float(colmax[k]), &inv);
+    const float s = x2_scale(__uint_as_float(TMAX ? tm : colmax[k]), &inv);
     unsigned short *hi = planes + (int64_t)k * 2 * mp + m0 + mq * 16, *lo = hi + mp;
     if (m0 + mq * 16 < mp) {                                      // (mp is a multiple of 16: whole 16-element pieces)
         unsigned short h[16], l[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) x2_split(tile[mq * 16 + i][kl] * s, h[i], l[i]);
+        for (int i = 0; i < 16; ++i) x2_split(tv[i] * s, h[i], l[i]);
         uint4 *ph = reinterpret_cast<uint4 *>(hi), *pl = reinterpret_cast<uint4 *>(lo);
         ph[0] = *reinterpret_cast<uint4 *>(&h[0]); ph[1] = *reinterpret_cast<uint4 *>(&h[8]);
         pl[0] = *reinterpret_cast<uint4 *>(&l[0]); pl[1] = *reinterpret_cast<uint4 *>(&l[8]);
@@ -249,8 +276,8 @@ __global__ void x2_reduce_kernel(const float *P, int S, int M, int N, float *C, 
 
 }  // namespace
 
-extern "C" int la_split_f16x2_act(const float *x, int64_t ldx, int32_t rows, int32_t cols, void *planes, int64_t kp, float *inv_scale,
-                                  int32_t act, void *stream_) {
+extern "C" int la_split_f16x2_max(const float *x, int64_t ldx, int32_t rows, int32_t cols, void *planes, int64_t kp, float *inv_scale,
+                                  int32_t act, uint32_t *tmax, void *stream_) {
     if (rows == 0) return LA_OK;
     LA_CHECK_ARG(act == 0 || act == 1, "split_f16x2: act is 0 (none) or 1 (GELU)");
     LA_CHECK_ARG(x && planes && inv_scale && rows > 0 && cols > 0, "split_f16x2: bad arguments");
@@ -258,9 +285,14 @@ extern "C" int la_split_f16x2_act(const float *x, int64_t ldx, int32_t rows, int
     hipStream_t stream = (hipStream_t)stream_;
     la::TimerScope ts("split_f16x2", stream, (double)rows * cols * 8.0);
     hipLaunchKernelGGL(split_rows_kernel, dim3(la::cdiv(rows, 4)), dim3(256), 0, stream, x, ldx, rows, cols,
-                       reinterpret_cast<unsigned short *>(planes), kp, inv_scale, act);
+                       reinterpret_cast<unsigned short *>(planes), kp, inv_scale, act, tmax);
     LA_LAUNCH_CHECK();
     return LA_OK;
+}
+
+extern "C" int la_split_f16x2_act(const float *x, int64_t ldx, int32_t rows, int32_t cols, void *planes, int64_t kp, float *inv_scale,
+                                  int32_t act, void *stream_) {
+    return la_split_f16x2_max(x, ldx, rows, cols, planes, kp, inv_scale, act, nullptr, stream_);
 }
 
 extern "C" int la_split_f16x2(const float *x, int64_t ldx, int32_t rows, int32_t cols, void *planes, int64_t kp, float *inv_scale, void *stream_) {
@@ -271,18 +303,35 @@ extern "C" int la_colsum_f32(const float *in, int64_t ld, int32_t rows, int32_t 
 
 // colsum != NULL (act must be 0): also out[c] = sum_r x[r][c] -- the bias gradient next to the weight gradient whose operand this split
 // makes, from the same pass over x that finds the column maxima
-extern "C" int la_split_f16x2_t_colsum(const float *x, int64_t ldx, int32_t rows, int32_t cols, void *planes_t, int64_t mp, float *inv_scale_t,
-                                       int32_t act, float *colsum, void *stream_) {
+// tmax != NULL: the 64 words a plain split of the SAME operand (same act) left with la_split_f16x2_max -- the planes take one scale for
+// the whole operand and the pass for column maxima is skipped; the column sums (colsum != NULL) then come out of the split kernel itself.
+extern "C" int la_split_f16x2_t_tmax(const float *x, int64_t ldx, int32_t rows, int32_t cols, void *planes_t, int64_t mp, float *inv_scale_t,
+                                     int32_t act, float *colsum, const uint32_t *tmax, void *stream_) {
     if (cols == 0) return LA_OK;
     LA_CHECK_ARG(act == 0 || act == 1, "split_f16x2_t: act is 0 (none) or 1 (GELU)");
     LA_CHECK_ARG(!colsum || act == 0, "split_f16x2_t: column sums are those of x itself (act = 0)");
     LA_CHECK_ARG(x && planes_t && inv_scale_t && rows > 0 && cols > 0, "split_f16x2_t: bad arguments");
     LA_CHECK_ARG(mp >= rows && mp % 16 == 0 && ldx >= cols && (uintptr_t)planes_t % 16 == 0, "split_f16x2_t: mp must be >= rows and a multiple of 16, planes 16-byte aligned");
     hipStream_t stream = (hipStream_t)stream_;
+    la::TimerScope ts("split_f16x2", stream, (double)rows * cols * 12.0);
+    unsigned short *pl = reinterpret_cast<unsigned short *>(planes_t);
+    const dim3 tgrid(la::cdiv(cols, 64), la::cdiv(mp, 64));
+    if (tmax) {
+        if (colsum) {
+            double *part = static_cast<double *>(la::stream_scratch(stream, la::SCRATCH_COLSUM, sizeof(double) * (size_t)tgrid.y * cols));
+            if (!part) { la::set_error("split_f16x2_t: scratch allocation failed"); return LA_EHIP; }
+            hipLaunchKernelGGL((split_transposed_kernel<true, true>), tgrid, dim3(256), 0, stream, x, ldx, rows, cols, tmax, pl, mp, inv_scale_t, act, part);
+            hipLaunchKernelGGL(colsum_blocks_kernel, dim3(la::cdiv(cols, 32)), dim3(256), 0, stream, part, (int)tgrid.y, cols, colsum);
+        } else {
+            hipLaunchKernelGGL((split_transposed_kernel<true, false>), tgrid, dim3(256), 0, stream, x, ldx, rows, cols, tmax, pl, mp, inv_scale_t, act,
+                               (double *)nullptr);
+        }
+        LA_LAUNCH_CHECK();
+        return LA_OK;
+    }
     unsigned *colmax = static_cast<unsigned *>(la::stream_scratch(stream, la::SCRATCH_X2, (size_t)cols * sizeof(unsigned)));
     if (!colmax) { la::set_error("split_f16x2_t: scratch allocation failed"); return LA_EHIP; }
     LA_HIP(hipMemsetAsync(colmax, 0, (size_t)cols * sizeof(unsigned), stream));
-    la::TimerScope ts("split_f16x2", stream, (double)rows * cols * 12.0);
     const int rpb = 512;
     if (cols % 4 == 0 && ldx % 4 == 0 && (uintptr_t)x % 16 == 0) {
         const dim3 grid(la::cdiv(cols, 256), la::cdiv(rows, 128));
@@ -290,7 +339,7 @@ extern "C" int la_split_f16x2_t_colsum(const float *x, int64_t ldx, int32_t rows
             double *part = static_cast<double *>(la::stream_scratch(stream, la::SCRATCH_COLSUM, sizeof(double) * (size_t)grid.y * cols));
             if (!part) { la::set_error("split_f16x2_t: scratch allocation failed"); return LA_EHIP; }
             hipLaunchKernelGGL(colmax4_kernel<true>, grid, dim3(256), 0, stream, x, ldx, rows, cols, 128, colmax, act, part);
-            hipLaunchKernelGGL(colsum_blocks_kernel, dim3(la::cdiv(cols, 64)), dim3(256), 0, stream, part, (int)grid.y, cols, colsum);
+            hipLaunchKernelGGL(colsum_blocks_kernel, dim3(la::cdiv(cols, 32)), dim3(256), 0, stream, part, (int)grid.y, cols, colsum);
         } else {
             hipLaunchKernelGGL(colmax4_kernel<false>, grid, dim3(256), 0, stream, x, ldx, rows, cols, 128, colmax, act, (double *)nullptr);
         }
@@ -302,10 +351,15 @@ extern "C" int la_split_f16x2_t_colsum(const float *x, int64_t ldx, int32_t rows
         }
     }
     LA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(split_transposed_kernel, dim3(la::cdiv(cols, 64), la::cdiv(mp, 64)), dim3(256), 0, stream, x, ldx, rows, cols, colmax,
-                       reinterpret_cast<unsigned short *>(planes_t), mp, inv_scale_t, act);
+    hipLaunchKernelGGL((split_transposed_kernel<false, false>), tgrid, dim3(256), 0, stream, x, ldx, rows, cols, colmax, pl, mp, inv_scale_t, act,
+                       (double *)nullptr);
     LA_LAUNCH_CHECK();
     return LA_OK;
+}
+
+extern "C" int la_split_f16x2_t_colsum(const float *x, int64_t ldx, int32_t rows, int32_t cols, void *planes_t, int64_t mp, float *inv_scale_t,
+                                       int32_t act, float *colsum, void *stream_) {
+    return la_split_f16x2_t_tmax(x, ldx, rows, cols, planes_t, mp, inv_scale_t, act, colsum, nullptr, stream_);
 }
 
 extern "C" int la_split_f16x2_t_act(const float *x, int64_t ldx, int32_t rows, int32_t cols, void *planes_t, int64_t mp, float *inv_scale_t,

@@ -47,31 +47,53 @@ class Planes:
 
 
 ACT = {None: 0, "gelu": 1}
+# LA_F32X2_TMAX=0: a transposed split always makes its own pass for column maxima (A/B partner; read at import)
+REUSE_MAX = os.environ.get("LA_F32X2_TMAX", "1") != "0"
 
 
-def split(x: torch.Tensor, kp: Optional[int] = None, act: Optional[str] = None) -> Planes:
+class OperandMax:
+    """The largest magnitude of an operand, left by its plain split (la_split_f16x2_max: 64 words, atomicMax) for a later TRANSPOSED split
+    of the same operand (la_split_f16x2_t_tmax), which then takes one power-of-two scale for the whole operand and skips its pass for
+    column maxima.  dy is split both ways in one backward step (dx = dy w, dw = dy^T x); an activation is split plain in the forward and
+    transposed for its weight gradient."""
+
+    def __init__(self, device):
+        self.words = torch.zeros((64 * 32,), dtype=torch.int32, device=device)      # 64 words, one per 128-byte line
+        self.act: Optional[str] = None
+        self.valid = False
+
+
+def split(x: torch.Tensor, kp: Optional[int] = None, act: Optional[str] = None, omax: Optional[OperandMax] = None) -> Planes:
     """x [rows, k] float32 (row view, unit inner stride) -> its planes along k, zero-padded to kp (default: k rounded up to 128).
-    act = "gelu": the planes of gelu(x) (exact erf), applied inside the split."""
+    act = "gelu": the planes of gelu(x) (exact erf), applied inside the split.  omax: receives the operand's largest magnitude."""
     if x.dtype != torch.float32 or x.dim() != 2 or x.stride(1) != 1:
         raise ValueError("f32x2.split: a float32 [rows, k] row view is expected")
     rows, k = x.shape
     kp = _rup(k, 128) if kp is None else kp
     planes = torch.empty((rows, 2, kp), dtype=torch.float16, device=x.device)
     inv = torch.empty((rows,), dtype=torch.float32, device=x.device)
-    check(lib().la_split_f16x2_act(ptr(x), x.stride(0), rows, k, ptr(planes), kp, ptr(inv), ACT[act], stream_ptr()), "split_f16x2")
+    if omax is not None and REUSE_MAX:
+        check(lib().la_split_f16x2_max(ptr(x), x.stride(0), rows, k, ptr(planes), kp, ptr(inv), ACT[act], ptr(omax.words), stream_ptr()), "split_f16x2")
+        omax.act, omax.valid = act, True
+    else:
+        check(lib().la_split_f16x2_act(ptr(x), x.stride(0), rows, k, ptr(planes), kp, ptr(inv), ACT[act], stream_ptr()), "split_f16x2")
     return Planes(planes, inv, rows, k, kp)
 
 
-def split_t(x: torch.Tensor, mp: Optional[int] = None, act: Optional[str] = None, colsum: Optional[torch.Tensor] = None) -> Planes:
+def split_t(x: torch.Tensor, mp: Optional[int] = None, act: Optional[str] = None, colsum: Optional[torch.Tensor] = None,
+            omax: Optional[OperandMax] = None) -> Planes:
     """x [m, k] float32 -> the planes of x^T (of act(x)^T): rows = k, contraction length m zero-padded to mp (default: m rounded up to 128).
-    colsum [k] float32 (act None): also filled with the column sums of x, from the pass that finds the column maxima."""
+    colsum [k] float32 (act None): also filled with the column sums of x, from the pass that finds the column maxima.
+    omax (valid, same act): the operand's maximum from its plain split -- one scale for the whole operand, no pass for column maxima."""
     if x.dtype != torch.float32 or x.dim() != 2 or x.stride(1) != 1:
         raise ValueError("f32x2.split_t: a float32 [m, k] row view is expected")
     m, k = x.shape
     mp = _rup(m, 128) if mp is None else mp
     planes = torch.empty((k, 2, mp), dtype=torch.float16, device=x.device)
     inv = torch.empty((k,), dtype=torch.float32, device=x.device)
-    check(lib().la_split_f16x2_t_colsum(ptr(x), x.stride(0), m, k, ptr(planes), mp, ptr(inv), ACT[act], ptr(colsum), stream_ptr()), "split_f16x2_t")
+    words = omax.words if (omax is not None and omax.valid and omax.act == act and REUSE_MAX) else None
+    check(lib().la_split_f16x2_t_tmax(ptr(x), x.stride(0), m, k, ptr(planes), mp, ptr(inv), ACT[act], ptr(colsum), ptr(words), stream_ptr()),
+          "split_f16x2_t")
     return Planes(planes, inv, k, m, mp)
 
 
@@ -135,7 +157,7 @@ def _apply(x: torch.Tensor, act: Optional[str]) -> torch.Tensor:
 
 
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
-           x_act: Optional[str] = None) -> torch.Tensor:
+           x_act: Optional[str] = None, x_max: Optional[OperandMax] = None) -> torch.Tensor:
     """y = act(x) w^T (+ bias) (+ residual), float32 in and out (F.linear; whisper/model.py Linear; x_act = "gelu": the MLP's second
     Linear on gelu(x), the activation applied inside the operand split)."""
     from . import ops
@@ -145,11 +167,11 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
         kp = padded_k(M, N, K)
         if not FUSE_ACT:
             x, x_act = _apply(x, x_act), None
-        return gemm(split(x, kp, act=x_act), split(w, kp), bias=bias, residual=residual)
+        return gemm(split(x, kp, act=x_act, omax=x_max), split(w, kp), bias=bias, residual=residual)
     return ops.gemm(_apply(x, x_act), w, bias=bias, residual=residual)
 
 
-def gemm_nn(dy: torch.Tensor, w: torch.Tensor, gelu_grad_of: Optional[torch.Tensor] = None) -> torch.Tensor:
+def gemm_nn(dy: torch.Tensor, w: torch.Tensor, gelu_grad_of: Optional[torch.Tensor] = None, dy_max: Optional[OperandMax] = None) -> torch.Tensor:
     """dy [M, N] . w [N, K] -> [M, K]: the input gradient of y = x w^T.  gelu_grad_of = u [M, K]: times gelu'(u) -- the gradient at the
     pre-activation u of x = gelu(u), in the product's epilogue on the f16x2 path (la_gelu_bwd_f32 on the result otherwise)."""
     from . import head_train
@@ -158,7 +180,7 @@ def gemm_nn(dy: torch.Tensor, w: torch.Tensor, gelu_grad_of: Optional[torch.Tens
     fused = gelu_grad_of is not None and FUSE_ACT and _plain2d(gelu_grad_of)
     if _plain2d(dy) and _plain2d(w) and eligible(M, K, N):
         np_ = padded_k(M, K, N)
-        dx = gemm(split(dy, np_), split_t(w, np_), gelu_grad_of=gelu_grad_of if fused else None)
+        dx = gemm(split(dy, np_, omax=dy_max), split_t(w, np_), gelu_grad_of=gelu_grad_of if fused else None)
         if fused:
             return dx
     else:
@@ -169,7 +191,8 @@ def gemm_nn(dy: torch.Tensor, w: torch.Tensor, gelu_grad_of: Optional[torch.Tens
     return dx
 
 
-def gemm_tn(dy: torch.Tensor, x: torch.Tensor, x_act: Optional[str] = None, colsum: Optional[torch.Tensor] = None) -> torch.Tensor:
+def gemm_tn(dy: torch.Tensor, x: torch.Tensor, x_act: Optional[str] = None, colsum: Optional[torch.Tensor] = None,
+            dy_max: Optional[OperandMax] = None, x_max: Optional[OperandMax] = None) -> torch.Tensor:
     """dy [M, N]^T . act(x) [M, K] -> [N, K]: the weight gradient of y = act(x) w^T (contraction over the M rows of both).
     colsum [N] float32: also filled with the bias gradient sum_m dy[m, :] (from the split's pass over dy, or la_colsum_f32)."""
     from . import head_train
@@ -179,7 +202,7 @@ def gemm_tn(dy: torch.Tensor, x: torch.Tensor, x_act: Optional[str] = None, cols
         mp = padded_k(N, K, M)
         if not FUSE_ACT:
             x, x_act = _apply(x, x_act), None
-        return gemm(split_t(dy, mp, colsum=colsum), split_t(x, mp, act=x_act))
+        return gemm(split_t(dy, mp, colsum=colsum, omax=dy_max), split_t(x, mp, act=x_act, omax=x_max))
     if colsum is not None:
         check(lib().la_colsum_f32(ptr(dy), dy.stride(0), M, N, ptr(colsum), stream_ptr()), "colsum")
     return head_train.gemm_tn_f32(dy, _apply(x, x_act))

@@ -78,12 +78,13 @@ def _gemm_ex_flags(Mg: int, Ng: int, Kg: int, a: torch.Tensor, w: torch.Tensor, 
     return out
 
 
-def linear_grads(dy: torch.Tensor, x: torch.Tensor, x_act: Optional[str] = None):
+def linear_grads(dy: torch.Tensor, x: torch.Tensor, x_act: Optional[str] = None, dy_max=None, x_max=None):
     """(dw, db) of y = act(x) w^T + b from dy [M, N] and x [M, K]: dw = dy^T act(x), db = the column sums of dy -- on the f16x2 path from the
-    one pass over dy that the operand split makes anyway (la_split_f16x2_t_colsum), otherwise la_colsum_f32."""
+    one pass over dy that the operand split makes anyway (la_split_f16x2_t_colsum), otherwise la_colsum_f32.  dy_max / x_max
+    (f32x2.OperandMax): the operands' maxima from their plain splits (dy: gemm_nn of the same step; x: the forward's Linear)."""
     from . import f32x2
     db = torch.empty((dy.shape[1],), dtype=torch.float32, device=dy.device)
-    return f32x2.gemm_tn(dy, x, x_act=x_act, colsum=db), db
+    return f32x2.gemm_tn(dy, x, x_act=x_act, colsum=db, dy_max=dy_max, x_max=x_max), db
 
 
 def gemm_tn(a: torch.Tensor, b: torch.Tensor, b_act: Optional[str] = None) -> torch.Tensor:
@@ -93,11 +94,11 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, b_act: Optional[str] = None) -> to
     return f32x2.gemm_tn(a, b, x_act=b_act)
 
 
-def gemm_nn(a: torch.Tensor, w: torch.Tensor, gelu_grad_of: Optional[torch.Tensor] = None) -> torch.Tensor:
+def gemm_nn(a: torch.Tensor, w: torch.Tensor, gelu_grad_of: Optional[torch.Tensor] = None, a_max=None) -> torch.Tensor:
     """a [M,N] . w [N,K] -> [M,K]: the input gradient of a Linear (gelu_grad_of = u [M,K]: times gelu'(u), the gradient at the
     pre-activation of the MLP's hidden layer).  Large products on the f16x2 path, the rest gemm_nn_f32."""
     from . import f32x2
-    return f32x2.gemm_nn(a, w, gelu_grad_of=gelu_grad_of)
+    return f32x2.gemm_nn(a, w, gelu_grad_of=gelu_grad_of, dy_max=a_max)
 
 
 def gemm_tn_f32(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:

@@ -764,6 +764,22 @@ def test_f16x2_gradient_products_with_split_k_slots():
         e_x2 = float((got.double() - ref).abs().max() / ref.abs().max())
         e_f32 = float((nat.double() - ref).abs().max() / ref.abs().max())
         assert e_x2 <= max(e_f32, 4e-7) and e_x2 < 3e-6, (e_x2, e_f32)
+    # the operands' maxima from their plain splits (f32x2.OperandMax) scale the transposed splits: one power-of-two scale per operand, no pass
+    # for column maxima; the weight gradient and the bias gradient (now from the split kernel itself) keep the float32-level accuracy
+    m_dy, m_x = f32x2.OperandMax(dyd.device), f32x2.OperandMax(dyd.device)
+    f32x2.gemm_nn(dyd, wd, dy_max=m_dy)
+    f32x2.linear(xd, _rand(1536, K, seed=25, scale=K ** -0.5).cuda(), x_max=m_x)
+    assert m_dy.valid and m_x.valid
+    assert float(torch.from_numpy(m_dy.words.cpu().numpy().view("float32")).max()) == float(dy.abs().max())
+    Pt = f32x2.split_t(dyd, 6016, omax=m_dy)
+    assert int(Pt.inv_scale.unique().numel()) == 1                       # one scale for the whole operand
+    rec = (Pt.planes[:, 0, :M].double() + Pt.planes[:, 1, :M].double()).cpu() * Pt.inv_scale.cpu().double()[:, None]
+    assert float((rec - dy.double().t()).abs().max()) <= float(dy.abs().max()) * 2.0 ** -21
+    db_m = torch.empty((N,), dtype=torch.float32, device=dyd.device)
+    dw_m = f32x2.gemm_tn(dyd, xd, colsum=db_m, dy_max=m_dy, x_max=m_x)
+    e_m = float((dw_m.cpu().double() - ref_dw).abs().max() / ref_dw.abs().max())
+    assert e_m < 3e-6 and torch.equal(dw_m, f32x2.gemm_tn(dyd, xd, dy_max=m_dy, x_max=m_x)), e_m
+    assert float((db_m.cpu().double() - dy.double().sum(0)).abs().max()) <= 1e-6 * float(dy.abs().sum(0).max())
     # dx times gelu'(u) in the product's epilogue (LA_EPI_RES_GELU_GRAD): the bits of la_gelu_bwd_f32 on the plain product
     from lyricalignment_amd import encoder_train
     u = _rand(M, K, seed=24, scale=1.5).cuda()
