@@ -27,6 +27,9 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 
+#ifndef LA_X2F_KO
+#define LA_X2F_KO 0                     // timing-only builds (tools/ab_x2f_knockouts.sh; results are garbage): bit mask of parts of the forward
+#endif                                  // tile loop left out -- 1 exponentials, 2 V^T fragment reads, 4 K fragment reads, 8 staging, 16 MFMAs, 32 barrier
 constexpr int KT = 64;                  // keys per tile
 constexpr int IMG = KT * 128;           // one plane of one K or V tile: [64 keys][128 B]
 constexpr float kLog2e = 1.4426950408889634f;
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_x2_fwd_kernel(FwdParams 
         constexpr int cur = decltype(curc)::value;
         const unsigned char *kl = lds + cur * 4 * IMG;
         const unsigned char *vl = kl + 2 * IMG;
-        if (t + 1 < nkv) stage(t + 1, lds0 + (cur ^ 1) * 4 * IMG);
+        if (t + 1 < nkv && !(LA_X2F_KO & 8)) stage(t + 1, lds0 + (cur ^ 1) * 4 * IMG);
         // ---- S^T = K Q^T: two 32-key sub-tiles, three products each (small terms first); all sixteen K fragments requested before the
         // first MFMA (64 VGPRs): the reads return under the MFMAs ----
         f32x16 s[2];
@@ -248,21 +251,31 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_x2_fwd_kernel(FwdParams 
                 for (int sub = 0; sub < 2; ++sub) {
                     const int row = sub * 32 + i32;
                     const int off = row * 128 + (((2 * c + h) ^ kswz(row)) << 4);
-                    kfh[sub][c] = *reinterpret_cast<const uint4 *>(kl + off);
-                    kfl[sub][c] = *reinterpret_cast<const uint4 *>(kl + IMG + off);
+                    if constexpr (LA_X2F_KO & 4) { kfh[sub][c] = qh[(c + sub) & 3]; kfl[sub][c] = ql[(c + sub) & 3]; }
+                    else {
+                        kfh[sub][c] = *reinterpret_cast<const uint4 *>(kl + off);
+                        kfl[sub][c] = *reinterpret_cast<const uint4 *>(kl + IMG + off);
+                    }
                 }
+            if constexpr (LA_X2F_KO & 16) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
+                for (int c = 0; c < 4; ++c)
 #pragma unroll
-                for (int sub = 0; sub < 2; ++sub) s[sub] = mfma(__builtin_bit_cast(f16x8, kfl[sub][c]), __builtin_bit_cast(f16x8, qh[c]), s[sub]);
+                    for (int sub = 0; sub < 2; ++sub) s[sub][c] += __builtin_bit_cast(float, kfh[sub][c].x) + __builtin_bit_cast(float, kfl[sub][c].w);
+            } else {
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
+                for (int c = 0; c < 4; ++c)
 #pragma unroll
-                for (int sub = 0; sub < 2; ++sub) s[sub] = mfma(__builtin_bit_cast(f16x8, kfh[sub][c]), __builtin_bit_cast(f16x8, ql[c]), s[sub]);
+                    for (int sub = 0; sub < 2; ++sub) s[sub] = mfma(__builtin_bit_cast(f16x8, kfl[sub][c]), __builtin_bit_cast(f16x8, qh[c]), s[sub]);
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
+                for (int c = 0; c < 4; ++c)
 #pragma unroll
-                for (int sub = 0; sub < 2; ++sub) s[sub] = mfma(__builtin_bit_cast(f16x8, kfh[sub][c]), __builtin_bit_cast(f16x8, qh[c]), s[sub]);
+                    for (int sub = 0; sub < 2; ++sub) s[sub] = mfma(__builtin_bit_cast(f16x8, kfh[sub][c]), __builtin_bit_cast(f16x8, ql[c]), s[sub]);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int sub = 0; sub < 2; ++sub) s[sub] = mfma(__builtin_bit_cast(f16x8, kfh[sub][c]), __builtin_bit_cast(f16x8, qh[c]), s[sub]);
+            }
         }
         if constexpr (decltype(maskc)::value) {
             const int kmax = p.causal ? min(T - 1, qrow) : T - 1;
@@ -288,8 +301,13 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_x2_fwd_kernel(FwdParams 
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                s[sub][r] = __builtin_amdgcn_exp2f(fmaf(s[sub][r], kScale, mneg));
-                s[sub][r + 1] = __builtin_amdgcn_exp2f(fmaf(s[sub][r + 1], kScale, mneg));
+                if constexpr (LA_X2F_KO & 1) {
+                    s[sub][r] = fmaf(s[sub][r], kScale, mneg);
+                    s[sub][r + 1] = fmaf(s[sub][r + 1], kScale, mneg);
+                } else {
+                    s[sub][r] = __builtin_amdgcn_exp2f(fmaf(s[sub][r], kScale, mneg));
+                    s[sub][r + 1] = __builtin_amdgcn_exp2f(fmaf(s[sub][r + 1], kScale, mneg));
+                }
                 ps0 += s[sub][r];
                 ps1 += s[sub][r + 1];
             }
@@ -320,17 +338,27 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_x2_fwd_kernel(FwdParams 
                     const int r0 = key0 + q4, r1 = key0 + 8 + q4;
                     const int a0 = r0 * 128 + ((slot ^ vswz(r0)) << 4) + (pp & 1) * 8, a1 = r1 * 128 + ((slot ^ vswz(r1)) << 4) + (pp & 1) * 8;
                     typedef __attribute__((address_space(3))) s16x4 *lds_s16x4;
-                    const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(vl + a0)), h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(vl + a1));
-                    const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(vl + IMG + a0)), l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(vl + IMG + a1));
-                    const f16x8 vh = __builtin_bit_cast(f16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
-                    const f16x8 vlo = __builtin_bit_cast(f16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
-                    o[b] = mfma(vlo, phv, o[b]);
-                    o[b] = mfma(vh, plv, o[b]);
-                    o[b] = mfma(vh, phv, o[b]);
+                    f16x8 vh, vlo;
+                    if constexpr (LA_X2F_KO & 2) {
+                        vh = __builtin_bit_cast(f16x8, qh[(2 * sub + ks + b) & 3]);
+                        vlo = __builtin_bit_cast(f16x8, ql[(2 * sub + ks + b) & 3]);
+                    } else {
+                        const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(vl + a0)), h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(vl + a1));
+                        const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(vl + IMG + a0)), l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(vl + IMG + a1));
+                        vh = __builtin_bit_cast(f16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
+                        vlo = __builtin_bit_cast(f16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+                    }
+                    if constexpr (LA_X2F_KO & 16) {
+                        o[b][2 * sub + ks] += (float)vh[0] + (float)vlo[7] + (float)phv[0] + (float)plv[7];
+                    } else {
+                        o[b] = mfma(vlo, phv, o[b]);
+                        o[b] = mfma(vh, plv, o[b]);
+                        o[b] = mfma(vh, phv, o[b]);
+                    }
                 }
             }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if constexpr (!(LA_X2F_KO & 32)) __syncthreads();
     };
     auto step = [&](int t, auto curc) __attribute__((always_inline)) {
         if (__builtin_expect((t + 1) * KT > T || p.causal, 0)) tile(t, curc, std::true_type{});
