@@ -14,7 +14,10 @@ large ones: >= 192 tiles of 256 x 256, counting split-K slots), their operand sp
 with the float32 MFMA kernel (ops.gemm / head_train.gemm_nn / gemm_tn) for every shape outside that domain.
 LA_F32X2=0 keeps every product on the float32 kernel (the A/B partner; read at import).  The MLP's gelu(u) operand is split
 straight from u (x_act / act = "gelu": the activation runs inside the split kernels, no float32 buffer of gelu(u) in the forward
-or in the weight gradient); LA_F32X2_ACT=0 goes through the buffer (same bits).
+or in the weight gradient) and gemm_nn(..., gelu_grad_of=u) multiplies the input gradient by gelu'(u) in the product's epilogue;
+LA_F32X2_ACT=0 goes through the buffers (same bits).  An operand that is split both ways leaves its largest magnitude with the plain
+split for the transposed one (OperandMax: no pass for column maxima; LA_F32X2_TMAX=0 keeps the pass), and gemm_tn(..., colsum=db) returns
+the bias gradient from the transposed split's own tiles.
 """
 from __future__ import annotations
 
