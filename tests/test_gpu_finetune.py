@@ -233,6 +233,49 @@ def test_attention_forward_f16x2_matches_float64_at_float32_accuracy(B, Tq, Tk, 
     assert res["f16x2"][1] <= 1.5 * res["f32"][1] + 5e-7 and res["f16x2"][1] < 2e-5, res
 
 
+def test_attention_f16x2_on_sequences_longer_than_a_clip():
+    """1700 tokens (beyond the 1536 the per-head split keeps in registers: its two-pass form; 27 key tiles, ragged last tiles of both sweeps):
+    forward and backward of the f16x2 attention against the float32-MFMA kernels, self-attention and a cross shape."""
+    from lyricalignment_amd import encoder_train as et, ops
+    for (B, Tq, Tk, H) in ((1, 1700, 1700, 2), (1, 1600, 300, 1)):
+        d = 64 * H
+        g = torch.Generator().manual_seed(Tq - Tk)
+        q = (torch.randn(B * Tq, d, generator=g) * 0.35).cuda()
+        kv = torch.randn(B * Tk, 2 * d, generator=g).cuda()
+        do = torch.randn(B * Tq, d, generator=g).cuda()
+        res = []
+        for flag in (True, False):
+            ops.ATTN_F16X2 = flag
+            try:
+                lse = torch.empty((B, H, Tq), dtype=torch.float32, device="cuda")
+                o = ops.attention_ex(q, kv[:, :d], kv[:, d:], B, Tq, Tk, H, lse=lse)
+                dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+                et.attention_bwd_ex(q, kv[:, :d], kv[:, d:], do, dq, dkv[:, :d], dkv[:, d:], B, Tq, Tk, H, o=o, lse=lse)
+            finally:
+                ops.ATTN_F16X2 = True
+            res.append((o, lse, dq, dkv))
+        for a, b, name in zip(res[0], res[1], ("out", "lse", "dq", "dkv")):
+            assert _rel(a, b) < 5e-6, (name, _rel(a, b))
+
+
+def test_layernorm_backward_with_sums_matches_torch_autograd():
+    """la_layernorm_bwd_sums_f32 (one pass: dx + the residual gradient, dgamma, dbeta) against torch autograd in float64: the register form
+    (d = 1024, 768; rows not a multiple of the 128-row blocks) and the fallback widths (d = 320: la_layernorm_bwd_f32 + column sums + add)."""
+    from lyricalignment_amd import encoder_train as et
+    for (M, d) in ((3000, 1024), (517, 768), (300, 320)):
+        g = torch.Generator().manual_seed(M + d)
+        x = torch.randn(M, d, generator=g) * torch.exp(torch.randn(M, 1, generator=g))
+        dy, res, gamma = torch.randn(M, d, generator=g), torch.randn(M, d, generator=g), torch.rand(d, generator=g) + 0.5
+        xr, gr = x.double().requires_grad_(True), gamma.double().requires_grad_(True)
+        br = torch.zeros(d, dtype=torch.float64, requires_grad=True)
+        torch.nn.functional.layer_norm(xr, (d,), gr, br, 1e-5).backward(dy.double())
+        dx, dg, db = et.layernorm_bwd(x.cuda(), dy.cuda(), gamma.cuda(), residual=res.cuda())
+        assert _rel(dx.cpu().double(), xr.grad + res.double()) < 2e-5
+        assert _rel(dg.cpu().double(), gr.grad) < 2e-5 and _rel(db.cpu().double(), br.grad) < 2e-5
+        dx2, _, _ = et.layernorm_bwd(x.cuda(), dy.cuda(), gamma.cuda())
+        assert _rel(dx2.cpu().double(), xr.grad) < 2e-5
+
+
 def test_attention_backward_f16x2_is_deterministic_and_matches_the_float32_sweeps():
     """la_attention_bwd_f16x2 twice on the same operands: the same bits (the split of P and dS runs in inline assembly whose wait states
     before the consuming MFMA are placed by hand -- without them dK differed from run to run); and within 5e-6 of the float32-MFMA sweeps

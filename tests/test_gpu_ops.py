@@ -703,6 +703,13 @@ def test_split_f16x2_planes_reconstruct_the_float32_values():
         assert bool(((scaled[nz] >= 2.0 ** 13) & (scaled[nz] < 2.0 ** 14)).all()) and bool((inv[~nz] == 1.0).all())
     a, b = f32x2.split_t(xd, 1024), f32x2.split(xd.t().contiguous(), 1024)
     assert torch.equal(a.planes.view(torch.int16), b.planes.view(torch.int16)) and torch.equal(a.inv_scale, b.inv_scale)
+    # rows longer than the 4096 columns the split keeps in registers (its two-pass form), odd row pitch (scalar loads)
+    for cols, pitch in ((4200, 4200), (4200, 4201), (1000, 1001)):
+        w = _heavy(70, pitch, seed=cols + pitch)[:, :cols]
+        P = f32x2.split(w.cuda(), 4224 if cols > 4096 else 1024)
+        rec = (P.planes[:, 0, :cols].double() + P.planes[:, 1, :cols].double()).cpu() * P.inv_scale.cpu().double()[:, None]
+        bound = torch.maximum(w.double().abs() * 2.0 ** -21, w.abs().amax(dim=1, keepdim=True).double() * 2.0 ** -38)
+        assert bool(((rec - w.double()).abs() <= bound).all()), (cols, pitch)
 
 
 def test_split_f16x2_with_gelu_equals_the_split_of_the_gelu_buffer():
