@@ -26,7 +26,9 @@ def test_losses_match_reference_golden():
     np.testing.assert_allclose(g.cpu().numpy(), 0.125 * (z["g_ce"] + z["g_ctc"]), rtol=0, atol=2e-6)   # loss / accum_grad_steps
 
 
-@pytest.mark.parametrize("B,T,V,Ls", [(2, 300, 500, [26, 9]), (3, 120, 2000, [40, 1, 17]), (2, 1500, 21128, [26, 11])])
+@pytest.mark.parametrize("B,T,V,Ls", [(2, 300, 500, [26, 9]), (3, 120, 2000, [40, 1, 17]), (2, 1500, 21128, [26, 11]),
+                                      (3, 200, 300, [31, 1, 5]),      # 63 lattice states: the widest the one-wave lattice takes; a single label
+                                      (2, 1501, 64, [3, 30])])        # a frame count that is not a multiple of the 8-step prefetch blocks
 def test_losses_match_torch(B, T, V, Ls):
     from lyricalignment_amd import finetune as ft
     rs = np.random.RandomState(B * T)
