@@ -214,15 +214,15 @@ class EncoderFunction(torch.autograd.Function):
             wqkv = torch.cat([scale(wq, 0.125), wk, wv], 0).contiguous()          # (head_dim^-0.25)^2 folded into q: exact
             bqkv = torch.cat([scale(bq, 0.125), torch.zeros_like(bq), bv], 0).contiguous()
             # (the operands' maxima from these plain splits scale the transposed splits of the weight gradients: f32x2.OperandMax)
-            mx = [f32x2.OperandMax(x.device) for _ in range(4)]
+            mx = [f32x2.OperandMax(x.device) for _ in range(8)]        # 0-3 the activations, 4-7 the weights (for dx = dy w)
             h1 = ops.layernorm(x, g1, be1, torch.float32)
-            qkv = f32x2.linear(h1, wqkv, bias=bqkv, x_max=mx[0])
+            qkv = f32x2.linear(h1, wqkv, bias=bqkv, x_max=mx[0], w_max=mx[4])
             lse = torch.empty((B, H, N_CTX), dtype=torch.float32, device=qkv.device)        # row statistic for the fused backward
             att = ops.attention_ex(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, N_CTX, N_CTX, H, lse=lse)
-            x_mid = f32x2.linear(att, wo, bias=bo, residual=x, x_max=mx[1])
+            x_mid = f32x2.linear(att, wo, bias=bo, residual=x, x_max=mx[1], w_max=mx[5])
             h2 = ops.layernorm(x_mid, g2, be2, torch.float32)
-            u_pre = f32x2.linear(h2, w1, bias=b1, x_max=mx[2])
-            x_next = f32x2.linear(u_pre, w2, bias=b2, residual=x_mid, x_act="gelu", x_max=mx[3])
+            u_pre = f32x2.linear(h2, w1, bias=b1, x_max=mx[2], w_max=mx[6])
+            x_next = f32x2.linear(u_pre, w2, bias=b2, residual=x_mid, x_act="gelu", x_max=mx[3], w_max=mx[7])
             saved.append((x, h1, qkv, att, x_mid, h2, u_pre, lse, mx))
             packed.append((g1, wqkv, wo, g2, w1, w2))
             x = x_next
@@ -248,16 +248,16 @@ class EncoderFunction(torch.autograd.Function):
             # of the weight-gradient product (no pass for column maxima)
             my = [f32x2.OperandMax(dx.device) for _ in range(4)]
             # x_next = x_mid + gelu(u_pre) W2^T + b2
-            du_pre = gemm_nn(dx, w2, gelu_grad_of=u_pre, a_max=my[0])
+            du_pre = gemm_nn(dx, w2, gelu_grad_of=u_pre, a_max=my[0], w_max=mx[7])
             G[13], G[14] = linear_grads(dx, u_pre, x_act="gelu", dy_max=my[0], x_max=mx[3])
-            dh2 = gemm_nn(du_pre, w1, a_max=my[1])
+            dh2 = gemm_nn(du_pre, w1, a_max=my[1], w_max=mx[6])
             G[11], G[12] = linear_grads(du_pre, h2, dy_max=my[1], x_max=mx[2])
             dx_mid, G[9], G[10] = layernorm_bwd(x_mid, dh2, g2, residual=dx)
             # x_mid = x + att Wo^T + bo
-            datt = gemm_nn(dx_mid, wo, a_max=my[2])
+            datt = gemm_nn(dx_mid, wo, a_max=my[2], w_max=mx[5])
             G[7], G[8] = linear_grads(dx_mid, att, dy_max=my[2], x_max=mx[1])
             dqkv = attention_bwd(qkv, datt, B, N_CTX, H, att=att, lse=lse)
-            dh1 = gemm_nn(dqkv, wqkv, a_max=my[3])
+            dh1 = gemm_nn(dqkv, wqkv, a_max=my[3], w_max=mx[4])
             dwqkv, dbqkv = linear_grads(dqkv, h1, dy_max=my[3], x_max=mx[0])
             G[2], G[3] = scale(dwqkv[:d], 0.125), scale(dbqkv[:d], 0.125)
             G[4], G[5], G[6] = dwqkv[d:2 * d], dwqkv[2 * d:], dbqkv[2 * d:]

@@ -160,7 +160,7 @@ def _apply(x: torch.Tensor, act: Optional[str]) -> torch.Tensor:
 
 
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
-           x_act: Optional[str] = None, x_max: Optional[OperandMax] = None) -> torch.Tensor:
+           x_act: Optional[str] = None, x_max: Optional[OperandMax] = None, w_max: Optional[OperandMax] = None) -> torch.Tensor:
     """y = act(x) w^T (+ bias) (+ residual), float32 in and out (F.linear; whisper/model.py Linear; x_act = "gelu": the MLP's second
     Linear on gelu(x), the activation applied inside the operand split)."""
     from . import ops
@@ -170,11 +170,12 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
         kp = padded_k(M, N, K)
         if not FUSE_ACT:
             x, x_act = _apply(x, x_act), None
-        return gemm(split(x, kp, act=x_act, omax=x_max), split(w, kp), bias=bias, residual=residual)
+        return gemm(split(x, kp, act=x_act, omax=x_max), split(w, kp, omax=w_max), bias=bias, residual=residual)
     return ops.gemm(_apply(x, x_act), w, bias=bias, residual=residual)
 
 
-def gemm_nn(dy: torch.Tensor, w: torch.Tensor, gelu_grad_of: Optional[torch.Tensor] = None, dy_max: Optional[OperandMax] = None) -> torch.Tensor:
+def gemm_nn(dy: torch.Tensor, w: torch.Tensor, gelu_grad_of: Optional[torch.Tensor] = None, dy_max: Optional[OperandMax] = None,
+            w_max: Optional[OperandMax] = None) -> torch.Tensor:
     """dy [M, N] . w [N, K] -> [M, K]: the input gradient of y = x w^T.  gelu_grad_of = u [M, K]: times gelu'(u) -- the gradient at the
     pre-activation u of x = gelu(u), in the product's epilogue on the f16x2 path (la_gelu_bwd_f32 on the result otherwise)."""
     from . import head_train
@@ -183,7 +184,7 @@ def gemm_nn(dy: torch.Tensor, w: torch.Tensor, gelu_grad_of: Optional[torch.Tens
     fused = gelu_grad_of is not None and FUSE_ACT and _plain2d(gelu_grad_of)
     if _plain2d(dy) and _plain2d(w) and eligible(M, K, N):
         np_ = padded_k(M, K, N)
-        dx = gemm(split(dy, np_, omax=dy_max), split_t(w, np_), gelu_grad_of=gelu_grad_of if fused else None)
+        dx = gemm(split(dy, np_, omax=dy_max), split_t(w, np_, omax=w_max), gelu_grad_of=gelu_grad_of if fused else None)
         if fused:
             return dx
     else:
