@@ -53,14 +53,14 @@ def colsum(a: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, a_max=None, w_max=None) -> torch.Tensor:
     """a [M,K] . w [N,K]^T (+ bias), float32 in and out: the large products as three f16 products over split operands (f32x2.linear:
     float32 accuracy at 3/16 of the float32 pipe's cost), the others on the float32 MFMA kernel (K zero-padded to its granule)."""
     if a.shape[1] != w.shape[1]:
         raise ValueError("gemm_nt: K mismatch")
     from . import f32x2
     if f32x2.eligible(a.shape[0], w.shape[0], a.shape[1]):
-        return f32x2.linear(a, w, bias=bias)
+        return f32x2.linear(a, w, bias=bias, x_max=a_max, w_max=w_max)
     return ops.gemm(_padK(a), _padK(w), bias=bias, out_f32=True)
 
 
@@ -199,7 +199,9 @@ class HeadFunction(torch.autograd.Function):
         out1 = saved[1][1].view(B * T, 2 * H)
         act = torch.empty_like(out1)
         check(lib().la_mish_f32(ptr(out1), ptr(act), act.numel(), stream_ptr()), "mish")
-        logits = gemm_nt(act, w_fc, bias=b_fc)
+        from . import f32x2
+        ctx.fc_max = (f32x2.OperandMax(dev), f32x2.OperandMax(dev))      # of act and of fc.weight, for the transposed splits of the backward
+        logits = gemm_nt(act, w_fc, bias=b_fc, a_max=ctx.fc_max[0], w_max=ctx.fc_max[1])
         ctx.defer = bool(DEFER_FLAG_CHECKS)
         _flag_check(flag, "persistent GRU kernel: a bounded inter-workgroup wait timed out", ctx.defer)
         ctx.layers, ctx.w_fc, ctx.saved, ctx.mask, ctx.act = layers, w_fc, saved, mask, act
@@ -213,9 +215,10 @@ class HeadFunction(torch.autograd.Function):
         M = B * T
         dl = dlogits.to(torch.float32).contiguous().view(M, -1)
         # ---- Linear ----
-        dact = gemm_nn(dl, ctx.w_fc)                                     # [M, 2H]
-        dw_fc = gemm_tn(dl, ctx.act)                                     # [V, 2H]
-        db_fc = colsum(dl)
+        from . import f32x2
+        m_dl = f32x2.OperandMax(dev)
+        dact = gemm_nn(dl, ctx.w_fc, a_max=m_dl, w_max=ctx.fc_max[1])    # [M, 2H]
+        dw_fc, db_fc = linear_grads(dl, ctx.act, dy_max=m_dl, x_max=ctx.fc_max[0])      # [V, 2H], [V]
         # ---- Mish ----
         out1 = ctx.saved[1][1].view(M, 2 * H)
         dout = torch.empty_like(out1)
