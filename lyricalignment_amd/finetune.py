@@ -182,17 +182,34 @@ class OverlappedAllReduce:
         self._works, self._launched = [], [False] * len(self.chunks)
         self._ready, self._next = [False] * len(self.chunks), 0
         self._armed = True
+        # the stream the backward is started from: with the head on a stream of its own (module/align_model.py) a hook may fire on
+        # either; a collective is handed to the backend only after BOTH have been waited for (_launch_in_order)
+        self._main_stream = torch.cuda.current_stream(self.chunks[0][0].device) if self.chunks and self.chunks[0][0].is_cuda else None
 
     def _launch_in_order(self, everything: bool = False) -> None:
         """Hand chunks to the backend strictly in `order`: up to the first one that is not ready yet (all of them from finish())."""
         import torch.distributed as dist
+        joined = False
         while self._next < len(self.order):
             ci = self.order[self._next]
             if not (everything or self._ready[ci]):
                 return
+            if not joined and self.chunks[ci][0].is_cuda:
+                # the backend orders the collective behind the CURRENT stream only: make that one wait for the other streams gradients
+                # were written on (the chunks go out back to front, so by the time one is ready the other stream has long been idle)
+                cur = torch.cuda.current_stream(self.chunks[ci][0].device)
+                for st in (getattr(self, "_main_stream", None), *self.extra_streams()):
+                    if st is not None and st != cur:
+                        cur.wait_stream(st)
+                joined = True
             self._works.append(dist.all_reduce(self.chunks[ci][0], op=dist.ReduceOp.SUM, async_op=True))
             self._launched[ci] = True
             self._next += 1
+
+    def extra_streams(self):
+        """Streams besides the backward's own that gradients may be written on (set by FineTuner: the model's head stream)."""
+        f = getattr(self, "_extra_streams_fn", None)
+        return [st for st in (f() if f else []) if st is not None]
 
     def _on_grad(self, p) -> None:
         if not self._armed:
@@ -304,9 +321,11 @@ class FineTuner:
         self.opt = FlatAdamW(opt_groups, weight_decay=weight_decay)
         # the exchange step, overlapped with the last backward (allreduce_chunks = 0: the single blocking all-reduce per bucket)
         self.overlap = OverlappedAllReduce(self.groups, self.grad, self.world, allreduce_chunks) if allreduce_chunks > 0 else None
-        # head and decoder branch on two streams (module/align_model.py): single process only -- with more ranks the gradient chunks
-        # leave for the all-reduce from inside the backward, on whatever stream produced the last of them
-        model._branch_streams = self.world == 1
+        # head and decoder branch on two streams (module/align_model.py); with more ranks the gradient chunks leave for the all-reduce
+        # from inside the backward on whichever stream produced the last of them: the exchange joins both streams before every collective
+        model._branch_streams = True
+        if self.overlap is not None:
+            self.overlap._extra_streams_fn = lambda: [getattr(model, "_head_stream", None)]
 
     @property
     def allreduce_exposed_ms(self) -> float:
