@@ -126,16 +126,17 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float *x, cons
 }
 
 // The same with the two column sums taken on the way (dgamma = sum_r dy xhat, dbeta = sum_r dy): a row lives in registers (NV float4 per
-// lane, d = 256 NV), x and dy are read once, dy * xhat is never written.  A workgroup takes 128 rows, 32 per wave; a lane adds its columns'
-// terms over its wave's rows in float32 (32 terms), the four waves' sums are added in float64 in wave order and written per workgroup;
+// lane, d = 256 NV), x and dy are read once, dy * xhat is never written.  A workgroup takes 4 x rpw rows (rpw <= 32 per wave, fewer when the input is short: the host picks it so that a few hundred
+// workgroups exist); a lane adds its columns'
+// terms over its wave's rows in float32 (<= 32 terms), the four waves' sums are added in float64 in wave order and written per workgroup;
 // ln_sums_final_kernel adds the workgroups in order (deterministic).  137 us + two column-sum passes -> one pass.
 template <int NV>
 __global__ __launch_bounds__(256) void layernorm_bwd_sums_kernel(const float *x, const float *dy, const float *gamma, const float *resid, int M,
-                                                                 float *dx, double *part) {
+                                                                 int rpw, float *dx, double *part) {
     constexpr int d = 256 * NV;
     __shared__ float red[2][4][d];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int row0 = blockIdx.x * 128 + wave * 32;
+    const int row0 = (blockIdx.x * 4 + wave) * rpw;          // rpw rows per wave (host: 32 down to 2, so that a few hundred workgroups exist)
     float4 gm[NV], sg_[NV], sb_[NV];
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_sums_kernel(const float *x,
         sg_[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         sb_[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    for (int i = 0; i < 32; ++i) {
+    for (int i = 0; i < rpw; ++i) {
         const int row = row0 + i;
         if (row >= M) break;                                   // wave-uniform
         const float4 *xr = reinterpret_cast<const float4 *>(x + (int64_t)row * d), *gr = reinterpret_cast<const float4 *>(dy + (int64_t)row * d);
@@ -449,11 +450,15 @@ extern "C" int la_layernorm_bwd_sums_f32(const float *x, const float *dy, const 
         if (rc == LA_OK && residual) rc = la_add_f32(residual, dx, dx, (int64_t)M * d, stream_);
         return rc;
     }
-    const int blocks = la::cdiv(M, 128);
+    // rows per wave: 32 for tall inputs, fewer when that would leave the chip short of workgroups (3000 rows, a micro-batch of the
+    // reference's own loop: 24 workgroups of 128 rows took 93 us, the time of 24000 rows)
+    int rpw = 32;
+    while (rpw > 2 && la::cdiv(M, 4 * rpw) < 512) rpw >>= 1;
+    const int blocks = la::cdiv(M, 4 * rpw);
     double *part = static_cast<double *>(la::stream_scratch(st, la::SCRATCH_COLSUM, sizeof(double) * (size_t)blocks * 2 * d));
     if (!part) { la::set_error("layernorm_bwd_sums: scratch allocation failed"); return LA_EHIP; }
     switch (d / 256) {
-#define LA_LN_CASE(nv) case nv: hipLaunchKernelGGL(layernorm_bwd_sums_kernel<nv>, dim3(blocks), dim3(256), 0, st, x, dy, gamma, residual, M, dx, part); break;
+#define LA_LN_CASE(nv) case nv: hipLaunchKernelGGL(layernorm_bwd_sums_kernel<nv>, dim3(blocks), dim3(256), 0, st, x, dy, gamma, residual, M, rpw, dx, part); break;
         LA_LN_CASE(1) LA_LN_CASE(2) LA_LN_CASE(3) LA_LN_CASE(4) LA_LN_CASE(5) LA_LN_CASE(6) LA_LN_CASE(7) LA_LN_CASE(8)
 #undef LA_LN_CASE
     }
