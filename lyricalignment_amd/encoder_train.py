@@ -209,12 +209,13 @@ class EncoderFunction(torch.autograd.Function):
         # ---- blocks ----
         saved = []
         packed = []
+        all_mx = f32x2.OperandMax.many(x.device, 8 * n_layer)
         for i in range(n_layer):
             (g1, be1, wq, bq, wk, wv, bv, wo, bo, g2, be2, w1, b1, w2, b2) = P[4 + i * 15: 4 + (i + 1) * 15]
             wqkv = torch.cat([scale(wq, 0.125), wk, wv], 0).contiguous()          # (head_dim^-0.25)^2 folded into q: exact
             bqkv = torch.cat([scale(bq, 0.125), torch.zeros_like(bq), bv], 0).contiguous()
             # (the operands' maxima from these plain splits scale the transposed splits of the weight gradients: f32x2.OperandMax)
-            mx = [f32x2.OperandMax(x.device) for _ in range(8)]        # 0-3 the activations, 4-7 the weights (for dx = dy w)
+            mx = all_mx[8 * i: 8 * i + 8]                            # 0-3 the activations, 4-7 the weights (for dx = dy w)
             h1 = ops.layernorm(x, g1, be1, torch.float32)
             qkv = f32x2.linear(h1, wqkv, bias=bqkv, x_max=mx[0], w_max=mx[4])
             lse = torch.empty((B, H, N_CTX), dtype=torch.float32, device=qkv.device)        # row statistic for the fused backward
@@ -240,13 +241,14 @@ class EncoderFunction(torch.autograd.Function):
         dyf = dy.to(torch.float32).contiguous().view(M, d)
         grads: List[Optional[torch.Tensor]] = [None] * (6 + 15 * n_layer)
         dx, grads[-2], grads[-1] = layernorm_bwd(ctx.x_last, dyf, ctx.lnp_g)
+        all_my = f32x2.OperandMax.many(dyf.device, 4 * n_layer)
         for i in reversed(range(n_layer)):
             x, h1, qkv, att, x_mid, h2, u_pre, lse, mx = ctx.saved[i]
             g1, wqkv, wo, g2, w1, w2 = ctx.packed[i]
             G = [None] * 15
             # every incoming gradient is split plain first (its input-gradient product), which leaves its maximum for the transposed split
             # of the weight-gradient product (no pass for column maxima)
-            my = [f32x2.OperandMax(dx.device) for _ in range(4)]
+            my = all_my[4 * i: 4 * i + 4]
             # x_next = x_mid + gelu(u_pre) W2^T + b2
             du_pre = gemm_nn(dx, w2, gelu_grad_of=u_pre, a_max=my[0], w_max=mx[7])
             G[13], G[14] = linear_grads(dx, u_pre, x_act="gelu", dy_max=my[0], x_max=mx[3])

@@ -60,10 +60,19 @@ class OperandMax:
     column maxima.  dy is split both ways in one backward step (dx = dy w, dw = dy^T x); an activation is split plain in the forward and
     transposed for its weight gradient."""
 
-    def __init__(self, device):
-        self.words = torch.zeros((64 * 32,), dtype=torch.int32, device=device)      # 64 words, one per 128-byte line
+    WORDS = 64 * 32                          # 64 words in use, one per 128-byte line
+
+    def __init__(self, device, words: Optional[torch.Tensor] = None):
+        # `words`: a zeroed slice of a buffer the caller allocated for many operands at once (OperandMax.many)
+        self.words = words if words is not None else torch.zeros((self.WORDS,), dtype=torch.int32, device=device)
         self.act: Optional[str] = None
         self.valid = False
+
+    @classmethod
+    def many(cls, device, count: int):
+        """`count` of them over one zeroed buffer (one fill instead of `count`)."""
+        buf = torch.zeros((count, cls.WORDS), dtype=torch.int32, device=device)
+        return [cls(device, buf[i]) for i in range(count)]
 
 
 def split(x: torch.Tensor, kp: Optional[int] = None, act: Optional[str] = None, omax: Optional[OperandMax] = None) -> Planes:
