@@ -46,6 +46,8 @@ struct FwdParams {
 
 // ---- operand split: one workgroup per (head, clip) ------------------------------------------------------------------------------------
 // x rows [clip * T + t][head * 64 ..] (row pitch ld) -> planes [(clip * T + t) * 2 + plane][C] and inv_scale[clip * H + head]
+// gridDim.z = parts: with few (clip, head) slices (a micro-batch of two clips: 32) every slice is taken by `parts` workgroups -- each finds the
+// slice's maximum itself (the slice is L2-resident) and writes every parts-th group of 64 token rows
 __global__ __launch_bounds__(1024) void heads_split_kernel(const float *x, int64_t ld, int T, int H, unsigned short *planes, float *inv_scale) {
     __shared__ float red[16];
     const int head = blockIdx.x, clip = blockIdx.y, tid = threadIdx.x;
@@ -80,8 +82,9 @@ __global__ __launch_bounds__(1024) void heads_split_kernel(const float *x, int64
     for (int i = 1; i < 16; ++i) mx = fmaxf(mx, red[i]);
     float inv;
     const float s = la::x2::scale_for(mx, &inv);
-    if (tid == 0) inv_scale[clip * H + head] = inv;
+    if (tid == 0 && blockIdx.z == 0) inv_scale[clip * H + head] = inv;
     const int64_t C = 64 * (int64_t)H;
+    const int parts = gridDim.z, part = blockIdx.z;
     unsigned short *dst = planes + (int64_t)clip * T * 2 * C + head * 64 + c4 * 4;
     auto put = [&](int r, const float4 &w) {
         const unsigned a = la::x2::pack_hi_lo(w.x * s), b = la::x2::pack_hi_lo(w.y * s), c = la::x2::pack_hi_lo(w.z * s), d = la::x2::pack_hi_lo(w.w * s);
@@ -92,10 +95,11 @@ __global__ __launch_bounds__(1024) void heads_split_kernel(const float *x, int64
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const int r = r0 + 64 * j;
-            if (r < T) put(r, v[j]);
+            if (r < T && j % parts == part) put(r, v[j]);
         }
     } else {
-        for (int r = r0; r < T; r += 64) put(r, *reinterpret_cast<const float4 *>(src + (int64_t)r * ld));
+        for (int r = r0, j = 0; r < T; r += 64, ++j)
+            if (j % parts == part) put(r, *reinterpret_cast<const float4 *>(src + (int64_t)r * ld));
     }
 }
 
@@ -750,6 +754,29 @@ __global__ __launch_bounds__(64 * BWD_NW, 2) void attention_x2_bwd_q_kernel(BwdP
     }
 }
 
+// workgroups per (clip, head) slice of the operand split: enough to fill the chip when the batch is small
+static dim3 heads_split_grid(int n_head, int batch) {
+    int parts = 1;
+    while (parts < 8 && n_head * batch * parts < 256) parts *= 2;
+    return dim3(n_head, batch, parts);
+}
+
+// D_i = sum_d dO_id O_id per (clip, head, query): one 16-lane group per row and head (the statistics launch of la_attention_bwd_f32 also
+// recomputes lse when the forward did not hand it over; with lse at hand this is all that is left of it)
+__global__ __launch_bounds__(256) void attn_dvec_kernel(const float *o, int64_t ld_o, const float *dout, int64_t ld_do, int B, int Tq, int H, float *dvec) {
+    const int64_t item = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);          // (row, head)
+    const int part = threadIdx.x & 15;
+    const int64_t rows = (int64_t)B * Tq;
+    if (item >= rows * H) return;
+    const int64_t row = item / H;
+    const int head = (int)(item % H);
+    const float4 a = *reinterpret_cast<const float4 *>(o + row * ld_o + head * 64 + part * 4);
+    const float4 g = *reinterpret_cast<const float4 *>(dout + row * ld_do + head * 64 + part * 4);
+    float s = (a.x * g.x + a.y * g.y) + (a.z * g.z + a.w * g.w);
+    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+    if (part == 0) dvec[((int64_t)(row / Tq) * H + head) * Tq + row % Tq] = s;
+}
+
 struct FwdWorkspace {
     unsigned short *qp, *kp, *vp;
     float *sq, *sk, *sv;
@@ -790,9 +817,10 @@ extern "C" int la_attention_lse_f16x2(const float *q, int64_t ld_q, const float 
     const FwdWorkspace ws = fwd_workspace(workspace, batch, q_len, kv_len, n_head);
     LA_CHECK_ARG(workspace && (uintptr_t)workspace % 256 == 0 && workspace_bytes >= ws.bytes, "attention_lse_f16x2: workspace missing, misaligned or too small");
     la::TimerScope ts("attention_f16x2", stream);
-    hipLaunchKernelGGL(heads_split_kernel, dim3(n_head, batch), dim3(1024), 0, stream, q, ld_q, q_len, n_head, ws.qp, ws.sq);
-    hipLaunchKernelGGL(heads_split_kernel, dim3(n_head, batch), dim3(1024), 0, stream, k, ld_kv, kv_len, n_head, ws.kp, ws.sk);
-    hipLaunchKernelGGL(heads_split_kernel, dim3(n_head, batch), dim3(1024), 0, stream, v, ld_kv, kv_len, n_head, ws.vp, ws.sv);
+    const dim3 sgrid = heads_split_grid(n_head, batch);
+    hipLaunchKernelGGL(heads_split_kernel, sgrid, dim3(1024), 0, stream, q, ld_q, q_len, n_head, ws.qp, ws.sq);
+    hipLaunchKernelGGL(heads_split_kernel, sgrid, dim3(1024), 0, stream, k, ld_kv, kv_len, n_head, ws.kp, ws.sk);
+    hipLaunchKernelGGL(heads_split_kernel, sgrid, dim3(1024), 0, stream, v, ld_kv, kv_len, n_head, ws.vp, ws.sv);
     FwdParams p{ws.qp, ws.kp, ws.vp, ws.sq, ws.sk, ws.sv, out, ld_out, lse, q_len, kv_len, n_head, causal ? 1 : 0, batch};
     hipLaunchKernelGGL((attention_x2_fwd_kernel<8>), dim3(la::cdiv(q_len, 256) * n_head * batch), dim3(512), 0, stream, p);
     LA_LAUNCH_CHECK();
@@ -857,10 +885,15 @@ extern "C" int la_attention_bwd_f16x2(const float *q, int64_t ld_q, const float 
         attr_once.mark();
     }
     // row statistics: D = sum dO o O per query (and lse unless the forward handed it over)
-    const int rc = la_attention_bwd_stats_f32(q, ld_q, k, ld_kv, o, ld_o, dout, ld_do, batch, q_len, kv_len, n_head, causal, lse, ws.lse, ws.dvec, stream_);
-    if (rc != LA_OK) return rc;
+    if (lse) {
+        const int64_t items = (int64_t)batch * q_len * n_head;
+        hipLaunchKernelGGL(attn_dvec_kernel, dim3((unsigned)((items + 15) / 16)), dim3(256), 0, stream, o, ld_o, dout, ld_do, batch, q_len, n_head, ws.dvec);
+    } else {
+        const int rc = la_attention_bwd_stats_f32(q, ld_q, k, ld_kv, o, ld_o, dout, ld_do, batch, q_len, kv_len, n_head, causal, lse, ws.lse, ws.dvec, stream_);
+        if (rc != LA_OK) return rc;
+    }
     la::TimerScope ts("attention_bwd_f16x2", stream);
-    const dim3 sg(n_head, batch), sb(1024);
+    const dim3 sg = heads_split_grid(n_head, batch), sb(1024);
     hipLaunchKernelGGL(heads_split_kernel, sg, sb, 0, stream, q, ld_q, q_len, n_head, ws.qp, ws.sq);
     hipLaunchKernelGGL(heads_split_kernel, sg, sb, 0, stream, k, ld_kv, kv_len, n_head, ws.kp, ws.sk);
     hipLaunchKernelGGL(heads_split_kernel, sg, sb, 0, stream, v, ld_kv, kv_len, n_head, ws.vp, ws.sv);

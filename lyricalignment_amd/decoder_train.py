@@ -63,17 +63,21 @@ class DecoderFunction(torch.autograd.Function):
             bkv_c = torch.cat([torch.zeros_like(bvc), bvc], 0).contiguous()
             h1 = ops.layernorm(x, g1, be1, torch.float32)
             qkv = f32x2.linear(h1, wqkv, bias=bqkv)
-            a = ops.attention_ex(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, n, n, H, causal=True)
+            # (the row statistic of both attentions goes to the backward: its statistics launch then takes D alone instead of sweeping
+            #  the scores once more for the log-sum-exp)
+            lse_s = torch.empty((B, H, n), dtype=torch.float32, device=qkv.device)
+            lse_c = torch.empty((B, H, n), dtype=torch.float32, device=qkv.device)
+            a = ops.attention_ex(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, n, n, H, causal=True, lse=lse_s)
             x1 = f32x2.linear(a, wo, bias=bo, residual=x)
             hc = ops.layernorm(x1, gc, bec, torch.float32)
             qc = f32x2.linear(hc, wq_c, bias=bq_c)
             kv = f32x2.linear(xa2, wkv_c, bias=bkv_c)
-            ac = ops.attention_ex(qc, kv[:, :d], kv[:, d:], B, n, Ta, H, causal=False)
+            ac = ops.attention_ex(qc, kv[:, :d], kv[:, d:], B, n, Ta, H, causal=False, lse=lse_c)
             x2 = f32x2.linear(ac, woc, bias=boc, residual=x1)
             h2 = ops.layernorm(x2, g2, be2, torch.float32)
             u_pre = f32x2.linear(h2, w1, bias=b1)
             x3 = f32x2.linear(u_pre, w2, bias=b2, residual=x2, x_act="gelu")
-            saved.append((x, h1, qkv, a, x1, hc, qc, kv, ac, x2, h2, u_pre))
+            saved.append((x, h1, qkv, a, x1, hc, qc, kv, ac, x2, h2, u_pre, lse_s, lse_c))
             packed.append((g1, wqkv, wo, gc, wq_c, wkv_c, woc, g2, w1, w2))
             x = x3
         hf = ops.layernorm(x, P[-2], P[-1], torch.float32)
@@ -97,7 +101,7 @@ class DecoderFunction(torch.autograd.Function):
         dx, grads[-2], grads[-1] = layernorm_bwd(x_last, gemm_nn(dl, tok_emb), ln_g)
         dxa = None
         for i in reversed(range(n_layer)):
-            x, h1, qkv, a, x1, hc, qc, kv, ac, x2, h2, u_pre = ctx.saved[i]
+            x, h1, qkv, a, x1, hc, qc, kv, ac, x2, h2, u_pre, lse_s, lse_c = ctx.saved[i]
             g1, wqkv, wo, gc, wq_c, wkv_c, woc, g2, w1, w2 = ctx.packed[i]
             G = [None] * NB
             # MLP
@@ -110,7 +114,7 @@ class DecoderFunction(torch.autograd.Function):
             dac = gemm_nn(dx2, woc)
             dqc = torch.empty((M, d), dtype=torch.float32, device=dev)
             dkv = torch.empty((B * Ta, 2 * d), dtype=torch.float32, device=dev)
-            attention_bwd_ex(qc, kv[:, :d], kv[:, d:], dac, dqc, dkv[:, :d], dkv[:, d:], B, n, Ta, H, causal=False, o=ac)
+            attention_bwd_ex(qc, kv[:, :d], kv[:, d:], dac, dqc, dkv[:, :d], dkv[:, d:], B, n, Ta, H, causal=False, o=ac, lse=lse_c)
             G[11], G[12] = scale(gemm_tn(dqc, hc), 0.125), scale(colsum(dqc), 0.125)
             dwkv, dbkv = linear_grads(dkv, xa2)
             G[13], G[14], G[15] = dwkv[:d], dwkv[d:], dbkv[d:]
@@ -120,7 +124,7 @@ class DecoderFunction(torch.autograd.Function):
             dx1, G[9], G[10] = layernorm_bwd(x1, gemm_nn(dqc, wq_c), gc, residual=dx2)
             # causal self-attention
             G[7], G[8] = linear_grads(dx1, a)
-            dqkv = attention_bwd(qkv, gemm_nn(dx1, wo), B, n, H, causal=True, att=a)
+            dqkv = attention_bwd(qkv, gemm_nn(dx1, wo), B, n, H, causal=True, att=a, lse=lse_s)
             dwqkv, dbqkv = linear_grads(dqkv, h1)
             G[2], G[3] = scale(dwqkv[:d], 0.125), scale(dbqkv[:d], 0.125)
             G[4], G[5], G[6] = dwqkv[d:2 * d], dwqkv[2 * d:], dbqkv[2 * d:]
