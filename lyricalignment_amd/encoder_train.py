@@ -19,6 +19,8 @@ from typing import Dict, List, Optional, Sequence
 
 import os
 
+import weakref
+
 import torch
 
 from . import _lib, f32x2, ops
@@ -168,6 +170,36 @@ def attention_bwd(qkv: torch.Tensor, datt: torch.Tensor, B: int, T: int, H: int,
     return dqkv
 
 
+# Per-layer derived weights (the packed q | k | v projection with the 1/8 folded in) and the split planes of the four weight matrices, kept
+# while the parameters are unchanged: key = the layer's Parameter objects (weakly held), entry = (versions, wqkv, bqkv, [f32x2.WeightPlanes x 4]).
+# The reference's accumulation loop (train_multitask.py:240-326) runs eight micro-steps between two optimizer steps; torch optimizers bump
+# the parameters' versions, FlatAdamW bumps its flat buffers' (finetune.py).
+_LAYER_CACHE: Dict[tuple, tuple] = {}
+
+
+def _layer_weights(layer_params, sources):
+    """layer_params: the float32 device tensors of one block; sources: the tensors they came from (the module's Parameters): the cache entry
+    is theirs -- held by weak references (a freed model's storage address comes back with the next one) and their versions."""
+    (g1, be1, wq, bq, wk, wv, bv, wo, bo, g2, be2, w1, b1, w2, b2) = layer_params
+    src = [sources[j] for j in (2, 3, 4, 5, 6, 7, 11, 13)]                   # wq, bq, wk, wv, bv, wo, w1, w2
+    key = tuple(id(t) for t in src)
+    ver = tuple(t._version for t in src)
+    hit = _LAYER_CACHE.get(key)
+    if hit is not None and hit[0] == ver and all(r() is t for r, t in zip(hit[4], src)):
+        return hit[1], hit[2], hit[3]
+    wqkv = torch.cat([scale(wq, 0.125), wk, wv], 0).contiguous()          # (head_dim^-0.25)^2 folded into q: exact
+    bqkv = torch.cat([scale(bq, 0.125), torch.zeros_like(bq), bv], 0).contiguous()
+    wc = [f32x2.WeightPlanes() for _ in range(4)]                          # of wqkv, wo, w1, w2
+    if len(_LAYER_CACHE) > 256:
+        _LAYER_CACHE.clear()
+    try:
+        refs = [weakref.ref(t) for t in src]
+    except TypeError:
+        return wqkv, bqkv, wc
+    _LAYER_CACHE[key] = (ver, wqkv, bqkv, wc, refs)
+    return wqkv, bqkv, wc
+
+
 class EncoderFunction(torch.autograd.Function):
     """y = AudioEncoder(mel);  params in encoder_param_names() order, `pos` the positional_embedding buffer [1500, d]."""
 
@@ -212,20 +244,19 @@ class EncoderFunction(torch.autograd.Function):
         all_mx = f32x2.OperandMax.many(x.device, 8 * n_layer)
         for i in range(n_layer):
             (g1, be1, wq, bq, wk, wv, bv, wo, bo, g2, be2, w1, b1, w2, b2) = P[4 + i * 15: 4 + (i + 1) * 15]
-            wqkv = torch.cat([scale(wq, 0.125), wk, wv], 0).contiguous()          # (head_dim^-0.25)^2 folded into q: exact
-            bqkv = torch.cat([scale(bq, 0.125), torch.zeros_like(bq), bv], 0).contiguous()
+            wqkv, bqkv, wc = _layer_weights(P[4 + i * 15: 4 + (i + 1) * 15], params[4 + i * 15: 4 + (i + 1) * 15])
             # (the operands' maxima from these plain splits scale the transposed splits of the weight gradients: f32x2.OperandMax)
             mx = all_mx[8 * i: 8 * i + 8]                            # 0-3 the activations, 4-7 the weights (for dx = dy w)
             h1 = ops.layernorm(x, g1, be1, torch.float32)
-            qkv = f32x2.linear(h1, wqkv, bias=bqkv, x_max=mx[0], w_max=mx[4])
+            qkv = f32x2.linear(h1, wqkv, bias=bqkv, x_max=mx[0], w_max=mx[4], w_cache=wc[0])
             lse = torch.empty((B, H, N_CTX), dtype=torch.float32, device=qkv.device)        # row statistic for the fused backward
             att = ops.attention_ex(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, N_CTX, N_CTX, H, lse=lse)
-            x_mid = f32x2.linear(att, wo, bias=bo, residual=x, x_max=mx[1], w_max=mx[5])
+            x_mid = f32x2.linear(att, wo, bias=bo, residual=x, x_max=mx[1], w_max=mx[5], w_cache=wc[1])
             h2 = ops.layernorm(x_mid, g2, be2, torch.float32)
-            u_pre = f32x2.linear(h2, w1, bias=b1, x_max=mx[2], w_max=mx[6])
-            x_next = f32x2.linear(u_pre, w2, bias=b2, residual=x_mid, x_act="gelu", x_max=mx[3], w_max=mx[7])
+            u_pre = f32x2.linear(h2, w1, bias=b1, x_max=mx[2], w_max=mx[6], w_cache=wc[2])
+            x_next = f32x2.linear(u_pre, w2, bias=b2, residual=x_mid, x_act="gelu", x_max=mx[3], w_max=mx[7], w_cache=wc[3])
             saved.append((x, h1, qkv, att, x_mid, h2, u_pre, lse, mx))
-            packed.append((g1, wqkv, wo, g2, w1, w2))
+            packed.append((g1, wqkv, wo, g2, w1, w2, wc))
             x = x_next
         y = ops.layernorm(x, P[-2], P[-1], torch.float32)
         ctx.dims = (B, d, H, n_mels, n_layer)
@@ -244,22 +275,22 @@ class EncoderFunction(torch.autograd.Function):
         all_my = f32x2.OperandMax.many(dyf.device, 4 * n_layer)
         for i in reversed(range(n_layer)):
             x, h1, qkv, att, x_mid, h2, u_pre, lse, mx = ctx.saved[i]
-            g1, wqkv, wo, g2, w1, w2 = ctx.packed[i]
+            g1, wqkv, wo, g2, w1, w2, wc = ctx.packed[i]
             G = [None] * 15
             # every incoming gradient is split plain first (its input-gradient product), which leaves its maximum for the transposed split
             # of the weight-gradient product (no pass for column maxima)
             my = all_my[4 * i: 4 * i + 4]
             # x_next = x_mid + gelu(u_pre) W2^T + b2
-            du_pre = gemm_nn(dx, w2, gelu_grad_of=u_pre, a_max=my[0], w_max=mx[7])
+            du_pre = gemm_nn(dx, w2, gelu_grad_of=u_pre, a_max=my[0], w_max=mx[7], w_cache=wc[3])
             G[13], G[14] = linear_grads(dx, u_pre, x_act="gelu", dy_max=my[0], x_max=mx[3])
-            dh2 = gemm_nn(du_pre, w1, a_max=my[1], w_max=mx[6])
+            dh2 = gemm_nn(du_pre, w1, a_max=my[1], w_max=mx[6], w_cache=wc[2])
             G[11], G[12] = linear_grads(du_pre, h2, dy_max=my[1], x_max=mx[2])
             dx_mid, G[9], G[10] = layernorm_bwd(x_mid, dh2, g2, residual=dx)
             # x_mid = x + att Wo^T + bo
-            datt = gemm_nn(dx_mid, wo, a_max=my[2], w_max=mx[5])
+            datt = gemm_nn(dx_mid, wo, a_max=my[2], w_max=mx[5], w_cache=wc[1])
             G[7], G[8] = linear_grads(dx_mid, att, dy_max=my[2], x_max=mx[1])
             dqkv = attention_bwd(qkv, datt, B, N_CTX, H, att=att, lse=lse)
-            dh1 = gemm_nn(dqkv, wqkv, a_max=my[3], w_max=mx[4])
+            dh1 = gemm_nn(dqkv, wqkv, a_max=my[3], w_max=mx[4], w_cache=wc[0])
             dwqkv, dbqkv = linear_grads(dqkv, h1, dy_max=my[3], x_max=mx[0])
             G[2], G[3] = scale(dwqkv[:d], 0.125), scale(dbqkv[:d], 0.125)
             G[4], G[5], G[6] = dwqkv[d:2 * d], dwqkv[2 * d:], dbqkv[2 * d:]

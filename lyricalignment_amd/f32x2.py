@@ -109,6 +109,15 @@ def split_t(x: torch.Tensor, mp: Optional[int] = None, act: Optional[str] = None
     return Planes(planes, inv, k, m, mp)
 
 
+class WeightPlanes:
+    """The split planes of ONE weight matrix, kept for as long as the weight is unchanged: the reference's accumulation loop runs eight
+    micro-steps on the same weights (train_multitask.py:240-326), each of which would split every weight twice (plain for the forward,
+    transposed for dx = dy w).  {("n" | "t", plane length): Planes}; the owner drops it when the weight's version moves on."""
+
+    def __init__(self):
+        self.planes = {}
+
+
 def slots_for(M: int, N: int) -> int:
     """Split-K slots that bring a product with few 256 x 256 tiles up to the kernel's domain (1 = none needed)."""
     tiles = -(-M // 256) * -(-N // 256)
@@ -169,7 +178,8 @@ def _apply(x: torch.Tensor, act: Optional[str]) -> torch.Tensor:
 
 
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
-           x_act: Optional[str] = None, x_max: Optional[OperandMax] = None, w_max: Optional[OperandMax] = None) -> torch.Tensor:
+           x_act: Optional[str] = None, x_max: Optional[OperandMax] = None, w_max: Optional[OperandMax] = None,
+           w_cache: Optional[WeightPlanes] = None) -> torch.Tensor:
     """y = act(x) w^T (+ bias) (+ residual), float32 in and out (F.linear; whisper/model.py Linear; x_act = "gelu": the MLP's second
     Linear on gelu(x), the activation applied inside the operand split)."""
     from . import ops
@@ -179,12 +189,17 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
         kp = padded_k(M, N, K)
         if not FUSE_ACT:
             x, x_act = _apply(x, x_act), None
-        return gemm(split(x, kp, act=x_act, omax=x_max), split(w, kp, omax=w_max), bias=bias, residual=residual)
+        wp = w_cache.planes.get(("n", kp)) if w_cache is not None else None
+        if wp is None:
+            wp = split(w, kp, omax=w_max)
+            if w_cache is not None:
+                w_cache.planes[("n", kp)] = wp
+        return gemm(split(x, kp, act=x_act, omax=x_max), wp, bias=bias, residual=residual)
     return ops.gemm(_apply(x, x_act), w, bias=bias, residual=residual)
 
 
 def gemm_nn(dy: torch.Tensor, w: torch.Tensor, gelu_grad_of: Optional[torch.Tensor] = None, dy_max: Optional[OperandMax] = None,
-            w_max: Optional[OperandMax] = None) -> torch.Tensor:
+            w_max: Optional[OperandMax] = None, w_cache: Optional[WeightPlanes] = None) -> torch.Tensor:
     """dy [M, N] . w [N, K] -> [M, K]: the input gradient of y = x w^T.  gelu_grad_of = u [M, K]: times gelu'(u) -- the gradient at the
     pre-activation u of x = gelu(u), in the product's epilogue on the f16x2 path (la_gelu_bwd_f32 on the result otherwise)."""
     from . import head_train
@@ -193,7 +208,12 @@ def gemm_nn(dy: torch.Tensor, w: torch.Tensor, gelu_grad_of: Optional[torch.Tens
     fused = gelu_grad_of is not None and FUSE_ACT and _plain2d(gelu_grad_of)
     if _plain2d(dy) and _plain2d(w) and eligible(M, K, N):
         np_ = padded_k(M, K, N)
-        dx = gemm(split(dy, np_, omax=dy_max), split_t(w, np_, omax=w_max), gelu_grad_of=gelu_grad_of if fused else None)
+        wt = w_cache.planes.get(("t", np_)) if w_cache is not None else None
+        if wt is None:
+            wt = split_t(w, np_, omax=w_max)
+            if w_cache is not None:
+                w_cache.planes[("t", np_)] = wt
+        dx = gemm(split(dy, np_, omax=dy_max), wt, gelu_grad_of=gelu_grad_of if fused else None)
         if fused:
             return dx
     else:

@@ -95,6 +95,9 @@ class FlatAdamW:
                                       self.betas[0], self.betas[1], self.eps, self.wd, self.t,
                                       ptr(self._sumsq) if max_norm is not None else 0, float(max_norm or 0.0),
                                       float(grad_prescale), s), "adamw_step")
+            # the kernel wrote through a raw pointer: tell torch the buffer (and with it every parameter view of it) changed -- caches
+            # keyed on parameter versions (encoder_train._LAYER_CACHE, module/align_model.encoder_only_engine) must not outlive the step
+            torch.autograd.graph.increment_version(grp["params"])
         return self._sumsq
 
 

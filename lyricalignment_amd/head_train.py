@@ -94,11 +94,11 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, b_act: Optional[str] = None) -> to
     return f32x2.gemm_tn(a, b, x_act=b_act)
 
 
-def gemm_nn(a: torch.Tensor, w: torch.Tensor, gelu_grad_of: Optional[torch.Tensor] = None, a_max=None, w_max=None) -> torch.Tensor:
+def gemm_nn(a: torch.Tensor, w: torch.Tensor, gelu_grad_of: Optional[torch.Tensor] = None, a_max=None, w_max=None, w_cache=None) -> torch.Tensor:
     """a [M,N] . w [N,K] -> [M,K]: the input gradient of a Linear (gelu_grad_of = u [M,K]: times gelu'(u), the gradient at the
     pre-activation of the MLP's hidden layer).  Large products on the f16x2 path, the rest gemm_nn_f32."""
     from . import f32x2
-    return f32x2.gemm_nn(a, w, gelu_grad_of=gelu_grad_of, dy_max=a_max, w_max=w_max)
+    return f32x2.gemm_nn(a, w, gelu_grad_of=gelu_grad_of, dy_max=a_max, w_max=w_max, w_cache=w_cache)
 
 
 def gemm_tn_f32(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
