@@ -235,6 +235,44 @@ def test_attention_forward_f16x2_matches_float64_at_float32_accuracy(B, Tq, Tk, 
     assert res["f16x2"][1] <= 1.5 * res["f32"][1] + 5e-7 and res["f16x2"][1] < 2e-5, res
 
 
+def test_encoder_weight_cache_follows_the_parameters():
+    """encoder_train._LAYER_CACHE (a block's packed q|k|v projection and the split planes of its weights, kept across the micro-steps of an
+    accumulation window): the same output on a second call, a changed output after an in-place update of a weight (the version moved) equal
+    to the one computed with an empty cache, no entry shared between two models whose parameters happen to sit at the same addresses, and
+    FlatAdamW.step leaves every parameter view of its flat buffer with a new version."""
+    from oracle import model_oracle as mo
+    from lyricalignment_amd import encoder_train as et, finetune as ft
+    d, L = 256, 2
+    names = et.encoder_param_names(L)
+
+    def make(seed):
+        p = mo.random_encoder_params(d, L, seed=seed)
+        prm = [torch.nn.Parameter(torch.as_tensor(p["encoder." + n] if ("encoder." + n) in p else p[n]).float().cuda()) for n in names]
+        return prm, torch.as_tensor(p["encoder.positional_embedding"]).float().cuda()
+
+    mel = torch.randn(1, 80, 3000, generator=torch.Generator().manual_seed(3)).cuda()
+    prm, pos = make(1)
+    with torch.no_grad():
+        y0 = et.EncoderFunction.apply(mel, pos, d // 64, *prm).clone()
+        assert torch.equal(et.EncoderFunction.apply(mel, pos, d // 64, *prm), y0)
+        prm[names.index("blocks.0.attn.query.weight")].mul_(1.5)
+        y1 = et.EncoderFunction.apply(mel, pos, d // 64, *prm).clone()
+        et._LAYER_CACHE.clear()
+        assert torch.equal(et.EncoderFunction.apply(mel, pos, d // 64, *prm), y1) and not torch.equal(y1, y0)
+        ptrs = [t.data_ptr() for t in prm]
+        del prm
+        prm2, pos2 = make(2)                                   # (often the same addresses: the allocator hands the freed blocks out again)
+        y2 = et.EncoderFunction.apply(mel, pos2, d // 64, *prm2).clone()
+        et._LAYER_CACHE.clear()
+        assert torch.equal(et.EncoderFunction.apply(mel, pos2, d // 64, *prm2), y2)
+    flat = torch.zeros(64, device="cuda")
+    views = [flat[:32], flat[32:]]
+    v0 = [t._version for t in views]
+    opt = ft.FlatAdamW([dict(params=flat, lr=1e-3)])
+    opt.step([torch.ones(64, device="cuda")], max_norm=None)
+    assert all(t._version > a for t, a in zip(views, v0))
+
+
 def test_attention_f16x2_on_sequences_longer_than_a_clip():
     """1700 tokens (beyond the 1536 the per-head split keeps in registers: its two-pass form; 27 key tiles, ragged last tiles of both sweeps):
     forward and backward of the f16x2 attention against the float32-MFMA kernels, self-attention and a cross shape."""
