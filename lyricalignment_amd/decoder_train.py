@@ -15,7 +15,7 @@ import torch
 
 from . import _lib, f32x2, ops
 from ._lib import check, lib, ptr, stream_ptr
-from .encoder_train import add, attention_bwd, attention_bwd_ex, gelu, gelu_bwd, layernorm_bwd, scale
+from .encoder_train import add, attention_bwd, attention_bwd_ex, cached_for, gelu, gelu_bwd, layernorm_bwd, scale
 from .head_train import colsum, gemm_nn, gemm_tn, grads_to, linear_grads
 
 PER_BLOCK = ("attn_ln.weight", "attn_ln.bias", "attn.query.weight", "attn.query.bias", "attn.key.weight", "attn.value.weight",
@@ -56,11 +56,13 @@ class DecoderFunction(torch.autograd.Function):
         for i in range(n_layer):
             (g1, be1, wq, bq, wk, wv, bv, wo, bo, gc, bec, wqc, bqc, wkc, wvc, bvc, woc, boc, g2, be2, w1, b1, w2, b2) = \
                 P[2 + i * NB: 2 + (i + 1) * NB]
-            wqkv = torch.cat([scale(wq, 0.125), wk, wv], 0).contiguous()
-            bqkv = torch.cat([scale(bq, 0.125), torch.zeros_like(bq), bv], 0).contiguous()
-            wq_c, bq_c = scale(wqc, 0.125), scale(bqc, 0.125)
-            wkv_c = torch.cat([wkc, wvc], 0).contiguous()
-            bkv_c = torch.cat([torch.zeros_like(bvc), bvc], 0).contiguous()
+            def build(wq=wq, bq=bq, wk=wk, wv=wv, bv=bv, wqc=wqc, bqc=bqc, wkc=wkc, wvc=wvc, bvc=bvc):
+                return (torch.cat([scale(wq, 0.125), wk, wv], 0).contiguous(), torch.cat([scale(bq, 0.125), torch.zeros_like(bq), bv], 0).contiguous(),
+                        scale(wqc, 0.125), scale(bqc, 0.125), torch.cat([wkc, wvc], 0).contiguous(),
+                        torch.cat([torch.zeros_like(bvc), bvc], 0).contiguous(), f32x2.WeightPlanes())
+            # (derived weights and the planes of the audio-side k | v projection, kept while the block's parameters are unchanged)
+            src = params[2 + i * NB: 2 + (i + 1) * NB]
+            wqkv, bqkv, wq_c, bq_c, wkv_c, bkv_c, wc_kv = cached_for([src[j] for j in (2, 3, 4, 5, 6, 11, 12, 13, 14, 15)], build)
             h1 = ops.layernorm(x, g1, be1, torch.float32)
             qkv = f32x2.linear(h1, wqkv, bias=bqkv)
             # (the row statistic of both attentions goes to the backward: its statistics launch then takes D alone instead of sweeping
@@ -71,20 +73,22 @@ class DecoderFunction(torch.autograd.Function):
             x1 = f32x2.linear(a, wo, bias=bo, residual=x)
             hc = ops.layernorm(x1, gc, bec, torch.float32)
             qc = f32x2.linear(hc, wq_c, bias=bq_c)
-            kv = f32x2.linear(xa2, wkv_c, bias=bkv_c)
+            kv = f32x2.linear(xa2, wkv_c, bias=bkv_c, w_cache=wc_kv)
             ac = ops.attention_ex(qc, kv[:, :d], kv[:, d:], B, n, Ta, H, causal=False, lse=lse_c)
             x2 = f32x2.linear(ac, woc, bias=boc, residual=x1)
             h2 = ops.layernorm(x2, g2, be2, torch.float32)
             u_pre = f32x2.linear(h2, w1, bias=b1)
             x3 = f32x2.linear(u_pre, w2, bias=b2, residual=x2, x_act="gelu")
             saved.append((x, h1, qkv, a, x1, hc, qc, kv, ac, x2, h2, u_pre, lse_s, lse_c))
-            packed.append((g1, wqkv, wo, gc, wq_c, wkv_c, woc, g2, w1, w2))
+            packed.append((g1, wqkv, wo, gc, wq_c, wkv_c, woc, g2, w1, w2, wc_kv))
             x = x3
         hf = ops.layernorm(x, P[-2], P[-1], torch.float32)
-        logits = f32x2.linear(hf, tok_emb)
+        wc_tok = cached_for([params[0]], f32x2.WeightPlanes)                # planes of the tied token embedding (51865 x d: 212 MB a split)
+        logits = f32x2.linear(hf, tok_emb, w_cache=wc_tok)
         ctx.dims = (B, n, Ta, d, H, V, n_layer, pos.shape[0])
         ctx.saved, ctx.packed = saved, packed
         ctx.tail = (tokens, xa2, x, hf, tok_emb, P[-2])
+        ctx.wc_tok = wc_tok
         ctx.xa_needs_grad = xa.requires_grad
         ctx.param_devices = [p.device for p in params]
         return logits.view(B, n, V)
@@ -98,11 +102,11 @@ class DecoderFunction(torch.autograd.Function):
         dl = dlogits.to(torch.float32).contiguous().view(M, V)
         grads: List[Optional[torch.Tensor]] = [None] * (4 + NB * n_layer)
         dtok = gemm_tn(dl, hf)                                               # tied projection: logits = hf tok_emb^T
-        dx, grads[-2], grads[-1] = layernorm_bwd(x_last, gemm_nn(dl, tok_emb), ln_g)
+        dx, grads[-2], grads[-1] = layernorm_bwd(x_last, gemm_nn(dl, tok_emb, w_cache=ctx.wc_tok), ln_g)
         dxa = None
         for i in reversed(range(n_layer)):
             x, h1, qkv, a, x1, hc, qc, kv, ac, x2, h2, u_pre, lse_s, lse_c = ctx.saved[i]
-            g1, wqkv, wo, gc, wq_c, wkv_c, woc, g2, w1, w2 = ctx.packed[i]
+            g1, wqkv, wo, gc, wq_c, wkv_c, woc, g2, w1, w2, wc_kv = ctx.packed[i]
             G = [None] * NB
             # MLP
             G[22], G[23] = linear_grads(dx, u_pre, x_act="gelu")
@@ -119,7 +123,7 @@ class DecoderFunction(torch.autograd.Function):
             dwkv, dbkv = linear_grads(dkv, xa2)
             G[13], G[14], G[15] = dwkv[:d], dwkv[d:], dbkv[d:]
             if ctx.xa_needs_grad:
-                t = gemm_nn(dkv, wkv_c)
+                t = gemm_nn(dkv, wkv_c, w_cache=wc_kv)
                 dxa = t if dxa is None else add(dxa, t)
             dx1, G[9], G[10] = layernorm_bwd(x1, gemm_nn(dqc, wq_c), gc, residual=dx2)
             # causal self-attention

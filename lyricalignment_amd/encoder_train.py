@@ -171,33 +171,40 @@ def attention_bwd(qkv: torch.Tensor, datt: torch.Tensor, B: int, T: int, H: int,
 
 
 # Per-layer derived weights (the packed q | k | v projection with the 1/8 folded in) and the split planes of the four weight matrices, kept
-# while the parameters are unchanged: key = the layer's Parameter objects (weakly held), entry = (versions, wqkv, bqkv, [f32x2.WeightPlanes x 4]).
+# while the parameters are unchanged: key = the block's Parameter objects (weakly held), entry = (versions, value, weak references).
 # The reference's accumulation loop (train_multitask.py:240-326) runs eight micro-steps between two optimizer steps; torch optimizers bump
 # the parameters' versions, FlatAdamW bumps its flat buffers' (finetune.py).
 _LAYER_CACHE: Dict[tuple, tuple] = {}
 
 
-def _layer_weights(layer_params, sources):
-    """layer_params: the float32 device tensors of one block; sources: the tensors they came from (the module's Parameters): the cache entry
-    is theirs -- held by weak references (a freed model's storage address comes back with the next one) and their versions."""
-    (g1, be1, wq, bq, wk, wv, bv, wo, bo, g2, be2, w1, b1, w2, b2) = layer_params
-    src = [sources[j] for j in (2, 3, 4, 5, 6, 7, 11, 13)]                   # wq, bq, wk, wv, bv, wo, w1, w2
-    key = tuple(id(t) for t in src)
-    ver = tuple(t._version for t in src)
+def cached_for(sources, build):
+    """build() once per state of `sources` (tensors, typically the module's Parameters): the entry is theirs -- held by weak references (a
+    freed model's storage address and object ids come back with the next one) and their versions."""
+    key = tuple(id(t) for t in sources)
+    ver = tuple(t._version for t in sources)
     hit = _LAYER_CACHE.get(key)
-    if hit is not None and hit[0] == ver and all(r() is t for r, t in zip(hit[4], src)):
-        return hit[1], hit[2], hit[3]
-    wqkv = torch.cat([scale(wq, 0.125), wk, wv], 0).contiguous()          # (head_dim^-0.25)^2 folded into q: exact
-    bqkv = torch.cat([scale(bq, 0.125), torch.zeros_like(bq), bv], 0).contiguous()
-    wc = [f32x2.WeightPlanes() for _ in range(4)]                          # of wqkv, wo, w1, w2
-    if len(_LAYER_CACHE) > 256:
+    if hit is not None and hit[0] == ver and all(r() is t for r, t in zip(hit[2], sources)):
+        return hit[1]
+    value = build()
+    if len(_LAYER_CACHE) > 512:
         _LAYER_CACHE.clear()
     try:
-        refs = [weakref.ref(t) for t in src]
+        _LAYER_CACHE[key] = (ver, value, [weakref.ref(t) for t in sources])
     except TypeError:
-        return wqkv, bqkv, wc
-    _LAYER_CACHE[key] = (ver, wqkv, bqkv, wc, refs)
-    return wqkv, bqkv, wc
+        pass
+    return value
+
+
+def _layer_weights(layer_params, sources):
+    """One encoder block: (wqkv, bqkv, [f32x2.WeightPlanes of wqkv, wo, w1, w2]) from its float32 device tensors; `sources` = the tensors they
+    came from (the module's Parameters)."""
+    (g1, be1, wq, bq, wk, wv, bv, wo, bo, g2, be2, w1, b1, w2, b2) = layer_params
+
+    def build():
+        wqkv = torch.cat([scale(wq, 0.125), wk, wv], 0).contiguous()          # (head_dim^-0.25)^2 folded into q: exact
+        bqkv = torch.cat([scale(bq, 0.125), torch.zeros_like(bq), bv], 0).contiguous()
+        return wqkv, bqkv, [f32x2.WeightPlanes() for _ in range(4)]
+    return cached_for([sources[j] for j in (2, 3, 4, 5, 6, 7, 11, 13)], build)     # wq, bq, wk, wv, bv, wo, w1, w2
 
 
 class EncoderFunction(torch.autograd.Function):
