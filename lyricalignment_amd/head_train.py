@@ -53,14 +53,14 @@ def colsum(a: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, a_max=None, w_max=None) -> torch.Tensor:
+def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, a_max=None, w_max=None, w_cache=None) -> torch.Tensor:
     """a [M,K] . w [N,K]^T (+ bias), float32 in and out: the large products as three f16 products over split operands (f32x2.linear:
     float32 accuracy at 3/16 of the float32 pipe's cost), the others on the float32 MFMA kernel (K zero-padded to its granule)."""
     if a.shape[1] != w.shape[1]:
         raise ValueError("gemm_nt: K mismatch")
     from . import f32x2
     if f32x2.eligible(a.shape[0], w.shape[0], a.shape[1]):
-        return f32x2.linear(a, w, bias=bias, x_max=a_max, w_max=w_max)
+        return f32x2.linear(a, w, bias=bias, x_max=a_max, w_max=w_max, w_cache=w_cache)
     return ops.gemm(_padK(a), _padK(w), bias=bias, out_f32=True)
 
 
@@ -168,12 +168,21 @@ class HeadFunction(torch.autograd.Function):
         B, T, D = x.shape
         dev = x.device
         x0 = x.detach().to(torch.float32).contiguous().view(B * T, D)
-        layers = []
-        for l in range(2):
-            w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r = [p.detach().to(device=dev, dtype=torch.float32) for p in params[8 * l: 8 * l + 8]]
-            layers.append(dict(w_ih=torch.cat([w_ih, w_ih_r], 0).contiguous(), b_ih=torch.cat([b_ih, b_ih_r], 0).contiguous(),
-                               w_hh=torch.stack([w_hh, w_hh_r], 0).contiguous(), b_hh=torch.stack([b_hh, b_hh_r], 0).contiguous()))
+        from . import f32x2
+        from .encoder_train import cached_for
+
+        def build_layers():
+            out = []
+            for l in range(2):
+                w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r = [p.detach().to(device=dev, dtype=torch.float32) for p in params[8 * l: 8 * l + 8]]
+                out.append(dict(w_ih=torch.cat([w_ih, w_ih_r], 0).contiguous(), b_ih=torch.cat([b_ih, b_ih_r], 0).contiguous(),
+                                w_hh=torch.stack([w_hh, w_hh_r], 0).contiguous(), b_hh=torch.stack([b_hh, b_hh_r], 0).contiguous(),
+                                wc=f32x2.WeightPlanes()))
+            return out
+        # (the stacked direction pairs and the planes of the input projections / the output Linear, kept while the parameters are unchanged)
+        layers = cached_for(list(params[:16]), build_layers)
         w_fc, b_fc = [p.detach().to(device=dev, dtype=torch.float32).contiguous() for p in params[16:18]]
+        wc_fc = cached_for([params[16]], f32x2.WeightPlanes)
         ctx.param_devices = [p.device for p in params]
         H = layers[0]["w_hh"].shape[2]
         flag = torch.zeros((1,), dtype=torch.int32, device=dev)
@@ -181,7 +190,7 @@ class HeadFunction(torch.autograd.Function):
         inp = x0
         mask = None
         for l, lw in enumerate(layers):
-            gi = gemm_nt(inp, lw["w_ih"], bias=lw["b_ih"]).view(B, T, 2, 3 * H)
+            gi = gemm_nt(inp, lw["w_ih"], bias=lw["b_ih"], w_cache=lw["wc"]).view(B, T, 2, 3 * H)
             out = torch.empty((B, T, 2 * H), dtype=torch.float32, device=dev)
             gates = torch.empty((B, T, 2, 4 * H), dtype=torch.float32, device=dev)
             ws, nbytes = _gru_ws(B, T, H, dev)
@@ -199,9 +208,9 @@ class HeadFunction(torch.autograd.Function):
         out1 = saved[1][1].view(B * T, 2 * H)
         act = torch.empty_like(out1)
         check(lib().la_mish_f32(ptr(out1), ptr(act), act.numel(), stream_ptr()), "mish")
-        from . import f32x2
         ctx.fc_max = (f32x2.OperandMax(dev), f32x2.OperandMax(dev))      # of act and of fc.weight, for the transposed splits of the backward
-        logits = gemm_nt(act, w_fc, bias=b_fc, a_max=ctx.fc_max[0], w_max=ctx.fc_max[1])
+        ctx.wc_fc = wc_fc
+        logits = gemm_nt(act, w_fc, bias=b_fc, a_max=ctx.fc_max[0], w_max=ctx.fc_max[1], w_cache=wc_fc)
         ctx.defer = bool(DEFER_FLAG_CHECKS)
         _flag_check(flag, "persistent GRU kernel: a bounded inter-workgroup wait timed out", ctx.defer)
         ctx.layers, ctx.w_fc, ctx.saved, ctx.mask, ctx.act = layers, w_fc, saved, mask, act
@@ -217,7 +226,7 @@ class HeadFunction(torch.autograd.Function):
         # ---- Linear ----
         from . import f32x2
         m_dl = f32x2.OperandMax(dev)
-        dact = gemm_nn(dl, ctx.w_fc, a_max=m_dl, w_max=ctx.fc_max[1])    # [M, 2H]
+        dact = gemm_nn(dl, ctx.w_fc, a_max=m_dl, w_max=ctx.fc_max[1], w_cache=ctx.wc_fc)    # [M, 2H]
         dw_fc, db_fc = linear_grads(dl, ctx.act, dy_max=m_dl, x_max=ctx.fc_max[0])      # [V, 2H], [V]
         # ---- Mish ----
         out1 = ctx.saved[1][1].view(M, 2 * H)
@@ -259,7 +268,7 @@ class HeadFunction(torch.autograd.Function):
             grads[base + 2], grads[base + 6] = db_ih[: 3 * H], db_ih[3 * H:]
             grads[base + 3], grads[base + 7] = db_hh[: 3 * H], db_hh[3 * H:]
             if l == 1 or ctx.x_needs_grad:
-                dxin = gemm_nn(dgi2, lw["w_ih"])                          # [M, in]
+                dxin = gemm_nn(dgi2, lw["w_ih"], w_cache=lw["wc"])       # [M, in]
                 if l == 1:
                     if ctx.mask is not None:
                         dout = torch.empty_like(dxin)
