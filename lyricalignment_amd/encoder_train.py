@@ -186,6 +186,8 @@ def cached_for(sources, build):
     if hit is not None and hit[0] == ver and all(r() is t for r, t in zip(hit[2], sources)):
         return hit[1]
     value = build()
+    for k in [k for k, e in _LAYER_CACHE.items() if any(r() is None for r in e[2])]:      # entries of models that are gone: free their planes
+        del _LAYER_CACHE[k]
     if len(_LAYER_CACHE) > 512:
         _LAYER_CACHE.clear()
     try:
