@@ -171,27 +171,54 @@ def attention_bwd(qkv: torch.Tensor, datt: torch.Tensor, B: int, T: int, H: int,
 
 
 # Per-layer derived weights (the packed q | k | v projection with the 1/8 folded in) and the split planes of the four weight matrices, kept
-# while the parameters are unchanged: key = the block's Parameter objects (weakly held), entry = (versions, value, weak references).
-# The reference's accumulation loop (train_multitask.py:240-326) runs eight micro-steps between two optimizer steps; torch optimizers bump
-# the parameters' versions, FlatAdamW bumps its flat buffers' (finetune.py).
+# while the parameters are unchanged: key = the block's Parameter objects (weakly held), entry = (state, value, weak references) with
+# state = (cache epoch, the parameters' versions, their storage addresses).
+# The reference's accumulation loop (train_multitask.py:240-326) runs eight micro-steps between two optimizer steps.  What moves the state:
+#   * torch optimizers update `p` in place under no_grad -> p._version;
+#   * FineTuner binds parameters as `p.data = flat[...]` views: such a Parameter keeps a version counter of ITS OWN (set_data does not share the
+#     flat buffer's), so a kernel that writes the flat buffer through a raw pointer (la_adamw_step_f32) moves neither -- FlatAdamW.step
+#     therefore bumps the EPOCH (invalidate_weight_caches) and FineTuner.step the Parameters' own versions;
+#   * re-binding p.data to other storage -> the address.
+# Writes through `p.data.copy_()` / `p.data.add_()` move nothing torch can see: call invalidate_weight_caches() after them.
+# Footprint: derived weights + both split-plane sets (plain, transposed) of every weight ~ 2 x the model's float32 size on the device (incl.
+# 2 x 212 MB for the tied token embedding); clear_weight_cache() returns it.
 _LAYER_CACHE: Dict[tuple, tuple] = {}
+_EPOCH = [0]
+
+
+def invalidate_weight_caches() -> None:
+    """Every cached derived weight / split plane is stale from here on (they are rebuilt on their next use)."""
+    _EPOCH[0] += 1
+
+
+def clear_weight_cache() -> None:
+    """Drop the cached derived weights and split planes (device memory ~ 2 x the model's float32 size) now."""
+    _LAYER_CACHE.clear()
+    _EPOCH[0] += 1
+
+
+def _purge_dead() -> None:
+    for k in [k for k, e in _LAYER_CACHE.items() if any(r() is None for r in e[2])]:      # entries of models that are gone: free their planes
+        del _LAYER_CACHE[k]
 
 
 def cached_for(sources, build):
     """build() once per state of `sources` (tensors, typically the module's Parameters): the entry is theirs -- held by weak references (a
-    freed model's storage address and object ids come back with the next one) and their versions."""
+    freed model's storage address and object ids come back with the next one), their versions, their storage addresses and the cache epoch."""
     key = tuple(id(t) for t in sources)
-    ver = tuple(t._version for t in sources)
+    state = (_EPOCH[0], tuple(t._version for t in sources), tuple(t.data_ptr() for t in sources))
     hit = _LAYER_CACHE.get(key)
-    if hit is not None and hit[0] == ver and all(r() is t for r, t in zip(hit[2], sources)):
+    if hit is not None and hit[0] == state and all(r() is t for r, t in zip(hit[2], sources)):
         return hit[1]
+    if hit is not None:
+        del _LAYER_CACHE[key]                 # the stale value's planes go before the new ones are built
+        hit = None
+    _purge_dead()
     value = build()
-    for k in [k for k, e in _LAYER_CACHE.items() if any(r() is None for r in e[2])]:      # entries of models that are gone: free their planes
-        del _LAYER_CACHE[k]
     if len(_LAYER_CACHE) > 512:
         _LAYER_CACHE.clear()
     try:
-        _LAYER_CACHE[key] = (ver, value, [weakref.ref(t) for t in sources])
+        _LAYER_CACHE[key] = (state, value, [weakref.ref(t) for t in sources])
     except TypeError:
         pass
     return value

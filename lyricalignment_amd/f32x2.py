@@ -117,6 +117,13 @@ class WeightPlanes:
     def __init__(self):
         self.planes = {}
 
+    def put(self, orient: str, length: int, value: "Planes") -> None:
+        """Keep the most recent plane length per orientation (a different batch size pads the contraction differently; the planes of the
+        previous one are not kept beside the new ones)."""
+        for k in [k for k in self.planes if k[0] == orient]:
+            del self.planes[k]
+        self.planes[(orient, length)] = value
+
 
 def slots_for(M: int, N: int) -> int:
     """Split-K slots that bring a product with few 256 x 256 tiles up to the kernel's domain (1 = none needed)."""
@@ -193,7 +200,7 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
         if wp is None:
             wp = split(w, kp, omax=w_max)
             if w_cache is not None:
-                w_cache.planes[("n", kp)] = wp
+                w_cache.put("n", kp, wp)
         return gemm(split(x, kp, act=x_act, omax=x_max), wp, bias=bias, residual=residual)
     return ops.gemm(_apply(x, x_act), w, bias=bias, residual=residual)
 
@@ -212,7 +219,7 @@ def gemm_nn(dy: torch.Tensor, w: torch.Tensor, gelu_grad_of: Optional[torch.Tens
         if wt is None:
             wt = split_t(w, np_, omax=w_max)
             if w_cache is not None:
-                w_cache.planes[("t", np_)] = wt
+                w_cache.put("t", np_, wt)
         dx = gemm(split(dy, np_, omax=dy_max), wt, gelu_grad_of=gelu_grad_of if fused else None)
         if fused:
             return dx

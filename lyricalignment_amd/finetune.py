@@ -95,9 +95,12 @@ class FlatAdamW:
                                       self.betas[0], self.betas[1], self.eps, self.wd, self.t,
                                       ptr(self._sumsq) if max_norm is not None else 0, float(max_norm or 0.0),
                                       float(grad_prescale), s), "adamw_step")
-            # the kernel wrote through a raw pointer: tell torch the buffer (and with it every parameter view of it) changed -- caches
-            # keyed on parameter versions (encoder_train._LAYER_CACHE, module/align_model.encoder_only_engine) must not outlive the step
+            # the kernel wrote through a raw pointer: tell torch the buffer (and every plain view of it) changed
             torch.autograd.graph.increment_version(grp["params"])
+        # Parameters bound to the buffer with `p.data = flat[...]` keep version counters of their own which the line above does not move
+        # (FineTuner.step bumps those it knows): the derived-weight caches are keyed on an epoch as well
+        from .encoder_train import invalidate_weight_caches
+        invalidate_weight_caches()
         return self._sumsq
 
 
@@ -533,5 +536,9 @@ class FineTuner:
         self.steps_done += 1
         for g in self.grad:
             g.zero_()
+        # `p.data = flat[...]` gave every Parameter a version counter of its own: the update above went through the flat buffer's raw
+        # pointer, so the Parameters are bumped here -- everything keyed on p._version (encoder_train.cached_for, AlignModel.engine(),
+        # module/align_model.encoder_only_engine / decoder_engine_of) sees the new weights
+        torch.autograd.graph.increment_version([p for g in self.groups for p in g])
         self.model._engine_key = None        # parameters changed under the packed inference weights: re-pack on next use
         return sumsq

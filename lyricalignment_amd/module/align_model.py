@@ -106,7 +106,9 @@ class AlignModel(torch.nn.Module):
         return int(self.whisper_model.encoder.conv1.weight.shape[0]) // 64
 
     def _weights_version(self):
-        return tuple(p._version for p in self.parameters()) + (str(self.compute_dtype), bool(self.train_transcript))
+        from ..encoder_train import _EPOCH
+        return (tuple((p._version, p.data_ptr()) for p in self.parameters())
+                + (_EPOCH[0], str(self.compute_dtype), bool(self.train_transcript)))
 
     def engine(self) -> AlignEngine:
         """Packed device weights; re-packed when parameters were updated (optimizer step, load_state_dict)."""
@@ -320,7 +322,8 @@ def encoder_only_engine(whisper_model, mel: torch.Tensor) -> torch.Tensor:
     """embed_audio for a bare whisper_compat.Whisper that is not wrapped in an AlignModel (float32 compute)."""
     _lib.require_gpu()
     cache = getattr(whisper_model, "_la_engine", None)
-    key = tuple(p._version for p in whisper_model.encoder.parameters())
+    from ..encoder_train import _EPOCH
+    key = (_EPOCH[0],) + tuple((p._version, p.data_ptr()) for p in whisper_model.encoder.parameters())
     if cache is None or cache[0] != key:
         dev = torch.device(f"cuda:{torch.cuda.current_device()}")
         sd = {"encoder." + k: v for k, v in whisper_model.encoder.state_dict().items()}
@@ -337,7 +340,8 @@ def decoder_engine_of(whisper_model) -> AlignEngine:
     if whisper_model.decoder is None:
         raise RuntimeError("this Whisper object was built without a decoder")
     cache = getattr(whisper_model, "_la_dec_engine", None)
-    key = tuple(p._version for p in whisper_model.parameters())
+    from ..encoder_train import _EPOCH
+    key = (_EPOCH[0],) + tuple((p._version, p.data_ptr()) for p in whisper_model.parameters())
     if cache is None or cache[0] != key:
         dev = torch.device(f"cuda:{torch.cuda.current_device()}")
         enc_sd = {"encoder." + k: v for k, v in whisper_model.encoder.state_dict().items()}

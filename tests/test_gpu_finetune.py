@@ -273,6 +273,38 @@ def test_encoder_weight_cache_follows_the_parameters():
     assert all(t._version > a for t, a in zip(views, v0))
 
 
+def test_finetuner_steps_never_reuse_derived_weights_of_the_previous_step():
+    """Round-5 advisor finding: FineTuner binds parameters as `p.data = flat[...]` views, which keep version counters of their own; the fused
+    AdamW writes the flat buffer through a raw pointer, so nothing keyed on p._version alone saw the update and the packed q|k|v projection,
+    the decoder's cross projections, the stacked GRU weights and every cached split plane stayed at their first-step values.  Three optimizer
+    steps (large learning rates, dropout 0) with the caches alive against the same run with the caches emptied before every forward: the same
+    losses and the same parameters; and the Parameters' own versions move with every step."""
+    from lyricalignment_amd import encoder_train as et, finetune as ft
+    audios, labels, frame_labels, dec_in, dec_out = _tiny_batch()
+    runs = []
+    for clear in (False, True):
+        model = _tiny_full_model(dropout=0.0)
+        torch.manual_seed(5)
+        with torch.no_grad():
+            for p_ in model.align_rnn.parameters():
+                p_.copy_(torch.randn(p_.shape) * 0.1)
+        tuner = ft.FineTuner(model, lr=2e-2, backbone_lr=2e-2, warmup_steps=0, train_steps=50, vocab_size=40, world=1)
+        losses = []
+        for it in range(3):
+            v0 = [p_._version for g in tuner.groups for p_ in g]
+            for _ in range(2):
+                if clear:
+                    et.clear_weight_cache()
+                losses.append(tuner.micro_step(audios, labels, frame_labels, dec_in, dec_out, accum_grad_steps=2).cpu())
+            tuner.step()
+            assert all(p_._version > a for a, (p_) in zip(v0, [p_ for g in tuner.groups for p_ in g]))
+        runs.append((torch.stack(losses), [f.clone().cpu() for f in tuner.flat]))
+    assert not torch.equal(runs[0][0][0], runs[0][0][-1])                      # the steps did move the model
+    np.testing.assert_allclose(runs[0][0].numpy(), runs[1][0].numpy(), rtol=1e-6, atol=1e-7)
+    for a, b in zip(runs[0][1], runs[1][1]):
+        np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=0, atol=1e-6 * float(b.abs().max()))
+
+
 def test_attention_f16x2_on_sequences_longer_than_a_clip():
     """1700 tokens (beyond the 1536 the per-head split keeps in registers: its two-pass form; 27 key tiles, ragged last tiles of both sweeps):
     forward and backward of the f16x2 attention against the float32-MFMA kernels, self-attention and a cross shape."""

@@ -964,3 +964,29 @@ def test_cooperative_weight_build_gives_every_rank_the_sequential_model(tmp_path
         for (n, p), (_, q) in zip(ref.named_parameters(), m.named_parameters()):
             assert torch.equal(p, q), n
     assert not list(tmp_path.iterdir())            # the exchange files are removed
+
+
+def test_derived_weight_cache_follows_rebound_parameters_and_the_epoch():
+    """encoder_train.cached_for on the CPU: Parameters bound the way FineTuner binds them (`p.data = flat[...]`) keep a version counter of
+    their own, so a write to the flat buffer moves neither their version nor their address -- the epoch (FlatAdamW.step ->
+    invalidate_weight_caches) and an explicit bump of the Parameters (FineTuner.step) do; re-binding p.data moves the address."""
+    from lyricalignment_amd import encoder_train as et
+    flat = torch.zeros(8)
+    p = torch.nn.Parameter(torch.ones(2, 2))
+    p.data = flat[:4].view_as(p)
+    builds = []
+    build = lambda: builds.append(1) or len(builds)
+    assert et.cached_for([p], build) == 1 and et.cached_for([p], build) == 1
+    torch.autograd.graph.increment_version(flat)                 # what FlatAdamW.step did before: invisible to the bound Parameter
+    assert p._version == 0 and et.cached_for([p], build) == 1
+    et.invalidate_weight_caches()                                # ... hence the epoch
+    assert et.cached_for([p], build) == 2 and et.cached_for([p], build) == 2
+    torch.autograd.graph.increment_version([p])                  # FineTuner.step: the Parameters themselves
+    assert et.cached_for([p], build) == 3
+    p.data = flat[4:].view_as(p)                                 # re-bound storage: the address
+    assert et.cached_for([p], build) == 4 and et.cached_for([p], build) == 4
+    with torch.no_grad():
+        p.mul_(2.0)                                              # torch optimizers: in place on the Parameter
+    assert et.cached_for([p], build) == 5
+    et.clear_weight_cache()
+    assert not et._LAYER_CACHE and et.cached_for([p], build) == 6
