@@ -232,46 +232,66 @@ def build_model(name: str = "tiny", seed: int = 0, with_decoder: bool = False, s
     return model
 
 
+def _share_from_rank0(obj, rank: int):
+    """rank 0's `obj` on every rank of the default process group."""
+    import torch.distributed as dist
+    box = [obj if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    return box[0]
+
+
 def build_model_shared(name: str, seed: int, with_decoder: bool, rank: int, world: int, barrier, tag: str,
-                       shm_dir: str = "/dev/shm") -> Whisper:
+                       shm_dir: str = "/dev/shm", share=None) -> Whisper:
     """build_model for the `world` ranks of ONE node: every rank generates the parameters with index = rank (mod world), writes them
     to a file in shared memory, and reads the others' after `barrier()` -- the same bits as build_model on every rank, 1 / world of the
     generator work per rank (the generator is a single-threaded stream: 8 full builds on 2 threads each took 11 s apiece).
-    `tag` names this job's files (e.g. the rendezvous port); they are removed after a second barrier."""
+    RANK 0 ALONE decides where the pieces are exchanged -- a directory of its own making (mkdtemp: mode 0700, unpredictable name) under
+    `shm_dir` or the temporary directory, or nowhere (no room: every rank builds the whole model) -- and every rank follows that one
+    decision (`share(obj)`: rank 0's object on every rank; default = broadcast_object_list over the default process group), so all ranks
+    take the same path through the two barriers whatever each of them would have measured for itself.  Pieces are read with
+    weights_only=True.  `tag` names this job's directory (e.g. the rendezvous port); it is removed after the second barrier."""
     if world == 1:
         return build_model(name, seed=seed, with_decoder=with_decoder)
     import os
     import shutil
     import tempfile
+    if share is None:
+        share = lambda obj: _share_from_rank0(obj, rank)
     dims = dims_for(name)
-    # room for the whole model in the exchange directory?  (every rank of the node sees the same numbers; a container's /dev/shm can be 64 MB)
-    need = 4 * (12 * dims.n_audio_layer * dims.n_audio_state ** 2 + (16 * dims.n_text_layer * dims.n_text_state ** 2 + dims.n_vocab * dims.n_text_state
-                                                                      if with_decoder else 0)) + (64 << 20)
-    try:
-        if shutil.disk_usage(shm_dir).free < 2 * need:
-            shm_dir = tempfile.gettempdir()
-        if shutil.disk_usage(shm_dir).free < 2 * need:
-            return build_model(name, seed=seed, with_decoder=with_decoder)      # no room anywhere: every rank builds the whole model
-    except OSError:
-        return build_model(name, seed=seed, with_decoder=with_decoder)
+    exchange = None
+    if rank == 0:
+        # room for the whole model in the exchange directory?  (a container's /dev/shm can be 64 MB)
+        need = 4 * (12 * dims.n_audio_layer * dims.n_audio_state ** 2
+                    + (16 * dims.n_text_layer * dims.n_text_state ** 2 + dims.n_vocab * dims.n_text_state if with_decoder else 0)) + (64 << 20)
+        for base in (shm_dir, tempfile.gettempdir()):
+            try:
+                if shutil.disk_usage(base).free >= 2 * need:
+                    exchange = tempfile.mkdtemp(prefix=f"la_weights_{tag}_", dir=base)
+                    break
+            except OSError:
+                continue
+    exchange = share(exchange)
+    if exchange is None:                                         # no room anywhere: every rank builds the whole model (no barrier on this path,
+        return build_model(name, seed=seed, with_decoder=with_decoder)      # on any rank)
     model = build_model(name, seed=seed, with_decoder=with_decoder, part=(rank, world))
     params = list(model.named_parameters())
-    path = lambda r: os.path.join(shm_dir, f"la_weights_{tag}_{r}.pt")
+    path = lambda r: os.path.join(exchange, f"{r}.pt")
     torch.save({n: p.detach() for i, (n, p) in enumerate(params) if i % world == rank}, path(rank))
     barrier()
     with torch.no_grad():
         for r in range(world):
             if r == rank:
                 continue
-            piece = torch.load(path(r), map_location="cpu")
+            piece = torch.load(path(r), map_location="cpu", weights_only=True)
             for i, (n, p) in enumerate(params):
                 if i % world == r:
                     p.copy_(piece[n])
     barrier()
-    try:
-        os.remove(path(rank))
-    except OSError:
-        pass
+    for f in (lambda: os.remove(path(rank)), lambda: os.rmdir(exchange)):       # the last rank to leave takes the directory with it
+        try:
+            f()
+        except OSError:
+            pass
     return model
 
 
