@@ -86,7 +86,7 @@ typedef enum la_variant {
 /* ------------------------------------------------------------------------- */
 /* library                                                                    */
 /* ------------------------------------------------------------------------- */
-int la_version(void);                 /* ABI version, currently 1                              */
+int la_version(void);                 /* ABI version, currently 2 (la_encoder_block / la_head_weights carry the f16x2 planes) */
 const char *la_last_error(void);      /* thread-local text of the last LA_EHIP / LA_EINVAL     */
 int la_device_arch_ok(void);          /* 1 if the current device is gfx950                     */
 
@@ -124,6 +124,8 @@ int la_timer_read_work(double *total_ms, int64_t *timed_launches, double *timed_
  *   "head_clip_cap"   LA_HEAD_CLIP_CAP    0 = by residency (default) | n = clips per head launch set of la_align_head_forward
  *   "ln_fusion"       LA_LN_FUSION        1 = LayerNorm folded into the 16-bit encoder GEMMs where they run on the 256 x 256 kernel | 0 = never
  *   "resid_split"     LA_RESID_SPLIT      1 = the 16-bit encoder keeps its residual stream split (hi 16-bit + lo byte) | 0 = f32 stream
+ *   "x2_inference"    LA_X2_INFERENCE     1 = float32 inference (la_encoder_forward / la_align_head_forward with LA_F32 weights that carry f16x2
+ *                                         planes) on the f16 matrix pipe at float32 accuracy (default) | 0 = the float32-MFMA kernels (A/B partner)
  * A library built with -DLA_EXPERIMENTS (tools/build_variant.sh; la_has_experiments() == 1) additionally carries the measured-slower
  * kernel structures of rounds 2-4 and their per-launch developer switches; the shipped library has neither. */
 int la_set_option(const char *name, int64_t value);
@@ -349,6 +351,16 @@ int la_fc_emissions(int32_t dtype, const void *act, int64_t ld_act, const void *
                     int32_t max_labels,
                     float *em, int64_t em_batch_stride, int64_t em_row_stride,
                     void *workspace, size_t workspace_bytes, void *stream);
+/* la_fc_emissions for FLOAT32 rows with the normaliser product (the full [batch*frames] x V Linear) on the f16 matrix pipe at float32
+ * accuracy: w_fc_x2 / w_fc_x2s = W_fc as f16x2 planes [V][2][in_dim] (la_split_f16x2, kp = in_dim) and their per-row inverse scales; act is split
+ * inside (workspace).  Same results to float32 accuracy; shapes outside the 256 x 256 kernel's domain (in_dim % 128, < 192 tiles) take
+ * la_fc_emissions' float32 kernel. */
+int la_fc_emissions_x2_workspace_bytes(int32_t batch, int32_t frames, int32_t in_dim, int32_t vocab, int32_t max_labels, size_t *bytes);
+int la_fc_emissions_x2(const float *act, int64_t ld_act, const float *w_fc, const float *b_fc, const void *w_fc_x2, const float *w_fc_x2s,
+                       int32_t batch, int32_t frames, int32_t in_dim, int32_t vocab, int32_t variant,
+                       const int32_t *labels, int32_t labels_stride, const int32_t *n_labels, int32_t max_labels,
+                       float *em, int64_t em_batch_stride, int64_t em_row_stride, void *workspace,
+                       size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------- */
 /* fine-tune path: losses on the align logits and the optimizer step          */
@@ -482,6 +494,11 @@ int la_split_f16x2_t_tmax(const float *x, int64_t ldx, int32_t rows, int32_t col
                           float *colsum, const uint32_t *tmax, void *stream);
 int la_gemm_f16x2(int32_t M, int32_t N, int32_t K, int32_t slots, const void *A, const float *sa, const void *W, const float *sw,
                   float *C, int64_t ldc, const float *bias, const float *residual, int64_t ldr, int32_t epilogue, void *stream);
+/* la_layernorm (eps 1e-5, statistics in float32 over the row) whose result leaves as the f16x2 planes of the next Linear's operand instead of
+ * as float32 rows: planes [rows][2][kp] + inv_scale [rows] as la_split_f16x2 would make them from LN(x) gamma + beta (float32 inference on the
+ * f16x2 products: module/align_model.py:72-123 is float32 throughout).  d % 4 == 0, d <= 4096. */
+int la_layernorm_f16x2(const float *x, int64_t ldx, int32_t rows, int32_t d, const float *gamma, const float *beta, void *planes, int64_t kp,
+                       float *inv_scale, void *stream);
 
 /* Backward-pass building blocks of the Whisper encoder (float32): la_gemm with a row pitch for W and per-batch strides
  * (attention gradients batch over heads inside the packed [T][3d] projections), batched zero-padded transposes, exact-erf
@@ -590,6 +607,14 @@ typedef struct la_encoder_block {
     const void *w2; const float *b2;
     const void *wqkv_ln; const float *cqkv, *bqkv_ln;
     const void *w1_ln; const float *c1, *b1_ln;
+    /* float32 mode (ABI 2): the four weight matrices also as f16x2 planes [N][2][K] (la_split_f16x2 of wqkv, wo, w1, w2 with kp = K) and
+     * their per-row inverse scales [N] -- all eight given: the block's Linear layers, LayerNorms and attention run on the f16 matrix pipe
+     * at float32 accuracy (la_gemm_f16x2, la_layernorm_f16x2, la_attention_lse_f16x2) where the batch brings every product into that
+     * kernel's domain; NULL: the float32-MFMA kernels.  Ignored in the 16-bit modes. */
+    const void *wqkv_x2; const float *wqkv_x2s;
+    const void *wo_x2; const float *wo_x2s;
+    const void *w1_x2; const float *w1_x2s;
+    const void *w2_x2; const float *w2_x2s;
 } la_encoder_block;
 
 typedef struct la_encoder_weights {
@@ -617,6 +642,11 @@ typedef struct la_head_weights {
     const void *w_ih[2]; const float *b_ih[2];        /* per layer [6H][in] (forward rows, then reverse), [6H]     */
     const void *w_hh[2]; const float *b_hh[2];        /* per layer [2][3H][H], [2][3H]                              */
     const void *w_fc; const float *b_fc;              /* [V][2H], [V]                                               */
+    /* float32 mode (ABI 2): the input projections and the output Linear also as f16x2 planes ([6H][2][in], [V][2][2H]; la_split_f16x2 with
+     * kp = the matrix's own K) + per-row inverse scales -- given: those products and the recurrence's W_hh h run on the f16 matrix pipe at
+     * float32 accuracy; NULL: the float32-MFMA kernels.  Ignored in the 16-bit modes. */
+    const void *w_ih_x2[2]; const float *w_ih_x2s[2];
+    const void *w_fc_x2; const float *w_fc_x2s;
 } la_head_weights;
 
 /*

@@ -44,6 +44,9 @@ SYMBOLS = {
     "la_split_f16x2_max": (c_int32, [_P, _I64, _I32, _I32, _P, _I64, _P, _I32, _P, _P]),
     "la_split_f16x2_t_tmax": (c_int32, [_P, _I64, _I32, _I32, _P, _I64, _P, _I32, _P, _P, _P]),
     "la_gemm_f16x2": (c_int32, [_I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _I64, _P, _P, _I64, _I32, _P]),
+    "la_layernorm_f16x2": (c_int32, [_P, _I64, _I32, _I32, _P, _P, _P, _I64, _P, _P]),
+    "la_fc_emissions_x2_workspace_bytes": (c_int32, [_I32, _I32, _I32, _I32, _I32, POINTER(_SZ)]),
+    "la_fc_emissions_x2": (c_int32, [_P, _I64, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _I32, _P, _I32, _P, _I64, _I64, _P, _SZ, _P]),
     "la_set_option": (c_int32, [c_char_p, c_int64]),
     "la_get_option": (c_int32, [c_char_p, POINTER(c_int64)]),
     "la_has_experiments": (c_int32, []),
@@ -127,7 +130,8 @@ LAB_SYMBOLS = {}     # (none at present: the experiments left in csrc/lab/ are a
 class EncoderBlockC(ctypes.Structure):
     """la_encoder_block (include/lyricalign.h): device pointers of one residual attention block."""
     _fields_ = [(n, c_void_p) for n in ("ln1_g", "ln1_b", "wqkv", "bqkv", "wo", "bo", "ln2_g", "ln2_b", "w1", "b1", "w2", "b2",
-                                        "wqkv_ln", "cqkv", "bqkv_ln", "w1_ln", "c1", "b1_ln")]
+                                        "wqkv_ln", "cqkv", "bqkv_ln", "w1_ln", "c1", "b1_ln",
+                                        "wqkv_x2", "wqkv_x2s", "wo_x2", "wo_x2s", "w1_x2", "w1_x2s", "w2_x2", "w2_x2s")]
 
 
 class EncoderWeightsC(ctypes.Structure):
@@ -141,7 +145,8 @@ class HeadWeightsC(ctypes.Structure):
     """la_head_weights."""
     _fields_ = [("dtype", c_int32), ("hidden", c_int32), ("in_dim", c_int32), ("vocab", c_int32), ("n_layers", c_int32),
                 ("w_ih", c_void_p * 2), ("b_ih", c_void_p * 2), ("w_hh", c_void_p * 2), ("b_hh", c_void_p * 2),
-                ("w_fc", c_void_p), ("b_fc", c_void_p)]
+                ("w_fc", c_void_p), ("b_fc", c_void_p),
+                ("w_ih_x2", c_void_p * 2), ("w_ih_x2s", c_void_p * 2), ("w_fc_x2", c_void_p), ("w_fc_x2s", c_void_p)]
 
 
 _lib = None

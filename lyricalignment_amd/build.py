@@ -37,7 +37,7 @@ FLAGS_TAG = hashlib.sha256(" ".join([HIPCC] + CXXFLAGS).encode()).hexdigest()[:1
 # data without any error.  The build fails if one of them has spilled registers or scratch (round-2 advisor finding: the
 # LayerNorm-consumer instantiations sat at 256 VGPRs with 107-127 spills).  The one-wave-per-SIMD experiment (LA_PP_DBG=73) is
 # only reported: its spills are in the hipcc-scheduled epilogue, after the loop's last wait.
-NO_SPILL_KERNELS = re.compile(r"gemm_pp_kernel|gemm_pp_persist_kernel|gemm_q4_kernel|fc_lse_pp_kernel")
+NO_SPILL_KERNELS = re.compile(r"gemm_pp_kernel|gemm_pp_persist_kernel|gemm_q4_kernel|fc_lse_pp_kernel|fc_lse_x2_kernel")
 REPORT_KERNELS = re.compile(r"gemm_mono_kernel")
 
 

@@ -120,6 +120,73 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float *x, int64_t
     if (lane == 0) inv_scale[row] = inv;
 }
 
+// LayerNorm and the operand split in ONE pass over the rows (float32 inference on the f16x2 products, la_model.cpp): y = LN(x) gamma + beta is
+// what the next Linear multiplies, so its planes are made while the row is in registers -- the float32 copy of y (4 + 4 bytes per element
+// written and read back by la_layernorm + la_split_f16x2) never exists.  One wave per row, rows of up to 4096 columns; statistics as
+// la_layernorm (two passes over the registers: mean, then the mean of squared deviations; eps 1e-5).
+__global__ __launch_bounds__(256) void ln_split_rows_kernel(const float *x, int64_t ldx, int rows, int d, const float *gamma, const float *beta,
+                                                            unsigned short *planes, int64_t kp, float *inv_scale) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float *xr = x + (int64_t)row * ldx;
+    constexpr int NV = 16;
+    float4 v[NV];
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = (lane + 64 * j) * 4;
+        v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < d) {
+            v[j] = *reinterpret_cast<const float4 *>(xr + c);
+            sum += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mean = sum / (float)d;
+    float sq = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = (lane + 64 * j) * 4;
+        if (c < d) {
+            const float a = v[j].x - mean, b = v[j].y - mean, c2 = v[j].z - mean, d2 = v[j].w - mean;
+            sq += (a * a + b * b) + (c2 * c2 + d2 * d2);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    const float rstd = 1.0f / sqrtf(sq / (float)d + 1e-5f);
+    float mx = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = (lane + 64 * j) * 4;
+        if (c < d) {
+            const float4 g = *reinterpret_cast<const float4 *>(gamma + c), bt = *reinterpret_cast<const float4 *>(beta + c);
+            v[j] = make_float4((v[j].x - mean) * rstd * g.x + bt.x, (v[j].y - mean) * rstd * g.y + bt.y, (v[j].z - mean) * rstd * g.z + bt.z,
+                               (v[j].w - mean) * rstd * g.w + bt.w);
+            mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[j].x), fabsf(v[j].y)), fmaxf(fabsf(v[j].z), fabsf(v[j].w))));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float inv;
+    const float s = x2_scale(mx, &inv);
+    unsigned short *hi = planes + (int64_t)row * 2 * kp, *lo = hi + kp;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int i = lane + 64 * j;
+        if (i * 4 < d) {
+            ushort4 h, l;
+            x2_split(v[j].x * s, h.x, l.x); x2_split(v[j].y * s, h.y, l.y); x2_split(v[j].z * s, h.z, l.z); x2_split(v[j].w * s, h.w, l.w);
+            reinterpret_cast<ushort4 *>(hi)[i] = h;
+            reinterpret_cast<ushort4 *>(lo)[i] = l;
+        }
+    }
+    for (int i = d + lane; i < kp; i += 64) { hi[i] = 0; lo[i] = 0; }
+    if (lane == 0) inv_scale[row] = inv;
+}
+
 // column maxima of |x| as ordered unsigned bit patterns (|x| >= 0: the float order is the integer order)
 __global__ __launch_bounds__(256) void colmax_kernel(const float *x, int64_t ldx, int rows, int cols, int rows_per_block, unsigned *colmax, int act) {
     __shared__ float red[4][64];
@@ -297,6 +364,21 @@ extern "C" int la_split_f16x2_act(const float *x, int64_t ldx, int32_t rows, int
 
 extern "C" int la_split_f16x2(const float *x, int64_t ldx, int32_t rows, int32_t cols, void *planes, int64_t kp, float *inv_scale, void *stream_) {
     return la_split_f16x2_act(x, ldx, rows, cols, planes, kp, inv_scale, 0, stream_);
+}
+
+extern "C" int la_layernorm_f16x2(const float *x, int64_t ldx, int32_t rows, int32_t d, const float *gamma, const float *beta, void *planes,
+                                  int64_t kp, float *inv_scale, void *stream_) {
+    if (rows == 0) return LA_OK;
+    LA_CHECK_ARG(x && gamma && beta && planes && inv_scale && rows > 0, "layernorm_f16x2: bad arguments");
+    LA_CHECK_ARG(d > 0 && d % 4 == 0 && d <= 4096 && ldx % 4 == 0 && ldx >= d && (uintptr_t)x % 16 == 0 && (uintptr_t)gamma % 16 == 0 && (uintptr_t)beta % 16 == 0,
+                 "layernorm_f16x2: d=%d unsupported (a multiple of 4, at most 4096) or misaligned rows", d);
+    LA_CHECK_ARG(kp >= d && kp % 8 == 0 && (uintptr_t)planes % 16 == 0, "layernorm_f16x2: kp must be >= d and a multiple of 8, planes 16-byte aligned");
+    hipStream_t stream = (hipStream_t)stream_;
+    la::TimerScope ts("split_f16x2", stream, (double)rows * d * 8.0);
+    hipLaunchKernelGGL(ln_split_rows_kernel, dim3(la::cdiv(rows, 4)), dim3(256), 0, stream, x, ldx, rows, d, gamma, beta,
+                       reinterpret_cast<unsigned short *>(planes), kp, inv_scale);
+    LA_LAUNCH_CHECK();
+    return LA_OK;
 }
 
 extern "C" int la_colsum_f32(const float *in, int64_t ld, int32_t rows, int32_t cols, float *out, void *stream);

@@ -639,7 +639,8 @@ __global__ __launch_bounds__(512, 1) void gru_granule_kernel(GruGranuleParams p)
 // 4-wave workgroups (one wave per SIMD: 512 registers; the two W fragment sets are 288), 64 hidden units each.
 struct GruTrainX2Params {
     const float *gi, *w_hh, *b_hh;
-    float *out, *gates;
+    float *out, *gates;        // gates NULL: inference (float32 la_gru_layer on the f16x2 products), nothing but the layer output is stored
+    float *out_mish;           // optional: Mish(out), the head's last layer (module/align_model.py:36-37)
     int B, T, H;
     unsigned long long *xch;   // [groups][2 dirs][2 slots][16 clips][H] granules, zeroed per call
     int *abort_flag, *timeout_flag;
@@ -813,9 +814,13 @@ __global__ __launch_bounds__(256, 1) void gru_train_x2_kernel(GruTrainX2Params p
         for (int i = 0; i < 4; ++i) {
             const int bl = 4 * q + i;
             if (bl < nb) {
-                p.out[(int64_t)(b0 + bl) * out_bs + (int64_t)t * out_ts + dir * H + jcol] = hnew[i];
-                float *gp = p.gates + (((int64_t)(b0 + bl) * T_ + t) * 2 + dir) * 4 * H + jcol;
-                gp[0] = gr[i]; gp[H] = gz[i]; gp[2 * H] = gn[i]; gp[3 * H] = ghn[i];
+                const int64_t o = (int64_t)(b0 + bl) * out_bs + (int64_t)t * out_ts + dir * H + jcol;
+                p.out[o] = hnew[i];
+                if (p.out_mish) p.out_mish[o] = mish_fast(hnew[i]);
+                if (p.gates) {
+                    float *gp = p.gates + (((int64_t)(b0 + bl) * T_ + t) * 2 + dir) * 4 * H + jcol;
+                    gp[0] = gr[i]; gp[H] = gz[i]; gp[2 * H] = gn[i]; gp[3 * H] = ghn[i];
+                }
             }
         }
     }
@@ -869,13 +874,15 @@ static int gru_forward(int32_t dtype, const float *gi, const void *w_hh, const f
     }
     // float32 training forward (gates stored): recurrent product as f16x2 with the granule hand-off (gru_train_x2_kernel); option
     // gru_handoff = 1 keeps gru_kernel<float> (float32 MFMA, counter form): the A/B partner
-    if (dtype == LA_F32 && gates && hidden % 64 == 0 && hidden <= 384 && la::opts().gru_handoff == 0 && la::opts().gru_fence == 0 &&
-        (hidden / 64) * 2 * groups <= 224) {
+    // (inference, gates == NULL: the same kernel without the gate stores where option x2_inference is on and more than 4 clips share the launch --
+    //  la_align_head_forward's float32 route; a handful of clips keeps gru_kernel<float>, whose v_fma path is faster there)
+    if (dtype == LA_F32 && (gates || (la::opts().x2_inference && batch > 4)) && hidden % 64 == 0 && hidden <= 384 && la::opts().gru_handoff == 0 &&
+        la::opts().gru_fence == 0 && (hidden / 64) * 2 * groups <= 224) {
         unsigned char *wsb = reinterpret_cast<unsigned char *>(workspace);
         const size_t ctrb = gru_ctr_bytes(batch, frames);
         LA_HIP(hipMemsetAsync(wsb, 0, 16, stream));
         LA_HIP(hipMemsetAsync(wsb + ctrb, 0, gru_xch_fwd_bytes(batch, hidden), stream));
-        GruTrainX2Params tp{gi, reinterpret_cast<const float *>(w_hh), b_hh, reinterpret_cast<float *>(out), gates, batch, frames, hidden,
+        GruTrainX2Params tp{gi, reinterpret_cast<const float *>(w_hh), b_hh, reinterpret_cast<float *>(out), gates, reinterpret_cast<float *>(out_mish), batch, frames, hidden,
                             reinterpret_cast<unsigned long long *>(wsb + ctrb), reinterpret_cast<int *>(workspace), timeout_flag};
         const size_t lds_t = 16 + (size_t)2 * 2 * 16 * (hidden * 2 + 16);
         la::TimerScope ts("gru_f32", stream);

@@ -30,6 +30,8 @@ struct LseParams {
     int nparts;
     int lo, hi;        // inclusive column range of the normaliser
     int tiles_m, tiles_n, group;
+    // float32 rows on the f16x2 products (fc_lse_x2_kernel): A / W are half planes [.][2][K], sa / sw their per-row inverse scales
+    const float *sa = nullptr, *sw = nullptr;
 };
 
 template <typename T, typename C>
@@ -133,6 +135,64 @@ __global__ __launch_bounds__(PP::THREADS, 2) void fc_lse_pp_kernel(LseParams p) 
     }
 }
 
+// The same reduction for FLOAT32 rows on the f16 matrix pipe at float32 accuracy (la_f32x2.hip): act and W_fc as half planes [.][2][K] with
+// per-row power-of-two scales, three f16 products per k-step in the segmented main loop (mainloop_duo_seg_asm), the scales applied to the
+// accumulators before the bias.  K a multiple of 128, >= 256.
+__global__ __launch_bounds__(PP::THREADS, 2) void fc_lse_x2_kernel(LseParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    const TileCoord tc = tile_coord(tile, p.tiles_m, p.tiles_n, p.group);
+    const int tn = tc.tn;
+    const int m0 = tc.tm * PP::TM, n0 = tn * PP::TN;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 2, wc = wave & 3;
+    const int r = lane & 15, q = lane >> 4;
+    f32x4 acc[8][4];
+    mainloop_duo_seg_asm<la::f16_t>(reinterpret_cast<const la::f16_t *>(p.A), 2 * (int64_t)p.K, p.M, reinterpret_cast<const la::f16_t *>(p.W),
+                                    2 * (int64_t)p.K, p.N, p.K, p.K, p.K, m0, n0, lds, acc);
+    // (per-column / per-row operands are loaded AFTER the main loop: 56 more live registers across it spill the hand-placed loop's fragments)
+    float b4[4][4], sw4[4][4];
+    bool ok4[4][4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wc * 64 + ni * 16 + q * 4 + j;
+            const int nc = n < p.N ? n : p.N - 1;
+            ok4[ni][j] = n >= p.lo && n <= p.hi;
+            b4[ni][j] = p.bias[nc];
+            sw4[ni][j] = p.sw[nc];
+        }
+    float sa8[8];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) sa8[mi] = p.sa[min(m0 + wr * 128 + mi * 16 + r, p.M - 1)];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+        float v[16];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float x = ok4[ni][j] ? acc[mi][ni][j] * (sa8[mi] * sw4[ni][j]) + b4[ni][j] : -INFINITY;
+                v[ni * 4 + j] = x;
+                mx = fmaxf(mx, x);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+        if (mx > -INFINITY) {
+            const float mb = mx * kLog2e;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sum += __builtin_amdgcn_exp2f(fmaf(v[i], kLog2e, -mb));
+        }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const int m = m0 + wr * 128 + mi * 16 + r;
+        if (q == 0 && m < p.M) p.partials[(int64_t)m * p.nparts + tn * 4 + wc] = make_float2(mx, sum);
+    }
+}
+
 // Wg[b][s][:] = W_fc[col(b, s)][:], bg[b][s] = b_fc[col(b, s)];  col = silence column for s = 0, labels[b][s-1] otherwise
 template <typename T>
 __global__ void gather_rows_kernel(const T *w, const float *bias, int K, int vocab, int variant, const int32_t *labels,
@@ -201,11 +261,11 @@ __global__ __launch_bounds__(256) void merge_emissions_kernel(const float2 *part
 }
 
 struct HeadPlan {
-    size_t off_wg, off_bg, off_raw, off_part, total;
+    size_t off_wg, off_bg, off_raw, off_part, off_planes = 0, off_inv = 0, total;
     int tiles_n, nparts;
 };
 
-HeadPlan plan_head(int batch, int frames, int in_dim, int vocab, int max_labels, int es) {
+HeadPlan plan_head(int batch, int frames, int in_dim, int vocab, int max_labels, int es, bool x2 = false) {
     HeadPlan pl;
     const int64_t rows = (int64_t)batch * frames, S = max_labels + 1;
     pl.tiles_n = la::cdiv(vocab, BN);
@@ -215,8 +275,17 @@ HeadPlan plan_head(int batch, int frames, int in_dim, int vocab, int max_labels,
     pl.off_bg = o;   o += la::round_up((int64_t)batch * S * 4, 256);
     pl.off_raw = o;  o += la::round_up(rows * S * 4, 256);
     pl.off_part = o; o += la::round_up(rows * pl.nparts * 8, 256);
+    if (x2) {                                   // the half planes of act and their per-row inverse scales
+        pl.off_planes = o; o += la::round_up(rows * 2 * in_dim * 2, 256);
+        pl.off_inv = o;    o += la::round_up(rows * 4, 256);
+    }
     pl.total = o;
     return pl;
+}
+
+// Is the float32 normaliser product in the f16x2 kernel's domain?
+bool fc_x2_ok(int rows, int in_dim, int vocab) {
+    return in_dim % 128 == 0 && in_dim >= 256 && (int64_t)la::cdiv(rows, PP::TM) * la::cdiv(vocab, PP::TN) >= 192;
 }
 
 }  // namespace
@@ -228,11 +297,15 @@ extern "C" int la_fc_emissions_workspace_bytes(int32_t dtype, int32_t batch, int
     return LA_OK;
 }
 
-extern "C" int la_fc_emissions(int32_t dtype, const void *act, int64_t ld_act, const void *w_fc, const float *b_fc,
-                               int32_t batch, int32_t frames, int32_t in_dim, int32_t vocab, int32_t variant,
-                               const int32_t *labels, int32_t labels_stride, const int32_t *n_labels, int32_t max_labels,
-                               float *em, int64_t em_batch_stride, int64_t em_row_stride, void *workspace,
-                               size_t workspace_bytes, void *stream_) {
+extern "C" int la_split_f16x2(const float *x, int64_t ldx, int32_t rows, int32_t cols, void *planes, int64_t kp, float *inv_scale, void *stream);
+
+// w_x2 / w_x2s (float32 only, or NULL): W_fc as f16x2 planes [V][2][in_dim] + per-row inverse scales -- the normaliser product then runs on
+// the f16 matrix pipe at float32 accuracy (fc_lse_x2_kernel) where its shape allows
+static int fc_emissions_impl(int32_t dtype, const void *act, int64_t ld_act, const void *w_fc, const float *b_fc, const void *w_x2, const float *w_x2s,
+                             int32_t batch, int32_t frames, int32_t in_dim, int32_t vocab, int32_t variant,
+                             const int32_t *labels, int32_t labels_stride, const int32_t *n_labels, int32_t max_labels,
+                             float *em, int64_t em_batch_stride, int64_t em_row_stride, void *workspace,
+                             size_t workspace_bytes, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (batch == 0 || frames == 0) return LA_OK;
     LA_CHECK_ARG(act && w_fc && b_fc && labels && n_labels && em && workspace, "fc_emissions: null pointer");
@@ -244,7 +317,8 @@ extern "C" int la_fc_emissions(int32_t dtype, const void *act, int64_t ld_act, c
     LA_CHECK_ARG(in_dim % ke == 0, "fc_emissions: in_dim=%d must be a multiple of %d", in_dim, ke);
     LA_CHECK_ARG((ld_act * es) % 16 == 0 && (uintptr_t)act % 16 == 0 && (uintptr_t)w_fc % 16 == 0 && (uintptr_t)workspace % 256 == 0,
                  "fc_emissions: alignment");
-    const HeadPlan pl = plan_head(batch, frames, in_dim, vocab, max_labels, es);
+    const bool x2 = dtype == LA_F32 && w_x2 && w_x2s && fc_x2_ok(batch * frames, in_dim, vocab);
+    const HeadPlan pl = plan_head(batch, frames, in_dim, vocab, max_labels, es, x2);
     LA_CHECK_ARG(workspace_bytes >= pl.total, "fc_emissions: workspace too small (%zu < %zu)", workspace_bytes, pl.total);
     unsigned char *ws = reinterpret_cast<unsigned char *>(workspace);
     void *wg = ws + pl.off_wg;
@@ -277,8 +351,24 @@ extern "C" int la_fc_emissions(int32_t dtype, const void *act, int64_t ld_act, c
         const int force_tile = la::opts().gemm_tile;
         const bool pp_ok = dtype != LA_F32 && !force_tile && in_dim % 64 == 0 && in_dim >= 128 && (ld_act * 2) % 16 == 0 &&
                            (int64_t)la::cdiv(rows, PP::TM) * la::cdiv(vocab, PP::TN) >= 192;
-        if (!pp_ok) lp.nparts = 2 * pl.tiles_n;      // the 128-column kernels write two strips per tile
-        if (pp_ok) {
+        if (!pp_ok && !x2) lp.nparts = 2 * pl.tiles_n;      // the 128-column kernels write two strips per tile
+        if (x2) {
+            static la::DeviceOnce attr_x2;
+            if (attr_x2.pending()) {
+                LA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fc_lse_x2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PP::LDS));
+                attr_x2.mark();
+            }
+            void *planes = ws + pl.off_planes;
+            float *inv = reinterpret_cast<float *>(ws + pl.off_inv);
+            rc = la_split_f16x2(static_cast<const float *>(act), ld_act, rows, in_dim, planes, in_dim, inv, stream_);
+            if (rc != LA_OK) return rc;
+            lp.A = planes; lp.W = w_x2; lp.sa = inv; lp.sw = w_x2s;
+            lp.tiles_m = la::cdiv(rows, PP::TM);
+            lp.tiles_n = la::cdiv(vocab, PP::TN);
+            lp.group = std::max(1, pick_group(3 * in_dim, 2, la::cdiv(vocab, BN)) / 2);
+            la::TimerScope ts("fc_lse_f32", stream);
+            hipLaunchKernelGGL(fc_lse_x2_kernel, dim3(lp.tiles_m * lp.tiles_n), dim3(PP::THREADS), PP::LDS, stream, lp);
+        } else if (pp_ok) {
             // the strips of the last (partial) 256-column tile that no 128-column tile would have produced must still hold
             // neutral partials: every strip is written by this kernel, masked columns give (-inf, 0)
             if (!attr_pp) {
@@ -337,4 +427,29 @@ extern "C" int la_fc_emissions(int32_t dtype, const void *act, int64_t ld_act, c
                        em_row_stride);
     LA_LAUNCH_CHECK();
     return LA_OK;
+}
+
+extern "C" int la_fc_emissions(int32_t dtype, const void *act, int64_t ld_act, const void *w_fc, const float *b_fc,
+                               int32_t batch, int32_t frames, int32_t in_dim, int32_t vocab, int32_t variant,
+                               const int32_t *labels, int32_t labels_stride, const int32_t *n_labels, int32_t max_labels,
+                               float *em, int64_t em_batch_stride, int64_t em_row_stride, void *workspace,
+                               size_t workspace_bytes, void *stream) {
+    return fc_emissions_impl(dtype, act, ld_act, w_fc, b_fc, nullptr, nullptr, batch, frames, in_dim, vocab, variant, labels, labels_stride, n_labels,
+                             max_labels, em, em_batch_stride, em_row_stride, workspace, workspace_bytes, stream);
+}
+
+extern "C" int la_fc_emissions_x2_workspace_bytes(int32_t batch, int32_t frames, int32_t in_dim, int32_t vocab, int32_t max_labels, size_t *bytes) {
+    LA_CHECK_ARG(bytes && batch > 0 && frames > 0 && in_dim > 0 && vocab > 0 && max_labels > 0, "fc_emissions_x2_workspace_bytes: bad arguments");
+    *bytes = plan_head(batch, frames, in_dim, vocab, max_labels, 4, fc_x2_ok(batch * frames, in_dim, vocab)).total;
+    return LA_OK;
+}
+
+extern "C" int la_fc_emissions_x2(const float *act, int64_t ld_act, const float *w_fc, const float *b_fc, const void *w_fc_x2, const float *w_fc_x2s,
+                                  int32_t batch, int32_t frames, int32_t in_dim, int32_t vocab, int32_t variant,
+                                  const int32_t *labels, int32_t labels_stride, const int32_t *n_labels, int32_t max_labels,
+                                  float *em, int64_t em_batch_stride, int64_t em_row_stride, void *workspace,
+                                  size_t workspace_bytes, void *stream) {
+    LA_CHECK_ARG(w_fc_x2 && w_fc_x2s && (uintptr_t)w_fc_x2 % 16 == 0, "fc_emissions_x2: the planes of W_fc and their scales are required (16-byte aligned)");
+    return fc_emissions_impl(LA_F32, act, ld_act, w_fc, b_fc, w_fc_x2, w_fc_x2s, batch, frames, in_dim, vocab, variant, labels, labels_stride, n_labels,
+                             max_labels, em, em_batch_stride, em_row_stride, workspace, workspace_bytes, stream);
 }

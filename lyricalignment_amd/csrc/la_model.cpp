@@ -27,10 +27,29 @@ size_t esize(int dtype) { return dtype == LA_F32 ? 4 : 2; }
 struct EncBufs {
     void *rows0, *y1, *h, *qkv, *att, *u;
     float *x, *stats;
+    // float32 on the f16x2 products: operand planes of the d-wide operands (LN(x), attention output; one buffer, used in turn) and of the
+    // MLP's hidden operand, their per-row inverse scales, the attention's own workspace
+    void *pl_d = nullptr, *pl_u = nullptr, *attn_ws = nullptr;
+    float *inv = nullptr;
+    size_t attn_ws_bytes = 0;
     size_t total;
 };
 
-EncBufs carve_encoder(void *ws, int dtype, int batch, int d) {
+// Does the float32 encoder run its blocks on the f16 matrix pipe (la_gemm_f16x2 + la_layernorm_f16x2 + la_attention_lse_f16x2)?  The blocks
+// carry the weight planes, the option is on, and every Linear of a block lies in the 256 x 256 kernel's domain: >= 192 tiles for the narrowest
+// (N = d), K = d a multiple of 128 and >= 256.
+bool encoder_x2(const la_encoder_weights *w, int batch) {
+    if ((w->dtype & 0xff) != LA_F32 || w->n_layer < 1 || !la::opts().x2_inference) return false;
+    const int d = w->d;
+    if (d % 128 != 0 || d < 256 || d > 1024 * 4) return false;
+    for (int l = 0; l < w->n_layer; ++l) {
+        const la_encoder_block &k = w->blocks[l];
+        if (!(k.wqkv_x2 && k.wqkv_x2s && k.wo_x2 && k.wo_x2s && k.w1_x2 && k.w1_x2s && k.w2_x2 && k.w2_x2s)) return false;
+    }
+    return la::cdiv((int64_t)batch * N_CTX, 256) * la::cdiv(d, 256) >= 192;
+}
+
+EncBufs carve_encoder(void *ws, int dtype, int batch, int d, bool x2 = false, int n_head = 0) {
     Carve c(ws);
     const size_t es = esize(dtype), M = (size_t)batch * N_CTX;
     EncBufs b;
@@ -46,6 +65,13 @@ EncBufs carve_encoder(void *ws, int dtype, int batch, int d) {
     b.qkv = c.take(M * 3 * d * es);
     b.att = c.take(M * d * es);
     b.stats = static_cast<float *>(c.take(M * 2 * 4));
+    if (x2) {
+        b.pl_d = c.take(M * 2 * d * 2);
+        b.pl_u = c.take(M * 2 * 4 * d * 2);
+        b.inv = static_cast<float *>(c.take(M * 4));
+        la_attention_f16x2_workspace_bytes(batch, N_CTX, N_CTX, n_head, &b.attn_ws_bytes);
+        b.attn_ws = c.take(b.attn_ws_bytes);
+    }
     b.total = c.off;
     return b;
 }
@@ -68,7 +94,7 @@ bool encoder_fused_ln(const la_encoder_weights *w, int batch) {
 
 extern "C" int la_encoder_workspace_bytes(const la_encoder_weights *w, int32_t batch, size_t *bytes) {
     LA_CHECK_ARG(w && bytes && batch > 0 && w->d > 0, "encoder_workspace_bytes: bad arguments");
-    *bytes = carve_encoder(nullptr, w->dtype & 0xff, batch, w->d).total;
+    *bytes = carve_encoder(nullptr, w->dtype & 0xff, batch, w->d, encoder_x2(w, batch), w->n_head).total;
     return LA_OK;
 }
 
@@ -84,7 +110,8 @@ extern "C" int la_encoder_forward(const la_encoder_weights *w, const float *mel,
     LA_CHECK_ARG(w->n_mels > 0 && w->n_mels <= C_PAD && w->n_layer >= 0 && (w->n_layer == 0 || w->blocks), "encoder_forward: bad dimensions");
     LA_CHECK_ARG((uintptr_t)workspace % 256 == 0, "encoder_forward: workspace must be 256-byte aligned");
     const int dt = w->dtype & 0xff, dt_attn = w->dtype, d = w->d, M = batch * N_CTX;   // (LA_Q_LOG2 rides on the attention calls' dtype)
-    const EncBufs b = carve_encoder(workspace, dt, batch, d);
+    const bool x2 = encoder_x2(w, batch);
+    const EncBufs b = carve_encoder(workspace, dt, batch, d, x2, w->n_head);
     LA_CHECK_ARG(workspace_bytes >= b.total, "encoder_forward: workspace too small (%zu < %zu)", workspace_bytes, b.total);
     const size_t es = esize(dt);
     const int out_f32 = dt == LA_F32 ? 0 : LA_EPI_OUT_F32;       // the residual stream is f32 in every mode
@@ -140,6 +167,21 @@ extern "C" int la_encoder_forward(const la_encoder_weights *w, const float *mel,
             if (split) LA_TRY(la_gemm_split(dt, M, d, 4 * d, 1, b.u, 4 * d, 0, k.w2, b.h, lo, d, 0, k.b2, nullptr, 0, 0, LA_EPI_BIAS | LA_EPI_RESIDUAL, nullptr, stream));
             else LA_TRY(la_gemm_fused_ln(dt, M, d, 4 * d, 1, b.u, 4 * d, 0, k.w2, b.x, d, 0, k.b2, b.x, d, 0, epi_res, b.h, d, 0, nullptr, nullptr, nullptr, stream));
             if (!stats_in_loop) LA_TRY(la_row_stats16(dt, b.h, d, M, d, 1e-5f, b.stats, stream));
+        } else if (x2) {
+            // float32 on the f16 matrix pipe at float32 accuracy (csrc/la_f32x2.hip): every operand as two IEEE-half planes with a power-of-two
+            // scale per row, three f16 products per Linear in one pass of the 256 x 256 kernel.  LayerNorm leaves as the next Linear's planes
+            // (no float32 copy), the MLP's gelu(u) is applied inside its operand split, the residual adds stay in the float32 stream b.x.
+            float *qkv = static_cast<float *>(b.qkv), *att = static_cast<float *>(b.att), *u = static_cast<float *>(b.u);
+            LA_TRY(la_layernorm_f16x2(b.x, d, M, d, k.ln1_g, k.ln1_b, b.pl_d, d, b.inv, stream));
+            LA_TRY(la_gemm_f16x2(M, 3 * d, d, 1, b.pl_d, b.inv, k.wqkv_x2, k.wqkv_x2s, qkv, 3 * d, k.bqkv, nullptr, 0, LA_EPI_BIAS, stream));
+            LA_TRY(la_attention_lse_f16x2(qkv, 3 * d, qkv + d, qkv + 2 * d, 3 * d, att, d, batch, N_CTX, N_CTX, w->n_head, 0, nullptr, b.attn_ws,
+                                          b.attn_ws_bytes, stream));
+            LA_TRY(la_split_f16x2(att, d, M, d, b.pl_d, d, b.inv, stream));
+            LA_TRY(la_gemm_f16x2(M, d, d, 1, b.pl_d, b.inv, k.wo_x2, k.wo_x2s, b.x, d, k.bo, b.x, d, LA_EPI_BIAS | LA_EPI_RESIDUAL, stream));
+            LA_TRY(la_layernorm_f16x2(b.x, d, M, d, k.ln2_g, k.ln2_b, b.pl_d, d, b.inv, stream));
+            LA_TRY(la_gemm_f16x2(M, 4 * d, d, 1, b.pl_d, b.inv, k.w1_x2, k.w1_x2s, u, 4 * d, k.b1, nullptr, 0, LA_EPI_BIAS, stream));
+            LA_TRY(la_split_f16x2_act(u, 4 * d, M, 4 * d, b.pl_u, 4 * d, b.inv, 1 /* exact-erf GELU */, stream));
+            LA_TRY(la_gemm_f16x2(M, d, 4 * d, 1, b.pl_u, b.inv, k.w2_x2, k.w2_x2s, b.x, d, k.b2, b.x, d, LA_EPI_BIAS | LA_EPI_RESIDUAL, stream));
         } else {
             LA_TRY(la_layernorm(b.x, d, M, d, k.ln1_g, k.ln1_b, b.h, d, dt, stream));
             LA_TRY(la_gemm(dt, M, 3 * d, d, 1, b.h, d, 0, k.wqkv, b.qkv, 3 * d, 0, k.bqkv, nullptr, 0, 0, LA_EPI_BIAS, stream));
@@ -172,8 +214,18 @@ struct HeadBufs {
     float *gi, *em;
     void *gru[2], *act, *gru_ws, *fc_ws, *vit_ws;
     int32_t *n_frames;
+    // float32 on the f16x2 products: the planes of an input projection's operand rows (encoder output / first layer's output) + inverse scales
+    void *planes = nullptr;
+    float *inv = nullptr;
     size_t gru_ws_bytes, fc_ws_bytes, vit_ws_bytes, total;
 };
+
+// float32 head on the f16 matrix pipe (input projections, recurrence, output Linear's normaliser): the weights carry the planes and the option is on
+bool head_x2(const la_head_weights *w) {
+    return w->dtype == LA_F32 && la::opts().x2_inference && w->w_ih_x2[0] && w->w_ih_x2s[0] && w->w_ih_x2[1] && w->w_ih_x2s[1] && w->w_fc_x2 && w->w_fc_x2s;
+}
+// one input projection [rows][K] x [6H][K]^T in la_gemm_f16x2's domain?
+bool proj_x2_ok(int64_t rows, int K, int H) { return K % 128 == 0 && K >= 256 && la::cdiv(rows, 256) * la::cdiv(6 * H, 256) >= 192; }
 
 int carve_head(void *ws, const la_head_weights *w, int batch, int frames, int max_labels, HeadBufs *b) {
     Carve c(ws);
@@ -189,7 +241,14 @@ int carve_head(void *ws, const la_head_weights *w, int batch, int frames, int ma
     b->n_frames = static_cast<int32_t *>(c.take((size_t)bb * 4));
     LA_TRY(la_gru_workspace_bytes(bb, frames, H, &b->gru_ws_bytes));
     b->gru_ws = c.take(b->gru_ws_bytes);
-    LA_TRY(la_fc_emissions_workspace_bytes(w->dtype, bb, frames, 2 * H, w->vocab, max_labels, &b->fc_ws_bytes));
+    if (head_x2(w)) {
+        const int kmax = w->in_dim > 2 * H ? w->in_dim : 2 * H;
+        b->planes = c.take((size_t)bb * frames * 2 * kmax * 2);
+        b->inv = static_cast<float *>(c.take((size_t)bb * frames * 4));
+        LA_TRY(la_fc_emissions_x2_workspace_bytes(bb, frames, 2 * H, w->vocab, max_labels, &b->fc_ws_bytes));
+    } else {
+        LA_TRY(la_fc_emissions_workspace_bytes(w->dtype, bb, frames, 2 * H, w->vocab, max_labels, &b->fc_ws_bytes));
+    }
     b->fc_ws = c.take(b->fc_ws_bytes);
     LA_TRY(la_viterbi_workspace_bytes(bb, frames, max_labels, &b->vit_ws_bytes));
     b->vit_ws = c.take(b->vit_ws_bytes > 16 ? b->vit_ws_bytes : 16);
@@ -224,6 +283,7 @@ extern "C" int la_align_head_forward(const la_head_weights *w, const void *feats
     const size_t es = esize(dt);
     const int out_f32 = dt == LA_F32 ? 0 : LA_EPI_OUT_F32;
     const int cap = head_clip_cap(w, frames);
+    const bool x2 = head_x2(w);
     LA_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(b.n_frames), frames, batch < cap ? batch : cap, stream));
     const int64_t em_clip = (int64_t)frames * (max_labels + 1);
     for (int b0 = 0; b0 < batch; b0 += cap) {        // the persistent recurrence takes one launch set of clips at a time
@@ -232,6 +292,20 @@ extern "C" int la_align_head_forward(const la_head_weights *w, const void *feats
         int64_t lda = ld_feats, stride_a = clip_stride_rows * ld_feats;
         int in_dim = w->in_dim;
         for (int layer = 0; layer < 2; ++layer) {
+            if (x2 && proj_x2_ok((int64_t)nb * frames, in_dim, H)) {
+                // the layer's input rows as half planes (clip by clip where a clip's rows are not adjacent to the next one's: long form),
+                // then gi = x W_ih^T + b_ih as three f16 products
+                const float *xf = reinterpret_cast<const float *>(x);
+                if (stride_a == (int64_t)frames * lda) {
+                    LA_TRY(la_split_f16x2(xf, lda, nb * frames, in_dim, b.planes, in_dim, b.inv, stream));
+                } else {
+                    for (int c = 0; c < nb; ++c)
+                        LA_TRY(la_split_f16x2(xf + (int64_t)c * stride_a, lda, frames, in_dim, static_cast<unsigned char *>(b.planes) + (size_t)c * frames * 2 * in_dim * 2,
+                                              in_dim, b.inv + (size_t)c * frames, stream));
+                }
+                LA_TRY(la_gemm_f16x2(nb * frames, 6 * H, in_dim, 1, b.planes, b.inv, w->w_ih_x2[layer], w->w_ih_x2s[layer], b.gi, 6 * H, w->b_ih[layer],
+                                     nullptr, 0, LA_EPI_BIAS, stream));
+            } else
             LA_TRY(la_gemm(dt, frames, 6 * H, in_dim, nb, x, lda, stride_a, w->w_ih[layer], b.gi, 6 * H, (int64_t)frames * 6 * H, w->b_ih[layer],
                            nullptr, 0, 0, LA_EPI_BIAS | out_f32, stream));
             LA_TRY(la_gru_layer(dt, b.gi, w->w_hh[layer], w->b_hh[layer], b.gru[layer], layer == 1 ? b.act : nullptr, nb, frames, H, b.gru_ws,
@@ -242,6 +316,11 @@ extern "C" int la_align_head_forward(const la_head_weights *w, const void *feats
         // the slice's fused Linear + emission prep and its DP, on the slice's rows of the caller's label / result arrays
         float *em = emissions_out ? emissions_out + (int64_t)b0 * em_clip : b.em;
         const int32_t *lab = labels + (int64_t)b0 * labels_stride;
+        if (x2)
+            LA_TRY(la_fc_emissions_x2(static_cast<const float *>(b.act), 2 * H, static_cast<const float *>(w->w_fc), w->b_fc, w->w_fc_x2, w->w_fc_x2s, nb, frames,
+                                      2 * H, w->vocab, variant, lab, labels_stride, n_labels + b0, max_labels, em, em_clip, max_labels + 1, b.fc_ws,
+                                      b.fc_ws_bytes, stream));
+        else
         LA_TRY(la_fc_emissions(dt, b.act, 2 * H, w->w_fc, w->b_fc, nb, frames, 2 * H, w->vocab, variant, lab, labels_stride, n_labels + b0, max_labels,
                                em, em_clip, max_labels + 1, b.fc_ws, b.fc_ws_bytes, stream));
         LA_TRY(la_viterbi_batch(em, em_clip, max_labels + 1, lab, labels_stride, n_labels + b0, b.n_frames, nb, frames, max_labels,

@@ -60,6 +60,7 @@ const OptionDesc kOptions[] = {
     {"gru_handoff", "LA_GRU_HANDOFF", &Options::gru_handoff, false}, {"gru_poll_delay", "LA_GRU_POLL_DELAY", &Options::gru_poll_delay, false},
     {"viterbi_dpp", "LA_VITERBI_NO_DPP", &Options::viterbi_dpp, true}, {"head_clip_cap", "LA_HEAD_CLIP_CAP", &Options::head_clip_cap, false},
     {"ln_fusion", "LA_LN_FUSION", &Options::ln_fusion, false},       {"resid_split", "LA_RESID_SPLIT", &Options::resid_split, false},
+    {"x2_inference", "LA_X2_INFERENCE", &Options::x2_inference, false},
 };
 }  // namespace
 
@@ -126,7 +127,7 @@ TimerScope::~TimerScope() {
 
 }  // namespace la
 
-extern "C" int la_version(void) { return 1; }
+extern "C" int la_version(void) { return 2; }
 
 extern "C" const char *la_last_error(void) { return la::err_buf(); }
 

@@ -65,6 +65,43 @@ class BlockWeights:
     # LayerNorm folded into the QKV / MLP-up GEMMs (16-bit modes): W' = gamma o W, c = row sums of the ROUNDED W', b' = b + W beta
     wqkv_ln: Optional[torch.Tensor] = None; cqkv: Optional[torch.Tensor] = None; bqkv_ln: Optional[torch.Tensor] = None
     w1_ln: Optional[torch.Tensor] = None; c1: Optional[torch.Tensor] = None; b1_ln: Optional[torch.Tensor] = None
+    # float32 mode: the four weight matrices also as f16x2 planes [N, 2, K] + per-row inverse scales [N] (la_split_f16x2, once at pack time):
+    # with them the block runs on the f16 matrix pipe at float32 accuracy (la_encoder_forward's x2 route)
+    x2: Optional[List[Tuple[torch.Tensor, torch.Tensor]]] = None      # [(planes, inv_scale)] of wqkv, wo, w1, w2
+
+
+def _x2_planes(w: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """A float32 device weight [N, K] (K a multiple of 8) -> its f16x2 planes [N, 2, K] and per-row inverse scales [N] (la_split_f16x2)."""
+    N, K = w.shape
+    planes = torch.empty((N, 2, K), dtype=torch.float16, device=w.device)
+    inv = torch.empty((N,), dtype=torch.float32, device=w.device)
+    _lib.check(_lib.lib().la_split_f16x2(_lib.ptr(w), w.stride(0), N, K, _lib.ptr(planes), K, _lib.ptr(inv), _lib.stream_ptr()), "split_f16x2")
+    return planes, inv
+
+
+def x2_inference_on() -> bool:
+    """Library option "x2_inference" (include/lyricalign.h): float32 inference on the f16 matrix pipe at float32 accuracy."""
+    return _lib.get_option("x2_inference") != 0
+
+
+def _x2_domain(M: int, N: int, K: int) -> bool:
+    """la_gemm_f16x2's domain without split-K slots (the weight planes are packed at their own K)."""
+    return K % 128 == 0 and K >= 256 and N > 128 and -(-M // 256) * -(-N // 256) >= 192
+
+
+def _x2_linear(x: torch.Tensor, w_x2: Tuple[torch.Tensor, torch.Tensor], bias: Optional[torch.Tensor], out: Optional[torch.Tensor] = None,
+               residual: Optional[torch.Tensor] = None, x_planes=None) -> torch.Tensor:
+    """out [M, N] f32 = x [M, K] f32 (or its ready planes) . w^T + bias (+ residual) with w as packed f16x2 planes: three f16 products at float32 accuracy."""
+    from . import f32x2
+    planes, inv = w_x2
+    N, _, K = planes.shape
+    a = x_planes if x_planes is not None else f32x2.split(x, K)
+    return f32x2.gemm(a, f32x2.Planes(planes, inv, N, K, K), out=out, bias=bias, residual=residual)
+
+
+# LA_X2_PACK=0: float32 engines are packed without the f16x2 planes of their weights (every float32 product stays on the float32-MFMA
+# kernels; the planes double the packed weights' footprint).  The library option "x2_inference" switches the route at run time instead.
+X2_PACK = os.environ.get("LA_X2_PACK", "1") != "0"
 
 
 def _fold_ln(w: torch.Tensor, b: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, dtype: torch.dtype, device):
@@ -101,6 +138,9 @@ class HeadWeights:
     b_hh: List[torch.Tensor]   # per layer [2, 3H] f32
     w_fc: torch.Tensor         # [V, 2H]
     b_fc: torch.Tensor         # [V] f32
+    # float32 mode: f16x2 planes + inverse scales of the input projections and of the output Linear (la_align_head_forward's x2 route)
+    w_ih_x2: Optional[List[Tuple[torch.Tensor, torch.Tensor]]] = None
+    w_fc_x2: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
 
 
 def pack_encoder(sd: Dict[str, torch.Tensor], n_head: int, dtype: torch.dtype, device, prefix: str = "encoder.") -> EncoderWeights:
@@ -135,6 +175,8 @@ def pack_encoder(sd: Dict[str, torch.Tensor], n_head: int, dtype: torch.dtype, d
             _f32(g(b + "mlp_ln.weight"), device), _f32(g(b + "mlp_ln.bias"), device),
             g(b + "mlp.0.weight").detach().to(device=device, dtype=dtype).contiguous(), _f32(g(b + "mlp.0.bias"), device),
             g(b + "mlp.2.weight").detach().to(device=device, dtype=dtype).contiguous(), _f32(g(b + "mlp.2.bias"), device))
+        if dtype == torch.float32 and X2_PACK and d % 128 == 0 and d >= 256 and torch.device(device).type == "cuda":
+            blk.x2 = [_x2_planes(t) for t in (blk.wqkv, blk.wo, blk.w1, blk.w2)]
         if dtype in (torch.bfloat16, torch.float16):
             blk.wqkv_ln, blk.cqkv, blk.bqkv_ln = _fold_ln(wqkv, bqkv, g(b + "attn_ln.weight"), g(b + "attn_ln.bias"), dtype, device)
             blk.w1_ln, blk.c1, blk.b1_ln = _fold_ln(g(b + "mlp.0.weight"), g(b + "mlp.0.bias"), g(b + "mlp_ln.weight"),
@@ -232,8 +274,13 @@ def pack_head(sd: Dict[str, torch.Tensor], dtype: torch.dtype, device, prefix: s
     w_fc = g("fc.weight").float()
     if not bidir:
         w_fc = torch.cat([w_fc, torch.zeros_like(w_fc)], dim=1)
-    return HeadWeights(H, w_ih[0].shape[1], w_fc.shape[0], dtype, w_ih, b_ih, w_hh, b_hh,
-                       w_fc.to(device=device, dtype=dtype).contiguous(), _f32(g("fc.bias"), device))
+    hw = HeadWeights(H, w_ih[0].shape[1], w_fc.shape[0], dtype, w_ih, b_ih, w_hh, b_hh,
+                     w_fc.to(device=device, dtype=dtype).contiguous(), _f32(g("fc.bias"), device))
+    if (dtype == torch.float32 and X2_PACK and torch.device(device).type == "cuda" and len(w_ih) == 2
+            and all(w.shape[1] % 8 == 0 for w in w_ih) and hw.w_fc.shape[1] % 8 == 0):
+        hw.w_ih_x2 = [_x2_planes(w) for w in hw.w_ih]
+        hw.w_fc_x2 = _x2_planes(hw.w_fc)
+    return hw
 
 
 class AlignEngine:
@@ -254,8 +301,9 @@ class AlignEngine:
         P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
         blocks = (_lib.EncoderBlockC * max(1, len(e.blocks)))()
         for i, b in enumerate(e.blocks):
+            x2 = [P(t) for pair in (b.x2 or [(None, None)] * 4) for t in pair]
             blocks[i] = _lib.EncoderBlockC(P(b.ln1_g), P(b.ln1_b), P(b.wqkv), P(b.bqkv), P(b.wo), P(b.bo), P(b.ln2_g), P(b.ln2_b),
-                                           P(b.w1), P(b.b1), P(b.w2), P(b.b2), P(b.wqkv_ln), P(b.cqkv), P(b.bqkv_ln), P(b.w1_ln), P(b.c1), P(b.b1_ln))
+                                           P(b.w1), P(b.b1), P(b.w2), P(b.b2), P(b.wqkv_ln), P(b.cqkv), P(b.bqkv_ln), P(b.w1_ln), P(b.c1), P(b.b1_ln), *x2)
         c = _lib.EncoderWeightsC(_lib.dtype_code(e.dtype) | (_lib.LA_Q_LOG2 if e.q_log2 else 0), e.d, e.n_head, len(e.blocks), e.n_mels, P(e.conv1_w), P(e.conv1_b), P(e.conv2_w),
                                  P(e.conv2_b), P(e.pos), P(e.lnp_g), P(e.lnp_b), blocks)
         c._keep = blocks            # the struct points into this host array
@@ -265,8 +313,12 @@ class AlignEngine:
     def _head_struct(h: HeadWeights):
         V2 = ctypes.c_void_p * 2
         P = lambda t: t.data_ptr()
+        Pn = lambda t: t.data_ptr() if t is not None else None
+        ih = h.w_ih_x2 or [(None, None)] * 2
+        fc = h.w_fc_x2 or (None, None)
         return _lib.HeadWeightsC(_lib.dtype_code(h.dtype), h.hidden, h.in_dim, h.vocab, 2, V2(P(h.w_ih[0]), P(h.w_ih[1])), V2(P(h.b_ih[0]), P(h.b_ih[1])),
-                                 V2(P(h.w_hh[0]), P(h.w_hh[1])), V2(P(h.b_hh[0]), P(h.b_hh[1])), P(h.w_fc), P(h.b_fc))
+                                 V2(P(h.w_hh[0]), P(h.w_hh[1])), V2(P(h.b_hh[0]), P(h.b_hh[1])), P(h.w_fc), P(h.b_fc),
+                                 V2(Pn(ih[0][0]), Pn(ih[1][0])), V2(Pn(ih[0][1]), Pn(ih[1][1])), Pn(fc[0]), Pn(fc[1]))
 
     # ---- scratch -----------------------------------------------------------------
     def _get(self, name: str, shape, dtype, zero: bool = False) -> torch.Tensor:
@@ -355,6 +407,18 @@ class AlignEngine:
                 else:
                     ops.gemm(u, blk.w2, x, bias=blk.b2, residual=x, out_f32=True, out16=h, ln_part=part)     # x += mlp; h = bf16(x)
                 row_stats()
+        elif (dt == torch.float32 and e.blocks and all(b_.x2 is not None for b_ in e.blocks) and x2_inference_on() and d <= 4096
+              and -(-M // 256) * -(-d // 256) >= 192):
+            # float32 on the f16 matrix pipe at float32 accuracy: la_encoder_forward's x2 route, spelled out over the op-level calls
+            from . import f32x2
+            pl = lambda t: f32x2.Planes(t[0], t[1], t[0].shape[0], t[0].shape[2], t[0].shape[2])
+            for blk in e.blocks:
+                wq, wo_, w1_, w2_ = (pl(t) for t in blk.x2)
+                f32x2.gemm(f32x2.layernorm_split(x, blk.ln1_g, blk.ln1_b), wq, out=qkv, bias=blk.bqkv)
+                ops.attention_ex(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, N_CTX, N_CTX, e.n_head, out=att, x2=True)
+                f32x2.gemm(f32x2.split(att, d), wo_, out=x, bias=blk.bo, residual=x)
+                f32x2.gemm(f32x2.layernorm_split(x, blk.ln2_g, blk.ln2_b), w1_, out=u, bias=blk.b1)
+                f32x2.gemm(f32x2.split(u, 4 * d, act="gelu"), w2_, out=x, bias=blk.b2, residual=x)
         else:
             for blk in e.blocks:
                 ops.layernorm(x, blk.ln1_g, blk.ln1_b, dt, out=h)
@@ -588,8 +652,12 @@ class AlignEngine:
         n_layers = len(hw.w_ih)
         for layer in range(n_layers):
             gi = self._get("gi", (Bbuf, T, 2, 3 * H), torch.float32)[:B]
-            ops.gemm(x, hw.w_ih[layer], gi.view(B * T, 6 * H), bias=hw.b_ih[layer], out_f32=True, M=T, lda=lda, batch=B,
-                     stride_a=stride_a, stride_c=T * 6 * H, ldc=6 * H)
+            K = hw.w_ih[layer].shape[1]
+            if (hw.w_ih_x2 is not None and stride_a == T * lda and lda == K and _x2_domain(B * T, 6 * H, K) and x2_inference_on()):
+                _x2_linear(x[: B * T] if x.dim() == 2 else x.view(-1, K)[: B * T], hw.w_ih_x2[layer], hw.b_ih[layer], out=gi.view(B * T, 6 * H))
+            else:
+                ops.gemm(x, hw.w_ih[layer], gi.view(B * T, 6 * H), bias=hw.b_ih[layer], out_f32=True, M=T, lda=lda, batch=B,
+                         stride_a=stride_a, stride_c=T * 6 * H, ldc=6 * H)
             out = self._get(f"gru{layer}", (Bbuf, T, 2 * H), dt)[:B]
             last = layer == n_layers - 1
             if self._gru_flag is None:
@@ -603,13 +671,18 @@ class AlignEngine:
         """Materialised align logits [B, T, V] f32 (the reference's frame_manual_forward output)."""
         act = self.head_hidden(feats, B, T, feat_clip_stride)
         out = torch.empty((B * T, self.head.vocab), dtype=torch.float32, device=self.device)
-        ops.gemm(act, self.head.w_fc, out, bias=self.head.b_fc, out_f32=True)
-        return out.view(B, T, self.head.vocab)
+        hw = self.head
+        if hw.w_fc_x2 is not None and _x2_domain(B * T, hw.vocab, hw.w_fc.shape[1]) and x2_inference_on():
+            _x2_linear(act, hw.w_fc_x2, hw.b_fc, out=out)
+        else:
+            ops.gemm(act, hw.w_fc, out, bias=hw.b_fc, out_f32=True)
+        return out.view(B, T, hw.vocab)
 
     def emissions(self, feats: torch.Tensor, B: int, T: int, feat_clip_stride: int, labels: torch.Tensor,
                   n_labels: torch.Tensor, variant: int) -> torch.Tensor:
         act = self.head_hidden(feats, B, T, feat_clip_stride)
-        return ops.fc_emissions(act, self.head.w_fc, self.head.b_fc, B, T, labels, n_labels, variant)
+        return ops.fc_emissions(act, self.head.w_fc, self.head.b_fc, B, T, labels, n_labels, variant,
+                                w_x2=self.head.w_fc_x2 if (self.head.w_fc_x2 is not None and x2_inference_on()) else None)
 
     def align_feats(self, feats: torch.Tensor, B: int, T: int, feat_clip_stride: int, labels: torch.Tensor, n_labels: torch.Tensor,
                     variant: int):

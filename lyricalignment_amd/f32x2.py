@@ -92,6 +92,20 @@ def split(x: torch.Tensor, kp: Optional[int] = None, act: Optional[str] = None, 
     return Planes(planes, inv, rows, k, kp)
 
 
+def layernorm_split(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, kp: Optional[int] = None) -> Planes:
+    """LayerNorm(x) gamma + beta (eps 1e-5) straight into the planes of the next Linear's operand (la_layernorm_f16x2: the float32 rows of the
+    normalised activations are never written).  x [rows, d] float32 row view, d % 4 == 0, d <= 4096."""
+    if x.dtype != torch.float32 or x.dim() != 2 or x.stride(1) != 1:
+        raise ValueError("f32x2.layernorm_split: a float32 [rows, d] row view is expected")
+    rows, d = x.shape
+    kp = d if kp is None else kp
+    planes = torch.empty((rows, 2, kp), dtype=torch.float16, device=x.device)
+    inv = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    check(lib().la_layernorm_f16x2(ptr(x), x.stride(0), rows, d, ptr(gamma.contiguous()), ptr(beta.contiguous()), ptr(planes), kp, ptr(inv), stream_ptr()),
+          "layernorm_f16x2")
+    return Planes(planes, inv, rows, d, kp)
+
+
 def split_t(x: torch.Tensor, mp: Optional[int] = None, act: Optional[str] = None, colsum: Optional[torch.Tensor] = None,
             omax: Optional[OperandMax] = None) -> Planes:
     """x [m, k] float32 -> the planes of x^T (of act(x)^T): rows = k, contraction length m zero-padded to mp (default: m rounded up to 128).

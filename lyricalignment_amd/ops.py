@@ -356,9 +356,10 @@ def gru_layer(gi: torch.Tensor, w_hh: torch.Tensor, b_hh: torch.Tensor, out: Opt
 
 
 def fc_emissions(act: torch.Tensor, w_fc: torch.Tensor, b_fc: torch.Tensor, batch: int, frames: int,
-                 labels: torch.Tensor, n_labels: torch.Tensor, variant: int) -> torch.Tensor:
+                 labels: torch.Tensor, n_labels: torch.Tensor, variant: int, w_x2=None) -> torch.Tensor:
     """act [batch*frames, 2H] (Mish(GRU out)), w_fc [V,2H], b_fc [V] -> compact emissions [batch, frames, Lmax+1] f32.
-    The [batch, frames, V] logits are never materialised."""
+    The [batch, frames, V] logits are never materialised.  w_x2 = (planes [V,2,2H] f16, inv_scale [V]) of a float32 w_fc: the normaliser
+    product on the f16 matrix pipe at float32 accuracy (la_fc_emissions_x2)."""
     _dev(act, "act"); _dev(w_fc, "w_fc"); _dev(b_fc, "b_fc", torch.float32)
     _dev(labels, "labels", torch.int32); _dev(n_labels, "n_labels", torch.int32)
     dt = dtype_code(w_fc.dtype)
@@ -372,6 +373,17 @@ def fc_emissions(act: torch.Tensor, w_fc: torch.Tensor, b_fc: torch.Tensor, batc
         raise ValueError("fc_emissions: inconsistent label shapes")
     em = torch.empty((batch, frames, Lmax + 1), dtype=torch.float32, device=act.device)
     need = ctypes.c_size_t(0)
+    if w_x2 is not None:
+        planes, inv = w_x2
+        _dev(planes, "w_x2 planes", torch.float16); _dev(inv, "w_x2 scales", torch.float32)
+        if dt != LA_F32 or tuple(planes.shape) != (V, 2, K) or not planes.is_contiguous() or inv.numel() != V:
+            raise ValueError("fc_emissions: w_x2 goes with float32 operands, planes [V, 2, 2H] contiguous and [V] inverse scales")
+        check(lib().la_fc_emissions_x2_workspace_bytes(batch, frames, K, V, Lmax, ctypes.byref(need)), "fc_emissions_x2_workspace_bytes")
+        ws = torch.empty((need.value,), dtype=torch.uint8, device=act.device)
+        check(lib().la_fc_emissions_x2(ptr(act), act.stride(0), ptr(w_fc), ptr(b_fc), ptr(planes), ptr(inv), batch, frames, K, V, variant, ptr(labels),
+                                       labels.stride(0), ptr(n_labels.contiguous()), Lmax, ptr(em), em.stride(0), em.stride(1),
+                                       ptr(ws), need.value, stream_ptr()), "fc_emissions_x2")
+        return em
     check(lib().la_fc_emissions_workspace_bytes(dt, batch, frames, K, V, Lmax, ctypes.byref(need)), "fc_emissions_workspace_bytes")
     ws = torch.empty((need.value,), dtype=torch.uint8, device=act.device)
     check(lib().la_fc_emissions(dt, ptr(act), act.stride(0), ptr(w_fc), ptr(b_fc), batch, frames, K, V, variant, ptr(labels),
@@ -381,7 +393,7 @@ def fc_emissions(act: torch.Tensor, w_fc: torch.Tensor, b_fc: torch.Tensor, batc
 
 
 def attention_ex(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, q_len: int, kv_len: int, n_head: int,
-                 causal: bool = False, out: Optional[torch.Tensor] = None, lse: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 causal: bool = False, out: Optional[torch.Tensor] = None, lse: Optional[torch.Tensor] = None, x2: bool = False) -> torch.Tensor:
     """General attention for the text decoder: q [batch*q_len, >=d] / k, v [batch*kv_len, >=d] row views (column slices of
     packed projections are fine: only the row pitch and the 16-byte alignment matter), q pre-scaled by 1/8."""
     for name, t in (("q", q), ("k", k), ("v", v)):
@@ -396,6 +408,15 @@ def attention_ex(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, 
         raise ValueError("attention_ex: views smaller than batch*len x n_head*64")
     if out is None:
         out = torch.empty((batch * q_len, d), dtype=q.dtype, device=q.device)
+    if lse is None and x2 and q.dtype == torch.float32 and q_len >= 128 and kv_len >= 128:
+        # float32 inference on the f16 matrix pipe at float32 accuracy (la_attention_lse_f16x2 without the row statistic)
+        need = ctypes.c_size_t(0)
+        check(lib().la_attention_f16x2_workspace_bytes(batch, q_len, kv_len, n_head, ctypes.byref(need)), "attention_f16x2_workspace_bytes")
+        ws = torch.empty((need.value + 256,), dtype=torch.uint8, device=q.device)
+        off = (-ws.data_ptr()) % 256
+        check(lib().la_attention_lse_f16x2(ptr(q), q.stride(0), ptr(k), ptr(v), k.stride(0), ptr(out), out.stride(0), batch, q_len, kv_len,
+                                           n_head, 1 if causal else 0, None, ws.data_ptr() + off, need.value, stream_ptr()), "attention_lse_f16x2")
+        return out
     if lse is not None:                 # float32 training forward: also the row statistic for la_attention_bwd_f32
         _dev(lse, "lse", torch.float32)
         if q.dtype != torch.float32 or lse.numel() < batch * n_head * q_len or not lse.is_contiguous():

@@ -534,7 +534,7 @@ def test_library_options_round_trip_and_shipped_library_has_no_experiments():
     and the library the tests run on is the shipped one: la_has_experiments() == 0 unless LA_LIB_PATH selects another build."""
     import os
     from lyricalignment_amd import _lib
-    for name in ("gemm_tile", "gemm_loop", "gemm_splitk", "attn_nw", "gru_nw", "gru_fence", "gru_handoff", "viterbi_dpp", "head_clip_cap", "ln_fusion", "resid_split"):
+    for name in ("gemm_tile", "gemm_loop", "gemm_splitk", "attn_nw", "gru_nw", "gru_fence", "gru_handoff", "viterbi_dpp", "head_clip_cap", "ln_fusion", "resid_split", "x2_inference"):
         before = _lib.get_option(name)
         with _lib.option(name, 7):
             assert _lib.get_option(name) == 7

@@ -74,6 +74,40 @@ def _labels(L, seed=6):
 _flat = lambda r: np.array([x for u in r for seg in u for x in seg])
 
 
+class _count_launches:
+    """Launches of one kernel family of the library inside the block (la_timer_*: the family's launches are counted whether or not they are
+    bracketed) -- how a test knows which route a call took."""
+
+    def __init__(self, family):
+        self.family, self.n = family, 0
+
+    def __enter__(self):
+        from lyricalignment_amd import _lib
+        L = _lib.lib()
+        L.la_timer_reset(); L.la_timer_sample(1000003); L.la_timer_enable(self.family.encode())
+        return self
+
+    def __exit__(self, *exc):
+        import ctypes
+        from lyricalignment_amd import _lib
+        L = _lib.lib()
+        torch.cuda.synchronize()
+        L.la_timer_disable()
+        ms, timed, work, seen = ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_int64(0)
+        L.la_timer_read_work(ctypes.byref(ms), ctypes.byref(timed), ctypes.byref(work), ctypes.byref(seen))
+        self.n = int(seen.value)
+        L.la_timer_reset(); L.la_timer_sample(1)
+        return False
+
+
+# The float32 mode has two routes (include/lyricalign.h option "x2_inference"): the float32-MFMA kernels, and -- from the batch size on at
+# which every Linear of a block fills the 256 x 256 kernel (9 clips at d = 1024, 17 at d = 384) -- the f16 matrix pipe at float32 accuracy
+# (three f16 products per float32 product, csrc/la_f32x2.hip).  The oracle runs ONE clip; for the second route the device gets that clip
+# `copies` times in one batch (clips are independent in every stage after the log-mel, whose clamp at the batch maximum is the same for
+# identical clips) and the first and the last copy are held to the oracle.
+ROUTES = [("f32_mfma", 1), ("f16x2", 12)]
+
+
 @pytest.fixture(scope="module")
 def medium():
     """Whisper-medium random-init weights + the oracle's result for one 30 s clip (computed once: ~3 s of CPU)."""
@@ -84,34 +118,47 @@ def medium():
     return dict(wm=wm, dims=dims, audio=audio, labels=labels, ref=_oracle_run(model, dims, audio, labels))
 
 
-def test_medium_24_blocks_float32_within_1e3_of_oracle(medium):
+@pytest.mark.parametrize("route,copies", ROUTES)
+def test_medium_24_blocks_float32_within_1e3_of_oracle(medium, route, copies):
     """(a) of the full-depth list: every float the path hands on -- encoder output, align logits, CTC emissions -- within
     1e-3 of the oracle after all 24 blocks, and the seconds of the fused path and of the two-step drop-in path equal the
-    oracle's own end-to-end result exactly (utils/alignment.py:121-188; module/align_model.py:72-123)."""
+    oracle's own end-to-end result exactly (utils/alignment.py:121-188; module/align_model.py:72-123) -- on both routes of the float32
+    mode (ROUTES above)."""
+    from lyricalignment_amd import _lib
     from lyricalignment_amd.utils import alignment as ua
     from oracle import model_oracle as mo
     model, dims = _build("medium", torch.float32, medium["wm"])
     audio, labels = medium["audio"], medium["labels"]
     enc, logits, lp, ls, secs, T = medium["ref"]
     assert T == 1500
-    with torch.no_grad():
-        ours_enc = model.whisper_model.embed_audio(mo.pad_or_trim(mo.log_mel_spectrogram(audio[None]), 3000).cuda()).cpu()
-        lg, _ = model.frame_manual_forward([audio])
-        got = model.align([audio], labels, use_ctc=True)
-        two = ua.perform_viterbi_ctc(lg, labels)
-        em, lab = _device_emissions(model, audio, labels)
-    np.testing.assert_allclose(ours_enc.numpy(), enc.numpy(), rtol=0, atol=1e-3)
-    np.testing.assert_allclose(lg.cpu().numpy(), logits.numpy(), rtol=0, atol=1e-3)
+    audios, labs = [audio] * copies, labels.repeat(copies, 1)
+    with torch.no_grad(), _count_launches("gemm_f16x2") as x2:
+        mel1 = mo.pad_or_trim(mo.log_mel_spectrogram(audio[None]), 3000).cuda()
+        ours_enc = model.whisper_model.embed_audio(mel1.repeat(copies, 1, 1)).cpu()
+        lg, _ = model.frame_manual_forward(audios)
+        got = model.align(audios, labs, use_ctc=True)
+        two = ua.perform_viterbi_ctc(lg, labs)
+        eng = model.engine()
+        lab_dev, n_lab, lists = ua._labels_to_device(labs, copies, eng.device)
+        feats, B, Tn, stride = model._features(model._mel_of(audios), True)
+        em = eng.emissions(feats, B, Tn, stride, lab_dev, n_lab, _lib.LA_VARIANT_CTC).cpu()
+        lab = lists[0]
+    # the route under test is the one that ran: 4 Linear launches per block and call on the f16x2 route, none on the other
+    assert (x2.n >= 4 * 24 * 4) if route == "f16x2" else (x2.n <= 4), x2.n      # (one clip: only the output Linear [1500 x 21129] fills the 256 x 256 kernel)
     idx = torch.tensor(lab) - 1
-    np.testing.assert_allclose(em[0, :, 0].numpy(), ls[0, :, 0].numpy(), rtol=0, atol=1e-3)
-    np.testing.assert_allclose(em[0, :, 1:1 + len(lab)].numpy(), lp[0][:, idx].numpy(), rtol=0, atol=1e-3)
-    assert got == secs and two == secs
+    for c in sorted({0, copies - 1}):
+        np.testing.assert_allclose(ours_enc[c].numpy(), enc[0].numpy(), rtol=0, atol=1e-3)
+        np.testing.assert_allclose(lg[c].cpu().numpy(), logits[0].numpy(), rtol=0, atol=1e-3)
+        np.testing.assert_allclose(em[c, :, 0].numpy(), ls[0, :, 0].numpy(), rtol=0, atol=1e-3)
+        np.testing.assert_allclose(em[c, :, 1:1 + len(lab)].numpy(), lp[0][:, idx].numpy(), rtol=0, atol=1e-3)
+    assert got == secs * copies and two == secs * copies
 
 
-def test_medium_24_blocks_plain_variant_and_batch_of_two_equal_oracle(medium):
+@pytest.mark.parametrize("route,copies", [("f32_mfma", 1), ("f16x2", 6)])
+def test_medium_24_blocks_plain_variant_and_batch_of_two_equal_oracle(medium, route, copies):
     """The non-CTC variant (perform_viterbi, utils/alignment.py:13-71: log_softmax over all V, silence = column 0) at full
     depth, float32, on a batch of two clips of different lengths (ragged T via get_orig_len): seconds of the fused path and of the
-    two-step drop-in path == the oracle's perform_viterbi on the oracle's logits."""
+    two-step drop-in path == the oracle's perform_viterbi on the oracle's logits.  f16x2 route: the pair of clips six times in one batch."""
     from lyricalignment_amd.utils import alignment as ua
     from oracle import alignment_oracle as ao, model_oracle as mo
     model, dims = _build("medium", torch.float32, medium["wm"])
@@ -129,11 +176,14 @@ def test_medium_24_blocks_plain_variant_and_batch_of_two_equal_oracle(medium):
     with torch.no_grad():
         ref_logits = mo.gru_head_forward(p, mo.encoder_forward(p, mo.pad_or_trim(mo.log_mel_spectrogram(batch), 3000), n_head=dims.n_audio_head)[:, :T])
         want = ao.perform_viterbi(ref_logits, labels)
-        lg, _ = model.frame_manual_forward(audios)
-        got = model.align(audios, labels, use_ctc=False)
-        two = ua.perform_viterbi(lg, labels)
-    np.testing.assert_allclose(lg.cpu().numpy(), ref_logits.numpy(), rtol=0, atol=1e-3)
-    assert got == want and two == want
+        with _count_launches("gemm_f16x2") as x2:
+            lg, _ = model.frame_manual_forward(audios * copies)
+            got = model.align(audios * copies, labels.repeat(copies, 1), use_ctc=False)
+            two = ua.perform_viterbi(lg, labels.repeat(copies, 1))
+    assert (x2.n >= 4 * 24 * 2) if route == "f16x2" else (x2.n <= 4), x2.n      # (one clip: only the output Linear [1500 x 21129] fills the 256 x 256 kernel)
+    for c in sorted({0, copies - 1}):
+        np.testing.assert_allclose(lg[2 * c: 2 * c + 2].cpu().numpy(), ref_logits.numpy(), rtol=0, atol=1e-3)
+    assert got == want * copies and two == want * copies
 
 
 # Bounds calibrated on MI355X with tools/depth_parity.py (profiles/r2_depth_parity.json holds the measured table):
@@ -158,22 +208,26 @@ def test_medium_24_blocks_16bit_emission_error_and_boundary_match(medium, dtype,
     assert exact >= min_exact, (exact, dev)
 
 
+@pytest.mark.parametrize("route,copies", [("f32_mfma", 1), ("f16x2", 18)])
 @pytest.mark.parametrize("n_samples,L", [(60096, 11), (480000, 26)])
-def test_tiny_dims_cfg1_align_equals_oracle(n_samples, L):
+def test_tiny_dims_cfg1_align_equals_oracle(n_samples, L, route, copies):
     """BASELINE configs[0] on the HIP path: Whisper-tiny (d = 384, 6 heads, 4 blocks), float32, SURVEY 8(d) cfg-1 inputs.
-    align() seconds must equal alignment_oracle.perform_viterbi_ctc(oracle logits); logits within 1e-3."""
+    align() seconds must equal alignment_oracle.perform_viterbi_ctc(oracle logits); logits within 1e-3.  Both routes of the float32 mode
+    (ROUTES above; d = 384 fills the 256 x 256 kernel from 17 clips on)."""
     from lyricalignment_amd.utils import alignment as ua
     model, dims = _build("tiny", torch.float32)
     assert (dims.n_audio_state, dims.n_audio_head, dims.n_audio_layer) == (384, 6, 4)
     audio, labels = _wave(n_samples, 0), _labels(L, seed=1)
     enc, logits, lp, ls, secs, T = _oracle_run(model, dims, audio, labels)
     assert T == (188 if n_samples == 60096 else 1500)
-    with torch.no_grad():
-        lg, _ = model.frame_manual_forward([audio])
-        got = model.align([audio], labels, use_ctc=True)
-        two = ua.perform_viterbi_ctc(lg.cpu(), labels)
-    np.testing.assert_allclose(lg.cpu().numpy(), logits.numpy(), rtol=0, atol=1e-3)
-    assert got == secs and two == secs
+    with torch.no_grad(), _count_launches("gemm_f16x2") as x2:
+        lg, _ = model.frame_manual_forward([audio] * copies)
+        got = model.align([audio] * copies, labels.repeat(copies, 1), use_ctc=True)
+        two = ua.perform_viterbi_ctc(lg.cpu(), labels.repeat(copies, 1))
+    assert (x2.n >= 4 * 4 * 2) if route == "f16x2" else (x2.n <= 4), x2.n      # (one clip: only the output Linear [1500 x 21129] fills the 256 x 256 kernel)
+    for c in sorted({0, copies - 1}):
+        np.testing.assert_allclose(lg[c].cpu().numpy(), logits[0].numpy(), rtol=0, atol=1e-3)
+    assert got == secs * copies and two == secs * copies
 
 
 def test_large_v2_32_blocks_float16_one_clip():

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(raw, n), f"{n} declared in lyricalign.h but not exported"
     assert set(names) == set(_lib.SYMBOLS), set(names) ^ set(_lib.SYMBOLS)
-    assert L.la_version() == 1
+    assert L.la_version() == 2
 
 
 def test_argument_validation_without_gpu():
