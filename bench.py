@@ -453,8 +453,9 @@ def selfcheck(gpu_onset: np.ndarray, gpu_offset: np.ndarray, cpu_results, Ls, pl
     return out
 
 
-def finetune_mode(args, rank, world, local_rank, device, dist):
-    """BASELINE configs[2]: multitask fine-tune (CE + silence BCE + CTC on the align logits, decoder CE), float32 like the
+def run_finetune(args, rank, world, local_rank, device, dist):
+    """-> the bench line of BASELINE configs[2] as a dict (None on ranks other than 0).
+    BASELINE configs[2]: multitask fine-tune (CE + silence BCE + CTC on the align logits, decoder CE), float32 like the
     reference, data parallel: every rank runs `accum` micro-steps of 2 x 30 s clips (reference defaults, train_multitask.py:
     240,325), then ONE all-reduce (sum) per flat gradient bucket over RCCL / xGMI, the fused clip + AdamW (:337-340).
     A step = one optimizer step; value = audio-seconds the whole job trained on per wall-second."""
@@ -541,9 +542,10 @@ def finetune_mode(args, rank, world, local_rank, device, dist):
     achieved = work.value / (total_ms.value * 1e-3) / 1e12 if total_ms.value > 0 else 0.0
     ar_ms = float(np.mean([a.elapsed_time(b) for a, b in ar_events])) if ar_events else 0.0
     grad_bytes = int(sum(g.numel() for g in tuner.grad) * 4)
+    line = None
     if rank == 0:
         audio_sec = world * B * CLIP_SECONDS * args.accum * args.steps
-        print(json.dumps({
+        line = ({
             "metric": f"fine-tuned audio-sec/sec, Whisper-{args.model} multitask (CTC + CE + decoder CE), DP={world}",
             "value": audio_sec / elapsed, "unit": "audio-sec/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -573,15 +575,24 @@ def finetune_mode(args, rank, world, local_rank, device, dist):
                           "launches_per_step": seen.value / max(args.steps, 1), "avg_launch_ms": total_ms.value / max(launches.value, 1),
                           "timed_launches": launches.value, "linear_gflop_per_step": gemm_flops_step / 1e9}),
             "cpu_baseline": None,
-            "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9}), flush=True)
+            "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9})
+    del tuner, model
+    return line
+
+
+def finetune_mode(args, rank, world, local_rank, device, dist):
+    line = run_finetune(args, rank, world, local_rank, device, dist)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
 
-
-def other_config_mode(args, rank, world, local_rank, device, dist):
-    """BASELINE configs[3] / configs[4] through the same harness (their records under profiles/ come from tools/large_v2_fill.py and
+def run_other_config(args, rank, world, local_rank, device, dist, model=None):
+    """-> the bench line of BASELINE configs[3] / configs[4] as a dict (None on ranks other than 0); `model`: a ready AlignModel of the
+    mode's architecture and dtype (the in-process legs of the default run hand over the headline's).
+    BASELINE configs[3] / configs[4] through the same harness (their records under profiles/ come from tools/large_v2_fill.py and
     tools/longform_bench.py; this prints them in the bench line's format, clips / songs sharded over ranks with no collective).
     largev2: Whisper-large-v2, float16, --clips x 30 s per GPU and step, single stream (the batch is the parallelism).
     longform: --songs x 180 s per GPU and step (6 x 30 s chunks per song through the encoder as one song-major batch, GRU + DP over
@@ -594,8 +605,9 @@ def other_config_mode(args, rank, world, local_rank, device, dist):
     log(f"rank {rank}/{world}: building random-init whisper-{name} weights ({args.mode} mode)")
     dims = wc.dims_for(name)
     dt = torch.float16 if large else torch.bfloat16
-    model = AlignModel(build_weights(name, False, rank, world, dist), embed_dim=dims.n_audio_state, hidden_dim=HIDDEN, output_dim=VOCAB,
-                       device=f"cuda:{local_rank}", compute_dtype=dt).eval()
+    if model is None:
+        model = AlignModel(build_weights(name, False, rank, world, dist), embed_dim=dims.n_audio_state, hidden_dim=HIDDEN, output_dim=VOCAB,
+                           device=f"cuda:{local_rank}", compute_dtype=dt).eval()
     with torch.no_grad():
         eng = model.engine()
     rs = np.random.RandomState(2)
@@ -631,6 +643,7 @@ def other_config_mode(args, rank, world, local_rank, device, dist):
     eng.check_gru()
     L_ = _lib.lib()
     L_.la_timer_reset()
+    L_.la_timer_sample(1)                      # every launch of the family bracketed: total_ms below is the family's whole time
     L_.la_timer_enable(os.environ.get("LA_BENCH_TIMER", "gemm_bf16").encode())
     if dist is not None:
         dist.barrier()
@@ -653,11 +666,13 @@ def other_config_mode(args, rank, world, local_rank, device, dist):
     import ctypes
     total_ms, launches = ctypes.c_double(0.0), ctypes.c_int64(0)
     _lib.check(L_.la_timer_read(ctypes.byref(total_ms), ctypes.byref(launches)), "timer_read")
+    L_.la_timer_reset()
     clips30 = units if large else units * 6
     gemm_flops_step = algorithmic_gemm_flops_per_clip(dims.n_audio_state, dims.n_audio_layer) * clips30
     achieved = gemm_flops_step * args.steps / (total_ms.value * 1e-3) / 1e12 if total_ms.value > 0 else 0.0
+    line = None
     if rank == 0:
-        print(json.dumps({
+        line = ({
             "metric": f"aligned audio-sec/sec (RTF^-1), Whisper-{name} " + ("30 s clips" if large else "3-minute songs"),
             "value": world * units * unit_s * args.steps / elapsed, "unit": "audio-sec/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -670,10 +685,131 @@ def other_config_mode(args, rank, world, local_rank, device, dist):
             "roofline": {"bound": "mfma", "kernel": "gemm_pp_kernel / gemm_kernel <16-bit>", "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s",
                          "frac": achieved / 2500.0, "traffic": None, "launches_per_step": launches.value / max(args.steps, 1),
                          "avg_launch_ms": total_ms.value / max(launches.value, 1)},
-            "cpu_baseline": None, "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9}), flush=True)
+            "cpu_baseline": None, "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9})
+    return line
+
+
+def other_config_mode(args, rank, world, local_rank, device, dist):
+    line = run_other_config(args, rank, world, local_rank, device, dist)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+# ---- the default run's extra legs (N = 1): the other compute modes of the headline workload and the other BASELINE configs, measured on
+# short passes AFTER the timed region and the roofline pass.  None of them touches the headline keys or the exit code: a leg that fails
+# reports {"error": ...} in its place.
+EXTRA_LEGS_BUDGET_S = 150.0
+
+
+def mode_legs(wm, head_state, dims, device, local_rank, mel, labels, n_labels, head_group, encoder_streams, ref_frames, steps: int = 6) -> dict:
+    """The headline workload (same weights, same batch, same pipeline shape) in the two other compute modes:
+      f32_parity  float32 like the reference end to end (module/align_model.py:72-123) -- the one mode in which the seconds equal the
+                  oracle's -- on the f16 matrix pipe at float32 accuracy (three f16 MFMA products per float32 product, csrc/la_f32x2.hip);
+      f16         float16 operands (same MFMA rate as bfloat16, 3 more mantissa bits).
+    Per mode: ms per step and audio-s/s over `steps` pipelined steps, the GEMM family's achieved TFLOP/s from the library's sampled
+    HIP-event timer on that pass, and how many of the batch's onset / offset frames equal the float32 mode's (the precision side of the trade;
+    `ref_frames` = the bf16 headline's frames, compared the same way)."""
+    from lyricalignment_amd import _lib
+    from lyricalignment_amd.engine import PipelinedAligner
+    from lyricalignment_amd.module.align_model import AlignModel
+    import ctypes
+    L = _lib.lib()
+    out, frames = {}, {}
+    alg = algorithmic_gemm_flops_per_clip(dims.n_audio_state, dims.n_audio_layer)
+    for name, dt, family, note in (("f32_parity", torch.float32, "gemm_f16x2", "float32 in / out, every large product as a_lo w_hi + a_hi w_lo + a_hi w_hi in f16 MFMAs"),
+                                   ("f16", torch.float16, "gemm_bf16", "float16 operands, f32 accumulate")):
+        try:
+            m = AlignModel(wm, embed_dim=dims.n_audio_state, hidden_dim=HIDDEN, output_dim=VOCAB, device=f"cuda:{local_rank}", compute_dtype=dt).eval()
+            m.align_rnn.load_state_dict(head_state)
+            with torch.no_grad():
+                eng = m.engine()
+            pipe = PipelinedAligner(eng, head_group=head_group, encoder_streams=encoder_streams)
+            pinned = [torch.empty((BATCH, labels.shape[1]), dtype=torch.int32).pin_memory() for _ in range(2)]
+            status = torch.empty((BATCH,), dtype=torch.int32).pin_memory()
+
+            def run(n):
+                with torch.no_grad():
+                    for _ in range(n):
+                        pipe.submit(mel, labels, n_labels, n_frames=T_FRAMES, use_ctc=True, host_out=(pinned[0], pinned[1], status))
+                    pipe.drain()
+                torch.cuda.synchronize()
+
+            run(head_group)
+            t0 = time.perf_counter()
+            run(steps)
+            ms = (time.perf_counter() - t0) / steps * 1e3
+            # the GEMM family's own time, as the headline's roofline leg takes it: a pass through a pipeline with ONE encoder stream
+            # (two co-running GEMMs would each read twice their own time), every 7th launch bracketed
+            timed_frames = (pinned[0].numpy().copy(), pinned[1].numpy().copy())
+            pipe = PipelinedAligner(eng, head_group=head_group, encoder_streams=1)
+            run(head_group)
+            L.la_timer_reset(); L.la_timer_sample(7); L.la_timer_enable(family.encode())
+            run(4)
+            L.la_timer_disable()
+            if not (np.array_equal(pinned[0].numpy(), timed_frames[0]) and np.array_equal(pinned[1].numpy(), timed_frames[1])):
+                raise RuntimeError("one-encoder-stream pass and the two-stream pipeline disagree on the frames")
+            total_ms, launches, work, seen = ctypes.c_double(0.0), ctypes.c_int64(0), ctypes.c_double(0.0), ctypes.c_int64(0)
+            _lib.check(L.la_timer_read_work(ctypes.byref(total_ms), ctypes.byref(launches), ctypes.byref(work), ctypes.byref(seen)), "timer_read_work")
+            eng.check_gru()
+            tf = work.value / (total_ms.value * 1e-3) / 1e12 if total_ms.value > 0 else 0.0
+            frames[name] = (pinned[0].numpy().copy(), pinned[1].numpy().copy())
+            out[name] = {"ms_per_step": ms, "audio_s_per_s": BATCH * CLIP_SECONDS / (ms * 1e-3), "dtype": name.split("_")[0], "arithmetic": note,
+                         "status_ok": bool(int((status != 0).sum()) == 0),
+                         "gemm_family": family, "gemm_achieved_tflops": tf,
+                         # f32_parity: the library counts the ALGORITHMIC float32 flops of a launch; the kernel executes three times that in f16 MFMAs
+                         "gemm_mfma_executed_tflops": 3.0 * tf if name == "f32_parity" else tf,
+                         "gemm_frac_of_f16_peak": (3.0 * tf if name == "f32_parity" else tf) / 2500.0,
+                         "whole_path_tflops": total_flops_per_clip(dims.n_audio_state, dims.n_audio_layer) * BATCH / (ms * 1e-3) / 1e12,
+                         "timing": f"{steps} pipelined steps after the timed region, the headline's pipeline shape; GEMM family: HIP events around every 7th "
+                                   f"launch on a further pass of 4 steps with ONE encoder stream ({launches.value} launches bracketed; frames checked equal)"}
+            del pipe, eng, m
+        except Exception as e:          # noqa: BLE001 -- a leg never takes the headline down
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.empty_cache()
+    # the precision side: boundaries (onset + offset frames of every label of the batch) equal to the float32 mode's
+    if "f32_parity" in frames:
+        ref_on, ref_off = frames["f32_parity"]
+        Ls = n_labels.cpu().numpy()
+        total = int(2 * Ls.sum())
+
+        def same(on, off):
+            return int(sum((on[b, :Ls[b]] == ref_on[b, :Ls[b]]).sum() + (off[b, :Ls[b]] == ref_off[b, :Ls[b]]).sum() for b in range(BATCH)))
+        out["boundaries_equal_to_f32_parity"] = {"of": total, "bf16_headline": same(*ref_frames)}
+        if "f16" in frames:
+            out["boundaries_equal_to_f32_parity"]["f16"] = same(*frames["f16"])
+    return out
+
+
+def other_config_legs(headline_model, device, local_rank, deadline: float) -> dict:
+    """BASELINE configs[2], [3], [4] on short passes in the same process (their full runs: --mode finetune | largev2 | longform)."""
+    import types
+    out = {}
+
+    def leg(name, fn):
+        if time.perf_counter() > deadline:
+            out[name] = {"error": "skipped: the extra legs' time budget was used up"}
+            return
+        try:
+            t0 = time.perf_counter()
+            line = fn()
+            r = line.get("roofline") or {}
+            out[name] = {"ms_per_step": line["ms_per_step"], "audio_s_per_s": line["value"], "dtype": line["dtype"], "steps": line["steps"],
+                         "roofline_frac": r.get("frac"), "roofline_achieved_tflops": r.get("achieved"), "workload": line["config"]["workload"],
+                         "peak_mem_GB": line.get("peak_mem_GB"), "leg_wall_s": time.perf_counter() - t0}
+        except Exception as e:          # noqa: BLE001
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.empty_cache()
+
+    base = dict(timer_period=7, allreduce_chunks=4, accum=8, accum_mode="fused", model=MODEL)
+    leg("longform", lambda: run_other_config(types.SimpleNamespace(mode="longform", songs=16, clips=0, steps=6, warmup=2, **base), 0, 1, local_rank,
+                                             device, None, model=headline_model))
+    leg("largev2", lambda: run_other_config(types.SimpleNamespace(mode="largev2", songs=0, clips=512, steps=2, warmup=1, **base), 0, 1, local_rank,
+                                            device, None))
+    leg("finetune", lambda: run_finetune(types.SimpleNamespace(mode="finetune", steps=3, warmup=2, **base), 0, 1, local_rank, device, None))
+    return out
 
 
 def build_weights(name: str, with_decoder: bool, rank: int, world: int, dist):
@@ -739,6 +875,9 @@ def main():
     ap.add_argument("--from-waveform", action="store_true",
                     help="align mode: the step starts one stage earlier, at the resident 16 kHz waveform [32, 480000] f32 -- the device "
                          "log-mel (la_logmel_f32_prepared) runs inside the timed step and feeds the encoder; adds logmel_ms_per_step")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="align mode, N = 1: skip the short passes after the timed region that fill \"modes\" (float32-parity and float16 on the "
+                         "headline workload) and \"other_configs\" (BASELINE configs[2..4]) in the JSON line")
     ap.add_argument("--timer-period", type=int, default=7,
                     help="align mode: the roofline leg brackets every n-th launch of the GEMM family with HIP events (1 = every launch; odd and not a divisor of the 199 launches per pair of batches, so every shape is sampled alike)")
     args = ap.parse_args()
@@ -966,6 +1105,25 @@ def main():
             out["selfcheck"] = chk
             out["cpu_vs_gpu_onset_mae_s"] = chk["onset_mae_s"]
             selfcheck_failed = max(chk["onset_mae_s"], chk["offset_mae_s"]) > SELFCHECK_TOL_S
+        if world == 1 and not args.no_extra_legs and not args.no_overlap and wave is None:
+            # the headline dict above is complete; what follows only ADDS keys.  The headline's pipeline buffers go first (the fine-tune
+            # leg keeps ~60 GB of activations).
+            t_legs = time.perf_counter()
+            head_state = {k: v.detach().clone() for k, v in model.align_rnn.state_dict().items()}
+            pipe = None
+            torch.cuda.empty_cache()
+            try:
+                out["modes"] = mode_legs(wm, head_state, dims, device, local_rank, mel, labels, n_labels, args.head_group, args.encoder_streams,
+                                         (last_onset, last_offset))
+            except Exception as e:          # noqa: BLE001
+                out["modes"] = {"error": f"{type(e).__name__}: {e}"}
+            log(f"mode legs done in {time.perf_counter() - t_legs:.1f} s")
+            try:
+                out["other_configs"] = other_config_legs(model, device, local_rank, t_legs + EXTRA_LEGS_BUDGET_S)
+            except Exception as e:          # noqa: BLE001
+                out["other_configs"] = {"error": f"{type(e).__name__}: {e}"}
+            out["extra_legs_wall_s"] = time.perf_counter() - t_legs
+            log(f"extra legs done in {out['extra_legs_wall_s']:.1f} s")
         print(json.dumps(out), flush=True)
         if selfcheck_failed:
             log(f"SELF-CHECK FAILED: GPU vs oracle boundary MAE {chk['onset_mae_s']:.3f} / {chk['offset_mae_s']:.3f} s > {SELFCHECK_TOL_S} s")
