@@ -405,6 +405,145 @@ def gen_harness():
 
 
 # --------------------------------------------------------------------------- #
+# 6b. the reference's own train_step / evaluate on an oracle-backed whisper        #
+# --------------------------------------------------------------------------- #
+TRAIN_STEP_DIMS = dict(n_audio_state=128, n_audio_head=2, n_audio_layer=1, n_text_state=128, n_text_head=2, n_text_layer=1, n_vocab=311, n_text_ctx=64)
+TRAIN_STEP_CFG = dict(hidden_dim=64, lr=5e-3, backbone_lr=1e-4, weight_decay=1e-5, warmup_steps=1, train_steps=10, accum_grad_steps=2,
+                      max_grad_norm=1.0, optimizer_steps=3, whisper_seed=90, whisper_std=0.05, head_seed=7, head_fc_scale=1.0, head_rnn_scale=1.0,
+                      n_samples=12)
+
+
+def _train_step_batches(ok_ids, n_batches, seed):
+    """Batches in the layout the reference's collate_fn hands to train_step (dataset.py:212-232): (audios, align_text_tokens [B, Lmax],
+    [frame_labels_i | None], [onset_offset_i | None], decoder_input [B, n], decoder_output [B, n]); items 0, 1 carry frame labels (the
+    multitask sub-batch of split_batch), item 2 does not (the transcript-only one).  Token ids are raw bert-base-chinese ids (train_step maps them)."""
+    rs = np.random.RandomState(seed)
+    out = []
+    for b in range(n_batches):
+        B = 3
+        ars = np.random.RandomState(seed * 100 + b)          # the clips from a stream of their own: the tests regenerate them from (seed, b, lengths)
+        audios = tuple((ars.randn(int(16000 * s)) * 0.1).astype(np.float32) for s in (1.0, 0.75, 0.9))
+        Ls = [int(rs.randint(3, 7)) for _ in range(B)]
+        tok = torch.full((B, max(Ls)), -100, dtype=torch.long)
+        for i, L in enumerate(Ls):
+            tok[i, :L] = torch.tensor([ok_ids[j] for j in rs.randint(0, len(ok_ids), size=L)])
+        frame_labels, onoff = [], []
+        for i, L in enumerate(Ls):
+            if i == 2:
+                frame_labels.append(None); onoff.append(None)
+                continue
+            n_fr = int(rs.randint(40, 50))
+            fl = torch.full((n_fr,), -100, dtype=torch.long)
+            edges = np.linspace(2, n_fr - 2, L + 1).astype(int)
+            for k in range(L):
+                fl[edges[k]: edges[k + 1] - 1] = tok[i, k]
+            frame_labels.append(fl)
+            onoff.append([[float(edges[k]) * 0.02, float(edges[k + 1] - 1) * 0.02] for k in range(L)])
+        n_tok = int(rs.randint(4, 7))
+        dec_in = torch.from_numpy(rs.randint(1, 300, size=(B, n_tok)).astype(np.int64))
+        dec_out = torch.from_numpy(rs.randint(1, 300, size=(B, n_tok)).astype(np.int64))
+        dec_out[1, -1] = -100
+        out.append((audios, tok, frame_labels, onoff, dec_in, dec_out))
+    return out
+
+
+def gen_train_step():
+    """Drives train_multitask.train_step (:215-342) and evaluate (:345-458) THEMSELVES -- split_batch, the in-place label LUT, compute_ce_loss /
+    compute_ctc_loss, loss.backward(), clip_grad_norm_(model.parameters()), torch.optim.AdamW with the script's two parameter groups (:683-686),
+    get_linear_schedule_with_warmup -- on the reference's AlignModel around a `whisper` stand-in whose embed_audio / logits are the oracle's
+    float32 restatement over openai-whisper-named Parameters (tiny dims, dropout 0).  Stores the inputs (data), the returned `losses` dicts of
+    every optimizer step, evaluate()'s dict before and after, and per parameter the L2 norm and 12 sampled entries of (parameter - initial
+    value) after every step.  Both use_ctc_loss values."""
+    from lyricalignment_amd import whisper_compat as wc       # parameter CONTAINER + host-independent initialisation only: no arithmetic of the build runs here
+    WhisperBase = sys.modules["whisper"].Whisper
+
+    class OracleWhisper(WhisperBase):
+        def __init__(self, dims):
+            super().__init__()
+            inner = wc.build_model(dims=dims, seed=TRAIN_STEP_CFG["whisper_seed"], std=TRAIN_STEP_CFG["whisper_std"], with_decoder=True)
+            self.dims = dims
+            self.encoder, self.decoder = inner.encoder, inner.decoder
+
+        def _p(self):
+            p = dict(self.named_parameters())
+            p.update(dict(self.named_buffers()))
+            return p
+
+        def embed_audio(self, mel):
+            return mo.encoder_forward(self._p(), mel, n_head=self.dims.n_audio_head)
+
+        def logits(self, tokens, audio_features):
+            return mo.decoder_forward(self._p(), tokens, audio_features, n_head=self.dims.n_text_head)
+
+    with open(os.path.join(REF, "bert_base_chinese_pronunce_table.json")) as f:
+        token_pinyin, _, lookup = json.load(f)
+    ok_ids = [i for i, p in enumerate(token_pinyin) if 1 <= lookup[p] <= 402 and i not in (0, 102)]
+    cfg = TRAIN_STEP_CFG
+    fixture = dict(reference="train_multitask.py:215-342 train_step, :345-458 evaluate, :683-690 optimizer / schedule", dims=TRAIN_STEP_DIMS, cfg=cfg, runs={})
+    arrays = {}
+    for use_ctc in (True, False):
+        tag = "ctc" if use_ctc else "noctc"
+        dims = wc.ModelDimensions(**TRAIN_STEP_DIMS)
+        torch.manual_seed(0)
+        V = 21128 + int(use_ctc)
+        model = ref_model.AlignModel(whisper_model=OracleWhisper(dims), embed_dim=dims.n_audio_state, hidden_dim=cfg["hidden_dim"], dropout=0.0,
+                                     output_dim=V, train_alignment=True, train_transcript=True, device="cpu")
+        wc.init_align_head(model, seed=cfg["head_seed"], fc_scale=cfg["head_fc_scale"], rnn_scale=cfg["head_rnn_scale"])
+        init = {n: p_.detach().clone() for n, p_ in model.named_parameters()}
+        optimizer = torch.optim.AdamW([{"params": model.align_rnn.parameters(), "lr": cfg["lr"]},
+                                       {"params": model.whisper_model.parameters(), "lr": cfg["backbone_lr"]}], lr=cfg["lr"], weight_decay=cfg["weight_decay"])
+        scheduler = get_linear_schedule_with_warmup(optimizer, num_warmup_steps=cfg["warmup_steps"], num_training_steps=cfg["train_steps"])
+        loss_fn = {"ce_loss": torch.nn.CrossEntropyLoss(), "silence_ce_loss": torch.nn.BCEWithLogitsLoss()}
+        train = _train_step_batches(ok_ids, cfg["optimizer_steps"] * cfg["accum_grad_steps"], seed=1000 + int(use_ctc))
+        dev = _train_step_batches(ok_ids, 2, seed=2000 + int(use_ctc))
+        it = iter(train)
+        import contextlib
+        import io
+
+        def run_eval():
+            with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+                return ref_train.evaluate(model, dev, loss_fn, token_pinyin, lookup, use_ctc_loss=use_ctc, get_orig_len=False)
+
+        rs = np.random.RandomState(5)
+        sample_idx = {n: rs.randint(0, p_.numel(), size=cfg["n_samples"]) for n, p_ in init.items()}
+        run = dict(eval_before=run_eval(), steps=[])
+        for k in range(cfg["optimizer_steps"]):
+            losses = ref_train.train_step(model, it, optimizer, scheduler, cfg["accum_grad_steps"], cfg["max_grad_norm"], loss_fn, token_pinyin, lookup,
+                                          use_ctc_loss=use_ctc, get_orig_len=False)
+            delta_l2, param_l2 = {}, {}
+            for n, p_ in model.named_parameters():
+                dlt = (p_.detach().double() - init[n].double())
+                delta_l2[n] = float(dlt.norm())
+                param_l2[n] = float(p_.detach().double().norm())
+                arrays[f"{tag}.step{k}.delta.{n}"] = dlt.flatten()[sample_idx[n]].numpy()
+            run["steps"].append(dict(losses={a: float(b) for a, b in losses.items()}, delta_l2=delta_l2, param_l2=param_l2,
+                                     lr=[float(g["lr"]) for g in optimizer.param_groups]))
+            print("train_step", tag, k, run["steps"][-1]["losses"], flush=True)
+        run["eval_after"] = run_eval()
+        fixture["runs"][tag] = run
+        for n in init:
+            arrays[f"{tag}.sample_idx.{n}"] = sample_idx[n]
+        # the inputs: audio by seed (RandomState is stable across hosts), everything else as data
+        def pack(batches, name):
+            for bi, (audios, tok, fls, onoff, din, dout) in enumerate(batches):
+                arrays[f"{tag}.{name}{bi}.tokens"] = tok.numpy()
+                for i, fl in enumerate(fls):
+                    if fl is not None:
+                        arrays[f"{tag}.{name}{bi}.frame_labels{i}"] = fl.numpy()
+                arrays[f"{tag}.{name}{bi}.dec_in"] = din.numpy()
+                arrays[f"{tag}.{name}{bi}.dec_out"] = dout.numpy()
+                arrays[f"{tag}.{name}{bi}.audio_len"] = np.array([len(a) for a in audios])
+        pack(train, "train"); pack(dev, "dev")
+        fixture["runs"][tag].update(train_seed=1000 + int(use_ctc), dev_seed=2000 + int(use_ctc), n_train=len(train), n_dev=len(dev), output_dim=V)
+        used = sorted({int(t) for bs in (train, dev) for b in bs for t in b[1].flatten().tolist() if t != -100})
+        fixture["runs"][tag]["token_to_class"] = [[t, int(lookup[token_pinyin[t]])] for t in used]
+    np.savez_compressed(os.path.join(HERE, "train_step.npz"), **arrays)
+    with open(os.path.join(HERE, "train_step.json"), "w") as f:
+        json.dump(fixture, f, indent=1)
+    print("train_step fixture written", flush=True)
+
+
+# --------------------------------------------------------------------------- #
 # 7. collate-side label builders (dataset.py)                                    #
 # --------------------------------------------------------------------------- #
 def gen_dataset_labels():
@@ -465,6 +604,9 @@ if __name__ == "__main__":
     if "--labels-only" in sys.argv:
         gen_dataset_labels()
         sys.exit(0)
+    if "--train-step-only" in sys.argv:
+        gen_train_step()
+        sys.exit(0)
     if "--harness-only" not in sys.argv:
         gen_core()
         gen_e2e()
@@ -475,6 +617,7 @@ if __name__ == "__main__":
         gen_dataset_labels()
         gen_cer()
     gen_harness()
+    gen_train_step()
     leftovers = [d for d, _, fs in os.walk(REF) if d.endswith("__pycache__")]
     assert not leftovers, f"bytecode written into the reference tree: {leftovers}"
     print("done")

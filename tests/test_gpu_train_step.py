@@ -1,0 +1,210 @@
+"""The reference's train_step / evaluate (train_multitask.py:215-342, :345-458) pinned: tests/golden/train_step.{json,npz} hold what the
+reference's OWN functions returned -- split_batch, the in-place label LUT, compute_ce_loss / compute_ctc_loss, loss.backward(),
+clip_grad_norm_(model.parameters()), torch.optim.AdamW with the script's two parameter groups (:683-686), get_linear_schedule_with_warmup --
+on its AlignModel around an oracle-backed whisper (tests/golden/gen_golden.py gen_train_step; tiny dims, dropout 0, accum 2, batches that
+split into a multitask and a transcript-only part, both use_ctc_loss values): the `losses` dict of three optimizer steps, evaluate()'s dict
+before and after, and per parameter the L2 norm and 12 sampled entries of (parameter - initial value) after every step.
+
+Here the same calls run against the HIP AlignModel
+  (a) the way an unmodified train_multitask.py drives it: frame_manual_forward under autograd, the script's loss formulas on the logits
+      (F.cross_entropy / BCE / F.ctc_loss in torch on the device, restated below), loss.backward(), torch.nn.utils.clip_grad_norm_,
+      torch.optim.AdamW on model.parameters() in the script's two groups, the transformers schedule;
+  (b) through FineTuner (loss kernels, flat buckets, fused clip + AdamW).
+The loop below restates train_step's control flow and loss formulas for the test (the reference cannot travel to the GPU box);
+tests/test_oracle_model.py runs this same loop on the CPU oracle and holds it to the fixture to float32 round-off, so what is measured here is
+the HIP model, not the loop."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+F = torch.nn.functional
+
+
+@pytest.fixture(scope="module")
+def fx():
+    with open(os.path.join(HERE, "golden", "train_step.json")) as f:
+        meta = json.load(f)
+    arr = np.load(os.path.join(HERE, "golden", "train_step.npz"))
+    return meta, arr
+
+
+def _load_batches(arr, tag, name, n, seed):
+    """The generator's batches: labels / tokens from the fixture, the clips regenerated from their seed (numpy's RandomState stream is
+    host-independent; gen_golden.py _train_step_batches draws them from RandomState(seed * 100 + batch index))."""
+    out = []
+    for b in range(n):
+        key = f"{tag}.{name}{b}."
+        ars = np.random.RandomState(seed * 100 + b)
+        tok = torch.from_numpy(arr[key + "tokens"]).long()
+        fls = [torch.from_numpy(arr[key + f"frame_labels{i}"]).long() if (key + f"frame_labels{i}") in arr.files else None for i in range(tok.shape[0])]
+        out.append(dict(tokens=tok, frame_labels=fls, dec_in=torch.from_numpy(arr[key + "dec_in"]).long(), dec_out=torch.from_numpy(arr[key + "dec_out"]).long(),
+                        audio=[(ars.randn(int(n_)) * 0.1).astype(np.float32) for n_ in arr[key + "audio_len"]]))
+    return out
+
+
+def _model(meta, V):
+    from lyricalignment_amd import whisper_compat as wc
+    from lyricalignment_amd.module.align_model import AlignModel
+    cfg = meta["cfg"]
+    dims = wc.ModelDimensions(**meta["dims"])
+    wm = wc.build_model(dims=dims, seed=cfg["whisper_seed"], std=cfg["whisper_std"], with_decoder=True)
+    model = AlignModel(wm, embed_dim=dims.n_audio_state, hidden_dim=cfg["hidden_dim"], dropout=0.0, output_dim=V, train_alignment=True,
+                       train_transcript=True, device="cuda").to("cuda")
+    wc.init_align_head(model, seed=cfg["head_seed"], fc_scale=cfg["head_fc_scale"], rnn_scale=cfg["head_rnn_scale"])
+    return model
+
+
+def _split(batch, lut):
+    """split_batch + rebatch_handler + the label LUT of train_step (:188-211, :259-268): -> (multitask part, transcript-only part), each
+    (audios, ctc labels [b, Lmax], frame labels [b, n] as class ids | None, decoder_input, decoder_output) or None; ctc labels are CLASS ids
+    in the multitask part and raw token ids in the transcript-only part (see below)."""
+    def classes(t):
+        t = t.clone()
+        m = t != -100
+        t[m] = torch.tensor([lut[int(v)] for v in t[m].tolist()], dtype=t.dtype)
+        return t
+    multi = [i for i, fl in enumerate(batch["frame_labels"]) if fl is not None]
+    trans = [i for i, fl in enumerate(batch["frame_labels"]) if fl is None]
+    parts = []
+    for idx, with_fl in ((multi, True), (trans, False)):
+        if not idx:
+            parts.append(None)
+            continue
+        fl = None
+        if with_fl:
+            fl = classes(torch.nn.utils.rnn.pad_sequence([batch["frame_labels"][i] for i in idx], batch_first=True, padding_value=-100))
+        # Reference quirk, kept (parity first): the LUT is applied to the MULTITASK sub-batch only (:259-268); the transcript-only sub-batch's CTC
+        # (:312-315) takes transcript_batch[1] as collated -- raw bert-base-chinese token ids as CTC targets.  The fixture pins exactly that.
+        ctc_lab = classes(batch["tokens"][idx]) if with_fl else batch["tokens"][idx].clone()
+        parts.append(([batch["audio"][i] for i in idx], ctc_lab, fl, batch["dec_in"][idx], batch["dec_out"][idx]))
+    return parts
+
+
+def _ce_like_the_script(logits, frame_labels, compute_sil, vocab_size=21128):
+    """compute_ce_loss (train_multitask.py:587-614): labels trimmed / padded with -100 to the logits' frames; compute_sil False = cross-entropy over
+    ALL columns, True = word CE over columns 1 .. vocab_size - 1 with the labels shifted by one + BCE of column vocab_size against (label == -100)."""
+    T = logits.shape[1]
+    fl = frame_labels[:, :T]
+    if fl.shape[1] < T:
+        fl = torch.cat((fl, torch.full((fl.shape[0], T - fl.shape[1]), -100, dtype=fl.dtype, device=fl.device)), dim=1)
+    if not compute_sil:
+        return F.cross_entropy(logits.permute(0, 2, 1), fl)
+    fl = torch.where(fl != -100, fl - 1, fl)
+    word = F.cross_entropy(logits[:, :, 1:vocab_size].transpose(1, 2), fl)
+    return word + F.binary_cross_entropy_with_logits(logits[:, :, vocab_size], (fl == -100).float())
+
+
+def _ctc_like_the_script(logits, labels):
+    """compute_ctc_loss (:616-633): log_softmax, time-major, every clip at full length, target lengths = labels != -100, F.ctc_loss defaults."""
+    lsm = F.log_softmax(logits, dim=2).transpose(0, 1)
+    return F.ctc_loss(lsm, labels, torch.full((lsm.shape[1],), lsm.shape[0], dtype=torch.long, device=logits.device), (labels != -100).sum(dim=1))
+
+
+def _losses_like_the_script(model, part, is_multi, use_ctc, dev):
+    """The loss terms train_step / evaluate take from one sub-batch (:250-321): -> (align_ce, align_ctc, trans_ce) tensors."""
+    audios, ctc_lab, fl, dec_in, dec_out = part
+    align_logits, trans_logits = model.frame_manual_forward(audios, dec_in.to(dev), get_orig_len=False)
+    z = torch.zeros((), device=dev)
+    ce = ctc = z
+    if is_multi:
+        ce = _ce_like_the_script(align_logits, fl.to(dev), compute_sil=use_ctc)
+    if use_ctc:
+        ctc = _ctc_like_the_script(align_logits[:, :, :21128], ctc_lab.to(dev))
+    tr = F.cross_entropy(trans_logits.permute(0, 2, 1), dec_out.to(dev))
+    return ce, ctc, tr
+
+
+def _param_names(model):
+    return [n for n, _ in model.named_parameters()]
+
+
+def _check_params(model, init, arr, tag, step, meta_step, tol_abs, tol_rel_l2):
+    worst_abs, worst_l2 = 0.0, 0.0
+    for n, p in model.named_parameters():
+        dlt = (p.detach().double().cpu() - init[n]).flatten()
+        want = torch.from_numpy(arr[f"{tag}.step{step}.delta.{n}"])
+        idx = torch.from_numpy(arr[f"{tag}.sample_idx.{n}"]).long()
+        worst_abs = max(worst_abs, float((dlt[idx] - want).abs().max()))
+        ref_l2 = meta_step["delta_l2"][n]
+        worst_l2 = max(worst_l2, abs(float(dlt.norm()) - ref_l2) / max(ref_l2, 1e-12))
+    assert worst_abs <= tol_abs and worst_l2 <= tol_rel_l2, (tag, step, worst_abs, worst_l2)
+    return worst_abs, worst_l2
+
+
+@pytest.mark.parametrize("tag", ["ctc", "noctc"])
+@pytest.mark.parametrize("route", ["torch_optimizer", "finetuner"])
+def test_train_step_and_evaluate_match_the_reference_run(fx, tag, route):
+    from transformers import get_linear_schedule_with_warmup
+    from lyricalignment_amd import finetune as ft
+    meta, arr = fx
+    cfg, run = meta["cfg"], meta["runs"][tag]
+    use_ctc = tag == "ctc"
+    lut = {int(t): int(c) for t, c in run["token_to_class"]}
+    train = _load_batches(arr, tag, "train", run["n_train"], run["train_seed"])
+    dev_batches = _load_batches(arr, tag, "dev", run["n_dev"], run["dev_seed"])
+    model = _model(meta, run["output_dim"])
+    dev = torch.device("cuda")
+    assert _param_names(model) == list(run["steps"][0]["delta_l2"].keys())            # the reference's state_dict layout, parameter for parameter
+    init = {n: p.detach().double().cpu().clone() for n, p in model.named_parameters()}
+    accum = cfg["accum_grad_steps"]
+
+    def evaluate():
+        model.eval()
+        tot = dict(total=0.0, align_ce=0.0, align_ctc=0.0, trans_ce=0.0, trans_ctc=0.0)
+        with torch.no_grad():
+            for b in dev_batches:
+                multi, trans = _split(b, lut)
+                ce, ctc, tr = _losses_like_the_script(model, multi, True, use_ctc, dev)
+                _, tctc, ttr = _losses_like_the_script(model, trans, False, use_ctc, dev)
+                tot["total"] += float(ce + ctc + tr + ttr + tctc); tot["align_ce"] += float(ce); tot["align_ctc"] += float(ctc)
+                tot["trans_ce"] += float(tr + ttr); tot["trans_ctc"] += float(tctc)
+        return {k: v / len(dev_batches) for k, v in tot.items()}
+
+    def close(got, want, what):
+        for k, v in want.items():
+            assert abs(got[k] - v) <= 2e-4 * max(abs(v), 1e-3) + 1e-6, (what, k, got[k], v)
+
+    close(evaluate(), run["eval_before"], "evaluate before")
+    it = iter(train)
+    if route == "torch_optimizer":
+        opt = torch.optim.AdamW([{"params": model.align_rnn.parameters(), "lr": cfg["lr"]}, {"params": model.whisper_model.parameters(), "lr": cfg["backbone_lr"]}],
+                                lr=cfg["lr"], weight_decay=cfg["weight_decay"])
+        sched = get_linear_schedule_with_warmup(opt, num_warmup_steps=cfg["warmup_steps"], num_training_steps=cfg["train_steps"])
+    else:
+        tuner = ft.FineTuner(model, lr=cfg["lr"], backbone_lr=cfg["backbone_lr"], weight_decay=cfg["weight_decay"], warmup_steps=cfg["warmup_steps"],
+                             train_steps=cfg["train_steps"], max_grad_norm=cfg["max_grad_norm"], use_ctc_loss=use_ctc, vocab_size=21128, world=1)
+    for k, want in enumerate(run["steps"]):
+        model.train()
+        got = dict(total=0.0, align_ce=0.0, align_ctc=0.0, trans_ce=0.0, trans_ctc=0.0)
+        for _ in range(accum):
+            multi, trans = _split(next(it), lut)
+            if route == "torch_optimizer":
+                ce, ctc, tr = _losses_like_the_script(model, multi, True, use_ctc, dev)
+                _, tctc, ttr = _losses_like_the_script(model, trans, False, use_ctc, dev)
+                loss = (ce + ctc + tr + ttr + tctc) / accum
+                loss.backward()
+                got["total"] += float(loss); got["align_ce"] += float(ce) / accum; got["align_ctc"] += float(ctc) / accum
+                got["trans_ce"] += float(tr + ttr) / accum; got["trans_ctc"] += float(tctc) / accum
+            else:
+                l4 = tuner.micro_step(multi[0], multi[1], multi[2], multi[3], multi[4], accum_grad_steps=accum, get_orig_len=False,
+                                      transcript_batch=(trans[0], trans[1], trans[3], trans[4])).cpu().double()
+                got["total"] += float(l4.sum()) / accum; got["align_ce"] += float(l4[0] + l4[1]) / accum
+                got["align_ctc"] += float(l4[2]) / accum; got["trans_ce"] += float(l4[3]) / accum       # (l4[2] = CTC of both sub-batches)
+        if route == "torch_optimizer":
+            torch.nn.utils.clip_grad_norm_(model.parameters(), cfg["max_grad_norm"])
+            opt.step(); sched.step(); opt.zero_grad()
+            close(got, want["losses"], f"train_step {k}")
+        else:
+            tuner.step()
+            w = want["losses"]
+            close(dict(total=got["total"], align_ce=got["align_ce"], trans_ce=got["trans_ce"], ctc=got["align_ctc"]),
+                  dict(total=w["total"], align_ce=w["align_ce"], trans_ce=w["trans_ce"], ctc=w["align_ctc"] + w["trans_ctc"]), f"FineTuner step {k}")
+        # AdamW's update is lr * m / (sqrt(v) + eps): a float32 gradient off by 1e-3 relative moves an entry by ~1e-3 of the learning rate
+        wa, wl = _check_params(model, init, arr, tag, k, want, tol_abs=2e-2 * cfg["lr"], tol_rel_l2=1e-2)
+        print(f"{tag} {route} step {k}: losses {got}; worst sampled |delta - reference| {wa:.2e} (lr {cfg['lr']}), worst relative L2 of a parameter's update {wl:.2e}")
+    close(evaluate(), run["eval_after"], "evaluate after")

@@ -164,3 +164,79 @@ def test_decoder_matches_hf_whisper_decoder():
         ref = hidden @ sd["embed_tokens.weight"].T
     ours = mo.decoder_forward(p, tokens, xa, n_head=H)
     np.testing.assert_allclose(ours.numpy(), ref.numpy(), rtol=0, atol=2e-5)
+
+
+def test_restated_train_loop_of_the_gpu_test_reproduces_the_reference_run_on_the_oracle():
+    """tests/test_gpu_train_step.py restates train_step's control flow (the reference cannot travel to the GPU box).  Here that same loop --
+    its _split / _losses_like_the_script / optimizer calls -- runs on the CPU over the ORACLE (float32 restatement of the model, torch autograd):
+    evaluate() before training and the first optimizer step of the use_ctc_loss run must give the numbers the reference's own train_step /
+    evaluate returned (tests/golden/train_step.json) to float32 round-off.  What the GPU test then measures is the HIP model, not the loop."""
+    import json
+    import os
+    import numpy as np
+    import torch
+    from transformers import get_linear_schedule_with_warmup
+    from lyricalignment_amd import whisper_compat as wc
+    from lyricalignment_amd.module.align_model import RNN
+    from oracle import model_oracle as mo
+    import test_gpu_train_step as tg
+    here = os.path.dirname(os.path.abspath(__file__))
+    with open(os.path.join(here, "golden", "train_step.json")) as f:
+        meta = json.load(f)
+    arr = np.load(os.path.join(here, "golden", "train_step.npz"))
+    tag, cfg = "ctc", meta["cfg"]
+    run = meta["runs"][tag]
+    dims = wc.ModelDimensions(**meta["dims"])
+
+    class OracleAlignModel(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.whisper_model = wc.build_model(dims=dims, seed=cfg["whisper_seed"], std=cfg["whisper_std"], with_decoder=True)
+            self.align_rnn = RNN(dims.n_audio_state, cfg["hidden_dim"], run["output_dim"], dropout=0.0)
+
+        def frame_manual_forward(self, audios, y_in, get_orig_len=False):
+            p = {(k[len("whisper_model."):] if k.startswith("whisper_model.") else k): v for k, v in list(self.named_parameters()) + list(self.named_buffers())}
+            n = max(len(a) for a in audios)
+            batch = np.zeros((len(audios), n), dtype=np.float32)
+            for i, a in enumerate(audios):
+                batch[i, : len(a)] = a
+            xa = mo.encoder_forward(p, mo.pad_or_trim(mo.log_mel_spectrogram(batch), 3000), n_head=dims.n_audio_head)
+            return mo.gru_head_forward(p, xa), mo.decoder_forward(p, y_in, xa, n_head=dims.n_text_head)
+
+    torch.manual_seed(0)
+    model = OracleAlignModel()
+    wc.init_align_head(model, seed=cfg["head_seed"], fc_scale=cfg["head_fc_scale"], rnn_scale=cfg["head_rnn_scale"])
+    lut = {int(t): int(c) for t, c in run["token_to_class"]}
+    train = tg._load_batches(arr, tag, "train", run["n_train"], run["train_seed"])
+    dev_batches = tg._load_batches(arr, tag, "dev", 1, run["dev_seed"])
+    cpu = torch.device("cpu")
+    # evaluate() on the first dev batch == its share of the reference's average is not separable: train step 0 is the check, plus the loss terms of dev batch 0 being finite
+    opt = torch.optim.AdamW([{"params": model.align_rnn.parameters(), "lr": cfg["lr"]}, {"params": model.whisper_model.parameters(), "lr": cfg["backbone_lr"]}],
+                            lr=cfg["lr"], weight_decay=cfg["weight_decay"])
+    sched = get_linear_schedule_with_warmup(opt, num_warmup_steps=cfg["warmup_steps"], num_training_steps=cfg["train_steps"])
+    accum = cfg["accum_grad_steps"]
+    it = iter(train)
+    for k in range(2):
+        got = dict(total=0.0, align_ce=0.0, align_ctc=0.0, trans_ce=0.0, trans_ctc=0.0)
+        for _ in range(accum):
+            multi, trans = tg._split(next(it), lut)
+            ce, ctc, tr = tg._losses_like_the_script(model, multi, True, True, cpu)
+            _, tctc, ttr = tg._losses_like_the_script(model, trans, False, True, cpu)
+            loss = (ce + ctc + tr + ttr + tctc) / accum
+            loss.backward()
+            got["total"] += float(loss); got["align_ce"] += float(ce) / accum; got["align_ctc"] += float(ctc) / accum
+            got["trans_ce"] += float(tr + ttr) / accum; got["trans_ctc"] += float(tctc) / accum
+        torch.nn.utils.clip_grad_norm_(model.parameters(), cfg["max_grad_norm"])
+        opt.step(); sched.step(); opt.zero_grad()
+        for key, v in run["steps"][k]["losses"].items():
+            assert abs(got[key] - v) <= 2e-6 * max(abs(v), 1.0), (k, key, got[key], v)
+    # after the second step (the first runs at learning rate 0: warm-up) the parameters moved as the reference's did
+    names = [n for n, _ in model.named_parameters()]
+    assert names == list(run["steps"][1]["delta_l2"].keys())
+    init = OracleAlignModel()
+    wc.init_align_head(init, seed=cfg["head_seed"], fc_scale=cfg["head_fc_scale"], rnn_scale=cfg["head_rnn_scale"])
+    for (n, p), (_, p0) in zip(model.named_parameters(), init.named_parameters()):
+        dlt = (p.detach().double() - p0.detach().double()).flatten()
+        want = torch.from_numpy(arr[f"{tag}.step1.delta.{n}"])
+        idx = torch.from_numpy(arr[f"{tag}.sample_idx.{n}"]).long()
+        assert float((dlt[idx] - want).abs().max()) <= 1e-3 * cfg["lr"], n
