@@ -235,8 +235,9 @@ def test_restated_train_loop_of_the_gpu_test_reproduces_the_reference_run_on_the
     assert names == list(run["steps"][1]["delta_l2"].keys())
     init = OracleAlignModel()
     wc.init_align_head(init, seed=cfg["head_seed"], fc_scale=cfg["head_fc_scale"], rnn_scale=cfg["head_rnn_scale"])
-    for (n, p), (_, p0) in zip(model.named_parameters(), init.named_parameters()):
-        dlt = (p.detach().double() - p0.detach().double()).flatten()
-        want = torch.from_numpy(arr[f"{tag}.step1.delta.{n}"])
-        idx = torch.from_numpy(arr[f"{tag}.sample_idx.{n}"]).long()
-        assert float((dlt[idx] - want).abs().max()) <= 1e-3 * cfg["lr"], n
+    init_d = {n: p0.detach().double() for n, p0 in init.named_parameters()}
+    # The reference's head is torch's fused nn.GRU, the oracle's an explicit recurrence: gradients differ in the last float32 bits, and AdamW's
+    # m / (sqrt(v) + eps) passes that on at up to ~0.6 % of the learning rate for entries whose gradient is tiny (measured here, CPU against CPU).
+    # The same two bounds hold the HIP model in tests/test_gpu_train_step.py: 2 % of the learning rate per sampled entry, 1 % of a parameter's update in L2.
+    wa, wl = tg._check_params(model, init_d, arr, tag, 1, run["steps"][1], tol_abs=2e-2 * cfg["lr"], tol_rel_l2=1e-2)
+    print(f"oracle loop vs reference run: worst sampled |delta - reference| {wa:.2e} (lr {cfg['lr']}), worst relative L2 of an update {wl:.2e}")
