@@ -99,9 +99,12 @@ def _ce_like_the_script(logits, frame_labels, compute_sil, vocab_size=21128):
     return word + F.binary_cross_entropy_with_logits(logits[:, :, vocab_size], (fl == -100).float())
 
 
+CTC_DTYPE = [torch.float32]          # (the twin run of the FineTuner case switches the script's CTC to float64: see the test)
+
+
 def _ctc_like_the_script(logits, labels):
     """compute_ctc_loss (:616-633): log_softmax, time-major, every clip at full length, target lengths = labels != -100, F.ctc_loss defaults."""
-    lsm = F.log_softmax(logits, dim=2).transpose(0, 1)
+    lsm = F.log_softmax(logits.to(CTC_DTYPE[0]), dim=2).transpose(0, 1)
     return F.ctc_loss(lsm, labels, torch.full((lsm.shape[1],), lsm.shape[0], dtype=torch.long, device=logits.device), (labels != -100).sum(dim=1))
 
 
@@ -124,24 +127,25 @@ def _param_names(model):
 
 
 def _check_params(model, init, arr, tag, step, meta_step, tol_abs, tol_rel_l2):
-    worst_abs, worst_l2 = 0.0, 0.0
+    worst_abs, worst_l2, rows = 0.0, 0.0, []
     for n, p in model.named_parameters():
         dlt = (p.detach().double().cpu() - init[n]).flatten()
         want = torch.from_numpy(arr[f"{tag}.step{step}.delta.{n}"])
         idx = torch.from_numpy(arr[f"{tag}.sample_idx.{n}"]).long()
-        worst_abs = max(worst_abs, float((dlt[idx] - want).abs().max()))
+        e = float((dlt[idx] - want).abs().max())
         ref_l2 = meta_step["delta_l2"][n]
-        worst_l2 = max(worst_l2, abs(float(dlt.norm()) - ref_l2) / max(ref_l2, 1e-12))
-    assert worst_abs <= tol_abs and worst_l2 <= tol_rel_l2, (tag, step, worst_abs, worst_l2)
+        l2 = abs(float(dlt.norm()) - ref_l2) / max(ref_l2, 1e-12)
+        rows.append((e, l2, n))
+        worst_abs, worst_l2 = max(worst_abs, e), max(worst_l2, l2)
+    top = sorted(rows, reverse=True)[:4]
+    assert worst_abs <= tol_abs and worst_l2 <= tol_rel_l2, (tag, step, worst_abs, worst_l2, top)
     return worst_abs, worst_l2
 
 
-@pytest.mark.parametrize("tag", ["ctc", "noctc"])
-@pytest.mark.parametrize("route", ["torch_optimizer", "finetuner"])
-def test_train_step_and_evaluate_match_the_reference_run(fx, tag, route):
+def _run(meta, arr, tag, route):
+    """Three optimizer steps + evaluate before / after on a fresh HIP model.  -> (model, init, per-step (losses, {name: delta}), eval_before, eval_after)"""
     from transformers import get_linear_schedule_with_warmup
     from lyricalignment_amd import finetune as ft
-    meta, arr = fx
     cfg, run = meta["cfg"], meta["runs"][tag]
     use_ctc = tag == "ctc"
     lut = {int(t): int(c) for t, c in run["token_to_class"]}
@@ -165,11 +169,7 @@ def test_train_step_and_evaluate_match_the_reference_run(fx, tag, route):
                 tot["trans_ce"] += float(tr + ttr); tot["trans_ctc"] += float(tctc)
         return {k: v / len(dev_batches) for k, v in tot.items()}
 
-    def close(got, want, what):
-        for k, v in want.items():
-            assert abs(got[k] - v) <= 2e-4 * max(abs(v), 1e-3) + 1e-6, (what, k, got[k], v)
-
-    close(evaluate(), run["eval_before"], "evaluate before")
+    eval_before = evaluate()
     it = iter(train)
     if route == "torch_optimizer":
         opt = torch.optim.AdamW([{"params": model.align_rnn.parameters(), "lr": cfg["lr"]}, {"params": model.whisper_model.parameters(), "lr": cfg["backbone_lr"]}],
@@ -178,9 +178,10 @@ def test_train_step_and_evaluate_match_the_reference_run(fx, tag, route):
     else:
         tuner = ft.FineTuner(model, lr=cfg["lr"], backbone_lr=cfg["backbone_lr"], weight_decay=cfg["weight_decay"], warmup_steps=cfg["warmup_steps"],
                              train_steps=cfg["train_steps"], max_grad_norm=cfg["max_grad_norm"], use_ctc_loss=use_ctc, vocab_size=21128, world=1)
-    for k, want in enumerate(run["steps"]):
+    steps = []
+    for k in range(len(run["steps"])):
         model.train()
-        got = dict(total=0.0, align_ce=0.0, align_ctc=0.0, trans_ce=0.0, trans_ctc=0.0)
+        got = dict(total=0.0, align_ce=0.0, ctc=0.0, trans_ce=0.0)
         for _ in range(accum):
             multi, trans = _split(next(it), lut)
             if route == "torch_optimizer":
@@ -188,23 +189,100 @@ def test_train_step_and_evaluate_match_the_reference_run(fx, tag, route):
                 _, tctc, ttr = _losses_like_the_script(model, trans, False, use_ctc, dev)
                 loss = (ce + ctc + tr + ttr + tctc) / accum
                 loss.backward()
-                got["total"] += float(loss); got["align_ce"] += float(ce) / accum; got["align_ctc"] += float(ctc) / accum
-                got["trans_ce"] += float(tr + ttr) / accum; got["trans_ctc"] += float(tctc) / accum
+                got["total"] += float(loss.detach()); got["align_ce"] += float(ce.detach()) / accum; got["ctc"] += float((ctc + tctc).detach()) / accum
+                got["trans_ce"] += float((tr + ttr).detach()) / accum
             else:
                 l4 = tuner.micro_step(multi[0], multi[1], multi[2], multi[3], multi[4], accum_grad_steps=accum, get_orig_len=False,
                                       transcript_batch=(trans[0], trans[1], trans[3], trans[4])).cpu().double()
                 got["total"] += float(l4.sum()) / accum; got["align_ce"] += float(l4[0] + l4[1]) / accum
-                got["align_ctc"] += float(l4[2]) / accum; got["trans_ce"] += float(l4[3]) / accum       # (l4[2] = CTC of both sub-batches)
+                got["ctc"] += float(l4[2]) / accum; got["trans_ce"] += float(l4[3]) / accum          # (l4[2] = CTC of both sub-batches)
         if route == "torch_optimizer":
             torch.nn.utils.clip_grad_norm_(model.parameters(), cfg["max_grad_norm"])
             opt.step(); sched.step(); opt.zero_grad()
-            close(got, want["losses"], f"train_step {k}")
         else:
             tuner.step()
-            w = want["losses"]
-            close(dict(total=got["total"], align_ce=got["align_ce"], trans_ce=got["trans_ce"], ctc=got["align_ctc"]),
-                  dict(total=w["total"], align_ce=w["align_ce"], trans_ce=w["trans_ce"], ctc=w["align_ctc"] + w["trans_ctc"]), f"FineTuner step {k}")
-        # AdamW's update is lr * m / (sqrt(v) + eps): a float32 gradient off by 1e-3 relative moves an entry by ~1e-3 of the learning rate
-        wa, wl = _check_params(model, init, arr, tag, k, want, tol_abs=2e-2 * cfg["lr"], tol_rel_l2=1e-2)
-        print(f"{tag} {route} step {k}: losses {got}; worst sampled |delta - reference| {wa:.2e} (lr {cfg['lr']}), worst relative L2 of a parameter's update {wl:.2e}")
-    close(evaluate(), run["eval_after"], "evaluate after")
+        steps.append((got, {n: (p.detach().double().cpu() - init[n]).flatten() for n, p in model.named_parameters()}))
+    return steps, eval_before, evaluate()
+
+
+def _close(got, want, what, rel=2e-4):
+    for k, v in want.items():
+        assert abs(got[k] - v) <= rel * max(abs(v), 1e-3) + 1e-6, (what, k, got[k], v)
+
+
+def _against_fixture(steps, arr, tag, run, lr, tol_abs, tol_rel_l2):
+    """Every step's parameters against the reference run's: sampled entries of (parameter - initial) and each parameter's update in L2."""
+    out = []
+    for k, (_, deltas) in enumerate(steps):
+        rows = []
+        for n, dlt in deltas.items():
+            want = torch.from_numpy(arr[f"{tag}.step{k}.delta.{n}"])
+            idx = torch.from_numpy(arr[f"{tag}.sample_idx.{n}"]).long()
+            ref_l2 = run["steps"][k]["delta_l2"][n]
+            rows.append((float((dlt[idx] - want).abs().max()), abs(float(dlt.norm()) - ref_l2) / max(ref_l2, 1e-12), n))
+        wa, wl = max(r[0] for r in rows), max(r[1] for r in rows)
+        assert wa <= tol_abs and wl <= tol_rel_l2, (tag, k, wa, wl, sorted(rows, reverse=True)[:3])
+        out.append((wa, wl))
+    return out
+
+
+def _ref_losses(run, k):
+    w = run["steps"][k]["losses"]
+    return dict(total=w["total"], align_ce=w["align_ce"], trans_ce=w["trans_ce"], ctc=w["align_ctc"] + w["trans_ctc"])
+
+
+@pytest.mark.parametrize("tag", ["ctc", "noctc"])
+def test_unmodified_script_route_matches_the_reference_run(fx, tag):
+    """(a): the HIP AlignModel driven the way train_multitask.py drives it -- torch losses, loss.backward(), clip_grad_norm_, torch.optim.AdamW in the
+    script's two groups, the transformers schedule -- against what the reference's own train_step / evaluate returned: every loss term of every
+    optimizer step and of evaluate() within 2e-4 relative; after every step each sampled parameter entry within 2 % of the learning rate of the
+    reference's and each parameter's update within 1 % in L2 (AdamW's m / (sqrt(v) + eps) passes float32 gradient round-off on at that scale:
+    tests/test_oracle_model.py measures 0.6 % between two CPU implementations)."""
+    meta, arr = fx
+    cfg, run = meta["cfg"], meta["runs"][tag]
+    steps, ev0, ev1 = _run(meta, arr, tag, "torch_optimizer")
+    _close(ev0, run["eval_before"], "evaluate before")
+    for k, (got, _) in enumerate(steps):
+        _close(got, _ref_losses(run, k), f"train_step {k}")
+    worst = _against_fixture(steps, arr, tag, run, cfg["lr"], tol_abs=2e-2 * cfg["lr"], tol_rel_l2=1e-2)
+    _close(ev1, run["eval_after"], "evaluate after")
+    print(f"{tag} torch-optimizer route: worst (sampled |delta - reference|, relative L2 of an update) per step {worst} at lr {cfg['lr']}")
+
+
+@pytest.mark.parametrize("tag", ["ctc", "noctc"])
+def test_finetuner_route_matches_the_reference_run(fx, tag):
+    """(b): FineTuner (loss kernels incl. the float64 CTC lattice, flat buckets, fused clip + AdamW) against the same fixture.
+    Without CTC: the bounds of route (a).  With CTC the reference's own arithmetic is the limit: torch's float32 F.ctc_loss returns a gradient
+    that is ~1 % (relative L2 over the logits) away from the float64 recursion's on 1500 frames -- CPU and device implementations alike, which is
+    why route (a), using it, reproduces the reference to 1e-5 -- while la_multitask_loss agrees with float64 torch to 1e-6.  So:
+      * against the FIXTURE: losses within 2e-4, every parameter's update within 1 % in L2, sampled entries within 50 % of the learning rate
+        (entries whose two accumulated gradients nearly cancel in AdamW's first moment turn a 1 % gradient difference into tens of percent);
+      * against a twin run of route (a) whose script-side CTC is computed in FLOAT64: the bounds of route (a).
+    Together: FineTuner is train_step with an exact CTC; the reference is train_step with torch's float32 CTC."""
+    meta, arr = fx
+    cfg, run = meta["cfg"], meta["runs"][tag]
+    steps, ev0, ev1 = _run(meta, arr, tag, "finetuner")
+    for k, (got, _) in enumerate(steps):
+        # (with CTC the two trajectories part after the first real update -- the exact and the float32 CTC gradient differ by 1 % -- so from the
+        #  third step on the losses are those of slightly different weights: 2e-3; the twin run below is held to 2e-4 throughout)
+        _close(got, _ref_losses(run, k), f"FineTuner step {k}", rel=2e-3 if (tag == "ctc" and k >= 2) else 2e-4)
+    _close(ev1, run["eval_after"], "evaluate after", rel=2e-3 if tag == "ctc" else 2e-4)
+    if tag == "noctc":
+        worst = _against_fixture(steps, arr, tag, run, cfg["lr"], tol_abs=2e-2 * cfg["lr"], tol_rel_l2=1e-2)
+        print(f"noctc FineTuner route vs the reference run: {worst}")
+        return
+    worst = _against_fixture(steps, arr, tag, run, cfg["lr"], tol_abs=0.5 * cfg["lr"], tol_rel_l2=1e-2)
+    CTC_DTYPE[0] = torch.float64
+    try:
+        twin, _, tw_ev1 = _run(meta, arr, tag, "torch_optimizer")
+    finally:
+        CTC_DTYPE[0] = torch.float32
+    tw = []
+    _close(ev1, tw_ev1, "evaluate after, against the float64-CTC twin")
+    for k, ((got, a), (got_t, b)) in enumerate(zip(steps, twin)):
+        _close(got, got_t, f"FineTuner step {k} against the float64-CTC twin")
+        rows = [(float((a[n] - b[n]).abs().max()), float((a[n] - b[n]).norm() / b[n].norm().clamp_min(1e-12)), n) for n in a]
+        wa, wl = max(r[0] for r in rows), max(r[1] for r in rows)
+        assert wa <= 2e-2 * cfg["lr"] and wl <= 1e-2, (k, wa, wl, sorted(rows, reverse=True)[:3])
+        tw.append((wa, wl))
+    print(f"ctc FineTuner route: vs the reference run (float32 CTC) {worst}; vs the script route with a float64 CTC (max |difference| over ALL entries, relative L2 of the difference) {tw}")
