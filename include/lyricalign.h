@@ -124,6 +124,11 @@ int la_timer_read_work(double *total_ms, int64_t *timed_launches, double *timed_
  *   "head_clip_cap"   LA_HEAD_CLIP_CAP    0 = by residency (default) | n = clips per head launch set of la_align_head_forward
  *   "ln_fusion"       LA_LN_FUSION        1 = LayerNorm folded into the 16-bit encoder GEMMs where they run on the 256 x 256 kernel | 0 = never
  *   "resid_split"     LA_RESID_SPLIT      1 = the 16-bit encoder keeps its residual stream split (hi 16-bit + lo byte) | 0 = f32 stream
+ *   "gru_timeout_us"  LA_GRU_TIMEOUT_US   0 = 3 s (default) | n = bound of one inter-workgroup wait of the persistent GRU kernels in microseconds (a launch
+ *                                         whose workgroups are not all co-resident never completes a hand-off: the bounded wait sets timeout_flag)
+ *   "gru_fault_step"  LA_GRU_FAULT_STEP   test hook, ONE launch (the launch that reads it clears it): workgroup (0, 0, 0) of the next GRU forward launch
+ *                                         leaves at step n without publishing, as if it had never become resident -- the other workgroups
+ *                                         time out.  0 = off (default)
  *   "x2_inference"    LA_X2_INFERENCE     1 = float32 inference (la_encoder_forward / la_align_head_forward with LA_F32 weights that carry f16x2
  *                                         planes) on the f16 matrix pipe at float32 accuracy (default) | 0 = the float32-MFMA kernels (A/B partner)
  * A library built with -DLA_EXPERIMENTS (tools/build_variant.sh; la_has_experiments() == 1) additionally carries the measured-slower

@@ -47,7 +47,7 @@ void *stream_scratch(hipStream_t stream, int purpose, size_t bytes);
 // ---- library options (include/lyricalign.h la_set_option): resolved once per process from the environment, read by the launch paths
 struct Options {
     int gemm_tile = 0, gemm_loop = 0, gemm_splitk = 1, attn_nw = 0, gru_nw = 0, gru_fence = 0, gru_handoff = 0, gru_poll_delay = 0, viterbi_dpp = 1,
-        head_clip_cap = 0, ln_fusion = 1, resid_split = 1, x2_inference = 1;
+        head_clip_cap = 0, ln_fusion = 1, resid_split = 1, x2_inference = 1, gru_timeout_us = 0, gru_fault_step = 0;
 };
 Options &opts();
 // Developer switches of the experiment build (-DLA_EXPERIMENTS, tools/build_variant.sh): re-read on every launch there, so that

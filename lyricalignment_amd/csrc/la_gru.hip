@@ -48,6 +48,8 @@ struct GruParams {
     int *timeout_flag;   // caller's (optional)
     int nsplit;
     float *gates;        // optional [B][T][2][4H] f32: r, z, n, (W_hn h + b_hn) of every step, for the backward sweep
+    unsigned long long poll_budget = 300000000ull;   // bound of one inter-workgroup wait in 100 MHz ticks (option gru_timeout_us; default 3 s)
+    int fault_step = 0;  // test hook (option gru_fault_step, one launch): workgroup (0, 0, 0) leaves at this step without publishing, as if it had never become resident
 };
 
 // Gate non-linearities on the hardware exponential / reciprocal (v_exp_f32, v_rcp_f32: 1 ulp each).  The libm forms
@@ -76,14 +78,14 @@ __device__ __forceinline__ unsigned short round16(float v) {
 }
 
 // bounded wait for `*ctr >= target`; returns false on timeout / abort
-__device__ __forceinline__ bool wait_counter(unsigned *ctr, unsigned target, int *abort_flag) {
+__device__ __forceinline__ bool wait_counter(unsigned *ctr, unsigned target, int *abort_flag, unsigned long long budget = 300000000ull) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
     unsigned spins = 0;
     while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
         __builtin_amdgcn_s_sleep(1);
         if ((++spins & 255u) == 0) {
             if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
-            if (__builtin_amdgcn_s_memrealtime() - t0 > 300000000ull) {  // 3 s
+            if (__builtin_amdgcn_s_memrealtime() - t0 > budget) {  // 3 s by default (option gru_timeout_us)
                 __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 return false;
             }
@@ -211,6 +213,7 @@ __global__ __launch_bounds__(NW * 64, 1) void gru_kernel(GruParams p) {
 
     bool alive = true;
     for (int step = 0; step < T_; ++step) {
+        if (p.fault_step > 0 && step == p.fault_step && (blockIdx.x | blockIdx.y | blockIdx.z) == 0) return;   // test hook: see the parameter
         const int t = dir == 0 ? step : T_ - 1 - step;
         const int tprev = dir == 0 ? t - 1 : t + 1;
         f32x4 acc[3][MT];
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(NW * 64, 1) void gru_kernel(GruParams p) {
         if (step > 0) {
             // ---- wait until every slice of this (direction, group) has published h_{t-1} ----
             if (tid == 0) {
-                const bool ok = wait_counter(ctr + (step - 1), (unsigned)p.nsplit, p.abort_flag);
+                const bool ok = wait_counter(ctr + (step - 1), (unsigned)p.nsplit, p.abort_flag, p.poll_budget);
                 if (!WT) {
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -463,6 +466,8 @@ struct GruGranuleParams {
     int *abort_flag, *timeout_flag;
     int nsplit;
     int poll_delay;            // 64-clock sleeps between a step's publish and its first poll (option gru_poll_delay)
+    unsigned long long poll_budget = 300000000ull;
+    int fault_step = 0;
 };
 
 #ifndef LA_GRU_PROBE
@@ -537,6 +542,7 @@ __global__ __launch_bounds__(512, 1) void gru_granule_kernel(GruGranuleParams p)
 
     bool alive = true;
     for (int step = 0; step < T_; ++step) {
+        if (p.fault_step > 0 && step == p.fault_step && (blockIdx.x | blockIdx.y | blockIdx.z) == 0) return;   // test hook: see the parameter
         const int t = dir == 0 ? step : T_ - 1 - step;
         f32x4 acc[3];
 #pragma unroll
@@ -572,7 +578,7 @@ __global__ __launch_bounds__(512, 1) void gru_granule_kernel(GruGranuleParams p)
                     }
                 if (pending && (++spins & 63u) == 0) {
                     if (__hip_atomic_load(p.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { *ok_s = 0; break; }
-                    if (__builtin_amdgcn_s_memrealtime() - t0 > 300000000ull) {
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > p.poll_budget) {
                         __hip_atomic_store(p.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         *ok_s = 0;
                         break;
@@ -644,6 +650,8 @@ struct GruTrainX2Params {
     int B, T, H;
     unsigned long long *xch;   // [groups][2 dirs][2 slots][16 clips][H] granules, zeroed per call
     int *abort_flag, *timeout_flag;
+    unsigned long long poll_budget = 300000000ull;
+    int fault_step = 0;
 };
 
 __device__ __forceinline__ unsigned x2_pack_hi_lo(float x) {          // x (already scaled) -> f16 hi | f16 lo << 16
@@ -733,6 +741,7 @@ __global__ __launch_bounds__(256, 1) void gru_train_x2_kernel(GruTrainX2Params p
 
     bool alive = true;
     for (int step = 0; step < T_; ++step) {
+        if (p.fault_step > 0 && step == p.fault_step && (blockIdx.x | blockIdx.y | blockIdx.z) == 0) return;   // test hook: see the parameter
         const int t = dir == 0 ? step : T_ - 1 - step;
         f32x4 acc[3];
 #pragma unroll
@@ -764,7 +773,7 @@ __global__ __launch_bounds__(256, 1) void gru_train_x2_kernel(GruTrainX2Params p
                     }
                 if (pending && (++spins & 63u) == 0) {
                     if (__hip_atomic_load(p.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { *ok_s = 0; break; }
-                    if (__builtin_amdgcn_s_memrealtime() - t0 > 300000000ull) {
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > p.poll_budget) {
                         __hip_atomic_store(p.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         *ok_s = 0;
                         break;
@@ -859,6 +868,9 @@ static int gru_forward(int32_t dtype, const float *gi, const void *w_hh, const f
     la_gru_workspace_bytes(batch, frames, hidden, &need);
     LA_CHECK_ARG(workspace_bytes >= need, "gru_layer: workspace too small (%zu < %zu)", workspace_bytes, need);
     const int groups = gru_groups(batch);
+    const unsigned long long budget = la::opts().gru_timeout_us > 0 ? (unsigned long long)la::opts().gru_timeout_us * 100ull : 300000000ull;
+    const int fault = la::opts().gru_fault_step;              // one-shot test hook: the launch that reads it clears it
+    if (fault) la::opts().gru_fault_step = 0;
     if (hidden % 64 != 0 || (dtype != LA_F32 && hidden > 512) || (dtype == LA_F32 && hidden > 384)) {
         la::set_error("gru_layer: hidden=%d unsupported (multiple of 64; bf16 <= 512, f32 <= 384)", hidden);
         return LA_EUNSUPPORTED;
@@ -883,7 +895,7 @@ static int gru_forward(int32_t dtype, const float *gi, const void *w_hh, const f
         LA_HIP(hipMemsetAsync(wsb, 0, 16, stream));
         LA_HIP(hipMemsetAsync(wsb + ctrb, 0, gru_xch_fwd_bytes(batch, hidden), stream));
         GruTrainX2Params tp{gi, reinterpret_cast<const float *>(w_hh), b_hh, reinterpret_cast<float *>(out), gates, reinterpret_cast<float *>(out_mish), batch, frames, hidden,
-                            reinterpret_cast<unsigned long long *>(wsb + ctrb), reinterpret_cast<int *>(workspace), timeout_flag};
+                            reinterpret_cast<unsigned long long *>(wsb + ctrb), reinterpret_cast<int *>(workspace), timeout_flag, budget, fault};
         const size_t lds_t = 16 + (size_t)2 * 2 * 16 * (hidden * 2 + 16);
         la::TimerScope ts("gru_f32", stream);
         hipLaunchKernelGGL((gru_train_x2_kernel<12>), dim3(hidden / 64, 2, groups), dim3(256), lds_t, stream, tp);
@@ -902,7 +914,7 @@ static int gru_forward(int32_t dtype, const float *gi, const void *w_hh, const f
         LA_HIP(hipMemsetAsync(wsb, 0, 16, stream));
         LA_HIP(hipMemsetAsync(wsb + ctrb, 0, gru_xch_fwd_bytes(batch, hidden), stream));
         GruGranuleParams gp{gi, w_hh, b_hh, out, out_mish, batch, frames, hidden, reinterpret_cast<unsigned long long *>(wsb + ctrb),
-                            reinterpret_cast<int *>(workspace), timeout_flag, nsplit, la::opts().gru_poll_delay};
+                            reinterpret_cast<int *>(workspace), timeout_flag, nsplit, la::opts().gru_poll_delay, budget, fault};
         const size_t lds_g = 16 + (size_t)2 * 16 * (hidden * 2 + 16);          // flag + two h stages
         la::TimerScope ts("gru_bf16", stream);
         if (dtype == LA_F16) hipLaunchKernelGGL((gru_granule_kernel<la::f16_t, 12>), dim3(nsplit, 2, groups), dim3(512), lds_g, stream, gp);
@@ -913,7 +925,7 @@ static int gru_forward(int32_t dtype, const float *gi, const void *w_hh, const f
     LA_HIP(hipMemsetAsync(workspace, 0, gru_ctr_bytes(batch, frames), stream));
     GruParams p{gi, w_hh, b_hh, out, out_mish, batch, frames, hidden,
                 reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(workspace) + 16),
-                reinterpret_cast<int *>(workspace), timeout_flag, nsplit, gates};
+                reinterpret_cast<int *>(workspace), timeout_flag, nsplit, gates, budget, fault};
     const dim3 grid(nsplit, 2, groups);
     // Hand-off forms (tools/kbench.py gru, 32 clips, T=1500, H=384; tools/handoff_bench.hip for the bare protocol costs):
     // write-through (sc1 stores, drained; relaxed counter; sc1 loads) 5.4 ms per layer, release / acquire fences 9.0 ms.
@@ -997,6 +1009,7 @@ struct GruBwdParams {
     int *abort_flag;
     int *timeout_flag;
     int nsplit;
+    unsigned long long poll_budget = 300000000ull;
 };
 
 // Backward recurrence dh_{t-1} = dh_t * z_t + dgh_t W_hh: the contraction runs over all 3H gate units, so (as in the
@@ -1067,7 +1080,7 @@ __global__ __launch_bounds__(128, 1) void gru_bwd_kernel(GruBwdParams p) {
             }
         if (step > 0) {
             if (tid == 0) {
-                const bool ok = wait_counter(ctr + (step - 1), (unsigned)p.nsplit, p.abort_flag);
+                const bool ok = wait_counter(ctr + (step - 1), (unsigned)p.nsplit, p.abort_flag, p.poll_budget);
                 *ok_s = ok ? 1 : 0;
             }
             __syncthreads();
@@ -1193,6 +1206,7 @@ struct GruBwdX2Params {
     int B, T, H;
     unsigned long long *xch;   // [groups][2 dirs][2 slots][NS dest][NS src][16 clips][64 units] granules, zeroed per call
     int *abort_flag, *timeout_flag;
+    unsigned long long poll_budget = 300000000ull;
 };
 
 template <int NS>                                               // NS = H / 64: workgroups per (group, direction) = column tiles per wave
@@ -1311,7 +1325,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_x2_kernel(GruBwdX2Params p) {
                     }
                 if (pending && (++spins & 63u) == 0) {
                     if (__hip_atomic_load(p.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { *ok_s = 0; break; }
-                    if (__builtin_amdgcn_s_memrealtime() - t0 > 300000000ull) {
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > p.poll_budget) {
                         __hip_atomic_store(p.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         *ok_s = 0;
                         break;
@@ -1438,7 +1452,8 @@ extern "C" int la_gru_layer_bwd(const float *gates, const float *out, const floa
         LA_HIP(hipMemsetAsync(wsb, 0, 16, stream));
         LA_HIP(hipMemsetAsync(wsb + ctrb, 0, gru_xch_bwd_bytes(batch, hidden), stream));
         GruBwdX2Params xp{gates, out, dout, w_hh, dgi, dgh, batch, frames, hidden, reinterpret_cast<unsigned long long *>(wsb + ctrb),
-                          reinterpret_cast<int *>(workspace), timeout_flag};
+                          reinterpret_cast<int *>(workspace), timeout_flag,
+                          la::opts().gru_timeout_us > 0 ? (unsigned long long)la::opts().gru_timeout_us * 100ull : 300000000ull};
         const size_t lds_x = 16 + 4 * 16 * 4 + (size_t)2 * 16 * (192 * 2 + 16) + (size_t)(hidden / 64) * 1024 * 4;
         la::TimerScope ts("gru_bwd_f32", stream);
         switch (hidden / 64) {
@@ -1458,7 +1473,8 @@ extern "C" int la_gru_layer_bwd(const float *gates, const float *out, const floa
     LA_HIP(hipMemsetAsync(workspace, 0, need, stream));
     GruBwdParams p{gates, out, dout, w_hh, dgi, dgh, batch, frames, hidden,
                    reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(workspace) + 16),
-                   reinterpret_cast<int *>(workspace), timeout_flag, nsplit};
+                   reinterpret_cast<int *>(workspace), timeout_flag, nsplit,
+                   la::opts().gru_timeout_us > 0 ? (unsigned long long)la::opts().gru_timeout_us * 100ull : 300000000ull};
     const size_t lds_bytes = 16 + (size_t)2 * 16 * 3 * hidden * 4;
     static la::DeviceOnce attr_once;
     if (attr_once.pending()) {

@@ -61,6 +61,7 @@ const OptionDesc kOptions[] = {
     {"viterbi_dpp", "LA_VITERBI_NO_DPP", &Options::viterbi_dpp, true}, {"head_clip_cap", "LA_HEAD_CLIP_CAP", &Options::head_clip_cap, false},
     {"ln_fusion", "LA_LN_FUSION", &Options::ln_fusion, false},       {"resid_split", "LA_RESID_SPLIT", &Options::resid_split, false},
     {"x2_inference", "LA_X2_INFERENCE", &Options::x2_inference, false},
+    {"gru_timeout_us", "LA_GRU_TIMEOUT_US", &Options::gru_timeout_us, false}, {"gru_fault_step", "LA_GRU_FAULT_STEP", &Options::gru_fault_step, false},
 };
 }  // namespace
 

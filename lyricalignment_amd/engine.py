@@ -685,17 +685,39 @@ class AlignEngine:
                                 w_x2=self.head.w_fc_x2 if (self.head.w_fc_x2 is not None and x2_inference_on()) else None)
 
     def align_feats(self, feats: torch.Tensor, B: int, T: int, feat_clip_stride: int, labels: torch.Tensor, n_labels: torch.Tensor,
-                    variant: int):
+                    variant: int, flag: Optional[torch.Tensor] = None):
         """Encoder rows -> (onset, offset, final_score, status): head + emission prep + DP (one C call unless LA_ENGINE_PY=1).
         The op-by-op Python sequence below is also taken when HEAD_CLIPS_MAX was lowered (a test knob of that sequence; the C
         call slices by its own cap, LA_HEAD_CLIP_CAP) and for heads the C struct does not describe (not 2 GRU layers)."""
-        if ENGINE_PY or self._head_c is None or HEAD_CLIPS_MAX != 256:
-            em = self.emissions(feats, B, T, feat_clip_stride, labels, n_labels, variant)
-            nf = torch.full((B,), T, dtype=torch.int32, device=self.device)
-            return ops.viterbi_batch(em, labels, n_labels, nf)
         if self._gru_flag is None:
             self._gru_flag = torch.zeros((1,), dtype=torch.int32, device=self.device)
-        return ops.align_head_forward(self._head_c, feats, feat_clip_stride, B, T, labels, n_labels, variant, self._gru_flag, ws_cache=self._ws)
+        if ENGINE_PY or self._head_c is None or HEAD_CLIPS_MAX != 256:
+            own, self._gru_flag = self._gru_flag, (flag if flag is not None else self._gru_flag)
+            try:
+                em = self.emissions(feats, B, T, feat_clip_stride, labels, n_labels, variant)
+            finally:
+                self._gru_flag = own
+            nf = torch.full((B,), T, dtype=torch.int32, device=self.device)
+            return ops.viterbi_batch(em, labels, n_labels, nf)
+        return ops.align_head_forward(self._head_c, feats, feat_clip_stride, B, T, labels, n_labels, variant,
+                                      flag if flag is not None else self._gru_flag, ws_cache=self._ws)
+
+    def align_feats_checked(self, feats: torch.Tensor, B: int, T: int, feat_clip_stride: int, labels: torch.Tensor, n_labels: torch.Tensor,
+                            variant: int):
+        """align_feats with the persistent GRU's time-out handled (synchronises): the recurrence needs every workgroup of its launch set
+        co-resident, which HIP does not promise while other streams own the CUs; a launch that waited out its bound (option
+        gru_timeout_us, 3 s) leaves garbage.  The device is then idle -- the head is re-enqueued ONCE, alone, as a fresh launch -- and only a
+        second time-out raises TimeoutError.  self.gru_recoveries counts the re-launches."""
+        if self._gru_flag is None:
+            self._gru_flag = torch.zeros((1,), dtype=torch.int32, device=self.device)
+        res = self.align_feats(feats, B, T, feat_clip_stride, labels, n_labels, variant)
+        if int(self._gru_flag.item()) != 0:
+            self._gru_flag.zero_()
+            torch.cuda.synchronize(self.device)
+            self.gru_recoveries = getattr(self, "gru_recoveries", 0) + 1
+            res = self.align_feats(feats, B, T, feat_clip_stride, labels, n_labels, variant)
+            self.check_gru()
+        return res
 
     def check_gru(self) -> None:
         """Host check of the persistent GRU kernel's bounded waits (synchronises): every launch since the last check."""
@@ -751,6 +773,13 @@ class PipelinedAligner:
         self._pending_events: List[torch.cuda.Event] = []   # one per submitted batch of the open group (its encoder is done)
         self._key = None
         self._feats = [None, None]  # per buffer set: [G*B*1500, d] encoder outputs
+        # Time-out of the persistent recurrence (co-residency of its workgroups is not guaranteed while the encoders own the CUs): every group's
+        # head gets a flag word of its own, copied to pinned host memory behind the head; a group is VERIFIED (lazily in submit(), at the
+        # latest in drain()) once its head is done and the word is zero.  Until then its inputs are kept, and a group whose word is set is
+        # recomputed -- encoder and head, alone on an idle device, a fresh launch -- into the result tensors it already handed out.
+        self._unverified: List[dict] = []
+        self._host_flags = torch.zeros((256,), dtype=torch.int32).pin_memory()      # one word per group in flight (ring)
+        self.recovered_groups = 0
 
     def submit(self, mel: torch.Tensor, labels: torch.Tensor, n_labels: torch.Tensor, n_frames: int = N_CTX,
                use_ctc: bool = True, host_out=None):
@@ -813,9 +842,10 @@ class PipelinedAligner:
         # allocator must not hand these blocks back to the caller's stream before the head has consumed them
         labels.record_stream(self.stream_h)
         n_labels.record_stream(self.stream_h)
-        self._pending.append(dict(labels=labels, n_labels=n_labels, out=out, host_out=host_out))
+        self._pending.append(dict(labels=labels, n_labels=n_labels, out=out, host_out=host_out, mel=mel))
         if len(self._pending) == self.G:
             self._flush()
+        self._verify(block=False)
         return out
 
     def _flush(self):
@@ -832,7 +862,9 @@ class PipelinedAligner:
             n_labels = self._pending[0]["n_labels"] if n == 1 else torch.cat([q["n_labels"] for q in self._pending], dim=0)
             variant = LA_VARIANT_CTC if use_ctc else LA_VARIANT_PLAIN
             feats = self._feats[slot][: n * B * clip_rows]
-            res = eng.align_feats(feats, n * B, n_frames, clip_rows, labels, n_labels, variant)
+            flag = torch.zeros((1,), dtype=torch.int32, device=eng.device)
+            flag.record_stream(self.stream_h)
+            res = eng.align_feats(feats, n * B, n_frames, clip_rows, labels, n_labels, variant, flag=flag)
             for j, q in enumerate(self._pending):
                 for dst, src in zip(q["out"], res):
                     dst.copy_(src[j * B:(j + 1) * B], non_blocking=True)
@@ -840,14 +872,55 @@ class PipelinedAligner:
                     q["host_out"][0].copy_(q["out"][0], non_blocking=True)
                     q["host_out"][1].copy_(q["out"][1], non_blocking=True)
                     q["host_out"][2].copy_(q["out"][3], non_blocking=True)
+            if len(self._unverified) >= self._host_flags.numel() - 1:
+                self._verify(block=True)                                # (never in practice: submit() verifies finished groups as it goes)
+            host_flag = self._host_flags[self.gi % self._host_flags.numel(): self.gi % self._host_flags.numel() + 1]
+            host_flag.copy_(flag, non_blocking=True)
             self.head_done[slot].record(self.stream_h)
+            done = torch.cuda.Event()
+            done.record(self.stream_h)
             self._head_used[slot] = True
+        self._unverified.append(dict(batches=self._pending, key=self._key, host_flag=host_flag, done=done))
         self._pending = []
         self.gi += 1
+
+    def _verify(self, block: bool) -> None:
+        """Groups whose head has finished: time-out word zero -> their inputs are released; set -> _recover.  block: wait for every group."""
+        while self._unverified:
+            g = self._unverified[0]
+            if block:
+                g["done"].synchronize()
+            elif not g["done"].query():
+                return
+            self._unverified.pop(0)
+            if int(g["host_flag"][0]) != 0:
+                self._recover(g)
+
+    def _recover(self, g: dict) -> None:
+        """One re-run of a group whose recurrence timed out: everything in flight is waited for (the device is idle, so the launch set
+        is co-resident), then each of its batches goes through encoder and head again on the current stream, into the result tensors
+        (and pinned host copies) it had handed out.  A second time-out raises TimeoutError."""
+        eng = self.eng
+        torch.cuda.synchronize(eng.device)
+        B, _, n_frames, use_ctc, clip_rows = g["key"]
+        variant = LA_VARIANT_CTC if use_ctc else LA_VARIANT_PLAIN
+        flag = torch.zeros((1,), dtype=torch.int32, device=eng.device)
+        for q in g["batches"]:
+            feats = eng.encode(q["mel"])
+            res = eng.align_feats(feats, B, n_frames, clip_rows, q["labels"], q["n_labels"], variant, flag=flag)
+            for dst, src in zip(q["out"], res):
+                dst.copy_(src)
+            if q["host_out"] is not None:
+                q["host_out"][0].copy_(q["out"][0]); q["host_out"][1].copy_(q["out"][1]); q["host_out"][2].copy_(q["out"][3])
+        torch.cuda.synchronize(eng.device)
+        self.recovered_groups += 1
+        if int(flag.item()) != 0:
+            raise TimeoutError("persistent GRU kernel: a bounded inter-workgroup wait timed out again on the re-run of its group (alone on the device)")
 
     def drain(self):
         self._flush()
         for st in self._enc_streams:
             st.synchronize()
         self.stream_h.synchronize()
+        self._verify(block=True)
         self.eng.check_gru()

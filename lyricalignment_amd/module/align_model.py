@@ -312,9 +312,8 @@ class AlignModel(torch.nn.Module):
             mel = self._mel_of(audios)
         feats, B, T, stride = self._features(mel.to(eng.device), get_orig_len)
         lab_dev, n_lab, lab_lists = _labels_to_device(labels, B, eng.device)
-        onset, offset, score, status = eng.align_feats(feats, B, T, stride, lab_dev, n_lab,
-                                                       _lib.LA_VARIANT_CTC if use_ctc else _lib.LA_VARIANT_PLAIN)
-        eng.check_gru()
+        onset, offset, score, status = eng.align_feats_checked(feats, B, T, stride, lab_dev, n_lab,
+                                                               _lib.LA_VARIANT_CTC if use_ctc else _lib.LA_VARIANT_PLAIN)
         if return_frames:
             return onset, offset, score, status
         return _seconds_from_frames(onset, offset, status, lab_lists, hop_size_second)

@@ -1,0 +1,100 @@
+"""Time-out of the persistent GRU recurrence, end to end (round-5 verdict: "no test forces the time-out path").  The recurrence's workgroups
+hand h over through HBM step by step, so the launch set must be co-resident; HIP does not promise that while other streams own the CUs.
+Every inter-workgroup wait is bounded (option gru_timeout_us, default 3 s): a launch that waits one out sets its caller's flag word and leaves
+garbage.  The host side re-enqueues that head ONCE on an idle device before it raises.
+The test hook gru_fault_step (one launch) makes workgroup (0, 0, 0) of the next GRU forward launch leave mid-sequence without publishing, as a
+workgroup that never became resident would; the others run into the (shortened) bound."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(dtype, hidden=256):      # (two or more workgroups per direction and 16-clip group in every kernel form: there is a hand-off to lose)
+    from lyricalignment_amd import whisper_compat as wc
+    from lyricalignment_amd.module.align_model import AlignModel
+    dims = wc.ModelDimensions(n_audio_state=128, n_audio_head=2, n_audio_layer=1, n_text_state=128, n_text_head=2, n_text_layer=1, n_vocab=300, n_text_ctx=32)
+    wm = wc.build_model(dims=dims, seed=4, with_decoder=False)
+    model = AlignModel(wm, embed_dim=128, hidden_dim=hidden, output_dim=300, device="cuda", compute_dtype=dtype).eval()
+    wc.init_align_head(model, seed=7)
+    return model
+
+
+def _inputs(B, seed=0):
+    rs = np.random.RandomState(seed)
+    mel = torch.from_numpy(rs.uniform(-1, 1, size=(B, 80, 3000)).astype(np.float32)).cuda()
+    labels = torch.from_numpy(rs.randint(1, 298, size=(B, 9)))
+    return mel, labels
+
+
+@pytest.mark.parametrize("dtype,B,kernel", [(torch.bfloat16, 32, "granule hand-off"), (torch.bfloat16, 8, "counter hand-off"),
+                                            (torch.float32, 8, "float32 on the f16 pipe"), (torch.float32, 3, "float32 MFMA / v_fma")])
+def test_align_recovers_once_from_a_gru_timeout_and_returns_the_undisturbed_frames(dtype, B, kernel):
+    from lyricalignment_amd import _lib
+    model = _model(dtype)
+    mel, labels = _inputs(B)
+    want = model.align(mel=mel, labels=labels, get_orig_len=False)
+    eng = model.engine()
+    assert getattr(eng, "gru_recoveries", 0) == 0
+    with _lib.option("gru_timeout_us", 20000):
+        _lib.set_option("gru_fault_step", 700)
+        got = model.align(mel=mel, labels=labels, get_orig_len=False)
+    assert _lib.get_option("gru_fault_step") == 0                 # the faulted launch consumed the hook
+    assert eng.gru_recoveries == 1, kernel
+    assert got == want
+    # undisturbed again: no further recovery
+    assert model.align(mel=mel, labels=labels, get_orig_len=False) == want and eng.gru_recoveries == 1
+
+
+def test_second_timeout_on_the_rerun_raises(monkeypatch):
+    from lyricalignment_amd import _lib
+    model = _model(torch.bfloat16)
+    mel, labels = _inputs(20)
+    eng = model.engine()
+    real = eng.align_feats
+
+    def faulting(*a, **k):
+        _lib.set_option("gru_fault_step", 300)                    # every head call loses a workgroup
+        return real(*a, **k)
+
+    monkeypatch.setattr(eng, "align_feats", faulting)
+    with _lib.option("gru_timeout_us", 20000):
+        with pytest.raises(TimeoutError):
+            model.align(mel=mel, labels=labels, get_orig_len=False)
+    _lib.set_option("gru_fault_step", 0)
+    monkeypatch.undo()
+    torch.cuda.synchronize()
+    assert isinstance(model.align(mel=mel, labels=labels, get_orig_len=False), list)      # the engine is usable afterwards
+
+
+def test_pipeline_recomputes_the_group_that_timed_out():
+    """PipelinedAligner: six batches in groups of two over two encoder streams; the head of the SECOND group loses a workgroup.  drain() leaves
+    every batch with the frames of an undisturbed run, one group recomputed, the others untouched."""
+    from lyricalignment_amd import _lib
+    from lyricalignment_amd.engine import PipelinedAligner
+    from lyricalignment_amd.utils.alignment import _labels_to_device
+    model = _model(torch.bfloat16)
+    eng = model.engine()
+    B = 24
+    batches = [_inputs(B, seed=s) for s in range(6)]
+    dev_labels = [_labels_to_device(lab, B, eng.device)[:2] for _, lab in batches]
+
+    def run(fault_group=None):
+        pipe = PipelinedAligner(eng, head_group=2, encoder_streams=2)
+        outs = []
+        for i, ((mel, _), (lab, n_lab)) in enumerate(zip(batches, dev_labels)):
+            if fault_group is not None and i == 2 * fault_group + 1:
+                _lib.set_option("gru_fault_step", 500)            # read by the head launch this submit's flush enqueues
+            outs.append(pipe.submit(mel, lab, n_lab, n_frames=1500, use_ctc=True))
+        pipe.drain()
+        return pipe, [tuple(t.cpu().clone() for t in o) for o in outs]
+
+    _, want = run()
+    with _lib.option("gru_timeout_us", 20000):
+        pipe, got = run(fault_group=1)
+    assert pipe.recovered_groups == 1
+    for i, (a, b) in enumerate(zip(got, want)):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y), i
+        assert int((a[3] != 0).sum()) == 0
