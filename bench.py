@@ -51,7 +51,7 @@ def total_flops_per_clip(d: int, n_layer: int, H: int = HIDDEN, V: int = VOCAB) 
     return float(enc + gru + 2 * T * 2 * H * V)
 
 
-PMC_SUMMARY = "r5_pmc_gemm_pp.csv"   # FETCH_SIZE / WRITE_SIZE passes over bench.py itself (tools/pmc_traffic.sh r5)
+PMC_SUMMARY = "r6_pmc_gemm_pp.csv"   # FETCH_SIZE / WRITE_SIZE passes over bench.py itself (tools/pmc_traffic.sh r6)
 
 
 def measured_gemm_traffic_per_launch():

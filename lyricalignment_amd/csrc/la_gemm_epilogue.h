@@ -211,7 +211,8 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams &p, int z, f32x4 
                             }
                         }
                     } else {
-                        *reinterpret_cast<ushort4 *>(c) = la::Pack4<TC>::run(v[0], v[1], v[2], v[3]);
+                        if (!LA_DEV_BIT(epi, 2 << 16) || v[0] == 12345.678f)      // (experiment build, LA_EPI_PROBE & 2: no 16-bit store)
+                            *reinterpret_cast<ushort4 *>(c) = la::Pack4<TC>::run(v[0], v[1], v[2], v[3]);
                     }
                 }
             }

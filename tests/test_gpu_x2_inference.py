@@ -192,3 +192,69 @@ def test_model_level_routes_agree_with_each_other_and_the_oracle():
             eng_mod.ENGINE_PY = old
             model._engine = None
         assert torch.equal(enc_py, res["x2"][0])
+
+
+def test_documented_limits_raise_outside_and_work_at_the_edge():
+    """INTEGRATION.md "Limits that differ from the reference": the alignment DP takes up to 4095 labels per utterance, the CTC loss lattice
+    up to 511; one label beyond raises NotImplementedError / ValueError instead of computing garbage; a GRU launch set beyond the
+    co-residency cap is refused by la_gru_layer (callers slice), and the model-level call slices transparently."""
+    from lyricalignment_amd import finetune as ft, ops
+    T = 8300
+    for L, ok in ((4095, True), (4096, False)):
+        em = torch.zeros((1, T, L + 1), dtype=torch.float32, device="cuda")
+        labels = (torch.arange(L, dtype=torch.int32, device="cuda") % 7 + 1).view(1, L)
+        args = (em, labels, torch.tensor([L], dtype=torch.int32, device="cuda"), torch.tensor([T], dtype=torch.int32, device="cuda"))
+        if ok:
+            onset, offset, score, status = ops.viterbi_batch(*args)
+            assert int(status[0]) == 0 and int(onset[0, 0]) >= 0 and int(offset[0, L - 1]) == T          # (offset = last frame + 1: utils/alignment.py:183)
+        else:
+            with pytest.raises(NotImplementedError):
+                ops.viterbi_batch(*args)
+    V = 40
+    logits = torch.randn(1, 1100, V + 1, generator=torch.Generator().manual_seed(1)).cuda()
+    for L, ok in ((511, True), (512, False)):
+        lab = (torch.arange(L) % (V - 2) + 1).view(1, L)
+        if ok:
+            l3, dlog = ft.multitask_loss(logits, None, lab, vocab_size=V)
+            assert torch.isfinite(l3[2]) and torch.isfinite(dlog).all()
+        else:
+            with pytest.raises(ValueError):
+                ft.multitask_loss(logits, None, lab, vocab_size=V)
+    H = 384
+    gi = torch.zeros((608, 2, 2, 3 * H), dtype=torch.float32, device="cuda")
+    with pytest.raises(NotImplementedError):                       # 608 clips: 38 groups x 2 directions x 3 workgroups = 228 > the 224 co-resident workgroups of one launch
+        ops.gru_layer(gi, torch.zeros((2, 3 * H, H), dtype=torch.bfloat16, device="cuda"), torch.zeros((2, 3 * H), device="cuda"))
+
+
+def test_transposed_split_with_one_operand_scale_keeps_the_documented_precision():
+    """Round-5 advisor finding, pinned as documented behaviour: la_split_f16x2_t_tmax gives the transposed planes ONE power-of-two scale (from
+    the operand's maximum, left by its plain split) instead of one per column.  A weight gradient dW = dy^T x computed from such planes, dy with
+    columns spanning 2^36 of dynamic range, against float64, ROW BY ROW of dW (= column of dy): rows whose dy column lies within 2^17 of the
+    operand's maximum keep the full 22 bits (relative error of the row < 2^-19), rows down to 2^28 below keep at least the hi plane's 11 bits
+    (< 2^-9), and below that the ABSOLUTE error stays under 2^-36 of the largest row (half's subnormal floor) -- entries that small are
+    below AdamW's eps after the global-norm clip.  The per-column form (LA_F32X2_TMAX=0) keeps 22 bits in every row."""
+    from lyricalignment_amd import f32x2
+    M, N, K = 24000, 512, 1024
+    g = torch.Generator().manual_seed(2)
+    dy = torch.randn(M, N, generator=g)
+    expo = torch.linspace(0, -36, N)
+    dy = dy * torch.exp2(expo)[None, :]
+    x = torch.randn(M, K, generator=g)
+    ref = dy.double().T @ x.double()
+    dyd, xd = dy.cuda(), x.cuda()
+    mp = f32x2.padded_k(N, K, M)
+    omax = f32x2.OperandMax(dyd.device)
+    f32x2.split(dyd, omax=omax)                                                    # the plain split leaves the operand's maximum
+    res = {}
+    for name, om in (("one scale", omax), ("per column", None)):
+        dw = f32x2.gemm(f32x2.split_t(dyd, mp, omax=om), f32x2.split_t(xd, mp)).cpu().double()
+        res[name] = (dw - ref).norm(dim=1) / ref.norm(dim=1)
+    top = ref.norm(dim=1).max()
+    rel, per_col = res["one scale"], res["per column"]
+    assert float(per_col.max()) < 2.0 ** -19
+    near, mid, far = expo > -16, (expo <= -18) & (expo > -27), expo <= -30
+    assert float(rel[near].max()) < 2.0 ** -19 and float(rel[mid].max()) < 2.0 ** -9
+    abs_far = (rel * ref.norm(dim=1))[far]
+    assert float(abs_far.max()) < float(top) * 2.0 ** -36
+    print(f"dW rows by dy-column magnitude: within 2^16 of the maximum {float(rel[near].max()):.1e}, 2^18..2^27 below {float(rel[mid].max()):.1e}, "
+          f"2^30+ below: absolute {float(abs_far.max() / top):.1e} of the largest row; per-column scales {float(per_col.max()):.1e}")

@@ -145,6 +145,43 @@ def bench_epi_probe(iters):
             print(f"epi-probe {name} N={N} K={K} {names[probe]:45s}: {t*1e3:7.1f} us", flush=True)
 
 
+def bench_mlpup(iters):
+    """Knock-out table of the in-pipeline MLP-up launch gemm_pp_kernel<false, true, bf16, 2> at 48000 x 4096 x 1024 (round-5 verdict: 352 us
+    alone with a plain epilogue against 441 us inside the pipeline): the LayerNorm-consumer terms, the GELU and the 16-bit store each left out
+    alone and together, interleaved rounds of `iters` back-to-back launches each (the chip stays at its power cap as inside the pipeline), A
+    freshly written before every round's first launch as the producer GEMM leaves it.  Experiment build for the store knock-out (LA_EPI_PROBE=2)."""
+    M, N, K = 48000, 4096, 1024
+    a, w = rnd(M, K), rnd(N, K, scale=K ** -0.5)
+    bias, csum = torch.randn(N, device="cuda"), torch.randn(N, device="cuda") * 0.1
+    stats = torch.stack([torch.randn(M, device="cuda") * 0.01, torch.rand(M, device="cuda") + 0.5], dim=1).contiguous()
+    out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    lab = _lib.has_experiments()
+    forms = [("full: LN fold + bias + GELU + store", dict(ln=True, gelu=True), 0), ("no LN fold (plain bias + GELU)", dict(ln=False, gelu=True), 0),
+             ("no GELU (LN fold + bias)", dict(ln=True, gelu=False), 0), ("neither (plain bias)", dict(ln=False, gelu=False), 0)]
+    if lab:
+        forms += [("full, no 16-bit store", dict(ln=True, gelu=True), 2), ("neither, no store", dict(ln=False, gelu=False), 2)]
+    res = {n: [] for n, _, _ in forms}
+    for rd in range(5):
+        for name, f, probe in forms:
+            if probe:
+                os.environ["LA_EPI_PROBE"] = str(probe)
+            else:
+                os.environ.pop("LA_EPI_PROBE", None)
+            fn = lambda: ops.gemm(a, w, out, bias=bias, gelu=f["gelu"], ln_stats=stats if f["ln"] else None, ln_csum=csum if f["ln"] else None)
+            res[name].append(timeit(fn, iters)[0])
+    os.environ.pop("LA_EPI_PROBE", None)
+    fl = 2.0 * M * N * K
+    for name, ts in res.items():
+        t = sorted(ts)[len(ts) // 2]
+        print(f"mlp-up {name:40s}: {t*1e3:7.1f} us = {fl/t/1e9:7.1f} TF/s", flush=True)
+    if lab:
+        for mb in ("0", "32"):
+            os.environ["LA_GEMM_MBLOCK"] = mb
+            t = timeit(lambda: ops.gemm(a, w, out, bias=bias, gelu=True, ln_stats=stats, ln_csum=csum), iters)[0]
+            print(f"mlp-up full, LA_GEMM_MBLOCK={mb}: {t*1e3:7.1f} us", flush=True)
+        os.environ.pop("LA_GEMM_MBLOCK", None)
+
+
 def bench_tile_order(iters):
     """Tile order sweep of the 256x256 kernel (LA_GEMM_GROUP = column tiles per group, LA_GEMM_MBLOCK = row tiles per M block, 0 =
     groups sweep all of M), plain 16-bit epilogue, uniform random operands, interleaved rounds; torch.matmul beside it."""
@@ -524,6 +561,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if a.what == "order":
         bench_tile_order(a.iters)
+        sys.exit(0)
+    if a.what == "mlpup":
+        bench_mlpup(a.iters)
         sys.exit(0)
     if a.what == "epi":
         bench_epi_probe(a.iters)
