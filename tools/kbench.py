@@ -365,6 +365,26 @@ def bench_x2(iters):
             print(f"x2 {name:9s} {lab}: f16x2 incl. splits {tx*1e3:8.1f} us ({fl/tx/1e9:6.1f} TF/s algorithmic) | float32 kernel {tn*1e3:8.1f} us ({fl/tn/1e9:6.1f}) | {tn/tx:4.2f}x", flush=True)
 
 
+def bench_x2gemm(iters):
+    """la_gemm_f16x2 alone (operands pre-split) on the float32-inference shapes (48000 rows = 32 clips): the kernel's own time and the f16 MFMA
+    work it executes (3 x the algorithmic flops), interleaved rounds."""
+    from lyricalignment_amd import f32x2
+    M = 48000
+    shapes = (("qkv", 3072, 1024), ("mlp-up", 4096, 1024), ("out-proj", 1024, 1024), ("mlp-down", 1024, 4096))
+    ops_ = []
+    for name, N, K in shapes:
+        x, w = torch.randn(M, K, device="cuda"), torch.randn(N, K, device="cuda") * K ** -0.5
+        ops_.append((name, N, K, f32x2.split(x, K), f32x2.split(w, K), torch.empty(M, N, device="cuda"), torch.randn(N, device="cuda")))
+    res = {n: [] for n, _, _ in shapes}
+    for rd in range(3):
+        for name, N, K, a, b, out, bias in ops_:
+            res[name].append(timeit(lambda: f32x2.gemm(a, b, out=out, bias=bias), iters)[0])
+    for name, N, K in shapes:
+        t = sorted(res[name])[1]
+        fl = 2.0 * M * N * K
+        print(f"x2gemm {name:9s} M={M} N={N} K={K}: {t*1e3:8.1f} us  {fl/t/1e9:7.1f} TF/s algorithmic = {3*fl/t/1e9:7.1f} TF/s of f16 MFMA work ({3*fl/t/1e9/2500:.3f} of peak)", flush=True)
+
+
 def bench_attn_bwd(iters):
     """Fused float32 attention backward: the f16x2 sweeps (la_attention_bwd_f16x2) against the float32-MFMA sweeps (la_attention_bwd_f32) --
     time per layer at the fine-tune shape (16 clips x 1500 frames x 16 heads), and max |err| / max |ref| of dq / dk / dv of both against
@@ -576,6 +596,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if a.what == "x2":
         bench_x2(a.iters)
+        sys.exit(0)
+    if a.what == "x2gemm":
+        bench_x2gemm(a.iters)
         sys.exit(0)
     if a.what == "f32emu":
         bench_f32emu(a.iters)
