@@ -303,6 +303,11 @@ class EncoderFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        from . import head_train
+        if head_train._deferred_flags and not head_train.CALLER_CHECKS_FLAGS:
+            # a head that ran beside the decoder parked its GRU time-out flags (module/align_model.py): both branches' backward sweeps are
+            # enqueued by now -- read them (synchronises) before anything is built on their gradients
+            head_train.check_deferred_flags()
         B, d, H, n_mels, n_layer = ctx.dims
         M = B * N_CTX
         dyf = dy.to(torch.float32).contiguous().view(M, d)

@@ -338,6 +338,15 @@ class FineTuner:
         """Device time the last step() spent on the gradient exchange after the overlap with the backward (0 for world 1)."""
         return self.overlap.last_exposed_ms() if self.overlap is not None else 0.0
 
+    def _backward(self, roots, grads) -> None:
+        """torch.autograd.backward with this tuner as the reader of the head branch's parked GRU time-out flags (no host synchronisation inside
+        the backward; check_deferred_flags() follows every call)."""
+        prev, head_train.CALLER_CHECKS_FLAGS = head_train.CALLER_CHECKS_FLAGS, True
+        try:
+            torch.autograd.backward(roots, grads)
+        finally:
+            head_train.CALLER_CHECKS_FLAGS = prev
+
     def _check_grad_views(self) -> None:
         """autograd must have accumulated IN PLACE into the bucket views (it does while .grad is defined and grad mode is
         off in backward); a replaced .grad tensor would silently drop gradients from the all-reduce / update."""
@@ -394,7 +403,7 @@ class FineTuner:
                 out[3] += l
                 roots.append(trans_logit); grads.append(dl)
             if roots:
-                torch.autograd.backward(roots, grads)
+                self._backward(roots, grads)
             head_train.check_deferred_flags()                     # GRU time-out flags of a head that ran beside the decoder
         if has_tr:
             if last and self.overlap is not None:
@@ -411,7 +420,7 @@ class FineTuner:
                 out[2] += l3[2]
                 roots.append(align_logit); grads.append(dlog)
             if roots:
-                torch.autograd.backward(roots, grads)
+                self._backward(roots, grads)
             head_train.check_deferred_flags()                     # GRU time-out flags of a head that ran beside the decoder
         self._check_grad_views()
         return out
@@ -511,7 +520,7 @@ class FineTuner:
         if roots:
             if self.overlap is not None and accum == len(micro_batches):    # the one backward of the whole optimizer step
                 self.overlap.arm()
-            torch.autograd.backward(roots, grads)
+            self._backward(roots, grads)
             head_train.check_deferred_flags()                     # GRU time-out flags of a head that ran beside the decoder
         self._check_grad_views()
         return out

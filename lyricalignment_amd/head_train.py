@@ -139,6 +139,11 @@ def _gru_ws(B: int, T: int, H: int, device):
 # check_deferred_flags() -- FineTuner calls it after the backward of the step.
 DEFER_FLAG_CHECKS = False
 _deferred_flags: List = []
+# Who reads the parked flags.  False (default): the backward node where the two branches' gradients meet -- EncoderFunction.backward -- reads them
+# before it differentiates the encoder, so a plain `loss.backward(); optimizer.step()` loop (train_multitask.py:325-340) gets its TimeoutError out
+# of loss.backward(), before any update is computed from a timed-out sweep.  True (FineTuner, around its own backward calls): the caller reads
+# them after the backward (check_deferred_flags), with no host synchronisation inside the step.
+CALLER_CHECKS_FLAGS = False
 
 
 def _flag_check(flag: torch.Tensor, what: str, defer: bool) -> None:

@@ -223,9 +223,9 @@ class AlignModel(torch.nn.Module):
             embed, embed_pad = self._encoder_train_features(mel, get_orig_len)
             align_logit = transcribe_logit = None
             both = self.train_alignment and self.train_transcript and y_in is not None
-            # (opt-in: FineTuner sets _branch_streams and reads the deferred GRU time-out flags after every backward, before the gradients
-            # are used; a plain `loss.backward(); optimizer.step()` loop keeps one stream and the immediate flag checks)
-            if both and embed.is_cuda and getattr(self, "_branch_streams", False) and BRANCH_STREAMS:
+            # (the GRU time-out flags of this branch are parked and read before its gradients are used: by EncoderFunction.backward in a plain
+            # `loss.backward(); optimizer.step()` loop, by FineTuner after its backward -- head_train.CALLER_CHECKS_FLAGS)
+            if both and embed.is_cuda and getattr(self, "_branch_streams", True) and BRANCH_STREAMS:
                 # The two branches are independent until their losses, and the head's GRU sweeps are 2 x 1500 dependent steps on 12
                 # workgroups (13 ms forward, 19 ms backward with the other 244 CUs idle): the head runs on a stream of its own beside
                 # the decoder.  autograd runs a node's backward on the stream of its forward and joins the streams where gradients

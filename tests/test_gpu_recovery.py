@@ -98,3 +98,37 @@ def test_pipeline_recomputes_the_group_that_timed_out():
         for x, y in zip(a, b):
             assert torch.equal(x, y), i
         assert int((a[3] != 0).sum()) == 0
+
+
+def test_plain_training_loop_gets_the_timeout_out_of_backward_before_any_update():
+    """Round-5 advisor finding: with the head on a stream of its own beside the decoder the GRU time-out flags are parked instead of read at once
+    (a read is a host synchronisation between the two branches' launches).  A plain `loss.backward(); optimizer.step()` loop
+    (train_multitask.py:325-340) must still never step on gradients of a timed-out sweep: the node where both branches' gradients meet --
+    EncoderFunction.backward -- reads the parked flags before it differentiates the encoder, so loss.backward() raises and no encoder
+    parameter has received a gradient."""
+    from lyricalignment_amd import _lib, whisper_compat as wc
+    from lyricalignment_amd.module.align_model import AlignModel
+    dims = wc.ModelDimensions(n_audio_state=128, n_audio_head=2, n_audio_layer=1, n_text_state=128, n_text_head=2, n_text_layer=1, n_vocab=311, n_text_ctx=64)
+    wm = wc.build_model(dims=dims, seed=90, std=0.05, with_decoder=True)
+    model = AlignModel(wm, embed_dim=128, hidden_dim=128, output_dim=41, dropout=0.0, train_transcript=True, device="cuda").to("cuda").train()
+    rs = np.random.RandomState(3)
+    audios = [(rs.randn(16000) * 0.1).astype(np.float32), (rs.randn(12000) * 0.1).astype(np.float32)]
+    dec_in = torch.tensor([[1, 20, 33, 47], [1, 90, 91, 2]])
+
+    def loss_of():
+        a, t = model.frame_manual_forward(audios, dec_in.cuda(), get_orig_len=False)
+        return a.float().pow(2).mean() + t.float().pow(2).mean()
+
+    loss_of().backward()                                            # undisturbed: gradients everywhere
+    assert all(p.grad is not None for p in model.whisper_model.encoder.parameters())
+    model.zero_grad(set_to_none=True)
+    with _lib.option("gru_timeout_us", 20000):
+        _lib.set_option("gru_fault_step", 400)                      # the head's first training sweep loses a workgroup
+        loss = loss_of()
+        with pytest.raises(TimeoutError):
+            loss.backward()
+    assert all(p.grad is None for p in model.whisper_model.encoder.parameters())
+    torch.cuda.synchronize()
+    model.zero_grad(set_to_none=True)
+    loss_of().backward()                                            # and the model trains on afterwards
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.whisper_model.encoder.parameters())
