@@ -51,7 +51,7 @@ def headline():
             lp, ls = mo.emission_prep_ctc(logits)
             secs = ao.perform_viterbi_ctc(logits, labels[b:b + 1, :L].cpu().long())[0]
         oracle.append(dict(L=L, lp=lp[0], ls=ls[0], on=np.array([s[0] for s in secs]), off=np.array([s[1] for s in secs])))
-    return dict(bench=bench, eng=eng, mel=mel, labels=labels, n_labels=n_labels, Ls=Ls, oracle=oracle, plans=plans, fit=fit,
+    return dict(bench=bench, eng=eng, mel=mel, labels=labels, n_labels=n_labels, Ls=Ls, oracle=oracle, plans=plans, fit=fit, model=model, dims=dims,
                 ref=[t.cpu().numpy().copy() for t in ref[:2]])
 
 
@@ -183,3 +183,51 @@ def test_headline_pipeline_repeats_beside_a_side_stream_load_are_bit_identical(h
             assert (st == 0).all()
             assert (on[mask] == headline["ref"][0][mask]).all() and (off[mask] == headline["ref"][1][mask]).all(), f"repeat {rep} differs"
     headline["eng"].check_gru()
+
+
+def test_float32_parity_mode_at_the_headline_size_equals_the_oracle(headline):
+    """bench.py `modes.f32_parity`: BASELINE configs[1]'s own batch (32 x 30 s, the fitted head) in the reference's precision, on the f16 matrix
+    pipe at float32 accuracy (the route every Linear takes from 9 clips on), through the bench's pipeline shape.  "Onset / offset MAE identical to
+    the reference" at the headline size: EVERY boundary of the oracle's clips equals the fp32 oracle's own end-to-end result (no tolerance), their
+    emission log-probs (range 0 .. -35) are within 2e-3, the pipeline's frames equal the single-stream call's for the whole batch, and the
+    bfloat16 headline differs from this mode in a few per cent of the boundaries only (what `modes.boundaries_equal_to_f32_parity` reports)."""
+    import ctypes
+    from lyricalignment_amd import _lib
+    from lyricalignment_amd.engine import PipelinedAligner
+    from lyricalignment_amd.module.align_model import AlignModel
+    bench, dims = headline["bench"], headline["dims"]
+    m32 = AlignModel(headline["model"].whisper_model, embed_dim=dims.n_audio_state, hidden_dim=bench.HIDDEN, output_dim=bench.VOCAB, device="cuda:0",
+                     compute_dtype=torch.float32).eval()
+    m32.align_rnn.load_state_dict(headline["model"].align_rnn.state_dict())
+    L = _lib.lib()
+    with torch.no_grad():
+        eng = m32.engine()
+        L.la_timer_reset(); L.la_timer_sample(1000003); L.la_timer_enable(b"gemm_f16x2")
+        ref = eng.align_mel(headline["mel"], headline["labels"], headline["n_labels"], n_frames=bench.T_FRAMES, use_ctc=True)
+        torch.cuda.synchronize()
+        L.la_timer_disable()
+        ms, timed, work, seen = ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_int64(0)
+        L.la_timer_read_work(ctypes.byref(ms), ctypes.byref(timed), ctypes.byref(work), ctypes.byref(seen))
+        L.la_timer_reset(); L.la_timer_sample(1)
+        assert seen.value >= 4 * 24 + 2                                          # every block's four Linears and the head's two projections
+        assert int((ref[3] != 0).sum()) == 0
+        pipe = PipelinedAligner(eng, head_group=bench.DEFAULT_HEAD_GROUP, encoder_streams=bench.DEFAULT_ENCODER_STREAMS)
+        outs = [pipe.submit(headline["mel"], headline["labels"], headline["n_labels"], n_frames=bench.T_FRAMES, use_ctc=True) for _ in range(5)]
+        pipe.drain()
+        feats = eng.encode(headline["mel"])
+        em = eng.emissions(feats, bench.BATCH, bench.T_FRAMES, bench.T_FRAMES, headline["labels"], headline["n_labels"], _lib.LA_VARIANT_CTC)[:N_ORACLE_CLIPS].cpu()
+    on, off = ref[0].cpu().numpy(), ref[1].cpu().numpy()
+    mask = np.arange(headline["labels"].shape[1])[None, :] < headline["Ls"][:, None]
+    for o in outs:
+        assert (o[0].cpu().numpy()[mask] == on[mask]).all() and (o[1].cpu().numpy()[mask] == off[mask]).all() and int((o[3] != 0).sum()) == 0
+    for b, o in enumerate(headline["oracle"]):
+        Lb = o["L"]
+        assert (on[b, :Lb] * 0.02 == o["on"]).all() and (off[b, :Lb] * 0.02 == o["off"]).all(), f"clip {b}: boundaries differ from the oracle's"
+        idx = headline["labels"][b, :Lb].cpu().long() - 1
+        err = torch.cat([(em[b, :, 1:1 + Lb] - o["lp"][:, idx]).abs().flatten(), (em[b, :, 0] - o["ls"][:, 0]).abs()])
+        assert float(err.max()) < 2e-3, (b, float(err.max()))
+    same = int((on[mask] == headline["ref"][0][mask]).sum() + (off[mask] == headline["ref"][1][mask]).sum())
+    print(f"float32-parity mode at B = 32: all {sum(2 * o['L'] for o in headline['oracle'])} boundaries of the oracle's clips equal; bf16 headline vs this mode: "
+          f"{same} of {2 * int(mask.sum())} boundaries equal")
+    assert same >= 0.9 * 2 * int(mask.sum())
+    eng.check_gru()
