@@ -253,3 +253,20 @@ def test_large_v2_32_blocks_float16_one_clip():
     print(f"large-v2 f16: emission error mean {float(err.mean()):.4f} max {float(err.max()):.4f}; boundaries exact {exact:.3f}")
     assert float(err.mean()) < 0.015 and float(err.max()) < 0.1
     assert exact >= 0.9
+
+
+def test_large_v2_32_blocks_float32_on_the_f16x2_route_equals_oracle():
+    """BASELINE configs[3]'s architecture (d = 1280, 20 heads, 32 blocks: K = 1280 and 5120) in the reference's precision on the f16 matrix pipe:
+    nine copies of one 30 s clip in a batch (every Linear fills the 256 x 256 kernel), logits within 1e-3 of the fp32 oracle after 32 blocks and
+    the seconds of the fused path equal to the oracle's own end-to-end result."""
+    model, dims = _build("large-v2", torch.float32)
+    audio, labels = _wave(480000, 5), _labels(26)
+    enc, logits, lp, ls, secs, T = _oracle_run(model, dims, audio, labels)
+    copies = 9
+    with torch.no_grad(), _count_launches("gemm_f16x2") as x2:
+        lg, _ = model.frame_manual_forward([audio] * copies)
+        got = model.align([audio] * copies, labels.repeat(copies, 1), use_ctc=True)
+    assert x2.n >= 4 * 32 * 2, x2.n
+    for c in (0, copies - 1):
+        np.testing.assert_allclose(lg[c].cpu().numpy(), logits[0].numpy(), rtol=0, atol=1e-3)
+    assert got == secs * copies
