@@ -368,6 +368,16 @@ def test_bench_process_group_over_rccl_at_world_size_one(extra):
     assert len(lines) == 1, r.stdout[-1500:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 1 and out["steps"] == 2 and out["value"] > 0
+    if not extra:
+        # the default run's extra legs (round 6): the other compute modes of the headline workload and BASELINE configs[2..4], measured in the same
+        # process after the headline is complete -- present, error-free, and the float32-parity mode ran on the f16x2 GEMM family
+        modes, others = out["modes"], out["other_configs"]
+        assert modes["f32_parity"]["status_ok"] and modes["f32_parity"]["gemm_family"] == "gemm_f16x2" and modes["f32_parity"]["ms_per_step"] > 0
+        assert modes["f16"]["status_ok"] and modes["f16"]["ms_per_step"] > 0
+        eq = modes["boundaries_equal_to_f32_parity"]
+        assert eq["f16"] >= eq["bf16_headline"] >= 0.9 * eq["of"]
+        for name in ("longform", "largev2", "finetune"):
+            assert "error" not in others[name] and others[name]["ms_per_step"] > 0 and 0 < others[name]["roofline_frac"] < 1, (name, others[name])
 
 
 @pytest.mark.parametrize("mode_args", [["--mode", "longform", "--songs", "4"], ["--mode", "largev2", "--clips", "64"]])
