@@ -333,8 +333,12 @@ int la_mel_to_rows(const float *mel, int64_t mel_batch_stride, int64_t mel_row_s
  * {h, h | step} polled by the consumers (16-bit modes; option gru_handoff = 1: through `out` with write-through (sc1)
  * stores and per-step arrival counters).  H % 64 == 0;
  * at most 224 workgroups may be co-resident (16-bit modes, H=384: 8-wave workgroups, 2 * 3 per 16 clips).
- * `timeout_flag` (device int32, optional) is set non-zero if a bounded wait
- * gave up; the host wrapper maps it to LA_ETIMEOUT.
+ * dtype LA_F32, more than 4 clips, option x2_inference = 1 (round 6): the recurrent product h W_hh^T runs as three f16 MFMA products
+ * over split operands at float32 accuracy (W_hh rows scaled and split into two half fragment sets resident in registers, h exchanged as
+ * {hi | lo, step} granules): 4.4 instead of 11.4 us per step at 16 clips; fewer clips keep the float32 kernel's v_fma path.
+ * `timeout_flag` (device int32, optional) is set non-zero if a bounded wait (option gru_timeout_us, default 3 s) gave up: the launch set was
+ * not co-resident and `out` is garbage.  Recover by calling again after hipDeviceSynchronize (alone on the device the set is co-resident);
+ * INTEGRATION.md "GRU time-out and recovery".
  */
 int la_gru_workspace_bytes(int32_t batch, int32_t frames, int32_t hidden, size_t *bytes);
 int la_gru_layer(int32_t dtype, const float *gi, const void *w_hh, const float *b_hh,
