@@ -136,7 +136,9 @@ int launch_pp_loop(GemmParams p, int batch, hipStream_t stream) {
     // (16 MB at K = 1024) are re-read per group out of the Infinity Cache instead of once per sweep over all of M.  Alone on the chip
     // with cold A the MLP-up shape runs 438 -> 352 us (tools/kbench.py order); inside the pipeline, where A was just written, 0.6 %
     // of the step (profiles/r4_ab_mblock.txt).
-    p.mblock = p.tiles_n > p.group ? 32 : 0;
+    // (the f16x2 form -- LNM 6 -- stages both planes of every operand row: twice the bytes per row panel, and blocks of 8 row tiles measured best there:
+    //  QKV 767 -> 749 us, MLP-up 1036 -> 1015 us at 48000 rows, the N = 1024 shapes flat; profiles/r6_x2_tile_order.txt)
+    p.mblock = p.tiles_n > p.group ? (LNM == 6 ? 8 : 32) : 0;
     // (experiment build only: developer sweeps / probes, read per launch)
     if (const char *g = la::dev_env("LA_GEMM_MBLOCK")) p.mblock = atoi(g);
     if (const char *g = la::dev_env("LA_GELU_PK")) p.epilogue |= atoi(g) == 2 ? 8192 : 4096;

@@ -385,6 +385,26 @@ def bench_x2gemm(iters):
         print(f"x2gemm {name:9s} M={M} N={N} K={K}: {t*1e3:8.1f} us  {fl/t/1e9:7.1f} TF/s algorithmic = {3*fl/t/1e9:7.1f} TF/s of f16 MFMA work ({3*fl/t/1e9/2500:.3f} of peak)", flush=True)
 
 
+def bench_x2order(iters):
+    """Tile-order sweep for la_gemm_f16x2 at M = 48000 (experiment build: LA_GEMM_GROUP / LA_GEMM_MBLOCK are read per launch): the planes double
+    the bytes of a row panel, so the order tuned for the 16-bit kernel need not be the best one here."""
+    from lyricalignment_amd import f32x2
+    M = 48000
+    for name, N, K in (("qkv", 3072, 1024), ("mlp-up", 4096, 1024), ("out-proj", 1024, 1024), ("mlp-down", 1024, 4096)):
+        x, w = torch.randn(M, K, device="cuda"), torch.randn(N, K, device="cuda") * K ** -0.5
+        a, b, out = f32x2.split(x, K), f32x2.split(w, K), torch.empty(M, N, device="cuda")
+        res = {}
+        for rd in range(2):
+            for g, mb in ((None, None), (2, 32), (4, 16), (4, 64), (8, 32), (8, 16), (16, 32), (4, 8), (2, 16), (16, 0), (4, 0)):
+                for k_, v_ in (("LA_GEMM_GROUP", g), ("LA_GEMM_MBLOCK", mb)):
+                    if v_ is None: os.environ.pop(k_, None)
+                    else: os.environ[k_] = str(v_)
+                res.setdefault((g, mb), []).append(timeit(lambda: f32x2.gemm(a, b, out=out), iters)[0])
+        os.environ.pop("LA_GEMM_GROUP", None); os.environ.pop("LA_GEMM_MBLOCK", None)
+        for key, ts in res.items():
+            print(f"x2order {name:9s} (group, mblock)={key}: {min(ts)*1e3:8.1f} us", flush=True)
+
+
 def bench_attn_bwd(iters):
     """Fused float32 attention backward: the f16x2 sweeps (la_attention_bwd_f16x2) against the float32-MFMA sweeps (la_attention_bwd_f32) --
     time per layer at the fine-tune shape (16 clips x 1500 frames x 16 heads), and max |err| / max |ref| of dq / dk / dv of both against
@@ -599,6 +619,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if a.what == "x2gemm":
         bench_x2gemm(a.iters)
+        sys.exit(0)
+    if a.what == "x2order":
+        bench_x2order(a.iters)
         sys.exit(0)
     if a.what == "f32emu":
         bench_f32emu(a.iters)
