@@ -277,9 +277,9 @@ struct DuoCtx {
     unsigned piece0;               // LDS address of the wave's first piece in ring slot 0
     unsigned fa_lo, fa_hi, fw_lo, fw_hi;   // fragment read bases (slots 0-1 / 2-3)
     // SEGMENTED K (the f16x2 products, la_f32x2.hip): an operand row holds two PLANES of Kc elements (hi terms, lo terms of a float32
-    // value split into two halves; plane pitch below), and the k loop walks three segments of seg_stages stages each -- the products
-    // (lo, hi), (hi, lo), (hi, hi): small terms first -- so stage t of the flat loop reads plane seg_off[t / seg_stages] of this
-    // wave's operand at column (t % seg_stages) * 32.
+    // value split into two halves; plane pitch below), and the k loop walks 3 x seg_stages stages -- per 32-wide chunk of K the
+    // products (lo, hi), (hi, lo), (hi, hi) -- so stage t of the flat loop reads plane seg_off[t % 3] of this wave's operand at column (t / 3) * 32
+    // (duo_stage_src).
     int seg_stages = 0;
     unsigned seg_off0 = 0, seg_off1 = 0;   // byte offset of the first / second segment's plane inside a row (this wave's operand; the third reads plane 0)
 };
@@ -292,10 +292,22 @@ __device__ __forceinline__ const unsigned char *duo_stage_src(const DuoCtx &c, i
         // (masks, not selects between the context's fields: hipcc turns a select of two loads from the context into an indexed load
         //  and leaves the whole context in scratch)
         const int n = c.seg_stages;
+        // Round 6: the three products of one 32-wide k chunk run back to back -- stage t = chunk t / 3, product t % 3 = (lo, hi), (hi, lo),
+        // (hi, hi) -- so that the second read of the chunk's a_hi / w_hi tiles follows the first within two stages (an L2 hit) instead of a whole
+        // pass over K later: QKV 768 -> 752, MLP-up 1025 -> 995, out-proj 276 -> 270 us at 48000 rows, K = 4096 flat (profiles/r6_x2_interleave.txt;
+        // until round 5 each product ran over all of K in turn, small terms first; the error against float64 stays below the float32 kernel's own).
+        // -DLA_X2_SEGMENT_MAJOR keeps the old order (A/B partner).
+        (void)n;
+#ifdef LA_X2_SEGMENT_MAJOR
         const int seg = (t >= n ? 1 : 0) + (t >= 2 * n ? 1 : 0);
+        const int col = t - seg * n;
+#else
+        const int col = t / 3;
+        const int seg = t - 3 * col;
+#endif
         const unsigned off = ((unsigned)-(int)(seg == 0) & c.seg_off0) | ((unsigned)-(int)(seg == 1) & c.seg_off1);
         // (wave-uniform by construction; the DMA's base operand must sit in SGPRs, so say so to the compiler)
-        const uint64_t u = (uint64_t)(uintptr_t)(c.src0 + off + (int64_t)(t - seg * n) * 64);
+        const uint64_t u = (uint64_t)(uintptr_t)(c.src0 + off + (int64_t)col * 64);
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
         return reinterpret_cast<const unsigned char *>((uintptr_t)(((uint64_t)hi << 32) | lo));
     }

@@ -2,7 +2,7 @@
 
 The reference trains in float32 (train_multitask.py:325-326: loss.backward() through nn.Linear); gfx950 multiplies float32
 operands at 1/16 of its 16-bit MFMA rate.  A float32 matrix whose rows are scaled by powers of two splits exactly into two
-IEEE-half planes (hi + lo = 22 bits), and one pass of the 256 x 256 f16 kernel over three K segments accumulates
+IEEE-half planes (hi + lo = 22 bits), and one pass of the 256 x 256 f16 kernel (three products per 32-wide k chunk) accumulates
 a_lo w_hi + a_hi w_lo + a_hi w_hi in float32 -- 3/16 of the float32 pipe's cost, error against a float64 product smaller than
 the float32 kernel's own (profiles/r5_kbench_f32emu.txt).  This module is the host side: which products take that path (the
 large ones: >= 192 tiles of 256 x 256, counting split-K slots), their operand splits, and the three product shapes of a Linear
